@@ -1,0 +1,148 @@
+/* upright_oracle.h -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (upright_amd/, libupright_mi.so) never links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - setup-time data (bodies, contacts) is PINNED: tests/golden/arrangements.json is produced by
+ *     importing the reference's own Python (tests/golden/make_fixtures.py) and matches the
+ *     known answers in upright_core/tests/test_parsing.py.
+ *   - orc_object_dynamics / orc_friction_rows restate upright_core/include/upright_core/
+ *     contact_constraints.h:50-194 line by line; the headers need Eigen (absent here), so they
+ *     cannot be compiled into oracle/_ref: checked by physics known answers + a numpy twin.
+ *   - kinematics, SQP and QP live in un-vendored, un-pinned third-party code (utiasDSL/ocs2
+ *     branch `upright`, Pinocchio, HPIPM; /root/reference/README.md:44-51):  "parity unpinned".
+ *     The restatement follows the published algorithms (multiple-shooting SQP with filter line
+ *     search, Mehrotra predictor-corrector IPM over a stage-wise Riccati factorisation) and the
+ *     reference's call sites (upright_control/src/controller_interface.cpp:103-393).
+ */
+#ifndef UPRIGHT_ORACLE_H
+#define UPRIGHT_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_JOINTS 16
+#define ORC_MAX_CONTACTS 64
+#define ORC_MAX_BODIES 16
+#define ORC_MAX_WAYPOINTS 8
+#define ORC_MAX_NX 64
+#define ORC_MAX_NU 208
+
+typedef struct {
+    /* ---- dimensions (upright_control/include/upright_control/dimensions.h:18-46) ---- */
+    int nq;  /* robot joints: nq == nv; state x = [q, v, a] (3*nq) */
+    int nb;  /* balanced bodies */
+    int nc;  /* contact points */
+    int nf;  /* force variables per contact: 3 (friction) or 1 (frictionless) */
+    int N;   /* shooting intervals; N+1 knots */
+    double dt;
+
+    /* ---- kinematic chain: joint i frame = parent frame * (R_i, p_i) * motion(axis_i, q_i) ---- */
+    int joint_type[ORC_MAX_JOINTS]; /* 0 = prismatic, 1 = revolute */
+    double joint_axis[ORC_MAX_JOINTS][3];
+    double joint_R[ORC_MAX_JOINTS][9]; /* row-major */
+    double joint_p[ORC_MAX_JOINTS][3];
+    double tool_R[9];
+    double tool_p[3];
+
+    double gravity[3];
+
+    /* ---- bodies: 10 inertial parameters each [m, m*c, Ixx,Ixy,Ixz,Iyy,Iyz,Izz]
+     *      (upright_core/include/upright_core/rigid_body.h:36-51), std::map (sorted-name) order */
+    double body_params[ORC_MAX_BODIES][10];
+
+    /* ---- contacts (upright_core/include/upright_core/contact.h:10-46) ---- */
+    int contact_body1[ORC_MAX_CONTACTS]; /* index into bodies, -1 = EE / fixture (not balanced) */
+    int contact_body2[ORC_MAX_CONTACTS];
+    double contact_mu[ORC_MAX_CONTACTS];
+    double contact_normal[ORC_MAX_CONTACTS][3];
+    double contact_span[ORC_MAX_CONTACTS][6]; /* 2x3 row-major */
+    double contact_r1[ORC_MAX_CONTACTS][3];
+    double contact_r2[ORC_MAX_CONTACTS][3];
+
+    /* ---- cost (controller_interface.cpp:400-420, cost/end_effector_cost.h:33-84) ---- */
+    double Qdiag[ORC_MAX_NX];  /* state weight diagonal */
+    double Rdiag[ORC_MAX_NU];  /* input weight diagonal (jerk weights then force_weight) */
+    double xd[ORC_MAX_NX];     /* desired joint state */
+    double Wee[6];             /* EE pose weight diagonal; entries 3..5 must be 0 */
+
+    /* ---- bounds (controller_interface.cpp:157-169,330-357) ---- */
+    double x_lb[ORC_MAX_NX], x_ub[ORC_MAX_NX];
+    double u_lb[ORC_MAX_NU], u_ub[ORC_MAX_NU];
+
+    /* ---- target (wrappers.py:26-43; reference_trajectory.h:18-47) ---- */
+    int n_way;
+    double way_t[ORC_MAX_WAYPOINTS];
+    double way_p[ORC_MAX_WAYPOINTS][3];
+
+    /* ---- solver settings (controller.yaml:54-72) ---- */
+    int sqp_iters;
+    int qp_iter_max;
+    double qp_tol;       /* residual tolerance of the IPM */
+    double delta_tol;    /* controller.yaml:58 */
+    double cost_tol;     /* controller.yaml:59 */
+    int terminal_constraint; /* 1: stationary_desired_position_constraint at knot N */
+} orc_problem;
+
+int orc_nx(const orc_problem* P);
+int orc_nu(const orc_problem* P);
+
+/* ---- upright_core.bindings twins (upright_core/src/pybindings.cpp:53-56), unnormalised ---- */
+/* C row-major world<-EE, w/al angular vel/acc (world), a linear acc (world).  out[6*nb]. */
+void orc_object_dynamics(const orc_problem* P, const double* forces, const double* C,
+                         const double* w, const double* al, const double* a, double* out);
+/* forces[3*nc] -> out[5*nc] */
+void orc_friction_rows(const orc_problem* P, const double* forces, double* out);
+
+/* ---- end-effector kinematics: out = [p(3), C(9 row-major), v(3), w(3), a(3), al(3)] = 24 values;
+ *      dout (may be NULL) = d out / d x, 24 x nx row-major ---- */
+void orc_ee_kinematics(const orc_problem* P, const double* x, double* out, double* dout);
+
+/* ---- per-knot OCP terms at (t, x, u) ---- */
+/* object_dynamics equality (balancing_constraints.cpp:114-155): g[6nb] (scaled by 1/sqrt(6nb)),
+ * gx[6nb x nx], gu[6nb x nu] row-major (either Jacobian may be NULL) */
+void orc_eq_constraint(const orc_problem* P, const double* x, const double* u, double* g,
+                       double* gx, double* gu);
+/* contact_forces inequality (balancing_constraints.cpp:59-71): h[5nc] >= 0 (nf == 3 only) */
+void orc_ineq_constraint(const orc_problem* P, const double* u, double* h);
+/* intermediate cost (not scaled by dt): state_input_cost + end_effector_cost at time t.
+ * grad_x[nx], grad_u[nu], Hxx[nx*nx] (Gauss-Newton), Huu diag[nu] may be NULL */
+double orc_stage_cost(const orc_problem* P, double t, const double* x, const double* u,
+                      double* grad_x, double* grad_u, double* Hxx, double* Huu_diag);
+/* terminal equality (stationary_desired_position_constraint.h:35-74): c[3+2nq], cx row-major */
+void orc_terminal_constraint(const orc_problem* P, double t, const double* x, double* c, double* cx);
+/* discrete dynamics x+ = A x + B u (system_dynamics.h:15-22 integrated exactly) */
+void orc_dynamics(const orc_problem* P, const double* x, const double* u, double* xnext);
+
+/* ---- solve ---- */
+typedef struct {
+    int sqp_iters_done;
+    int qp_iters_last;
+    int qp_status_last;   /* 0 converged, 1 max iter, 2 numerical failure */
+    double step_alpha_last;
+    double cost;          /* merit after last step */
+    double constraint_violation; /* sqrt(dyn SSE + eq SSE + ineq SSE) after last step */
+    double qp_res[4];     /* stationarity, equality, inequality, complementarity of last QP */
+    double dx_norm, du_norm;
+} orc_stats;
+
+/* One MPC solve (MultipleShootingSolver::runImpl semantics): t0, x0 fixed; xs[(N+1)*nx],
+ * us[N*nu] hold the initial guess on entry and the solution on exit. */
+int orc_solve(const orc_problem* P, double t0, const double* x0, double* xs, double* us,
+              orc_stats* stats);
+
+/* Build the QP of one SQP iteration at (xs, us) and solve it; dxs/dus get the step.
+ * Exposed for QP-level parity tests. */
+int orc_qp_step(const orc_problem* P, double t0, const double* x0, const double* xs,
+                const double* us, double* dxs, double* dus, orc_stats* stats);
+
+/* merit terms at a trajectory: out = [cost, dyn_sse, eq_sse, ineq_sse] */
+void orc_performance(const orc_problem* P, double t0, const double* x0, const double* xs,
+                     const double* us, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,148 @@
+"""Flat, numeric description of one optimal-control problem family (shared by every instance of a batch).
+
+This is the data model of SURVEY.md section 7.1: dimensions, kinematic chain, balanced bodies
+(10 inertial parameters each), contact table, weights, bounds, target waypoints and solver settings.
+It mirrors what `ControllerInterface::ControllerInterface`
+(`upright_control/src/controller_interface.cpp:103-393`) reads out of `ControllerSettings`.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import robots
+
+
+@dataclass
+class Problem:
+    chain: robots.Chain
+    # bodies in std::map (sorted-name) order (contact_constraints.h:180)
+    body_names: list
+    body_params: np.ndarray  # (nb, 10)  [m, m*c, Ixx, Ixy, Ixz, Iyy, Iyz, Izz]  rigid_body.h:47-51
+    # contacts (contact.h:10-46)
+    contact_body1: np.ndarray  # (nc,) int, -1 = EE / fixture
+    contact_body2: np.ndarray
+    contact_mu: np.ndarray
+    contact_normal: np.ndarray  # (nc, 3)
+    contact_span: np.ndarray  # (nc, 2, 3)
+    contact_r1: np.ndarray
+    contact_r2: np.ndarray
+    nf: int = 3
+    N: int = 20
+    dt: float = 0.1
+    gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+    Qdiag: np.ndarray = None
+    Rdiag: np.ndarray = None
+    xd: np.ndarray = None
+    Wee: np.ndarray = field(default_factory=lambda: np.array([1.0, 1, 1, 0, 0, 0]))
+    x_lb: np.ndarray = None
+    x_ub: np.ndarray = None
+    u_lb: np.ndarray = None
+    u_ub: np.ndarray = None
+    way_t: np.ndarray = field(default_factory=lambda: np.zeros(1))
+    way_p: np.ndarray = field(default_factory=lambda: np.zeros((1, 3)))
+    sqp_iters: int = 1
+    qp_iter_max: int = 30
+    qp_tol: float = 1e-8
+    delta_tol: float = 1e-3
+    cost_tol: float = 1e-4
+    terminal_constraint: bool = True
+
+    @property
+    def nq(self):
+        return self.chain.nq
+
+    @property
+    def nb(self):
+        return len(self.body_names)
+
+    @property
+    def nc(self):
+        return len(self.contact_mu)
+
+    @property
+    def nx(self):
+        return 3 * self.nq
+
+    @property
+    def nu(self):
+        return self.nq + self.nf * self.nc
+
+    def validate(self):
+        nx, nu = self.nx, self.nu
+        for name, n in (("Qdiag", nx), ("xd", nx), ("x_lb", nx), ("x_ub", nx), ("Rdiag", nu), ("u_lb", nu), ("u_ub", nu)):
+            a = np.asarray(getattr(self, name), dtype=np.float64)
+            if a.shape != (n,):
+                raise ValueError(f"{name} has shape {a.shape}, expected ({n},)")
+        if self.nf not in (1, 3):
+            raise ValueError("nf must be 1 (frictionless) or 3")
+        if np.any(np.asarray(self.Wee)[3:] != 0):
+            raise ValueError("end-effector orientation weights are not supported (all shipped configs use 0)")
+        if self.body_params.shape != (self.nb, 10):
+            raise ValueError("body_params must be (nb, 10)")
+        return self
+
+
+def contacts_from_fixture(arr):
+    """(names, params, contact arrays) from one entry of tests/golden/arrangements.json or from the
+    output of the arrangement parser: bodies sorted by name, contacts in list order (the contact order
+    fixes the layout of the force block of u, balancing_constraints.cpp:63,118)."""
+    bodies = sorted(arr["bodies"], key=lambda b: b["name"])
+    names = [b["name"] for b in bodies]
+    params = np.array([b["params"] for b in bodies], dtype=np.float64).reshape(len(names), 10)
+    idx = {n: i for i, n in enumerate(names)}
+    cs = arr["contacts"]
+    b1 = np.array([idx.get(c["object1_name"], -1) for c in cs], dtype=np.int32)
+    b2 = np.array([idx[c["object2_name"]] for c in cs], dtype=np.int32)
+    return dict(
+        body_names=names,
+        body_params=params,
+        contact_body1=b1,
+        contact_body2=b2,
+        contact_mu=np.array([c["mu"] for c in cs], dtype=np.float64),
+        contact_normal=np.array([c["normal"] for c in cs], dtype=np.float64).reshape(len(cs), 3),
+        contact_span=np.array([c["span"] for c in cs], dtype=np.float64).reshape(len(cs), 2, 3),
+        contact_r1=np.array([c["r_co_o1"] for c in cs], dtype=np.float64).reshape(len(cs), 3),
+        contact_r2=np.array([c["r_co_o2"] for c in cs], dtype=np.float64).reshape(len(cs), 3),
+    )
+
+
+# upright_cmd/config/robots/thing.yaml:48,61-86
+THING_HOME = np.array([-1.0, 1.0, 0.0, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, 0.417 * np.pi])
+
+
+def thing_problem(arrangement, nf=3, N=20, dt=0.1, force_weight=0.001, waypoint_offset=(-2.0, 1.0, 0.0), x0=None, **kw):
+    """Headline configuration H: Thing + arrangement, weights/limits of
+    `robots/thing.yaml:61-86`, `controller.yaml:54-79`, target = EE(x0) + offset
+    (`wrappers.py:31-43`, `ral23/experiments/_point1.yaml:3-8`)."""
+    chain = robots.thing()
+    c = contacts_from_fixture(arrangement)
+    nq = 9
+    nc = len(c["contact_mu"])
+    nu = nq + nf * nc
+    two_pi = 2 * np.pi
+    x_ub = np.array([10, 10, 10] + [two_pi] * 6 + [1.1, 1.1, 2, 2, 2, 3, 3, 3, 3] + [2.5, 2.5, 1, 10, 10, 10, 10, 10, 10], dtype=np.float64)
+    j_ub = np.array([20, 20, 20, 80, 80, 80, 80, 80, 80], dtype=np.float64)
+    # controller_interface.cpp:330-357: forces in [0, 100] (nf = 1) or [-100, 100] (nf = 3)
+    f_lb = np.full(nf * nc, 0.0 if nf == 1 else -1e2)
+    f_ub = np.full(nf * nc, 1e2)
+    if x0 is None:
+        x0 = np.concatenate([THING_HOME, np.zeros(18)])
+    p0, _ = chain.forward(x0[:nq])
+    P = Problem(
+        chain=chain,
+        nf=nf,
+        N=N,
+        dt=dt,
+        Qdiag=0.01 * np.concatenate([np.zeros(9), 10 * np.ones(9), np.ones(9)]),
+        Rdiag=np.concatenate([0.001 * np.ones(9), force_weight * np.ones(nf * nc)]),
+        xd=np.zeros(27),
+        x_lb=-x_ub,
+        x_ub=x_ub,
+        u_lb=np.concatenate([-j_ub, f_lb]),
+        u_ub=np.concatenate([j_ub, f_ub]),
+        way_t=np.zeros(1),
+        way_p=(p0 + np.asarray(waypoint_offset, dtype=np.float64)).reshape(1, 3),
+        **c,
+        **kw,
+    )
+    return P.validate()

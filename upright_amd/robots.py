@@ -1,0 +1,194 @@
+"""Explicit kinematic chains for the robots the reference's configs name.
+
+The reference builds its Pinocchio model at run time from a xacro-generated URDF
+(`upright_cmd/config/robots/thing.yaml:52-55`) whose main include,
+`mobile_manipulation_central/urdf/xacro/thing_no_wheels.urdf.xacro`, is NOT vendored under
+/root/reference.  What IS in the reference:
+
+  * the root joint: a planar composite PX, PY, RZ (`upright_control/include/upright_control/util.h:28-32`),
+    locked at `base_pose` for the fixed-base UR10 configs (`util.h:35-47`, `robots/ur10.yaml:50`);
+  * the tool link `gripped_object`, attached to link `gripper` by the calibrated transform
+    `gripped_object_transform` (`upright_assets/thing/xacro/end_effectors/gripped_object.urdf.xacro:6-10`,
+    values in `upright_cmd/config/robots/calibration/tray_transforms_real.yaml`);
+  * the calibration delta `base_to_arm_transform` (same YAML);
+  * joint names/order (`upright_cmd/config/robots/thing.yaml:24-33`) and the home configuration
+    (`thing.yaml:16`).
+
+Everything else below is OUR documented model, so forward-kinematics parity with the authors' URDF is
+UNPINNED (stated in DESIGN.md):
+
+  * the arm is a UR10 with the public ROS-Industrial `ur_description` kinematic parameters
+    (d1 .1273, a2 -.612, a3 -.5723, d4 .163941, d5 .1157, d6 .0922, shoulder/elbow offsets
+    .220941/-.1719) and that package's joint-origin convention;
+  * `gripper` = UR10 `tool0` rotated by +pi/12 about its z axis.  This is inferred, not read: with it
+    the tray normal at the reference's home configuration (wrist_3 = 0.417 pi = pi/2 - pi/12) is
+    vertical to within the calibration residual (z_tray . z_world = 0.9999), which is the
+    physical situation the home pose exists for;
+  * arm mount on the mobile base: nominal offset ARM_MOUNT_XYZ, then the calibration delta.
+
+A chain is a list of joints; joint i's frame = parent frame * (R_i, p_i) * motion(axis_i, q_i), and a
+final fixed tool transform (tool_R, tool_p).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+PRISMATIC = 0
+REVOLUTE = 1
+
+# UR10 (ur_description, ur10.urdf.xacro)
+_SH = 0.1273
+_UA = 0.612
+_FA = 0.5723
+_SO = 0.220941
+_EO = -0.1719
+_W1 = 0.163941 - _EO - _SO
+_W2 = 0.1157
+_W3 = 0.0922
+
+# nominal mount of the arm base on the mobile base (documented assumption, see module docstring)
+ARM_MOUNT_XYZ = np.array([0.27, 0.01, 0.653])
+ARM_MOUNT_RPY = np.array([0.0, 0.0, 0.0])
+GRIPPER_YAW = np.pi / 12
+
+# upright_cmd/config/robots/calibration/tray_transforms_real.yaml (== ..._2025-01-28_11-09-50.yaml)
+CALIBRATION_REAL = {
+    "base_to_arm_transform": {
+        "rpy": [-0.0032362802885472775, -0.0005883892881684005, 0.0055597638711333275],
+        "xyz": [0.00890486128628254, -0.009501900523900986, 0.001751916715875268],
+    },
+    "gripped_object_transform": {
+        "rpy": [-2.8848612308502197, -1.5584771633148193, -0.24215367436408997],
+        "xyz": [0.038776129484176636, 0.0020609176717698574, 0.3146381676197052],
+    },
+}
+
+
+def rpy_to_rot(rpy):
+    """URDF fixed-axis roll-pitch-yaw: R = Rz(y) Ry(p) Rx(r)."""
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+@dataclass
+class Joint:
+    kind: int
+    axis: np.ndarray
+    R: np.ndarray = field(default_factory=lambda: np.eye(3))
+    p: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    name: str = ""
+
+
+@dataclass
+class Chain:
+    joints: list
+    tool_R: np.ndarray
+    tool_p: np.ndarray
+    name: str = ""
+
+    @property
+    def nq(self):
+        return len(self.joints)
+
+    def forward(self, q):
+        """EE pose (p, C) -- plain numpy, used for target construction (wrappers.py:31-43)."""
+        R = np.eye(3)
+        o = np.zeros(3)
+        for j, qi in zip(self.joints, q):
+            o = o + R @ j.p
+            R = R @ j.R
+            if j.kind == REVOLUTE:
+                R = R @ _axis_rot(j.axis, qi)
+            else:
+                o = o + R @ j.axis * qi
+        o = o + R @ self.tool_p
+        R = R @ self.tool_R
+        return o, R
+
+
+def _axis_rot(ax, th):
+    ax = np.asarray(ax, dtype=float)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def _compose(Ra, pa, Rb, pb):
+    return Ra @ Rb, pa + Ra @ pb
+
+
+def _ur10_joints(R0, p0):
+    """Six revolute joints; (R0, p0) is the fixed transform in front of shoulder_pan."""
+    hp = np.pi / 2
+    specs = [
+        ("ur10_arm_shoulder_pan_joint", (0, 0, _SH), (0, 0, 0), (0, 0, 1)),
+        ("ur10_arm_shoulder_lift_joint", (0, _SO, 0), (0, hp, 0), (0, 1, 0)),
+        ("ur10_arm_elbow_joint", (0, _EO, _UA), (0, 0, 0), (0, 1, 0)),
+        ("ur10_arm_wrist_1_joint", (0, 0, _FA), (0, hp, 0), (0, 1, 0)),
+        ("ur10_arm_wrist_2_joint", (0, _W1, 0), (0, 0, 0), (0, 0, 1)),
+        ("ur10_arm_wrist_3_joint", (0, 0, _W2), (0, 0, 0), (0, 1, 0)),
+    ]
+    joints = []
+    for i, (name, xyz, rpy, axis) in enumerate(specs):
+        R, p = rpy_to_rot(rpy), np.array(xyz, dtype=float)
+        if i == 0:
+            R, p = _compose(R0, p0, R, p)
+        joints.append(Joint(REVOLUTE, np.array(axis, dtype=float), R, p, name))
+    return joints
+
+
+def _tool(calibration):
+    # wrist_3 -> tool0 (ur_description) -> gripper (yaw pi/12) -> gripped_object (calibrated)
+    R, p = rpy_to_rot((-np.pi / 2, 0, 0)), np.array([0, _W3, 0.0])
+    R, p = _compose(R, p, rpy_to_rot((0, 0, GRIPPER_YAW)), np.zeros(3))
+    g = calibration["gripped_object_transform"]
+    R, p = _compose(R, p, rpy_to_rot(g["rpy"]), np.array(g["xyz"], dtype=float))
+    return R, p
+
+
+def _arm_mount(calibration):
+    R, p = rpy_to_rot(ARM_MOUNT_RPY), ARM_MOUNT_XYZ.copy()
+    b = calibration["base_to_arm_transform"]
+    return _compose(R, p, rpy_to_rot(b["rpy"]), np.array(b["xyz"], dtype=float))
+
+
+def thing(calibration=None):
+    """Omnidirectional base (PX, PY, RZ) + UR10: nq = 9 (`robots/thing.yaml:43-47`)."""
+    calibration = calibration or CALIBRATION_REAL
+    base = [
+        Joint(PRISMATIC, np.array([1.0, 0, 0]), name="x_to_world_joint"),
+        Joint(PRISMATIC, np.array([0, 1.0, 0]), name="y_to_x_joint"),
+        Joint(REVOLUTE, np.array([0, 0, 1.0]), name="base_to_y_joint"),
+    ]
+    R0, p0 = _arm_mount(calibration)
+    tR, tp = _tool(calibration)
+    return Chain(base + _ur10_joints(R0, p0), tR, tp, "thing")
+
+
+def ur10(base_pose=(-1.0, 1.0, 0.0), calibration=None):
+    """Fixed base: root joint locked at base_pose = (x, y, yaw) (`util.h:35-47`): nq = 6."""
+    calibration = calibration or CALIBRATION_REAL
+    Rb = rpy_to_rot((0, 0, base_pose[2]))
+    pb = np.array([base_pose[0], base_pose[1], 0.0])
+    R0, p0 = _compose(Rb, pb, *_arm_mount(calibration))
+    tR, tp = _tool(calibration)
+    return Chain(_ur10_joints(R0, p0), tR, tp, "ur10")
+
+
+def from_config(robot_config):
+    """Pick the chain for a controller `robot` config dict (`wrappers.py:143-147,246-260`)."""
+    base_type = str(robot_config.get("base_type", "omnidirectional")).lower()
+    nq = int(robot_config["dims"]["q"])
+    if base_type == "fixed":
+        chain = ur10(tuple(robot_config.get("base_pose", (0.0, 0.0, 0.0))))
+    elif base_type == "omnidirectional":
+        chain = thing()
+    else:
+        # base_type.h:24: nonholonomic/floating are declared but never used by a shipped config
+        raise ValueError(f"unsupported base type: {base_type}")
+    if chain.nq != nq:
+        raise ValueError(f"robot dims.q = {nq} does not match the {chain.name} chain ({chain.nq} joints)")
+    return chain
