@@ -1,0 +1,177 @@
+/* upright_mi.h -- C-ABI of libupright_mi.so, the MI355X-native batched MPC engine.
+ *
+ * Drop-in boundary for the reference's hot path.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repository root).  Plain C types
+ * only: pointers, sizes, doubles.  All functions return 0 on success, non-zero on failure, and
+ * upr_last_error() returns the message (the Python shim raises it as RuntimeError, mirroring how
+ * the reference's std::runtime_error surfaces through pybind11).
+ *
+ * Device policy: every compute entry point runs hand-written HIP kernels on the current HIP device.
+ * There is NO CPU fallback: without a GPU the calls fail with an error.
+ */
+#ifndef UPRIGHT_MI_H
+#define UPRIGHT_MI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPR_MAX_JOINTS 12
+#define UPR_MAX_CONTACTS 32
+#define UPR_MAX_BODIES 8
+#define UPR_MAX_WAYPOINTS 8
+#define UPR_MAX_NX 36  /* 3 * UPR_MAX_JOINTS */
+#define UPR_MAX_NU 108 /* UPR_MAX_JOINTS + 3 * UPR_MAX_CONTACTS */
+
+/* Problem family shared by all instances of a batch: what ControllerInterface's constructor reads
+ * from ControllerSettings (upright_control/src/controller_interface.cpp:103-393;
+ * upright_control/include/upright_control/controller_settings.h:47-119). */
+typedef struct upr_problem {
+    /* dims: upright_control/include/upright_control/dimensions.h:18-46 */
+    int nq; /* robot joints (nq == nv); x = [q, v, a] */
+    int nb; /* balanced bodies */
+    int nc; /* contact points */
+    int nf; /* 3 = frictional contact forces, 1 = frictionless (normal force only) */
+    int N;  /* shooting intervals: time_horizon / dt (controller.yaml:13,55) */
+    double dt;
+
+    /* serial chain (replaces the Pinocchio model of upright_control/include/upright_control/util.h:15-65):
+     * joint frame i = parent * (R_i, p_i) * motion(axis_i, q_i); type 0 prismatic, 1 revolute */
+    int joint_type[UPR_MAX_JOINTS];
+    double joint_axis[UPR_MAX_JOINTS][3];
+    double joint_R[UPR_MAX_JOINTS][9];
+    double joint_p[UPR_MAX_JOINTS][3];
+    double tool_R[9];
+    double tool_p[3];
+
+    double gravity[3]; /* controller.yaml:6 */
+
+    /* contacts: upright_core/include/upright_core/contact.h:10-46; body index -1 = EE / fixture */
+    int contact_body1[UPR_MAX_CONTACTS];
+    int contact_body2[UPR_MAX_CONTACTS];
+    double contact_mu[UPR_MAX_CONTACTS];
+    double contact_normal[UPR_MAX_CONTACTS][3];
+    double contact_span[UPR_MAX_CONTACTS][6];
+    double contact_r1[UPR_MAX_CONTACTS][3];
+    double contact_r2[UPR_MAX_CONTACTS][3];
+
+    /* costs: controller_interface.cpp:400-420, cost/end_effector_cost.h:33-84 */
+    double Qdiag[UPR_MAX_NX];
+    double Rdiag[UPR_MAX_NU];
+    double xd[UPR_MAX_NX];
+    double Wee[6]; /* entries 3..5 (orientation) must be 0 */
+
+    /* bounds: controller_interface.cpp:157-169,330-357 */
+    double x_lb[UPR_MAX_NX], x_ub[UPR_MAX_NX];
+    double u_lb[UPR_MAX_NU], u_ub[UPR_MAX_NU];
+
+    /* target waypoint times (positions are per instance): reference_trajectory.h:18-47 */
+    int n_way;
+    double way_t[UPR_MAX_WAYPOINTS];
+
+    /* solver settings: upright_control/src/pybindings.cpp:183-213, controller.yaml:54-72 */
+    int sqp_iters;
+    int qp_iter_max;
+    double qp_tol;
+    double delta_tol;
+    double cost_tol;
+    int terminal_constraint; /* stationary_desired_position_constraint at knot N */
+} upr_problem;
+
+const char* upr_last_error(void);
+/* 1 if a HIP device is usable, else 0 (never initialises anything else) */
+int upr_device_available(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * upright_core.bindings twins (upright_core/src/pybindings.cpp:53-56).  Batched: n states at once.
+ * contact/body tables come from `P` (nq, chain and cost fields are ignored).
+ *   upr_core_object_dynamics  <-> compute_object_dynamics_constraints (contact_constraints.h:162-194)
+ *       forces[n][nf*nc], C[n][9] row-major world<-EE, w/al/a[n][3]  ->  out[n][6*nb] (UNnormalised)
+ *   upr_core_friction_rows    <-> compute_contact_force_constraints_linearized (contact_constraints.h:50-77)
+ *       forces[n][3*nc] -> out[n][5*nc]
+ * body_params[nb][10] = [m, m*c, vech(I)] (rigid_body.h:47-51). Host pointers. */
+int upr_core_object_dynamics(const upr_problem* P, const double* body_params, int n, const double* forces,
+                             const double* C, const double* w, const double* al, const double* a, double* out);
+int upr_core_friction_rows(const upr_problem* P, int n, const double* forces, double* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched MPC: B independent instances of the same problem family.  One instance with B = 1 is what
+ * `bindings.ControllerInterface` (upright_control/src/pybindings.cpp:364-427) wraps.
+ * Per-instance data: body_params[B][nb][10] (the upright_robust parameter axis,
+ * balancing_constraints.cpp:92-102), way_p[B][n_way][3] (targets, wrappers.py:31-43). */
+typedef struct upr_batch upr_batch;
+
+upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_params, const double* way_p);
+void upr_batch_destroy(upr_batch* h);
+
+/* ControllerInterface.reset / setTargetTrajectories (pybindings.cpp:371-374): new targets, forget
+ * the previous solution (next advance starts from the DefaultInitializer guess,
+ * controller_interface.cpp:385-386). way_p may be NULL to keep targets. */
+int upr_batch_reset(upr_batch* h, const double* way_p);
+
+/* ControllerInterface.setObservation (pybindings.cpp:369-370): t[B] (or t[1] broadcast if
+ * t_stride == 0), x[B][nx]. Host pointers. */
+int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x);
+
+/* Overwrite the initial guess (operating points, controller_interface.cpp:376-383): xs[B][N+1][nx],
+ * us[B][N][nu]. */
+int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us);
+
+/* ControllerInterface.advanceMpc (pybindings.cpp:375): one MPC solve = `sqp_iters` SQP iterations
+ * (linearise -> QP -> filter line search) for every instance, all on the GPU. */
+int upr_batch_advance(upr_batch* h);
+
+/* Same, but inputs stay in HBM and no host synchronisation is done (used by bench.py so that the
+ * timed region contains only device work); upr_batch_sync waits for completion. */
+int upr_batch_advance_async(upr_batch* h);
+int upr_batch_sync(upr_batch* h);
+
+/* ControllerInterface.getMpcSolution (pybindings.cpp:376-377): ts[B][N+1], xs[B][N+1][nx], us[B][N][nu] */
+int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us);
+
+/* ControllerInterface.evaluateMpcSolution (pybindings.cpp:378-381): interpolate the stored solution
+ * at time t[B] -> x_out[B][nx], u_out[B][nu] (feed-forward policy). */
+int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out);
+
+/* ControllerInterface.getLastSolveTime (pybindings.cpp:366), milliseconds of the last advance */
+double upr_batch_last_solve_ms(const upr_batch* h);
+
+/* per-instance statistics of the last advance: stats[B][UPR_NSTATS] =
+ * [sqp_iters_done, qp_iters_last, qp_status_last, step_alpha_last, cost, constraint_violation,
+ *  qp_res_stat, qp_res_eq, qp_res_ineq, qp_res_comp, dx_norm, du_norm] */
+#define UPR_NSTATS 12
+int upr_batch_get_stats(upr_batch* h, double* stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * Term-level access (ControllerInterface.getStateInputEqualityConstraintValue("object_dynamics"),
+ * getStateInputInequalityConstraintValue("contact_forces"), getCostValue, pybindings.cpp:414-424;
+ * BalancingConstraintWrapper.getLinearApproximation, balancing_constraint_wrapper.h:45-60).
+ * Evaluates the per-knot linearisation kernel on arbitrary (x, u) pairs of instance family `h`:
+ *   n points, inst[n] instance index of each point (body parameters / target), t[n], x[n][nx], u[n][nu]
+ *   g[n][ne], gx[n][ne][nx]             object_dynamics equality and d/dx   (ne = 6 nb)
+ *   cost[n], grad[n][nq], hess[n][nq][nq]  end-effector cost, gradient and Gauss-Newton Hessian
+ *   ee[n][3]                            end-effector position
+ * Any output pointer may be NULL. */
+int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x,
+                               const double* u, double* g, double* gx, double* cost, double* grad,
+                               double* hess, double* ee);
+/* constant d(object_dynamics)/du of instance `inst`: gu[ne][nu] */
+int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu);
+
+/* One QP (the SQP sub-problem at the current trajectory of every instance) without the line
+ * search: dxs[B][N+1][nx], dus[B][N][nu].  For QP-level parity tests. */
+int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus);
+
+/* raw device pointers for zero-copy consumers (torch / RCCL all-gather of solved trajectories):
+ * xs (B*(N+1)*nx doubles) and us (B*N*nu doubles) */
+int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us);
+
+/* average device time (ms) of each kernel over the last advance, measured with HIP events on the
+ * engine's stream: out[0] = linearise, out[1] = QP, out[2] = line search; launches[3] = #launches */
+int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches);
+int upr_batch_enable_timing(upr_batch* h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -619,6 +620,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
             }
         }
         sol.res[0] = r_stat; sol.res[1] = r_eq; sol.res[2] = r_ineq; sol.res[3] = mu;
+        if (getenv("ORC_DEBUG")) printf("orc it %d res %.3e %.3e %.3e %.3e\n", it, r_stat, r_eq, r_ineq, mu);
         if (it > 0 && r_stat < tol && r_eq < tol && r_ineq < tol && mu < tol) { sol.status = 0; break; }
         if (it == iter_max) break;
 

@@ -1,0 +1,78 @@
+// upr_emu.cpp -- TEST-ONLY host emulation of the HIP kernel bodies (one thread per workgroup).
+// Compiles upright_amd/csrc/*.h with -DUPR_HOST_EMU under g++ so that index arithmetic and the math
+// of the kernels can be checked against the oracle without a GPU.  It is never part of
+// libupright_mi.so and no product code path calls it.
+#define UPR_HOST_EMU
+#include <algorithm>
+#include <vector>
+
+#include "../../upright_amd/csrc/upr_common.h"
+#include "../../upright_amd/csrc/upr_kin.h"
+#include "../../upright_amd/csrc/upr_linearize.h"
+#include "../../upright_amd/csrc/upr_linesearch.h"
+#include "../../upright_amd/csrc/upr_qp.h"
+
+template <int NQ>
+static void lin_all(const upr_lin_args& A) {
+    std::vector<double> sh(upr_lin_lds_doubles(A.d) + 8);
+    for (int p = 0; p < A.npoints; ++p) {
+        upr_lin_point q = upr_lin_locate(A, p);
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0(A, q, l, sh.data());
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0b(A, q, l, sh.data());
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ>(A, q, l, sh.data());
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase2<NQ>(A, q, l, sh.data());
+    }
+}
+
+extern "C" {
+
+void emu_dims(const upr_problem* P, int* out) {
+    upr_dims d = upr_make_dims(P);
+    out[0] = d.nx; out[1] = d.nu; out[2] = d.ne; out[3] = d.np; out[4] = d.lin_stride; out[5] = d.ws_stride;
+    out[6] = d.ws_dx; out[7] = d.ws_du; out[8] = d.lin_g; out[9] = d.lin_gx; out[10] = d.lin_cost; out[11] = d.lin_grad; out[12] = d.lin_hess;
+    out[13] = d.nfc;
+}
+
+void emu_make_Df(const upr_problem* P, int B, const double* body_params, double* Df) {
+    upr_dims d = upr_make_dims(P);
+    std::vector<double> unit(d.nfc), Fw(6 * d.nb);
+    const double scale = 1.0 / std::sqrt(6.0 * d.nb);
+    for (int b = 0; b < B; ++b) {
+        const double* bp = body_params + (size_t)b * d.nb * 10;
+        for (int j = 0; j < d.nfc; ++j) {
+            std::fill(unit.begin(), unit.end(), 0.0); unit[j] = 1.0;
+            upr_object_wrenches(P, bp, unit.data(), Fw.data());
+            for (int bb = 0; bb < d.nb; ++bb) for (int r = 0; r < 6; ++r)
+                Df[((size_t)b * d.ne + 6 * bb + r) * d.nfc + j] = -scale * Fw[6 * bb + r] / bp[10 * bb];
+        }
+    }
+}
+
+void emu_linearize(const upr_problem* P, int B, const double* body_params, const double* way_p, const double* t0,
+                   const double* xs, const double* us, double* lin) {
+    upr_lin_args A;
+    A.P = P; A.d = upr_make_dims(P); A.body_params = body_params; A.way_p = way_p; A.t0 = t0; A.xs = xs; A.us = us;
+    A.inst = nullptr; A.lin = lin; A.ee_out = nullptr; A.npoints = B * (P->N + 1);
+    if (P->nq == 6) lin_all<6>(A); else lin_all<9>(A);
+}
+
+void emu_qp(const upr_problem* P, int B, const double* xs, const double* us, const double* x0, const double* lin,
+            const double* Df, double* ws, double* stats) {
+    upr_qp_args A;
+    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats;
+    upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
+    std::vector<double> L(upr_qp_lds_layout(A.d, 1).total + 16);
+    for (int b = 0; b < B; ++b) upr_qp_solve(ctx, A, b, L.data());
+}
+
+void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const double* x0, const double* t0,
+                    const double* body_params, const double* way_p, const double* lin, const double* ws, double* stats,
+                    int* done, int iter) {
+    upr_ls_args A;
+    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
+    A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter;
+    upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
+    std::vector<double> L(64);
+    for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data()); else upr_ls_instance<9>(ctx, A, b, L.data()); }
+}
+}

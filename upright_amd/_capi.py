@@ -1,0 +1,141 @@
+"""ctypes view of the C-ABI in include/upright_mi.h (libupright_mi.so).
+
+This is the binding a maintainer of the reference would use in place of the pybind11 module
+`upright_control.bindings` / `upright_core.bindings`.  The library is compiled from
+upright_amd/csrc/*.hip by `__graft_entry__.build()`; if it is missing, importing the product fails
+loudly -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libupright_mi.so"
+
+MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU = 12, 32, 8, 8, 36, 108
+NSTATS = 12
+STAT_NAMES = (
+    "sqp_iters_done", "qp_iters_last", "qp_status_last", "step_alpha_last", "cost", "constraint_violation",
+    "qp_res_stat", "qp_res_eq", "qp_res_ineq", "qp_res_comp", "dx_norm", "du_norm",
+)
+d = C.c_double
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class UprProblem(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int), ("nb", C.c_int), ("nc", C.c_int), ("nf", C.c_int), ("N", C.c_int), ("dt", d),
+        ("joint_type", C.c_int * MAXJ), ("joint_axis", d * 3 * MAXJ), ("joint_R", d * 9 * MAXJ), ("joint_p", d * 3 * MAXJ),
+        ("tool_R", d * 9), ("tool_p", d * 3), ("gravity", d * 3),
+        ("contact_body1", C.c_int * MAXC), ("contact_body2", C.c_int * MAXC), ("contact_mu", d * MAXC),
+        ("contact_normal", d * 3 * MAXC), ("contact_span", d * 6 * MAXC), ("contact_r1", d * 3 * MAXC), ("contact_r2", d * 3 * MAXC),
+        ("Qdiag", d * MAXNX), ("Rdiag", d * MAXNU), ("xd", d * MAXNX), ("Wee", d * 6),
+        ("x_lb", d * MAXNX), ("x_ub", d * MAXNX), ("u_lb", d * MAXNU), ("u_ub", d * MAXNU),
+        ("n_way", C.c_int), ("way_t", d * MAXW),
+        ("sqp_iters", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", d), ("delta_tol", d), ("cost_tol", d),
+        ("terminal_constraint", C.c_int),
+    ]
+
+
+def _fill(arr, values):
+    flat = np.asarray(values, dtype=np.float64).ravel()
+    np.ctypeslib.as_array(arr).reshape(-1)[: flat.size] = flat
+
+
+def problem_to_c(P):
+    """upright_amd.problem.Problem -> UprProblem (shared part; body parameters and waypoint positions
+    are per instance and passed separately)."""
+    P.validate()
+    if P.nq > MAXJ or P.nc > MAXC or P.nb > MAXB or len(P.way_t) > MAXW:
+        raise ValueError("problem exceeds the compiled-in maxima of libupright_mi")
+    o = UprProblem()
+    o.nq, o.nb, o.nc, o.nf, o.N, o.dt = P.nq, P.nb, P.nc, P.nf, P.N, P.dt
+    for i, j in enumerate(P.chain.joints):
+        o.joint_type[i] = j.kind
+        _fill(o.joint_axis[i], j.axis)
+        _fill(o.joint_R[i], j.R)
+        _fill(o.joint_p[i], j.p)
+    _fill(o.tool_R, P.chain.tool_R)
+    _fill(o.tool_p, P.chain.tool_p)
+    _fill(o.gravity, P.gravity)
+    for i in range(P.nc):
+        o.contact_body1[i] = int(P.contact_body1[i])
+        o.contact_body2[i] = int(P.contact_body2[i])
+        o.contact_mu[i] = float(P.contact_mu[i])
+        _fill(o.contact_normal[i], P.contact_normal[i])
+        _fill(o.contact_span[i], P.contact_span[i])
+        _fill(o.contact_r1[i], P.contact_r1[i])
+        _fill(o.contact_r2[i], P.contact_r2[i])
+    _fill(o.Qdiag, P.Qdiag); _fill(o.Rdiag, P.Rdiag); _fill(o.xd, P.xd); _fill(o.Wee, P.Wee)
+    _fill(o.x_lb, P.x_lb); _fill(o.x_ub, P.x_ub); _fill(o.u_lb, P.u_lb); _fill(o.u_ub, P.u_ub)
+    o.n_way = len(P.way_t)
+    _fill(o.way_t, P.way_t)
+    o.sqp_iters, o.qp_iter_max, o.qp_tol = int(P.sqp_iters), int(P.qp_iter_max), float(P.qp_tol)
+    o.delta_tol, o.cost_tol, o.terminal_constraint = float(P.delta_tol), float(P.cost_tol), int(bool(P.terminal_constraint))
+    return o
+
+
+# every symbol include/upright_mi.h declares: (name, restype, argtypes)
+PROTOTYPES = [
+    ("upr_last_error", C.c_char_p, []),
+    ("upr_device_available", C.c_int, []),
+    ("upr_core_object_dynamics", C.c_int, [C.POINTER(UprProblem), dp, C.c_int, dp, dp, dp, dp, dp, dp]),
+    ("upr_core_friction_rows", C.c_int, [C.POINTER(UprProblem), C.c_int, dp, dp]),
+    ("upr_batch_create", C.c_void_p, [C.POINTER(UprProblem), C.c_int, dp, dp]),
+    ("upr_batch_destroy", None, [C.c_void_p]),
+    ("upr_batch_reset", C.c_int, [C.c_void_p, dp]),
+    ("upr_batch_set_observation", C.c_int, [C.c_void_p, dp, C.c_int, dp]),
+    ("upr_batch_set_guess", C.c_int, [C.c_void_p, dp, dp]),
+    ("upr_batch_advance", C.c_int, [C.c_void_p]),
+    ("upr_batch_advance_async", C.c_int, [C.c_void_p]),
+    ("upr_batch_sync", C.c_int, [C.c_void_p]),
+    ("upr_batch_get_solution", C.c_int, [C.c_void_p, dp, dp, dp]),
+    ("upr_batch_evaluate", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp]),
+    ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
+    ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),
+    ("upr_batch_linearize_points", C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    ("upr_batch_eq_input_jacobian", C.c_int, [C.c_void_p, C.c_int, dp]),
+    ("upr_batch_qp_step", C.c_int, [C.c_void_p, dp, dp]),
+    ("upr_batch_device_ptrs", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("upr_batch_kernel_times", C.c_int, [C.c_void_p, dp, ip]),
+    ("upr_batch_enable_timing", C.c_int, [C.c_void_p, C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libupright_mi.so; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). upright_amd has no CPU fallback."
+            )
+        L = C.CDLL(str(LIB_PATH))
+        for name, res, args in PROTOTYPES:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().upr_last_error().decode() or "libupright_mi call failed")
+
+
+def ptr(a):
+    return a.ctypes.data_as(dp) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(ip) if a is not None else None
+
+
+def cont(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)

@@ -1,0 +1,529 @@
+// upr_api.hip -- C-ABI of libupright_mi.so (include/upright_mi.h): host orchestration of the HIP kernels.
+// No CPU compute path: every entry point that computes launches kernels on the current HIP device.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "upr_common.h"
+#include "upr_kin.h"
+#include "upr_linearize.h"
+#include "upr_linesearch.h"
+#include "upr_qp.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define UPR_HIP(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T>
+int dev_alloc(T** p, size_t n) {
+    UPR_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    UPR_HIP(hipMemset(*p, 0, n * sizeof(T)));
+    return 0;
+}
+
+// ---- small kernels -----------------------------------------------------------------------------------
+__global__ void core_object_dynamics_kernel(const upr_problem* P, const double* body_params, int n, const double* forces,
+                                            const double* C, const double* w, const double* al, const double* a, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nb = P->nb, nfc = P->nf * P->nc;
+    upr_ee<double> E;
+    for (int r = 0; r < 9; ++r) E.C[r] = C[(size_t)i * 9 + r];
+    for (int r = 0; r < 3; ++r) { E.w[r] = w[(size_t)i * 3 + r]; E.al[r] = al[(size_t)i * 3 + r]; E.a[r] = a[(size_t)i * 3 + r]; E.p[r] = 0; E.v[r] = 0; }
+    double Fw[6 * UPR_MAX_BODIES];
+    upr_object_wrenches(P, body_params, forces + (size_t)i * nfc, Fw);
+    for (int b = 0; b < nb; ++b)
+        upr_body_residual<double>(E, body_params + 10 * b, P->gravity, Fw + 6 * b, Fw + 6 * b + 3, out + (size_t)i * 6 * nb + 6 * b);
+}
+
+__global__ void core_friction_rows_kernel(const upr_problem* P, int n, const double* forces, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * P->nc) return;
+    int s = i / P->nc, c = i % P->nc;
+    upr_friction_rows_contact(P, c, forces + ((size_t)s * P->nc + c) * 3, out + ((size_t)s * P->nc + c) * 5);
+}
+
+// initial guess of every instance: previous solution re-sampled on the new grid (warm start), or the
+// stationary guess x_k = x0, u = 0 (DefaultInitializer); the first node is always the observation.
+__global__ void prepare_kernel(const upr_problem* P, upr_dims d, int B, const int* has_prev, const double* tprev,
+                               const double* xs_prev, const double* us_prev, const double* t0, const double* x0,
+                               double* xs, double* us, double* stats, int* done) {
+    int b = blockIdx.x;
+    const int N = d.N, nx = d.nx, nu = d.nu;
+    const double* xp = xs_prev + (size_t)b * (N + 1) * nx;
+    const double* up = us_prev + (size_t)b * N * nu;
+    double* xo = xs + (size_t)b * (N + 1) * nx;
+    double* uo = us + (size_t)b * N * nu;
+    const bool warm = has_prev[b] != 0;
+    for (int e = threadIdx.x; e < (N + 1) * nx; e += blockDim.x) {
+        int k = e / nx, i = e % nx;
+        double v;
+        if (k == 0 || !warm) v = x0[(size_t)b * nx + i];
+        else upr_interp(d, P->dt, tprev[b], xp, up, t0[b] + k * P->dt, i, 0, &v, nullptr);
+        xo[e] = v;
+    }
+    for (int e = threadIdx.x; e < N * nu; e += blockDim.x) {
+        int k = e / nu, i = e % nu;
+        double v = 0.0;
+        if (warm) upr_interp(d, P->dt, tprev[b], xp, up, t0[b] + k * P->dt, 0, i, nullptr, &v);
+        uo[e] = v;
+    }
+    for (int e = threadIdx.x; e < UPR_NSTATS; e += blockDim.x) stats[(size_t)b * UPR_NSTATS + e] = 0.0;
+    if (threadIdx.x == 0) done[b] = 0;
+}
+
+__global__ void evaluate_kernel(const upr_problem* P, upr_dims d, int B, const double* tsol, const double* xs,
+                                const double* us, const double* t, int t_stride, double* x_out, double* u_out) {
+    int b = blockIdx.x;
+    const int N = d.N, nx = d.nx, nu = d.nu;
+    const double tau = t[(size_t)b * t_stride];
+    for (int i = threadIdx.x; i < nx; i += blockDim.x)
+        upr_interp(d, P->dt, tsol[b], xs + (size_t)b * (N + 1) * nx, us + (size_t)b * N * nu, tau, i, 0, x_out + (size_t)b * nx + i, nullptr);
+    for (int i = threadIdx.x; i < nu; i += blockDim.x)
+        upr_interp(d, P->dt, tsol[b], xs + (size_t)b * (N + 1) * nx, us + (size_t)b * N * nu, tau, 0, i, nullptr, u_out + (size_t)b * nu + i);
+}
+
+}  // namespace
+
+// ========================================================================================================
+struct upr_batch {
+    upr_problem P;
+    upr_dims d;
+    int B = 0;
+    hipStream_t stream = nullptr;
+    upr_problem* dP = nullptr;
+    double *body_params = nullptr, *way_p = nullptr, *t0 = nullptr, *x0 = nullptr;
+    double *xs = nullptr, *us = nullptr, *xs_prev = nullptr, *us_prev = nullptr, *tprev = nullptr;
+    double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
+    int *done = nullptr, *has_prev = nullptr;
+    bool guess_set = false;
+    double last_ms = 0.0;
+    int qp_nt = 64;
+    bool use_mfma = true;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double k_ms[3] = {0, 0, 0};
+    int k_launches[3] = {0, 0, 0};
+    std::vector<double> hDf;
+};
+
+namespace {
+
+int check_problem(const upr_problem* P) {
+    if (!P) return fail("upr_problem is NULL");
+    if (P->nq != 6 && P->nq != 9) return fail("unsupported chain length nq = " + std::to_string(P->nq) + " (kernels are instantiated for 6 and 9 joints)");
+    if (P->nb < 1 || P->nb > UPR_MAX_BODIES) return fail("nb out of range");
+    if (P->nc < 1 || P->nc > UPR_MAX_CONTACTS) return fail("nc out of range");
+    if (P->nf != 1 && P->nf != 3) return fail("nf must be 1 or 3");
+    if (P->N < 1 || P->N > 1000) return fail("N out of range");
+    if (!(P->dt > 0)) return fail("dt must be positive");
+    if (P->n_way < 1 || P->n_way > UPR_MAX_WAYPOINTS) return fail("n_way out of range");
+    if (P->Wee[3] != 0 || P->Wee[4] != 0 || P->Wee[5] != 0) return fail("end-effector orientation weights are not supported");
+    for (int i = 0; i < P->nc; ++i) {
+        if (P->contact_body2[i] < 0 || P->contact_body2[i] >= P->nb) return fail("contact_body2 must index a balanced body");
+        if (P->contact_body1[i] >= P->nb) return fail("contact_body1 out of range");
+    }
+    return 0;
+}
+
+int need_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) return fail("no HIP device available: libupright_mi has no CPU path");
+    return 0;
+}
+
+template <int NQ>
+int launch_linearize(upr_batch* h, const upr_lin_args& A) {
+    const int blocks = (A.npoints + 7) / 8;
+    const size_t lds = (size_t)8 * upr_lin_lds_doubles(A.d) * sizeof(double);
+    if (h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true>), dim3(blocks), dim3(256), lds, h->stream, A);
+    else hipLaunchKernelGGL((upr_linearize_kernel<NQ, false>), dim3(blocks), dim3(256), lds, h->stream, A);
+    UPR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qp(upr_batch* h, const upr_qp_args& A) {
+    const upr_qp_lds lay = upr_qp_lds_layout(A.d, h->qp_nt);
+    const size_t lds = (size_t)lay.total * sizeof(double);
+    if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
+    switch (h->qp_nt) {
+        case 64:
+            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(upr_qp_kernel<64>, dim3(h->B), dim3(64), lds, h->stream, A);
+            break;
+        case 128:
+            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(upr_qp_kernel<128>, dim3(h->B), dim3(128), lds, h->stream, A);
+            break;
+        case 256:
+            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(upr_qp_kernel<256>, dim3(h->B), dim3(256), lds, h->stream, A);
+            break;
+        default:
+            return fail("UPR_QP_NT must be 64, 128 or 256");
+    }
+    UPR_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int NQ>
+int launch_linesearch(upr_batch* h, const upr_ls_args& A) {
+    const size_t lds = (size_t)(4 * 64 + 8) * sizeof(double);
+    hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64>), dim3(h->B), dim3(64), lds, h->stream, A);
+    UPR_HIP(hipGetLastError());
+    return 0;
+}
+
+upr_lin_args traj_lin_args(upr_batch* h) {
+    upr_lin_args A;
+    A.P = h->dP; A.d = h->d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = h->t0;
+    A.xs = h->xs; A.us = h->us; A.inst = nullptr; A.lin = h->lin; A.ee_out = nullptr;
+    A.npoints = h->B * (h->d.N + 1);
+    return A;
+}
+upr_qp_args make_qp_args(upr_batch* h) {
+    upr_qp_args A;
+    A.P = h->dP; A.d = h->d; A.xs = h->xs; A.us = h->us; A.x0 = h->x0; A.lin = h->lin; A.Df = h->Df; A.ws = h->ws; A.stats = h->stats;
+    return A;
+}
+
+int do_linearize(upr_batch* h, const upr_lin_args& A) {
+    return (h->P.nq == 6) ? launch_linearize<6>(h, A) : launch_linearize<9>(h, A);
+}
+
+struct KernelTimer {
+    upr_batch* h; int slot;
+    KernelTimer(upr_batch* h_, int s) : h(h_), slot(s) { if (h->timing) hipEventRecord(h->ev[0], h->stream); }
+    void stop() {
+        if (!h->timing) return;
+        hipEventRecord(h->ev[1], h->stream);
+        hipEventSynchronize(h->ev[1]);
+        float ms = 0; hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+        h->k_ms[slot] += ms; h->k_launches[slot] += 1;
+    }
+};
+
+int advance_impl(upr_batch* h) {
+    const upr_dims& d = h->d;
+    if (!h->guess_set) {
+        hipLaunchKernelGGL(prepare_kernel, dim3(h->B), dim3(256), 0, h->stream, h->dP, d, h->B, h->has_prev, h->tprev,
+                           h->xs_prev, h->us_prev, h->t0, h->x0, h->xs, h->us, h->stats, h->done);
+        UPR_HIP(hipGetLastError());
+    } else {
+        UPR_HIP(hipMemsetAsync(h->stats, 0, sizeof(double) * h->B * UPR_NSTATS, h->stream));
+        UPR_HIP(hipMemsetAsync(h->done, 0, sizeof(int) * h->B, h->stream));
+        h->guess_set = false;
+    }
+    for (int it = 0; it < h->P.sqp_iters; ++it) {
+        { KernelTimer T(h, 0); if (do_linearize(h, traj_lin_args(h))) return 1; T.stop(); }
+        { KernelTimer T(h, 1); if (launch_qp(h, make_qp_args(h))) return 1; T.stop(); }
+        upr_ls_args L;
+        L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
+        L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it;
+        { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
+    }
+    // remember the solution for the next warm start / policy evaluation
+    UPR_HIP(hipMemcpyAsync(h->xs_prev, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->us_prev, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->tprev, h->t0, sizeof(double) * h->B, hipMemcpyDeviceToDevice, h->stream));
+    UPR_HIP(hipMemsetAsync(h->has_prev, 1, sizeof(int) * h->B, h->stream));  // any non-zero pattern
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* upr_last_error(void) { return g_err.c_str(); }
+
+int upr_device_available(void) {
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
+}
+
+int upr_core_object_dynamics(const upr_problem* P, const double* body_params, int n, const double* forces, const double* C,
+                             const double* w, const double* al, const double* a, double* out) {
+    if (need_device()) return 1;
+    if (!P || P->nb < 1 || P->nb > UPR_MAX_BODIES || P->nc < 0 || P->nc > UPR_MAX_CONTACTS) return fail("bad problem dims");
+    if (n <= 0) return 0;
+    const int nfc = P->nf * P->nc, nb = P->nb;
+    upr_problem* dP = nullptr; double *dbp, *df, *dC, *dw, *dal, *da, *dout;
+    UPR_HIP(hipMalloc((void**)&dP, sizeof(upr_problem)));
+    UPR_HIP(hipMemcpy(dP, P, sizeof(upr_problem), hipMemcpyHostToDevice));
+    if (dev_alloc(&dbp, (size_t)nb * 10) || dev_alloc(&df, (size_t)n * nfc + 1) || dev_alloc(&dC, (size_t)n * 9) || dev_alloc(&dw, (size_t)n * 3) ||
+        dev_alloc(&dal, (size_t)n * 3) || dev_alloc(&da, (size_t)n * 3) || dev_alloc(&dout, (size_t)n * 6 * nb)) return 1;
+    UPR_HIP(hipMemcpy(dbp, body_params, sizeof(double) * nb * 10, hipMemcpyHostToDevice));
+    if (nfc) UPR_HIP(hipMemcpy(df, forces, sizeof(double) * n * nfc, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dC, C, sizeof(double) * n * 9, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dw, w, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dal, al, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(da, a, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(core_object_dynamics_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, dP, dbp, n, df, dC, dw, dal, da, dout);
+    UPR_HIP(hipGetLastError());
+    UPR_HIP(hipMemcpy(out, dout, sizeof(double) * n * 6 * nb, hipMemcpyDeviceToHost));
+    hipFree(dP); hipFree(dbp); hipFree(df); hipFree(dC); hipFree(dw); hipFree(dal); hipFree(da); hipFree(dout);
+    return 0;
+}
+
+int upr_core_friction_rows(const upr_problem* P, int n, const double* forces, double* out) {
+    if (need_device()) return 1;
+    if (!P || P->nc < 1 || P->nc > UPR_MAX_CONTACTS) return fail("bad problem dims");
+    if (n <= 0) return 0;
+    upr_problem* dP = nullptr; double *df, *dout;
+    UPR_HIP(hipMalloc((void**)&dP, sizeof(upr_problem)));
+    UPR_HIP(hipMemcpy(dP, P, sizeof(upr_problem), hipMemcpyHostToDevice));
+    if (dev_alloc(&df, (size_t)n * 3 * P->nc) || dev_alloc(&dout, (size_t)n * 5 * P->nc)) return 1;
+    UPR_HIP(hipMemcpy(df, forces, sizeof(double) * n * 3 * P->nc, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(core_friction_rows_kernel, dim3((n * P->nc + 63) / 64), dim3(64), 0, 0, dP, n, df, dout);
+    UPR_HIP(hipGetLastError());
+    UPR_HIP(hipMemcpy(out, dout, sizeof(double) * n * 5 * P->nc, hipMemcpyDeviceToHost));
+    hipFree(dP); hipFree(df); hipFree(dout);
+    return 0;
+}
+
+upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_params, const double* way_p) {
+    if (check_problem(P)) return nullptr;
+    if (B < 1) { fail("B must be >= 1"); return nullptr; }
+    if (need_device()) return nullptr;
+    upr_batch* h = new upr_batch();
+    h->P = *P; h->d = upr_make_dims(P); h->B = B;
+    const upr_dims& d = h->d;
+    if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
+    if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
+    if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
+    auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };
+    if (hipStreamCreate(&h->stream) != hipSuccess) { fail("hipStreamCreate failed"); return bad(); }
+    for (int i = 0; i < 2; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { fail("hipEventCreate failed"); return bad(); }
+    if (hipMalloc((void**)&h->dP, sizeof(upr_problem)) != hipSuccess) { fail("hipMalloc failed"); return bad(); }
+    hipMemcpy(h->dP, P, sizeof(upr_problem), hipMemcpyHostToDevice);
+    const size_t n1 = d.N + 1;
+    if (dev_alloc(&h->body_params, (size_t)B * d.nb * 10) || dev_alloc(&h->way_p, (size_t)B * P->n_way * 3) || dev_alloc(&h->t0, B) ||
+        dev_alloc(&h->x0, (size_t)B * d.nx) || dev_alloc(&h->xs, (size_t)B * n1 * d.nx) || dev_alloc(&h->us, (size_t)B * d.N * d.nu) ||
+        dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
+        dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
+        dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) ||
+        dev_alloc(&h->has_prev, B))
+        return bad();
+    hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
+    hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
+    // constant d(object_dynamics)/d(forces): unit forces through the wrench map (contact_constraints.h:107-157),
+    // divided by the body mass and sqrt(6 nb) (balancing_constraints.cpp:144-151), sign of (GIF - F)
+    h->hDf.assign((size_t)B * d.ne * d.nfc, 0.0);
+    std::vector<double> unit(d.nfc), Fw(6 * d.nb);
+    const double scale = 1.0 / std::sqrt(6.0 * d.nb);
+    for (int b = 0; b < B; ++b) {
+        const double* bp = body_params + (size_t)b * d.nb * 10;
+        for (int j = 0; j < d.nfc; ++j) {
+            std::fill(unit.begin(), unit.end(), 0.0);
+            unit[j] = 1.0;
+            upr_object_wrenches(P, bp, unit.data(), Fw.data());
+            for (int bb = 0; bb < d.nb; ++bb)
+                for (int r = 0; r < 6; ++r) h->hDf[((size_t)b * d.ne + 6 * bb + r) * d.nfc + j] = -scale * Fw[6 * bb + r] / bp[10 * bb];
+        }
+    }
+    hipMemcpy(h->Df, h->hDf.data(), sizeof(double) * h->hDf.size(), hipMemcpyHostToDevice);
+    if (hipDeviceSynchronize() != hipSuccess) { fail("device synchronisation failed in create"); return bad(); }
+    return h;
+}
+
+void upr_batch_destroy(upr_batch* h) {
+    if (!h) return;
+    hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
+    hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
+    hipFree(h->done); hipFree(h->has_prev);
+    for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int upr_batch_reset(upr_batch* h, const double* way_p) {
+    if (!h) return fail("null batch");
+    if (way_p) UPR_HIP(hipMemcpyAsync(h->way_p, way_p, sizeof(double) * h->B * h->P.n_way * 3, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipMemsetAsync(h->has_prev, 0, sizeof(int) * h->B, h->stream));
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    h->guess_set = false;
+    return 0;
+}
+
+int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x) {
+    if (!h) return fail("null batch");
+    std::vector<double> tt(h->B);
+    for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
+    UPR_HIP(hipMemcpyAsync(h->t0, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->x0, x, sizeof(double) * h->B * h->d.nx, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    UPR_HIP(hipMemcpyAsync(h->xs, xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->us, us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    h->guess_set = true;
+    return 0;
+}
+
+int upr_batch_advance_async(upr_batch* h) {
+    if (!h) return fail("null batch");
+    return advance_impl(h);
+}
+
+int upr_batch_sync(upr_batch* h) {
+    if (!h) return fail("null batch");
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int upr_batch_advance(upr_batch* h) {
+    if (!h) return fail("null batch");
+    auto t0 = std::chrono::steady_clock::now();
+    if (advance_impl(h)) return 1;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    if (ts) {
+        std::vector<double> t0(h->B);
+        UPR_HIP(hipMemcpy(t0.data(), h->t0, sizeof(double) * h->B, hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->B; ++b) for (int k = 0; k <= d.N; ++k) ts[(size_t)b * (d.N + 1) + k] = t0[b] + k * h->P.dt;
+    }
+    if (xs) UPR_HIP(hipMemcpy(xs, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToHost));
+    if (us) UPR_HIP(hipMemcpy(us, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    double *dt_ = nullptr, *dx = nullptr, *du = nullptr;
+    if (dev_alloc(&dt_, h->B) || dev_alloc(&dx, (size_t)h->B * d.nx) || dev_alloc(&du, (size_t)h->B * d.nu)) return 1;
+    std::vector<double> tt(h->B);
+    for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
+    UPR_HIP(hipMemcpy(dt_, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, dt_, 1, dx, du);
+    UPR_HIP(hipGetLastError());
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    UPR_HIP(hipMemcpy(x_out, dx, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost));
+    UPR_HIP(hipMemcpy(u_out, du, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost));
+    hipFree(dt_); hipFree(dx); hipFree(du);
+    return 0;
+}
+
+double upr_batch_last_solve_ms(const upr_batch* h) { return h ? h->last_ms : 0.0; }
+
+int upr_batch_get_stats(upr_batch* h, double* stats) {
+    if (!h) return fail("null batch");
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    UPR_HIP(hipMemcpy(stats, h->stats, sizeof(double) * h->B * UPR_NSTATS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
+                               double* g, double* gx, double* cost, double* grad, double* hess, double* ee) {
+    if (!h) return fail("null batch");
+    if (n <= 0) return 0;
+    const upr_dims& d = h->d;
+    for (int i = 0; i < n; ++i) if (inst[i] < 0 || inst[i] >= h->B) return fail("instance index out of range");
+    int* dinst = nullptr; double *dt_, *dx, *du, *dlin, *dee;
+    if (dev_alloc(&dinst, n) || dev_alloc(&dt_, n) || dev_alloc(&dx, (size_t)n * d.nx) || dev_alloc(&du, (size_t)n * d.nu) ||
+        dev_alloc(&dlin, (size_t)n * d.lin_stride) || dev_alloc(&dee, (size_t)n * 3)) return 1;
+    UPR_HIP(hipMemcpy(dinst, inst, sizeof(int) * n, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dt_, t, sizeof(double) * n, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dx, x, sizeof(double) * n * d.nx, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(du, u, sizeof(double) * n * d.nu, hipMemcpyHostToDevice));
+    upr_lin_args A;
+    A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
+    A.lin = dlin; A.ee_out = dee; A.npoints = n;
+    if (do_linearize(h, A)) return 1;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> rec((size_t)n * d.lin_stride);
+    UPR_HIP(hipMemcpy(rec.data(), dlin, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+    if (ee) UPR_HIP(hipMemcpy(ee, dee, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        const double* r = rec.data() + (size_t)i * d.lin_stride;
+        if (g) std::memcpy(g + (size_t)i * d.ne, r + d.lin_g, sizeof(double) * d.ne);
+        if (gx) std::memcpy(gx + (size_t)i * d.ne * d.nx, r + d.lin_gx, sizeof(double) * d.ne * d.nx);
+        if (cost) cost[i] = r[d.lin_cost];
+        if (grad) std::memcpy(grad + (size_t)i * d.nq, r + d.lin_grad, sizeof(double) * d.nq);
+        if (hess) for (int a = 0; a < d.nq; ++a) for (int c = 0; c < d.nq; ++c) hess[((size_t)i * d.nq + a) * d.nq + c] = r[d.lin_hess + upr_tri(d.nq, a, c)];
+    }
+    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee);
+    return 0;
+}
+
+int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu) {
+    if (!h) return fail("null batch");
+    if (inst < 0 || inst >= h->B) return fail("instance index out of range");
+    const upr_dims& d = h->d;
+    for (int r = 0; r < d.ne; ++r) {
+        for (int j = 0; j < d.nq; ++j) gu[(size_t)r * d.nu + j] = 0.0;
+        for (int j = 0; j < d.nfc; ++j) gu[(size_t)r * d.nu + d.nq + j] = h->hDf[((size_t)inst * d.ne + r) * d.nfc + j];
+    }
+    return 0;
+}
+
+int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    if (do_linearize(h, traj_lin_args(h))) return 1;
+    if (launch_qp(h, make_qp_args(h))) return 1;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> ws((size_t)h->B * d.ws_stride);
+    UPR_HIP(hipMemcpy(ws.data(), h->ws, sizeof(double) * ws.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; ++b) {
+        const double* w = ws.data() + (size_t)b * d.ws_stride;
+        if (dxs) std::memcpy(dxs + (size_t)b * (d.N + 1) * d.nx, w + d.ws_dx, sizeof(double) * (d.N + 1) * d.nx);
+        if (dus) std::memcpy(dus + (size_t)b * d.N * d.nu, w + d.ws_du, sizeof(double) * d.N * d.nu);
+    }
+    return 0;
+}
+
+int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
+    if (!h) return fail("null batch");
+    if (xs) *xs = h->xs;
+    if (us) *us = h->us;
+    return 0;
+}
+
+int upr_batch_enable_timing(upr_batch* h, int on) {
+    if (!h) return fail("null batch");
+    h->timing = on != 0;
+    for (int i = 0; i < 3; ++i) { h->k_ms[i] = 0; h->k_launches[i] = 0; }
+    return 0;
+}
+
+int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches) {
+    if (!h) return fail("null batch");
+    for (int i = 0; i < 3; ++i) {
+        ms[i] = h->k_launches[i] ? h->k_ms[i] / h->k_launches[i] : 0.0;
+        if (launches) launches[i] = h->k_launches[i];
+    }
+    return 0;
+}
+
+}  // extern "C"

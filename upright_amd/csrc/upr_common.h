@@ -1,0 +1,87 @@
+// upr_common.h -- shared definitions of the HIP engine.
+//
+// Kernel bodies are written against three primitives -- UPR_FOR (block-strided loop), UPR_SYNC
+// (workgroup barrier) and a per-workgroup scratch pointer -- so that the very same source also
+// compiles with g++ as a one-thread-per-workgroup host emulation (-DUPR_HOST_EMU).  The emulation is a
+// TEST-ONLY build (tests/emu/) for debugging index arithmetic without a GPU; libupright_mi.so never
+// contains it and has no CPU path.
+#pragma once
+#include "../../include/upright_mi.h"
+
+#ifdef UPR_HOST_EMU
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#define UPR_HD
+#define UPR_D
+#define UPR_SYNC() ((void)0)
+struct upr_ctx { int tid; int nt; };
+#else
+#include <hip/hip_runtime.h>
+#define UPR_HD __host__ __device__
+#define UPR_D __device__ __forceinline__
+#define UPR_SYNC() __syncthreads()
+struct upr_ctx { int tid; int nt; };
+#endif
+
+#define UPR_FOR(i, n) for (int i = ctx.tid; i < (n); i += ctx.nt)
+
+// derived dimensions
+struct upr_dims {
+    int nq, nb, nc, nf, N, nx, nu, nfc, ne, np, neN;
+    // per-knot linearisation record (doubles): [g ne][gx ne*nx][cost 1][grad nq][hess nq(nq+1)/2]
+    int lin_g, lin_gx, lin_cost, lin_grad, lin_hess, lin_stride;
+    // inequality layout per stage: [x lo nx][x hi nx] (k >= 1) [u lo nu][u hi nu][poly np] (k < N)
+    int ni_stage;   // 2nx + 2nu + np  (slot size; stage 0 leaves the x part unused, stage N the u part)
+    // Riccati stage store (doubles)
+    int ss_kx, ss_hjj, ss_hff, ss_sinv, ss_ku0, ss_uf0, ss_snu, ss_pb, ss_stride;
+    // per-instance workspace (doubles)
+    int ws_dx, ws_du, ws_sx, ws_su, ws_pi, ws_nu, ws_yN, ws_pin, ws_nun, ws_dyN, ws_t, ws_lam, ws_rc, ws_store, ws_stride;
+};
+
+static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
+    upr_dims d;
+    d.nq = P->nq; d.nb = P->nb; d.nc = P->nc; d.nf = P->nf; d.N = P->N;
+    d.nx = 3 * P->nq; d.nfc = P->nf * P->nc; d.nu = P->nq + d.nfc;
+    d.ne = 6 * P->nb; d.np = (P->nf == 3) ? 5 * P->nc : 0;
+    d.neN = P->terminal_constraint ? 3 + 2 * P->nq : 0;
+    d.lin_g = 0; d.lin_gx = d.ne; d.lin_cost = d.lin_gx + d.ne * d.nx; d.lin_grad = d.lin_cost + 1;
+    d.lin_hess = d.lin_grad + d.nq; d.lin_stride = d.lin_hess + d.nq * (d.nq + 1) / 2;
+    d.ni_stage = 2 * d.nx + 2 * d.nu + d.np;
+    d.ss_kx = 0; d.ss_hjj = d.ss_kx + d.nq * d.nx; d.ss_hff = d.ss_hjj + d.nq * d.nq;
+    d.ss_sinv = d.ss_hff + ((d.nf == 3) ? 9 * d.nc : d.nc);
+    d.ss_ku0 = d.ss_sinv + d.ne * d.ne; d.ss_uf0 = d.ss_ku0 + d.nq; d.ss_snu = d.ss_uf0 + d.nfc;
+    d.ss_pb = d.ss_snu + d.ne; d.ss_stride = d.ss_pb + d.nx;
+    int n1 = d.N + 1;
+    d.ws_dx = 0; d.ws_du = d.ws_dx + n1 * d.nx; d.ws_sx = d.ws_du + d.N * d.nu; d.ws_su = d.ws_sx + n1 * d.nx;
+    d.ws_pi = d.ws_su + d.N * d.nu; d.ws_nu = d.ws_pi + n1 * d.nx; d.ws_yN = d.ws_nu + d.N * d.ne;
+    d.ws_pin = d.ws_yN + d.neN; d.ws_nun = d.ws_pin + n1 * d.nx; d.ws_dyN = d.ws_nun + d.N * d.ne;
+    d.ws_t = d.ws_dyN + d.neN; d.ws_lam = d.ws_t + n1 * d.ni_stage; d.ws_rc = d.ws_lam + n1 * d.ni_stage;
+    d.ws_store = d.ws_rc + n1 * d.ni_stage;
+    d.ws_stride = d.ws_store + d.N * d.ss_stride;
+    d.ws_stride = (d.ws_stride + 15) & ~15;
+    return d;
+}
+
+// packed upper-triangular index (i <= j) of an n x n symmetric matrix
+static inline UPR_HD int upr_tri(int n, int i, int j) {
+    if (i > j) { int t = i; i = j; j = t; }
+    return i * n - (i * (i - 1)) / 2 + (j - i);
+}
+
+// reference_trajectory.h:18-47 (position part), ocs2 LinearInterpolation::timeSegment convention:
+// value = alpha * lhs + (1 - alpha) * rhs
+static inline UPR_HD void upr_target_position(const upr_problem* P, const double* way_p, double t, double* pd) {
+    int n = P->n_way;
+    if (n <= 1) { pd[0] = way_p[0]; pd[1] = way_p[1]; pd[2] = way_p[2]; return; }
+    int idx; double alpha;
+    if (t <= P->way_t[0]) { idx = 0; alpha = 1.0; }
+    else if (t >= P->way_t[n - 1]) { idx = n - 2; alpha = 0.0; }
+    else {
+        idx = 0;
+        while (idx + 1 < n - 1 && t >= P->way_t[idx + 1]) ++idx;
+        alpha = (P->way_t[idx + 1] - t) / (P->way_t[idx + 1] - P->way_t[idx]);
+    }
+    for (int i = 0; i < 3; ++i) pd[i] = alpha * way_p[3 * idx + i] + (1.0 - alpha) * way_p[3 * (idx + 1) + i];
+}

@@ -1,0 +1,219 @@
+// upr_kin.h -- end-effector kinematics of a serial chain and the balancing-constraint math, written
+// for one GPU lane per forward-mode tangent direction.
+//
+// What it replaces: the CppAD tapes the reference evaluates once per knot per SQP iteration --
+//   get_rigid_body_state           upright_control/src/constraint/balancing_constraints.cpp:15-30
+//   ObjectDynamicsConstraints      upright_control/src/constraint/balancing_constraints.cpp:114-155
+//   compute_object_dynamics_*      upright_core/include/upright_core/contact_constraints.h:80-194
+//   dC_dtt / skew3                 upright_core/include/upright_core/util.h:27-50
+// In the kernel every lane evaluates the same straight-line recursion on a (value, tangent) pair whose
+// tangent is seeded with the lane's own state coordinate, so a wave produces a whole Jacobian column
+// set in one pass and the 18 x nx kinematic Jacobian never exists in memory.
+#pragma once
+#include "upr_common.h"
+
+struct upr_dd {  // value + one tangent
+    double v, d;
+};
+static inline UPR_HD upr_dd operator+(upr_dd a, upr_dd b) { return {a.v + b.v, a.d + b.d}; }
+static inline UPR_HD upr_dd operator-(upr_dd a, upr_dd b) { return {a.v - b.v, a.d - b.d}; }
+static inline UPR_HD upr_dd operator*(upr_dd a, upr_dd b) { return {a.v * b.v, fma(a.d, b.v, a.v * b.d)}; }
+static inline UPR_HD upr_dd operator*(double a, upr_dd b) { return {a * b.v, a * b.d}; }
+static inline UPR_HD upr_dd operator*(upr_dd b, double a) { return {a * b.v, a * b.d}; }
+static inline UPR_HD upr_dd upr_lift(double a, upr_dd*) { return {a, 0.0}; }
+static inline UPR_HD double upr_lift(double a, double*) { return a; }
+static inline UPR_HD double upr_seed(double v, bool on, double*) { return v; }
+static inline UPR_HD upr_dd upr_seed(double v, bool on, upr_dd*) { return {v, on ? 1.0 : 0.0}; }
+static inline UPR_HD void upr_sincos(double th, double* s, double* c) { *s = sin(th); *c = cos(th); }
+static inline UPR_HD void upr_sincos(upr_dd th, upr_dd* s, upr_dd* c) {
+    double sv = sin(th.v), cv = cos(th.v);
+    *s = {sv, cv * th.d};
+    *c = {cv, -sv * th.d};
+}
+
+template <class T> static inline UPR_HD void upr_cross(const T* a, const T* b, T* r) {
+    T r0 = a[1] * b[2] - a[2] * b[1];
+    T r1 = a[2] * b[0] - a[0] * b[2];
+    T r2 = a[0] * b[1] - a[1] * b[0];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+// r = R * c   (R row-major T, c constant)
+template <class T> static inline UPR_HD void upr_rot_const(const T* R, const double* c, T* r) {
+    for (int i = 0; i < 3; ++i) r[i] = R[3 * i] * c[0] + R[3 * i + 1] * c[1] + R[3 * i + 2] * c[2];
+}
+// R <- R * M  (M constant 3x3 row-major)
+template <class T> static inline UPR_HD void upr_rmul_const(T* R, const double* M) {
+    for (int i = 0; i < 3; ++i) {
+        T a = R[3 * i], b = R[3 * i + 1], c = R[3 * i + 2];
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = a * M[j] + b * M[3 + j] + c * M[6 + j];
+    }
+}
+template <class T> static inline UPR_HD void upr_rmul(T* R, const T* M) {
+    for (int i = 0; i < 3; ++i) {
+        T a = R[3 * i], b = R[3 * i + 1], c = R[3 * i + 2];
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = a * M[j] + b * M[3 + j] + c * M[6 + j];
+    }
+}
+
+template <class T>
+struct upr_ee {
+    T p[3], C[9], v[3], w[3], a[3], al[3];
+};
+
+// Rigidly carry the tracked point by the world-frame offset r (classical acceleration).
+template <class T> static inline UPR_HD void upr_carry(upr_ee<T>& E, const T* r) {
+    T wr[3], t[3];
+    upr_cross(E.w, r, wr);
+    for (int i = 0; i < 3; ++i) E.v[i] = E.v[i] + wr[i];
+    upr_cross(E.al, r, t);
+    for (int i = 0; i < 3; ++i) E.a[i] = E.a[i] + t[i];
+    upr_cross(E.w, wr, t);
+    for (int i = 0; i < 3; ++i) { E.a[i] = E.a[i] + t[i]; E.p[i] = E.p[i] + r[i]; }
+}
+
+// x: the knot's state [q, v, a] (plain values); dir: tangent direction of this lane (-1: none).
+// NQ is the compile-time joint count so that the chain loop unrolls and everything stays in registers.
+template <class T, int NQ>
+static inline UPR_HD void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E) {
+    T* tag = nullptr;
+    for (int i = 0; i < 9; ++i) E.C[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
+    for (int i = 0; i < 3; ++i) { E.p[i] = upr_lift(0.0, tag); E.v[i] = E.p[i]; E.w[i] = E.p[i]; E.a[i] = E.p[i]; E.al[i] = E.p[i]; }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        T q = upr_seed(x[j], dir == j, tag);
+        T qd = upr_seed(x[NQ + j], dir == NQ + j, tag);
+        T qdd = upr_seed(x[2 * NQ + j], dir == 2 * NQ + j, tag);
+        T r[3];
+        upr_rot_const(E.C, P->joint_p[j], r);
+        upr_carry(E, r);
+        upr_rmul_const(E.C, P->joint_R[j]);
+        T z[3];
+        upr_rot_const(E.C, P->joint_axis[j], z);
+        if (P->joint_type[j] == 1) {
+            T wz[3];
+            upr_cross(E.w, z, wz);
+            for (int i = 0; i < 3; ++i) {
+                E.al[i] = E.al[i] + z[i] * qdd + wz[i] * qd;
+                E.w[i] = E.w[i] + z[i] * qd;
+            }
+            // Rodrigues about the constant local axis
+            const double* ax = P->joint_axis[j];
+            T s, c;
+            upr_sincos(q, &s, &c);
+            T omc = upr_lift(1.0, tag) - c;
+            T M[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) M[3 * a + b] = (ax[a] * ax[b]) * omc + ((a == b) ? c : upr_lift(0.0, tag));
+            M[1] = M[1] - ax[2] * s; M[2] = M[2] + ax[1] * s;
+            M[3] = M[3] + ax[2] * s; M[5] = M[5] - ax[0] * s;
+            M[6] = M[6] - ax[1] * s; M[7] = M[7] + ax[0] * s;
+            upr_rmul(E.C, M);
+        } else {
+            T d[3], wz[3], t[3], wd[3];
+            for (int i = 0; i < 3; ++i) d[i] = z[i] * q;
+            upr_cross(E.w, z, wz);
+            upr_cross(E.w, d, wd);
+            upr_cross(E.al, d, t);
+            for (int i = 0; i < 3; ++i) E.a[i] = E.a[i] + t[i];
+            upr_cross(E.w, wd, t);
+            for (int i = 0; i < 3; ++i) {
+                E.a[i] = E.a[i] + t[i] + (2.0 * wz[i]) * qd + z[i] * qdd;
+                E.v[i] = E.v[i] + wd[i] + z[i] * qd;
+                E.p[i] = E.p[i] + d[i];
+            }
+        }
+    }
+    T r[3];
+    upr_rot_const(E.C, P->tool_p, r);
+    upr_carry(E, r);
+    upr_rmul_const(E.C, P->tool_R);
+}
+
+// Object-dynamics residual of body b (contact_constraints.h:80-102), unnormalised, given the summed
+// contact wrench (F, Tq) on the body (plain values: the wrench does not depend on the state).
+// bp = the body's 10 inertial parameters (rigid_body.h:36-51).
+template <class T>
+static inline UPR_HD void upr_body_residual(const upr_ee<T>& E, const double* bp, const double* g0, const double* F,
+                                            const double* Tq, T* out) {
+    T* tag = nullptr;
+    const double m = bp[0];
+    const double c[3] = {bp[1] / m, bp[2] / m, bp[3] / m};
+    const double I[9] = {bp[4], bp[5], bp[6], bp[5], bp[7], bp[8], bp[6], bp[8], bp[9]};
+    // ddC c = (S(al) + S(w) S(w)) (C c) = al x r + w x (w x r), r = C c      util.h:39-44
+    T r[3], t1[3], t2[3], acc[3];
+    upr_rot_const(E.C, c, r);
+    upr_cross(E.al, r, t1);
+    upr_cross(E.w, r, t2);
+    upr_cross(E.w, t2, t2);
+    for (int i = 0; i < 3; ++i) acc[i] = E.a[i] + t1[i] + t2[i] - upr_lift(g0[i], tag);
+    // C^T (.)
+    T we[3], ae[3], gif[3];
+    for (int i = 0; i < 3; ++i) {
+        gif[i] = m * (E.C[i] * acc[0] + E.C[3 + i] * acc[1] + E.C[6 + i] * acc[2]);
+        we[i] = E.C[i] * E.w[0] + E.C[3 + i] * E.w[1] + E.C[6 + i] * E.w[2];
+        ae[i] = E.C[i] * E.al[0] + E.C[3 + i] * E.al[1] + E.C[6 + i] * E.al[2];
+    }
+    T Iw[3], Ia[3], tau[3];
+    for (int i = 0; i < 3; ++i) {
+        Iw[i] = I[3 * i] * we[0] + I[3 * i + 1] * we[1] + I[3 * i + 2] * we[2];
+        Ia[i] = I[3 * i] * ae[0] + I[3 * i + 1] * ae[1] + I[3 * i + 2] * ae[2];
+    }
+    upr_cross(we, Iw, tau);
+    const double im = 1.0 / m;
+    for (int i = 0; i < 3; ++i) {
+        out[i] = im * (gif[i] - upr_lift(F[i], tag));
+        out[3 + i] = im * (tau[i] + Ia[i] - upr_lift(Tq[i], tag));
+    }
+}
+
+// contact_constraints.h:107-157: summed contact wrench on every balanced body.  forces = u tail.
+// Fw[nb][6] = [F(3), T(3)].  bodies: body_params[nb][10].
+static inline UPR_HD void upr_object_wrenches(const upr_problem* P, const double* body_params, const double* forces,
+                                              double* Fw) {
+    for (int i = 0; i < 6 * P->nb; ++i) Fw[i] = 0.0;
+    for (int i = 0; i < P->nc; ++i) {
+        double f[3];
+        if (P->nf == 1) { for (int a = 0; a < 3; ++a) f[a] = forces[i] * P->contact_normal[i][a]; }
+        else { f[0] = forces[3 * i]; f[1] = forces[3 * i + 1]; f[2] = forces[3 * i + 2]; }
+        int b1 = P->contact_body1[i], b2 = P->contact_body2[i];
+        if (b1 >= 0) {
+            const double* bp = body_params + 10 * b1;
+            double l[3] = {P->contact_r1[i][0] - bp[1] / bp[0], P->contact_r1[i][1] - bp[2] / bp[0], P->contact_r1[i][2] - bp[3] / bp[0]};
+            double* W = Fw + 6 * b1;
+            W[0] += f[0]; W[1] += f[1]; W[2] += f[2];
+            W[3] += l[1] * f[2] - l[2] * f[1]; W[4] += l[2] * f[0] - l[0] * f[2]; W[5] += l[0] * f[1] - l[1] * f[0];
+        }
+        {
+            const double* bp = body_params + 10 * b2;
+            double l[3] = {P->contact_r2[i][0] - bp[1] / bp[0], P->contact_r2[i][1] - bp[2] / bp[0], P->contact_r2[i][2] - bp[3] / bp[0]};
+            double* W = Fw + 6 * b2;
+            W[0] -= f[0]; W[1] -= f[1]; W[2] -= f[2];
+            W[3] -= l[1] * f[2] - l[2] * f[1]; W[4] -= l[2] * f[0] - l[0] * f[2]; W[5] -= l[0] * f[1] - l[1] * f[0];
+        }
+    }
+}
+
+// contact_constraints.h:50-77: the five pyramid rows of contact i
+static inline UPR_HD void upr_friction_rows_contact(const upr_problem* P, int i, const double* f, double* h) {
+    const double* n = P->contact_normal[i];
+    const double* S = P->contact_span[i];
+    double fn = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
+    double t0 = S[0] * f[0] + S[1] * f[1] + S[2] * f[2];
+    double t1 = S[3] * f[0] + S[4] * f[1] + S[5] * f[2];
+    double mu = P->contact_mu[i];
+    h[0] = fn;
+    h[1] = mu * fn - t0 - t1;
+    h[2] = mu * fn - t0 + t1;
+    h[3] = mu * fn + t0 - t1;
+    h[4] = mu * fn + t0 + t1;
+}
+// row r (0..4) of the constant 5x3 Jacobian d h / d f of contact i
+static inline UPR_HD void upr_friction_row_jac(const upr_problem* P, int i, int r, double* e) {
+    const double* n = P->contact_normal[i];
+    const double* S = P->contact_span[i];
+    double mu = P->contact_mu[i];
+    if (r == 0) { e[0] = n[0]; e[1] = n[1]; e[2] = n[2]; return; }
+    double s0 = (r == 1 || r == 2) ? -1.0 : 1.0;
+    double s1 = (r == 1 || r == 3) ? -1.0 : 1.0;
+    for (int a = 0; a < 3; ++a) e[a] = mu * n[a] + s0 * S[a] + s1 * S[3 + a];
+}

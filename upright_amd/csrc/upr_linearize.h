@@ -1,0 +1,209 @@
+// upr_linearize.h -- per-knot linearisation of the OCP terms (kernels K1..K5 of SURVEY.md 2b, fused).
+//
+// One group of LPK = 32 lanes per shooting knot (two knots per 64-wide wavefront).  Lane l < nx
+// carries the forward-mode tangent along state coordinate l through
+//   end-effector kinematics  ->  object-dynamics residual (balancing_constraints.cpp:114-155)
+// and writes column l of d g / d x; the value lane writes g.  The end-effector cost
+// (cost/end_effector_cost.h:48-84) gets its gradient J'We and Gauss-Newton Hessian J'WJ from the
+// position tangents exchanged through LDS (VALU path) or through one v_mfma_f64_16x16x4_f64 per knot
+// (MFMA path).  Friction-cone rows (contact_constraints.h:50-77) are linear in u with a constant
+// Jacobian, so they are formed where they are consumed (QP / line-search kernels), not stored.
+//
+// Record per knot (doubles), see upr_dims: [g ne][gx ne*nx][cost][grad nq][hess nq(nq+1)/2].
+// Terminal knot (k == N, stationary_desired_position_constraint.h:39-74): grad[0..2] = p_d - p,
+// hess[0..3nq) = J_p (3 x nq row-major); g/gx unused.
+//
+// Algorithmic HBM bytes per knot: 8 * [(nx + nu) + ne (1 + nx) + (nq + nq(nq+1)/2 + 1)].
+#pragma once
+#include "upr_kin.h"
+
+#define UPR_LPK 32
+
+// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[3 nq] e[3]
+static inline UPR_HD int upr_lin_lds_doubles(const upr_dims& d) { return d.nx + d.nu + 6 * d.nb + 3 * d.nq + 3 + 1; }
+
+struct upr_lin_args {
+    const upr_problem* P;
+    upr_dims d;
+    const double* body_params;  // [B][nb][10]
+    const double* way_p;        // [B][n_way][3]
+    const double* t0;           // [B] (trajectory mode) or per point (points mode)
+    const double* xs;           // trajectory mode: [B][N+1][nx]; points mode: [n][nx]
+    const double* us;           // trajectory mode: [B][N][nu];   points mode: [n][nu]
+    const int* inst;            // points mode: instance of each point; NULL in trajectory mode
+    double* lin;                // [npoints][lin_stride]
+    double* ee_out;             // optional [npoints][3] end-effector position
+    int npoints;
+};
+
+struct upr_lin_point {
+    int p, b, k;
+    bool terminal;
+    double t;
+    const double* x;
+    const double* u;
+    double* out;
+};
+
+static inline UPR_HD upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) {
+    upr_lin_point q;
+    const upr_dims& d = A.d;
+    q.p = p;
+    if (A.inst) {
+        q.b = A.inst[p]; q.k = 0; q.terminal = false; q.t = A.t0[p];
+        q.x = A.xs + (size_t)p * d.nx; q.u = A.us + (size_t)p * d.nu;
+    } else {
+        q.b = p / (d.N + 1); q.k = p % (d.N + 1); q.terminal = (q.k == d.N);
+        q.t = A.t0[q.b] + q.k * A.P->dt;
+        q.x = A.xs + (size_t)p * d.nx;
+        int ku = q.terminal ? d.N - 1 : q.k;
+        q.u = A.us + ((size_t)q.b * d.N + ku) * d.nu;
+    }
+    q.out = A.lin + (size_t)p * d.lin_stride;
+    return q;
+}
+
+// phase 0: stage x, u into LDS (coalesced: lane l loads element l) -- lanes 0..LPK-1 of the knot
+static inline UPR_HD void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+    const upr_dims& d = A.d;
+    double* sx = sh; double* su = sh + d.nx;
+    for (int i = lane; i < d.nx; i += UPR_LPK) sx[i] = q.x[i];
+    for (int i = lane; i < d.nu; i += UPR_LPK) su[i] = q.terminal ? 0.0 : q.u[i];
+}
+// phase 0b: summed contact wrench per body (contact x body loop out of the LDS-staged forces)
+static inline UPR_HD void upr_lin_phase0b(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+    const upr_dims& d = A.d;
+    if (lane == 0) {
+        double* Fw = sh + d.nx + d.nu;
+        upr_object_wrenches(A.P, A.body_params + (size_t)q.b * d.nb * 10, sh + d.nx + d.nq, Fw);
+    }
+}
+
+// phase 1: the tangent lanes
+template <int NQ>
+static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+    const upr_dims& d = A.d;
+    const upr_problem* P = A.P;
+    const double* sx = sh;
+    const double* Fw = sh + d.nx + d.nu;
+    double* sJ = sh + d.nx + d.nu + 6 * d.nb;
+    double* se = sJ + 3 * d.nq;
+    const int dir = (lane < d.nx) ? lane : -1;
+    upr_ee<upr_dd> E;
+    upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E);
+    if (!q.terminal) {
+        const double scale = 1.0 / sqrt(6.0 * d.nb);
+        const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
+        for (int b = 0; b < d.nb; ++b) {
+            upr_dd gb[6];
+            upr_body_residual<upr_dd>(E, bp + 10 * b, P->gravity, Fw + 6 * b, Fw + 6 * b + 3, gb);
+            for (int r = 0; r < 6; ++r) {
+                if (dir >= 0) q.out[d.lin_gx + (6 * b + r) * d.nx + dir] = scale * gb[r].d;
+                if (lane == 0) q.out[d.lin_g + 6 * b + r] = scale * gb[r].v;
+            }
+        }
+    }
+    if (dir >= 0 && dir < NQ)
+        for (int r = 0; r < 3; ++r) sJ[r * NQ + dir] = E.p[r].d;
+    if (lane == 0) {
+        double pd[3];
+        upr_target_position(P, A.way_p + (size_t)q.b * P->n_way * 3, q.t, pd);
+        for (int r = 0; r < 3; ++r) se[r] = E.p[r].v - pd[r];
+        if (A.ee_out) for (int r = 0; r < 3; ++r) A.ee_out[(size_t)q.p * 3 + r] = E.p[r].v;
+    }
+}
+
+// phase 2 (VALU path): gradient, Gauss-Newton Hessian, cost from the LDS-staged position Jacobian
+template <int NQ>
+static inline UPR_HD void upr_lin_phase2(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
+    const upr_dims& d = A.d;
+    const double* W = A.P->Wee;
+    const double* sJ = sh + d.nx + d.nu + 6 * d.nb;
+    const double* se = sJ + 3 * d.nq;
+    if (!q.terminal) {
+        if (lane < NQ) {
+            double g = 0.0;
+            for (int r = 0; r < 3; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
+            q.out[d.lin_grad + lane] = g;
+            for (int m = lane; m < NQ; ++m) {
+                double h = 0.0;
+                for (int r = 0; r < 3; ++r) h += W[r] * sJ[r * NQ + lane] * sJ[r * NQ + m];
+                q.out[d.lin_hess + upr_tri(NQ, lane, m)] = h;
+            }
+        }
+        if (lane == 0) q.out[d.lin_cost] = 0.5 * (W[0] * se[0] * se[0] + W[1] * se[1] * se[1] + W[2] * se[2] * se[2]);
+    } else {
+        if (lane < 3) q.out[d.lin_grad + lane] = -se[lane];
+        if (lane < NQ) for (int r = 0; r < 3; ++r) q.out[d.lin_hess + r * NQ + lane] = sJ[r * NQ + lane];
+        if (lane == 0) q.out[d.lin_cost] = 0.0;
+    }
+}
+
+#ifndef UPR_HOST_EMU
+// 256 threads = 8 knots x 32 lanes.  USE_MFMA: Gauss-Newton Hessian through v_mfma_f64_16x16x4_f64.
+template <int NQ, bool USE_MFMA>
+__global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int per = upr_lin_lds_doubles(A.d);
+    const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int p = blockIdx.x * 8 + sub;
+    const bool live = p < A.npoints;
+    double* sh = smem + sub * per;
+    upr_lin_point q;
+    if (live) { q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, sh); }
+    __syncthreads();
+    if (live) upr_lin_phase0b(A, q, lane, sh);
+    __syncthreads();
+    if (live) upr_lin_phase1<NQ>(A, q, lane, sh);
+    __syncthreads();
+    if (!USE_MFMA) {
+        if (live) upr_lin_phase2<NQ>(A, q, lane, sh);
+    } else {
+        // One MFMA per knot-half: D(16x16) = A(16x4) B(4x16) with A[i][k] = sqrt(W_k) J[k][i],
+        // B[k][j] = sqrt(W_k) J[k][j] (k < 3; k = 3 is zero padding).  Operand lane map (f64 16x16x4,
+        // cdna_hip_programming.md section 3): lane L supplies A[L & 15][L >> 4] and B[L >> 4][L & 15];
+        // result reg r of lane L is D[(L >> 4) + 4 r][L & 15].  The instruction is wave-wide, so it is
+        // issued once per half (h = 0, 1), every lane reading the Jacobian of knot-half h from LDS.
+        const int wl = threadIdx.x & 63;       // lane in wave
+        const int i16 = wl & 15, k4 = wl >> 4; // operand coordinates
+        const int wsub0 = (threadIdx.x >> 6) * 2;  // first knot slot of this wave
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        for (int h = 0; h < 2; ++h) {
+            const int slot = wsub0 + h;
+            const int ph = blockIdx.x * 8 + slot;
+            const double* shh = smem + slot * per;
+            const double* sJ = shh + A.d.nx + A.d.nu + 6 * A.d.nb;
+            double a = 0.0;
+            if (ph < A.npoints && k4 < 3 && i16 < NQ) a = sqrt(A.P->Wee[k4]) * sJ[k4 * NQ + i16];
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+            if (ph < A.npoints) {
+                upr_lin_point qh = upr_lin_locate(A, ph);
+                if (!qh.terminal) {
+                    const int col = wl & 15;
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = (wl >> 4) + 4 * r;
+                        if (row < NQ && col < NQ && row <= col) qh.out[A.d.lin_hess + upr_tri(NQ, row, col)] = acc[r];
+                    }
+                }
+            }
+        }
+        // gradient / cost / terminal record stay on the VALU lanes
+        if (live) {
+            const double* W = A.P->Wee;
+            const double* sJ = sh + A.d.nx + A.d.nu + 6 * A.d.nb;
+            const double* se = sJ + 3 * A.d.nq;
+            if (!q.terminal) {
+                if (lane < NQ) {
+                    double g = 0.0;
+                    for (int r = 0; r < 3; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
+                    q.out[A.d.lin_grad + lane] = g;
+                }
+                if (lane == 0) q.out[A.d.lin_cost] = 0.5 * (W[0] * se[0] * se[0] + W[1] * se[1] * se[1] + W[2] * se[2] * se[2]);
+            } else {
+                upr_lin_phase2<NQ>(A, q, lane, sh);
+            }
+        }
+    }
+}
+#endif

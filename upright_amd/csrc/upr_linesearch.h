@@ -1,0 +1,204 @@
+// upr_linesearch.h -- merit evaluation, filter line search and SQP convergence test, one workgroup per
+// instance, one lane per shooting knot.
+//
+// What it replaces: [UPSTREAM, absent] ocs2_sqp MultipleShootingSolver::takeStep / computePerformance /
+// checkConvergence with the ocs2_sqp defaults (alpha_decay 0.5, alpha_min 1e-4, gamma_c 1e-6,
+// g_max 1e6, g_min 1e-6, armijo 1e-4; none is bound at upright_control/src/pybindings.cpp:190-213).
+// The per-knot terms are the OCP terms of controller_interface.cpp:136-357 re-evaluated (values only)
+// at the trial iterate: quadratic state-input cost, end-effector cost, object-dynamics equality,
+// friction-cone rows, boxes, dynamics defects, terminal equality.
+#pragma once
+#include "upr_kin.h"
+
+struct upr_ls_args {
+    const upr_problem* P;
+    upr_dims d;
+    double* xs;            // [B][N+1][nx]  (updated in place when a step is accepted)
+    double* us;            // [B][N][nu]
+    const double* x0;      // [B][nx]
+    const double* t0;      // [B]
+    const double* body_params;
+    const double* way_p;
+    const double* lin;     // for the Armijo descent metric (cost gradient at the linearisation point)
+    const double* ws;      // dx, du live in the QP workspace
+    double* stats;         // [B][UPR_NSTATS]
+    int* done;             // [B] convergence flag
+    int iter;              // SQP iteration index (0-based)
+};
+
+// performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
+template <int NQ>
+static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
+    const upr_problem* P = A.P; const upr_dims& d = A.d;
+    const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
+    const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
+    const double* xs = A.xs + (size_t)b * (N + 1) * nx; const double* us = A.us + (size_t)b * N * nu;
+    const double* ws = A.ws + (size_t)b * d.ws_stride;
+    const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
+    double X[3 * NQ], U[UPR_MAX_NU];
+    for (int i = 0; i < nx; ++i) X[i] = xs[k * nx + i] + alpha * dx[k * nx + i];
+    double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
+    const double wt = (k < N) ? h : 1.0;
+    if (k == 0) for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
+    if (k >= 1) for (int i = 0; i < nx; ++i) {
+        double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
+        iq += wt * v * v;
+    }
+    upr_ee<double> E;
+    upr_ee_kinematics<double, NQ>(P, X, -1, E);
+    double pd[3];
+    upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * h, pd);
+    if (k < N) {
+        for (int i = 0; i < nu; ++i) U[i] = us[k * nu + i] + alpha * du[k * nu + i];
+        double c = 0.0;
+        for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
+        for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
+        for (int r = 0; r < 3; ++r) { double e = E.p[r] - pd[r]; c += 0.5 * P->Wee[r] * e * e; }
+        cost += h * c;
+        // dynamics defect against the next trial state
+        for (int j = 0; j < nq; ++j) {
+            double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
+            const double* xn = xs + (k + 1) * nx; const double* dn = dx + (k + 1) * nx;
+            double e0 = q + h * v + h2 * a + h3 * u - (xn[j] + alpha * dn[j]);
+            double e1 = v + h * a + h2 * u - (xn[nq + j] + alpha * dn[nq + j]);
+            double e2 = a + h * u - (xn[2 * nq + j] + alpha * dn[2 * nq + j]);
+            dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
+        }
+        // object-dynamics equality
+        double Fw[6 * UPR_MAX_BODIES];
+        const double* bp = A.body_params + (size_t)b * d.nb * 10;
+        upr_object_wrenches(P, bp, U + nq, Fw);
+        const double sc = 1.0 / sqrt(6.0 * d.nb);
+        for (int bb = 0; bb < d.nb; ++bb) {
+            double g[6];
+            upr_body_residual<double>(E, bp + 10 * bb, P->gravity, Fw + 6 * bb, Fw + 6 * bb + 3, g);
+            for (int r = 0; r < 6; ++r) eq += h * (sc * g[r]) * (sc * g[r]);
+        }
+        // friction rows and input box
+        if (d.np > 0) for (int ci = 0; ci < d.nc; ++ci) {
+            double hr[5];
+            upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
+            for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+        }
+        for (int i = 0; i < nu; ++i) {
+            double v = fmin(0.0, fmin(U[i] - P->u_lb[i], P->u_ub[i] - U[i]));
+            iq += h * v * v;
+        }
+    } else if (d.neN > 0) {
+        for (int r = 0; r < 3; ++r) { double e = pd[r] - E.p[r]; eq += e * e; }
+        for (int i = 0; i < 2 * nq; ++i) eq += X[nq + i] * X[nq + i];
+    }
+    out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
+}
+
+// block reduction of 4 partials; result broadcast in res[4]
+static inline UPR_HD void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double* part, double* res) {
+    for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] = part[c];
+    UPR_SYNC();
+    for (int s = 1; s < ctx.nt; s <<= 1) {
+        if ((ctx.tid & (2 * s - 1)) == 0 && ctx.tid + s < ctx.nt)
+            for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] += red[c * ctx.nt + ctx.tid + s];
+        UPR_SYNC();
+    }
+    for (int c = 0; c < 4; ++c) res[c] = red[c * ctx.nt];
+    UPR_SYNC();
+}
+
+// L: 4*nt + 8 doubles of workgroup scratch
+template <int NQ>
+static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
+    const upr_problem* P = A.P; const upr_dims& d = A.d;
+    const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
+    if (A.done[b]) return;
+    double* st = A.stats + (size_t)b * UPR_NSTATS;
+    const double qp_status = st[2];
+    const double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, g_max = 1e6, g_min = 1e-6, armijo = 1e-4;
+    double* xs = A.xs + (size_t)b * (N + 1) * nx; double* us = A.us + (size_t)b * N * nu;
+    const double* ws = A.ws + (size_t)b * d.ws_stride;
+    const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
+    const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
+    // baseline, step norms and Armijo descent metric (cost gradient . step)
+    double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
+    UPR_FOR(k, N + 1) upr_ls_knot<NQ>(A, b, k, 0.0, part);
+    upr_ls_reduce4(ctx, L, part, base);
+    UPR_FOR(k, N + 1) {
+        for (int i = 0; i < nx; ++i) {
+            double s = dx[k * nx + i];
+            aux[1] += s * s;
+            if (k < N) {
+                double g = P->Qdiag[i] * (xs[k * nx + i] - P->xd[i]);
+                if (i < nq) g += lin[(size_t)k * d.lin_stride + d.lin_grad + i];
+                aux[0] += P->dt * g * s;
+            }
+        }
+        if (k < N) for (int i = 0; i < nu; ++i) {
+            double s = du[k * nu + i];
+            aux[2] += s * s;
+            aux[0] += P->dt * P->Rdiag[i] * us[k * nu + i] * s;
+        }
+    }
+    upr_ls_reduce4(ctx, L, aux, auxr);
+    const double descent = auxr[0], dxn = sqrt(auxr[1]), dun = sqrt(auxr[2]);
+    const double base_viol = sqrt(base[1] + base[2] + base[3]);
+    double alpha = 1.0, perf[4] = {base[0], base[1], base[2], base[3]};
+    bool accepted = false;
+    if (qp_status != 2.0) {
+        do {
+            double p2[4] = {0, 0, 0, 0};
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ>(A, b, k, alpha, p2);
+            upr_ls_reduce4(ctx, L, p2, perf);
+            double viol = sqrt(perf[1] + perf[2] + perf[3]);
+            if (viol > g_max) accepted = false;
+            else if (viol < g_min) accepted = (descent < 0.0) ? (perf[0] < base[0] + armijo * alpha * descent) : true;
+            else accepted = (perf[0] < base[0] - gamma_c * base_viol) || (viol < (1.0 - gamma_c) * base_viol);
+            if (accepted) break;
+            alpha *= alpha_decay;
+        } while (alpha >= alpha_min);
+    }
+    double cost = base[0], viol = base_viol;
+    if (accepted) {
+        UPR_FOR(i, (N + 1) * nx) xs[i] += alpha * dx[i];
+        UPR_FOR(i, N * nu) us[i] += alpha * du[i];
+        cost = perf[0]; viol = sqrt(perf[1] + perf[2] + perf[3]);
+    }
+    bool conv = !accepted;                                                           // STEPSIZE
+    if (accepted && fabs(base[0] - cost) < P->cost_tol && viol < g_min) conv = true;  // METRICS
+    if (accepted && alpha * dxn < P->delta_tol && alpha * dun < P->delta_tol) conv = true;  // PRIMAL
+    if (ctx.tid == 0) {
+        st[0] = A.iter + 1; st[3] = accepted ? alpha : 0.0; st[4] = cost; st[5] = viol; st[10] = dxn; st[11] = dun;
+        if (conv) A.done[b] = 1;
+    }
+    UPR_SYNC();
+}
+
+#ifndef UPR_HOST_EMU
+template <int NQ, int NT>
+__global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
+    upr_ls_instance<NQ>(ctx, A, blockIdx.x, smem);
+}
+#endif
+
+// ---- warm start / policy evaluation ----------------------------------------------------------------
+// Linear interpolation of a stored solution (ts = tp0 + j dt) at time tau; beyond the stored horizon
+// the state is held and the input is zero (ocs2 DefaultInitializer, controller_interface.cpp:385-386).
+static inline UPR_HD void upr_interp(const upr_dims& d, double dt, double tp0, const double* xs, const double* us,
+                                     double tau, int i_x, int i_u, double* xo, double* uo) {
+    double s = (tau - tp0) / dt;
+    int N = d.N;
+    if (s < 0.0) s = 0.0;
+    if (xo) {
+        double v;
+        if (s >= N) v = xs[N * d.nx + i_x];
+        else { int j = (int)s; double a = s - j; v = (1.0 - a) * xs[j * d.nx + i_x] + a * xs[(j + 1) * d.nx + i_x]; }
+        *xo = v;
+    }
+    if (uo) {
+        double v;
+        if (s > N) v = 0.0;
+        else if (s >= N - 1) v = us[(N - 1) * d.nu + i_u];
+        else { int j = (int)s; double a = s - j; v = (1.0 - a) * us[j * d.nu + i_u] + a * us[(j + 1) * d.nu + i_u]; }
+        *uo = v;
+    }
+}
