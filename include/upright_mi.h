@@ -171,6 +171,14 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us);
 int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches);
 int upr_batch_enable_timing(upr_batch* h, int on);
 
+/* copy the current solution into caller-owned DEVICE buffers (torch tensors handed to the RCCL
+ * all-gather of solved trajectories): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the
+ * engine's stream, follow with upr_batch_sync. */
+int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst);
+
+/* upr_batch_reset without target change and without host synchronisation */
+int upr_batch_reset_async(upr_batch* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libupright_mi.so) against the CPU oracle on the
+same seeded inputs.  Tolerances: BASELINE.json's north_star asks for 1e-4 on state/input norms
+against the reference solver; kernel-level terms are checked to 1e-9 .. 1e-12, QP steps to 1e-7,
+one-iteration MPC solves to 1e-6, converged SQP solves to 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from upright_amd.engine import BatchMPC, core_friction_rows, core_object_dynamics
+from upright_amd.problem import thing_problem
+from upright_amd.sampling import level_tray_states, stationary_guess, waypoints_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, s = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - s * z), 2 * (x * z + s * y)],
+        [2 * (x * y + s * z), 1 - 2 * (x * x + z * z), 2 * (y * z - s * x)],
+        [2 * (x * z - s * y), 2 * (y * z + s * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "foam_die2", "box_arch", "wedge", "tests/cylinder_box"])
+def test_core_functions(arrangements, name):
+    """upright_core.bindings twins (contact_constraints.h:50-77,162-194) on random rigid-body states."""
+    P = thing_problem(arrangements[name])
+    O = Oracle(P)
+    rng = np.random.default_rng(1)
+    n = 64
+    forces = rng.normal(size=(n, 3 * P.nc))
+    Cm = np.stack([_rand_rot(rng) for _ in range(n)])
+    w, al, a = rng.normal(size=(3, n, 3))
+    got = core_object_dynamics(P, P.body_params, forces, Cm, w, al, a)
+    ref = np.stack([O.object_dynamics(forces[i], Cm[i], w[i], al[i], a[i]) for i in range(n)])
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    got = core_friction_rows(P, forces)
+    ref = np.stack([O.friction_rows(forces[i]) for i in range(n)])
+    assert np.abs(got - ref).max() < 1e-13
+
+
+@pytest.mark.parametrize("name,mfma", [("pink_bottle", "1"), ("pink_bottle", "0"), ("box_arch", "1"), ("foam_die2", "1")])
+def test_linearize_points(arrangements, name, mfma, monkeypatch):
+    """Per-knot linearisation kernel (both Gauss-Newton Hessian paths) against the oracle's terms."""
+    monkeypatch.setenv("UPR_LIN_MFMA", mfma)
+    P = thing_problem(arrangements[name])
+    O = Oracle(P)
+    rng = np.random.default_rng(2)
+    n = 37  # ragged: not a multiple of the 8 knots per workgroup
+    x = level_tray_states(n, seed=5) + rng.uniform(-0.1, 0.1, (n, 27))
+    u = rng.uniform(-2, 2, (n, P.nu))
+    t = rng.uniform(0, 2, n)
+    mpc = BatchMPC(P, 1)
+    out = mpc.linearize_points(x, u, t)
+    gu = mpc.eq_input_jacobian(0)
+    for i in range(n):
+        g, gx, gu_o = O.eq_constraint(x[i], u[i])
+        assert np.abs(out["g"][i] - g).max() < 1e-11 * max(1, np.abs(g).max())
+        assert np.abs(out["gx"][i] - gx).max() < 1e-10 * max(1, np.abs(gx).max())
+        assert np.abs(gu - gu_o).max() < 1e-13
+        c, cgx, _, H, _ = O.stage_cost(t[i], x[i], u[i])
+        c_joint = 0.5 * np.sum(P.Qdiag * (x[i] - P.xd) ** 2) + 0.5 * np.sum(P.Rdiag * u[i] ** 2)
+        assert abs(out["cost"][i] - (c - c_joint)) < 1e-11 * max(1, abs(c))
+        assert np.abs(out["grad"][i] - (cgx - P.Qdiag * (x[i] - P.xd))[:9]).max() < 1e-11
+        assert np.abs(out["hess"][i] - (H - np.diag(P.Qdiag))[:9, :9]).max() < 1e-11
+        assert np.abs(out["ee"][i] - O.ee_kinematics(x[i])[:3]).max() < 1e-12
+    mpc.close()
+
+
+def _setup(arrangements, B, seed, **kw):
+    P = thing_problem(arrangements["pink_bottle"], **kw)
+    x0 = level_tray_states(B, seed=seed)
+    way = waypoints_for(P, x0)
+    return P, x0, way
+
+
+def _oracle_solve(P, way, x0, xs0, us0):
+    outs = []
+    for b in range(x0.shape[0]):
+        P.way_p = way[b]
+        outs.append(Oracle(P).solve(0.0, x0[b], xs0[b], us0[b]))
+    return outs
+
+
+def test_qp_step(arrangements):
+    """The structured IPM/Riccati QP kernel against the oracle's dense-stage IPM on the same QP."""
+    B = 4
+    P, x0, way = _setup(arrangements, B, seed=11)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] == 0)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0
+        assert np.abs(dxs[b] - dxo).max() < 1e-7 * max(1, np.abs(dxo).max())
+        assert np.abs(dus[b] - duo).max() < 1e-7 * max(1, np.abs(duo).max())
+    mpc.close()
+
+
+@pytest.mark.parametrize("nt", ["64", "128", "256"])
+def test_mpc_solve_one_iteration(arrangements, nt, monkeypatch):
+    """advanceMpc with sqp_iteration = 1 (controller.yaml:56): GPU vs oracle, every workgroup size."""
+    monkeypatch.setenv("UPR_QP_NT", nt)
+    B = 8
+    P, x0, way = _setup(arrangements, B, seed=21)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
+        assert np.abs(xs[b] - xo).max() < 1e-6, b
+        assert np.abs(us[b] - uo).max() < 1e-6, b
+        assert st["step_alpha_last"][b] == so.step_alpha_last
+        assert abs(st["cost"][b] - so.cost) < 1e-8 * max(1, abs(so.cost))
+        # north_star tolerance on norms
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4
+        assert abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
+    mpc.close()
+
+
+def test_mpc_solve_converged(arrangements):
+    """SQP run to convergence (delta_tol / cost_tol of controller.yaml:58-59)."""
+    B = 3
+    P, x0, way = _setup(arrangements, B, seed=31, sqp_iters=12)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
+        assert st["sqp_iters_done"][b] == so.sqp_iters_done
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4
+        assert abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
+        assert np.abs(xs[b] - xo).max() < 1e-4
+        assert np.abs(us[b] - uo).max() < 1e-4
+    mpc.close()
+
+
+def test_warm_start_and_policy(arrangements):
+    """Second advance re-samples the previous solution on the shifted grid (ocs2 warm start) and
+    evaluateMpcSolution interpolates the stored plan."""
+    B = 2
+    P, x0, way = _setup(arrangements, B, seed=41)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    ts, xs, us = mpc.solution()
+    # policy evaluation at a knot and between knots
+    xe, ue = mpc.evaluate(0.1)
+    assert np.abs(xe - xs[:, 1]).max() < 1e-12 and np.abs(ue - us[:, 1]).max() < 1e-12
+    xe, ue = mpc.evaluate(0.25)
+    assert np.abs(xe - (0.5 * xs[:, 2] + 0.5 * xs[:, 3])).max() < 1e-12
+    assert np.abs(ue - (0.5 * us[:, 2] + 0.5 * us[:, 3])).max() < 1e-12
+    # next MPC tick at t = 0.05 from the planned state
+    t1 = 0.05
+    x1, _ = mpc.evaluate(t1)
+    mpc.set_observation(t1, x1)
+    mpc.advance()
+    _, xs2, us2 = mpc.solution()
+    # oracle with the same warm start built in numpy
+    N, h = P.N, P.dt
+    for b in range(B):
+        xg = np.zeros((N + 1, P.nx)); ug = np.zeros((N, P.nu))
+        for k in range(N + 1):
+            s = (t1 + k * h) / h
+            if s >= N: xg[k] = xs[b, N]
+            else:
+                j = int(s); a = s - j; xg[k] = (1 - a) * xs[b, j] + a * xs[b, j + 1]
+        for k in range(N):
+            s = (t1 + k * h) / h
+            if s >= N - 1: ug[k] = us[b, N - 1] if s <= N else 0
+            else:
+                j = int(s); a = s - j; ug[k] = (1 - a) * us[b, j] + a * us[b, j + 1]
+        xg[0] = x1[b]
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(t1, x1[b], xg, ug)
+        assert np.abs(xs2[b] - xo).max() < 1e-6
+        assert np.abs(us2[b] - uo).max() < 1e-6
+    mpc.close()
+
+
+def test_full_size_properties(arrangements):
+    """BASELINE config 2 at full size (B = 1024): size-independent properties of the solve --
+    every QP converged to tolerance, the accepted trajectory satisfies the dynamics exactly
+    (multiple-shooting defects closed), starts at the observation, respects boxes and friction rows,
+    and a second run is bit-identical (determinism)."""
+    B = 1024
+    P, x0, way = _setup(arrangements, B, seed=0)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] <= 1)
+    conv = st["qp_status_last"] == 0
+    assert conv.mean() > 0.95
+    for key in ("qp_res_stat", "qp_res_eq", "qp_res_ineq", "qp_res_comp"):
+        assert np.all(st[key][conv] < P.qp_tol)
+    assert np.all(st["step_alpha_last"] > 0)
+    assert np.abs(xs[:, 0] - x0).max() == 0.0
+    h = P.dt
+    q, v, a = xs[:, :-1, :9], xs[:, :-1, 9:18], xs[:, :-1, 18:]
+    j = us[:, :, :9]
+    pred = np.concatenate([q + h * v + 0.5 * h * h * a + h ** 3 / 6 * j, v + h * a + 0.5 * h * h * j, a + h * j], axis=2)
+    full = st["step_alpha_last"] == 1.0
+    assert np.abs(pred - xs[:, 1:])[full & conv].max() < 1e-7
+    assert np.all(xs[conv & full][:, 1:] >= P.x_lb - 1e-6) and np.all(xs[conv & full][:, 1:] <= P.x_ub + 1e-6)
+    assert np.all(us[conv & full] >= P.u_lb - 1e-6) and np.all(us[conv & full] <= P.u_ub + 1e-6)
+    rows = core_friction_rows(P, us[conv & full][:, :, 9:].reshape(-1, 12))
+    assert rows.min() > -1e-6
+    mpc2 = BatchMPC(P, B, way_p=way)
+    mpc2.set_observation(0.0, x0)
+    mpc2.advance()
+    _, xs_b, us_b = mpc2.solution()
+    assert np.array_equal(xs, xs_b) and np.array_equal(us, us_b)
+    mpc.close(); mpc2.close()

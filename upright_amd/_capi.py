@@ -101,6 +101,8 @@ PROTOTYPES = [
     ("upr_batch_device_ptrs", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("upr_batch_kernel_times", C.c_int, [C.c_void_p, dp, ip]),
     ("upr_batch_enable_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("upr_batch_copy_solution_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("upr_batch_reset_async", C.c_int, [C.c_void_p]),
 ]
 
 _lib = None

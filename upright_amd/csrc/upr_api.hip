@@ -118,10 +118,11 @@ struct upr_batch {
     int qp_nt = 64;
     bool use_mfma = true;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_slot;
 };
 
 namespace {
@@ -209,16 +210,19 @@ int do_linearize(upr_batch* h, const upr_lin_args& A) {
     return (h->P.nq == 6) ? launch_linearize<6>(h, A) : launch_linearize<9>(h, A);
 }
 
+// Per-launch device timing with HIP events recorded on the engine's stream (no host sync inside the
+// timed region); upr_batch_kernel_times() reads them back after a stream sync.
 struct KernelTimer {
-    upr_batch* h; int slot;
-    KernelTimer(upr_batch* h_, int s) : h(h_), slot(s) { if (h->timing) hipEventRecord(h->ev[0], h->stream); }
-    void stop() {
+    upr_batch* h; int slot; size_t idx;
+    KernelTimer(upr_batch* h_, int s) : h(h_), slot(s), idx(0) {
         if (!h->timing) return;
-        hipEventRecord(h->ev[1], h->stream);
-        hipEventSynchronize(h->ev[1]);
-        float ms = 0; hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-        h->k_ms[slot] += ms; h->k_launches[slot] += 1;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        idx = h->ev_pool.size();
+        h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_slot.push_back(slot);
+        (void)hipEventRecord(a, h->stream);
     }
+    void stop() { if (h->timing) (void)hipEventRecord(h->ev_pool[idx + 1], h->stream); }
 };
 
 int advance_impl(upr_batch* h) {
@@ -311,7 +315,6 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
     auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { fail("hipStreamCreate failed"); return bad(); }
-    for (int i = 0; i < 2; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { fail("hipEventCreate failed"); return bad(); }
     if (hipMalloc((void**)&h->dP, sizeof(upr_problem)) != hipSuccess) { fail("hipMalloc failed"); return bad(); }
     hipMemcpy(h->dP, P, sizeof(upr_problem), hipMemcpyHostToDevice);
     const size_t n1 = d.N + 1;
@@ -349,7 +352,7 @@ void upr_batch_destroy(upr_batch* h) {
     hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
     hipFree(h->done); hipFree(h->has_prev);
-    for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -519,10 +522,35 @@ int upr_batch_enable_timing(upr_batch* h, int on) {
 
 int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches) {
     if (!h) return fail("null batch");
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_slot.size(); ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]) == hipSuccess) { h->k_ms[h->ev_slot[i]] += t; h->k_launches[h->ev_slot[i]] += 1; }
+        (void)hipEventDestroy(h->ev_pool[2 * i]); (void)hipEventDestroy(h->ev_pool[2 * i + 1]);
+    }
+    h->ev_pool.clear(); h->ev_slot.clear();
     for (int i = 0; i < 3; ++i) {
         ms[i] = h->k_launches[i] ? h->k_ms[i] / h->k_launches[i] : 0.0;
         if (launches) launches[i] = h->k_launches[i];
     }
+    return 0;
+}
+
+/* copy the current solution into caller-owned DEVICE buffers (e.g. torch tensors handed to an RCCL
+ * all-gather): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the engine's stream. */
+int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    if (xs_dst) UPR_HIP(hipMemcpyAsync(xs_dst, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
+    if (us_dst) UPR_HIP(hipMemcpyAsync(us_dst, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+/* forget the previous solution without a host synchronisation (cold start for the next advance) */
+int upr_batch_reset_async(upr_batch* h) {
+    if (!h) return fail("null batch");
+    UPR_HIP(hipMemsetAsync(h->has_prev, 0, sizeof(int) * h->B, h->stream));
+    h->guess_set = false;
     return 0;
 }
 

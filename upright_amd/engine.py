@@ -1,0 +1,158 @@
+"""Batched MPC engine: thin Python owner of a `upr_batch` handle (include/upright_mi.h).
+
+One `BatchMPC` = B independent instances of one problem family on the current HIP device.  It is what
+`bindings.ControllerInterface` wraps with B = 1, and what the benchmark / multi-GPU driver shard over
+ranks.  All numerics run in libupright_mi.so; this file only moves arrays across the C-ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, cont, iptr, ptr
+
+
+class BatchMPC:
+    def __init__(self, problem, B=1, body_params=None, way_p=None):
+        self.problem = problem.validate()
+        self.B = int(B)
+        self.nx, self.nu, self.N = problem.nx, problem.nu, problem.N
+        self.ne = 6 * problem.nb
+        if body_params is None:
+            body_params = np.broadcast_to(problem.body_params, (self.B,) + problem.body_params.shape)
+        if way_p is None:
+            way_p = np.broadcast_to(problem.way_p, (self.B,) + problem.way_p.shape)
+        self.body_params = cont(body_params).reshape(self.B, problem.nb, 10)
+        self.way_p = cont(way_p).reshape(self.B, len(problem.way_t), 3)
+        self._c = _capi.problem_to_c(problem)
+        self._lib = _capi.lib()
+        self._h = self._lib.upr_batch_create(C.byref(self._c), self.B, ptr(self.body_params), ptr(self.way_p))
+        if not self._h:
+            raise RuntimeError(self._lib.upr_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.upr_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ControllerInterface surface, batched ------------------------------------------------------
+    def reset(self, way_p=None):
+        if way_p is not None:
+            self.way_p = cont(way_p).reshape(self.B, len(self.problem.way_t), 3)
+        check(self._lib.upr_batch_reset(self._h, ptr(self.way_p) if way_p is not None else None))
+
+    def set_observation(self, t, x):
+        x = cont(x).reshape(self.B, self.nx)
+        t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        check(self._lib.upr_batch_set_observation(self._h, ptr(t), 1, ptr(x)))
+
+    def set_guess(self, xs, us):
+        xs = cont(xs).reshape(self.B, self.N + 1, self.nx)
+        us = cont(us).reshape(self.B, self.N, self.nu)
+        check(self._lib.upr_batch_set_guess(self._h, ptr(xs), ptr(us)))
+
+    def advance(self):
+        check(self._lib.upr_batch_advance(self._h))
+
+    def advance_async(self):
+        check(self._lib.upr_batch_advance_async(self._h))
+
+    def sync(self):
+        check(self._lib.upr_batch_sync(self._h))
+
+    def solution(self):
+        ts = np.zeros((self.B, self.N + 1))
+        xs = np.zeros((self.B, self.N + 1, self.nx))
+        us = np.zeros((self.B, self.N, self.nu))
+        check(self._lib.upr_batch_get_solution(self._h, ptr(ts), ptr(xs), ptr(us)))
+        return ts, xs, us
+
+    def evaluate(self, t):
+        t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        x = np.zeros((self.B, self.nx))
+        u = np.zeros((self.B, self.nu))
+        check(self._lib.upr_batch_evaluate(self._h, ptr(t), 1, ptr(x), ptr(u)))
+        return x, u
+
+    def last_solve_ms(self):
+        return float(self._lib.upr_batch_last_solve_ms(self._h))
+
+    def stats(self):
+        s = np.zeros((self.B, _capi.NSTATS))
+        check(self._lib.upr_batch_get_stats(self._h, ptr(s)))
+        return {name: s[:, i] for i, name in enumerate(_capi.STAT_NAMES)}
+
+    # -- term-level access ----------------------------------------------------------------------------
+    def linearize_points(self, x, u, t=None, inst=None):
+        x = cont(x).reshape(-1, self.nx)
+        n = x.shape[0]
+        u = cont(u).reshape(n, self.nu)
+        t = cont(np.zeros(n) if t is None else np.broadcast_to(np.asarray(t, dtype=np.float64), (n,)))
+        inst = cont(np.zeros(n) if inst is None else inst, dtype=np.int32)
+        nq = self.problem.nq
+        out = dict(
+            g=np.zeros((n, self.ne)), gx=np.zeros((n, self.ne, self.nx)), cost=np.zeros(n),
+            grad=np.zeros((n, nq)), hess=np.zeros((n, nq, nq)), ee=np.zeros((n, 3)),
+        )
+        check(self._lib.upr_batch_linearize_points(
+            self._h, n, iptr(inst), ptr(t), ptr(x), ptr(u), ptr(out["g"]), ptr(out["gx"]), ptr(out["cost"]),
+            ptr(out["grad"]), ptr(out["hess"]), ptr(out["ee"])))
+        return out
+
+    def eq_input_jacobian(self, inst=0):
+        gu = np.zeros((self.ne, self.nu))
+        check(self._lib.upr_batch_eq_input_jacobian(self._h, int(inst), ptr(gu)))
+        return gu
+
+    def qp_step(self):
+        dxs = np.zeros((self.B, self.N + 1, self.nx))
+        dus = np.zeros((self.B, self.N, self.nu))
+        check(self._lib.upr_batch_qp_step(self._h, ptr(dxs), ptr(dus)))
+        return dxs, dus
+
+    def device_ptrs(self):
+        xs, us = C.c_void_p(), C.c_void_p()
+        check(self._lib.upr_batch_device_ptrs(self._h, C.byref(xs), C.byref(us)))
+        return xs.value, us.value
+
+    def copy_solution_device(self, xs_ptr, us_ptr):
+        check(self._lib.upr_batch_copy_solution_device(self._h, C.c_void_p(xs_ptr), C.c_void_p(us_ptr)))
+
+    def reset_async(self):
+        check(self._lib.upr_batch_reset_async(self._h))
+
+    def enable_timing(self, on=True):
+        check(self._lib.upr_batch_enable_timing(self._h, int(on)))
+
+    def kernel_times(self):
+        ms = np.zeros(3)
+        n = np.zeros(3, dtype=np.int32)
+        check(self._lib.upr_batch_kernel_times(self._h, ptr(ms), iptr(n)))
+        return dict(linearize_ms=ms[0], qp_ms=ms[1], linesearch_ms=ms[2], launches=n.tolist())
+
+
+def core_object_dynamics(problem, body_params, forces, Cm, w, al, a):
+    """upright_core.bindings.compute_object_dynamics_constraints, batched over the leading axis."""
+    c = _capi.problem_to_c(problem)
+    forces = cont(forces).reshape(-1, problem.nf * problem.nc)
+    n = forces.shape[0]
+    out = np.zeros((n, 6 * problem.nb))
+    check(_capi.lib().upr_core_object_dynamics(
+        C.byref(c), ptr(cont(body_params).reshape(problem.nb, 10)), n, ptr(forces), ptr(cont(Cm).reshape(n, 9)),
+        ptr(cont(w).reshape(n, 3)), ptr(cont(al).reshape(n, 3)), ptr(cont(a).reshape(n, 3)), ptr(out)))
+    return out
+
+
+def core_friction_rows(problem, forces):
+    c = _capi.problem_to_c(problem)
+    forces = cont(forces).reshape(-1, 3 * problem.nc)
+    n = forces.shape[0]
+    out = np.zeros((n, 5 * problem.nc))
+    check(_capi.lib().upr_core_friction_rows(C.byref(c), n, ptr(forces), ptr(out)))
+    return out
