@@ -176,6 +176,11 @@ int upr_batch_enable_timing(upr_batch* h, int on);
  * engine's stream, follow with upr_batch_sync. */
 int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst);
 
+/* debug / test accessors: per-phase cycle counters of the production QP kernel (first call arms it,
+ * later calls read and clear prof[B][16]); per-knot linearisation records lin[B][N+1][*stride] */
+int upr_batch_qp_profile(upr_batch* h, double* out);
+int upr_batch_get_lin(upr_batch* h, double* lin, int* stride);
+
 /* upr_batch_reset without target change and without host synchronisation */
 int upr_batch_reset_async(upr_batch* h);
 

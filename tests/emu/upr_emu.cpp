@@ -11,6 +11,7 @@
 #include "../../upright_amd/csrc/upr_linearize.h"
 #include "../../upright_amd/csrc/upr_linesearch.h"
 #include "../../upright_amd/csrc/upr_qp.h"
+#include "../../upright_amd/csrc/upr_qp2.h"
 
 template <int NQ>
 static void lin_all(const upr_lin_args& A) {
@@ -23,6 +24,14 @@ static void lin_all(const upr_lin_args& A) {
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase2<NQ>(A, q, l, sh.data());
     }
 }
+
+template <class D>
+static void qp2_all(const upr_qp_args& A, int B) {
+    upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
+    std::vector<double> L(upr_qp2_lds_doubles<D>(A.d.N, 1) + 16);
+    for (int b = 0; b < B; ++b) upr_qp2_solve<D>(ctx, A, b, L.data());
+}
+
 
 extern "C" {
 
@@ -59,10 +68,25 @@ void emu_linearize(const upr_problem* P, int B, const double* body_params, const
 void emu_qp(const upr_problem* P, int B, const double* xs, const double* us, const double* x0, const double* lin,
             const double* Df, double* ws, double* stats) {
     upr_qp_args A;
-    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats;
+    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
     std::vector<double> L(upr_qp_lds_layout(A.d, 1).total + 16);
     for (int b = 0; b < B; ++b) upr_qp_solve(ctx, A, b, L.data());
+}
+
+// production kernel body; returns the per-instance workspace size it needs (doubles) when ws == NULL
+long emu_qp2(const upr_problem* P, int B, const double* xs, const double* us, const double* x0, const double* lin,
+             const double* Df, double* ws, long ws_stride, double* stats) {
+    upr_qp_args A;
+    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
+    if (P->nq == 9 && P->nb == 1 && P->nc == 4 && P->nf == 3) {
+        typedef upr_qp2_dims<9, 1, 4, 3> D;
+        if (!ws) return (long)upr_qp2_ws_doubles<D>(A.d.N, A.d.neN);
+        A.d.ws_stride = (int)ws_stride;
+        qp2_all<D>(A, B);
+        return 0;
+    }
+    return -1;
 }
 
 void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const double* x0, const double* t0,

@@ -15,6 +15,7 @@
 #include "upr_linearize.h"
 #include "upr_linesearch.h"
 #include "upr_qp.h"
+#include "upr_qp2.h"
 
 namespace {
 
@@ -113,9 +114,11 @@ struct upr_batch {
     double *xs = nullptr, *us = nullptr, *xs_prev = nullptr, *us_prev = nullptr, *tprev = nullptr;
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr, *has_prev = nullptr;
+    double* prof = nullptr;
     bool guess_set = false;
     double last_ms = 0.0;
-    int qp_nt = 64;
+    int qp_nt = 128;
+    bool use_qp2 = false;
     bool use_mfma = true;
     bool timing = false;
     double k_ms[3] = {0, 0, 0};
@@ -161,28 +164,60 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     return 0;
 }
 
-int launch_qp(upr_batch* h, const upr_qp_args& A) {
-    const upr_qp_lds lay = upr_qp_lds_layout(A.d, h->qp_nt);
+// generic (runtime-dimension) QP kernel
+int launch_qp_generic(upr_batch* h, const upr_qp_args& A) {
+    const int nt = 64;
+    const upr_qp_lds lay = upr_qp_lds_layout(A.d, nt);
     const size_t lds = (size_t)lay.total * sizeof(double);
     if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
-    switch (h->qp_nt) {
-        case 64:
-            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(upr_qp_kernel<64>, dim3(h->B), dim3(64), lds, h->stream, A);
-            break;
-        case 128:
-            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(upr_qp_kernel<128>, dim3(h->B), dim3(128), lds, h->stream, A);
-            break;
-        case 256:
-            if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(upr_qp_kernel<256>, dim3(h->B), dim3(256), lds, h->stream, A);
-            break;
-        default:
-            return fail("UPR_QP_NT must be 64, 128 or 256");
-    }
+    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(upr_qp_kernel<64>, dim3(h->B), dim3(64), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
+}
+
+template <class D, int NT>
+int launch_qp2_nt(upr_batch* h, const upr_qp_args& A) {
+    const size_t lds = upr_qp2_lds_doubles<D>(A.d.N, NT) * sizeof(double);
+    if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
+    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp2_kernel<D, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((upr_qp2_kernel<D, NT>), dim3(h->B), dim3(NT), lds, h->stream, A);
+    UPR_HIP(hipGetLastError());
+    return 0;
+}
+template <class D>
+int launch_qp2(upr_batch* h, const upr_qp_args& A) {
+    switch (h->qp_nt) {
+        case 64: return launch_qp2_nt<D, 64>(h, A);
+        case 128: return launch_qp2_nt<D, 128>(h, A);
+        case 256: return launch_qp2_nt<D, 256>(h, A);
+        default: return fail("UPR_QP_NT must be 64, 128 or 256");
+    }
+}
+
+// shapes the production kernel is instantiated for: (nq, nb, nc, nf)
+#define UPR_QP2_SHAPES(X) X(9, 1, 4, 3) X(9, 1, 4, 1) X(6, 1, 4, 1) X(6, 1, 4, 3) X(9, 2, 8, 3)
+
+bool qp2_has_shape(const upr_problem& P) {
+#define X(a, b, c, e) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return true;
+    UPR_QP2_SHAPES(X)
+#undef X
+    return false;
+}
+size_t qp2_ws_doubles(const upr_problem& P, const upr_dims& d) {
+#define X(a, b, c, e) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return upr_qp2_ws_doubles<upr_qp2_dims<a, b, c, e>>(d.N, d.neN);
+    UPR_QP2_SHAPES(X)
+#undef X
+    return 0;
+}
+
+int launch_qp(upr_batch* h, const upr_qp_args& A) {
+    if (h->use_qp2) {
+#define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp2<upr_qp2_dims<a, b, c, e>>(h, A);
+        UPR_QP2_SHAPES(X)
+#undef X
+    }
+    return launch_qp_generic(h, A);
 }
 
 template <int NQ>
@@ -202,7 +237,7 @@ upr_lin_args traj_lin_args(upr_batch* h) {
 }
 upr_qp_args make_qp_args(upr_batch* h) {
     upr_qp_args A;
-    A.P = h->dP; A.d = h->d; A.xs = h->xs; A.us = h->us; A.x0 = h->x0; A.lin = h->lin; A.Df = h->Df; A.ws = h->ws; A.stats = h->stats;
+    A.P = h->dP; A.d = h->d; A.xs = h->xs; A.us = h->us; A.x0 = h->x0; A.lin = h->lin; A.Df = h->Df; A.ws = h->ws; A.stats = h->stats; A.prof = h->prof;
     return A;
 }
 
@@ -312,6 +347,12 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
     if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
+    h->use_qp2 = qp2_has_shape(*P);
+    if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) h->use_qp2 = false; }
+    {   // both QP kernels index the instance workspace with the same stride
+        size_t need = qp2_ws_doubles(*P, h->d);
+        if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;
+    }
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
     auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { fail("hipStreamCreate failed"); return bad(); }
@@ -351,7 +392,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (!h) return;
     hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->has_prev);
+    hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -510,6 +551,25 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
     if (!h) return fail("null batch");
     if (xs) *xs = h->xs;
     if (us) *us = h->us;
+    return 0;
+}
+
+/* debug: per-phase cycle counters of the production QP kernel, prof[B][16]; allocate on first use */
+int upr_batch_qp_profile(upr_batch* h, double* out) {
+    if (!h) return fail("null batch");
+    if (!h->prof) { if (dev_alloc(&h->prof, (size_t)h->B * 16)) return 1; return 0; }
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    if (out) UPR_HIP(hipMemcpy(out, h->prof, sizeof(double) * h->B * 16, hipMemcpyDeviceToHost));
+    UPR_HIP(hipMemset(h->prof, 0, sizeof(double) * h->B * 16));
+    return 0;
+}
+
+/* debug / test accessor: the per-knot linearisation records of the current trajectory, lin[B][N+1][stride] */
+int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
+    if (!h) return fail("null batch");
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    if (stride) *stride = h->d.lin_stride;
+    if (lin) UPR_HIP(hipMemcpy(lin, h->lin, sizeof(double) * h->B * (h->d.N + 1) * h->d.lin_stride, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -16,12 +16,16 @@
 #define UPR_HD
 #define UPR_D
 #define UPR_SYNC() ((void)0)
+#define UPR_WSYNC() ((void)0)
 struct upr_ctx { int tid; int nt; };
 #else
 #include <hip/hip_runtime.h>
 #define UPR_HD __host__ __device__
 #define UPR_D __device__ __forceinline__
 #define UPR_SYNC() __syncthreads()
+// wave-level ordering point: LDS operations of one wave are executed in program order, so only the
+// compiler has to be kept from moving code across it
+#define UPR_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 struct upr_ctx { int tid; int nt; };
 #endif
 

@@ -37,6 +37,7 @@ struct upr_qp_args {
     const double* Df;    // [B][ne][nfc] constant d(object_dynamics)/d(forces)
     double* ws;          // [B][ws_stride]
     double* stats;       // [B][UPR_NSTATS]
+    double* prof;        // optional [B][16] per-phase cycle counters (debug), NULL = off
 };
 
 // LDS layout (doubles)

@@ -127,6 +127,19 @@ class BatchMPC:
     def reset_async(self):
         check(self._lib.upr_batch_reset_async(self._h))
 
+    def qp_profile(self):
+        """Debug: arm (first call) / read-and-clear the per-phase cycle counters of the QP kernel."""
+        out = np.zeros((self.B, 16))
+        check(self._lib.upr_batch_qp_profile(self._h, ptr(out)))
+        return out
+
+    def lin_records(self):
+        stride = C.c_int(0)
+        check(self._lib.upr_batch_get_lin(self._h, None, C.byref(stride)))
+        lin = np.zeros((self.B, self.N + 1, stride.value))
+        check(self._lib.upr_batch_get_lin(self._h, ptr(lin), C.byref(stride)))
+        return lin
+
     def enable_timing(self, on=True):
         check(self._lib.upr_batch_enable_timing(self._h, int(on)))
 
