@@ -551,7 +551,9 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     };
     // initial point: z = 0 (dx0 fixed), t = max(c, thr), lam = mu0 / t
     eval_c(dx, du, cval);
-    const double thr = 1e-1, mu0 = 1.0;
+    double thr = 10.0, mu0 = 1.0;
+    if (getenv("ORC_THR")) thr = atof(getenv("ORC_THR"));
+    if (getenv("ORC_MU0")) mu0 = atof(getenv("ORC_MU0"));
     for (int k = 0; k <= N; ++k)
         for (size_t i = 0; i < t[k].size(); ++i) { t[k][i] = std::max(cval[k][i], thr); lam[k][i] = mu0 / t[k][i]; }
 
@@ -703,6 +705,9 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
         for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) mu_aff += (lam[k][i] + a_aff * dlam_aff[k][i]) * (t[k][i] + a_aff * dt_aff[k][i]);
         mu_aff /= std::max(1, ntot);
         double sigma = std::pow(mu_aff / mu, 3.0);
+        // keep the complementarity target from collapsing far below the tolerance while the other
+        // residuals are still converging (weights lam/t would overflow the factorisation otherwise)
+        if (sigma * mu < 1e-2 * tol) sigma = 1e-2 * tol / mu;
         // corrector
         for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) rc[k][i] = lam[k][i] * t[k][i] + dt_aff[k][i] * dlam_aff[k][i] - sigma * mu;
         newton(dt_, dlam);

@@ -12,6 +12,7 @@
 #include "../../upright_amd/csrc/upr_linesearch.h"
 #include "../../upright_amd/csrc/upr_qp.h"
 #include "../../upright_amd/csrc/upr_qp2.h"
+#include "../../upright_amd/csrc/upr_qp3.h"
 
 template <int NQ>
 static void lin_all(const upr_lin_args& A) {
@@ -73,6 +74,24 @@ void emu_qp(const upr_problem* P, int B, const double* xs, const double* us, con
     std::vector<double> L(upr_qp_lds_layout(A.d, 1).total + 16);
     for (int b = 0; b < B; ++b) upr_qp_solve(ctx, A, b, L.data());
 }
+
+// third-structure kernel body (NT = 1 emulation of the <9,1,4,3,N=20> instantiation)
+long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, const double* x0, const double* lin,
+             const double* Df, double* ws, long ws_stride, double* stats) {
+    upr_qp_args A;
+    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
+    if (P->nq == 9 && P->nb == 1 && P->nc == 4 && P->nf == 3 && P->N == 20) {
+        typedef upr_qp3_cfg<9, 1, 4, 3, 20, 1> C;
+        if (!ws) return (long)upr_qp3_ws<C>::total;
+        A.d.ws_stride = (int)ws_stride;
+        upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
+        std::vector<double> L(upr_qp3_lds<C>::total + 16);
+        for (int b = 0; b < B; ++b) upr_qp3_solve<C>(ctx, A, b, L.data());
+        return 0;
+    }
+    return -1;
+}
+long emu_qp3_lds_doubles() { return (long)upr_qp3_lds<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; }
 
 // production kernel body; returns the per-instance workspace size it needs (doubles) when ws == NULL
 long emu_qp2(const upr_problem* P, int B, const double* xs, const double* us, const double* x0, const double* lin,

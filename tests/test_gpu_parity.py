@@ -89,9 +89,8 @@ def _oracle_solve(P, way, x0, xs0, us0):
 
 
 def test_qp_step_fixed_iterations(arrangements):
-    """Same iterate path: both solvers run exactly 10 IPM iterations (tol = 0), so the steps must agree
-    to round-off amplified by the barrier conditioning -- this is the check that catches indexing bugs
-    and races in the QP kernel."""
+    """Same iterate path: both solvers run exactly 10 IPM iterations (tol = 0) and must stay on the same
+    path (the sharp race / indexing screen is test_qp_kernel_vs_host_emulation)."""
     B = 4
     P, x0, way = _setup(arrangements, B, seed=11, qp_tol=0.0, qp_iter_max=10)
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
@@ -104,10 +103,49 @@ def test_qp_step_fixed_iterations(arrangements):
     for b in range(B):
         P.way_p = way[b]
         dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
-        assert np.abs(dxs[b] - dxo).max() < 1e-9 * max(1, np.abs(dxo).max())
-        assert np.abs(dus[b] - duo).max() < 1e-9 * max(1, np.abs(duo).max())
+        # 1e-11 differences of the linearisation (FMA contraction, sin/cos) are amplified by the QP
+        # conditioning (terminal penalty 1e6 against 1e-4 weights): measured 2e-6 .. 2e-5 after 10 iterations
+        assert np.abs(dxs[b] - dxo).max() < 1e-4 * max(1, np.abs(dxo).max())
+        assert np.abs(dus[b] - duo).max() < 1e-4 * max(1, np.abs(duo).max())
         for i, key in enumerate(("qp_res_stat", "qp_res_eq", "qp_res_ineq", "qp_res_comp")):
-            assert abs(st[key][b] - so.qp_res[i]) < 1e-6 * max(so.qp_res[i], 1e-9) + 1e-12
+            assert abs(st[key][b] - so.qp_res[i]) < 1e-3 * max(so.qp_res[i], 1e-9) + 1e-10
+    mpc.close()
+
+
+@pytest.mark.parametrize("kernel,nt", [("1", "64"), ("2", "128"), ("3", "128"), ("3", "256"), ("3", "512")])
+def test_qp_kernel_vs_host_emulation(arrangements, kernel, nt, monkeypatch):
+    """Race / indexing screen: the SAME kernel source compiled for the host (tests/emu, one thread per
+    workgroup) is fed the GPU's own linearisation records, so any difference beyond summation order is
+    a synchronisation or indexing defect of the GPU execution.  Fixed 8 IPM iterations (tol = 0)."""
+    import ctypes as C
+    from pathlib import Path
+    from upright_amd import _capi
+
+    monkeypatch.setenv("UPR_QP_KERNEL", kernel)
+    monkeypatch.setenv("UPR_QP_NT", nt)
+    B = 6
+    P, x0, way = _setup(arrangements, B, seed=13, qp_tol=0.0, qp_iter_max=8)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    lin = mpc.lin_records()
+    E = C.CDLL(str(Path(__file__).resolve().parent / "emu" / "libupr_emu.so"))
+    E.emu_qp3.restype = C.c_long
+    cp = _capi.problem_to_c(P)
+    need = E.emu_qp3(C.byref(cp), B, None, None, None, None, None, None, C.c_long(0), None)
+    ws = np.zeros((B, need)); stats = np.zeros((B, 12))
+    bp = np.ascontiguousarray(np.broadcast_to(P.body_params, (B,) + P.body_params.shape))
+    Df = np.zeros((B, 6 * P.nb, P.nf * P.nc))
+    E.emu_make_Df(C.byref(cp), B, _capi.ptr(bp), _capi.ptr(Df))
+    xs0 = np.ascontiguousarray(xs0); us0 = np.ascontiguousarray(us0)
+    assert E.emu_qp3(C.byref(cp), B, _capi.ptr(xs0), _capi.ptr(us0), _capi.ptr(x0), _capi.ptr(lin), _capi.ptr(Df),
+                     _capi.ptr(ws), C.c_long(need), _capi.ptr(stats)) == 0
+    n1 = P.N + 1
+    dxe = ws[:, :n1 * P.nx].reshape(B, n1, P.nx); due = ws[:, n1 * P.nx:n1 * P.nx + P.N * P.nu].reshape(B, P.N, P.nu)
+    assert np.abs(dxs - dxe).max() < 1e-9 * max(1.0, np.abs(dxe).max())
+    assert np.abs(dus - due).max() < 1e-9 * max(1.0, np.abs(due).max())
     mpc.close()
 
 
@@ -135,9 +173,10 @@ def test_qp_step_converged(arrangements):
     mpc.close()
 
 
-@pytest.mark.parametrize("nt", ["64", "128", "256"])
-def test_mpc_solve_one_iteration(arrangements, nt, monkeypatch):
-    """advanceMpc with sqp_iteration = 1 (controller.yaml:56): GPU vs oracle, every workgroup size."""
+@pytest.mark.parametrize("kernel,nt", [("1", "64"), ("2", "256"), ("3", "128"), ("3", "512")])
+def test_mpc_solve_one_iteration(arrangements, kernel, nt, monkeypatch):
+    """advanceMpc with sqp_iteration = 1 (controller.yaml:56): GPU vs oracle, every QP kernel structure."""
+    monkeypatch.setenv("UPR_QP_KERNEL", kernel)
     monkeypatch.setenv("UPR_QP_NT", nt)
     B = 8
     P, x0, way = _setup(arrangements, B, seed=21)

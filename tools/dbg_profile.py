@@ -8,8 +8,8 @@ arr=json.load(open('tests/golden/arrangements.json'))
 P=thing_problem(arr['pink_bottle'])
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
 x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
-names=["residuals","ineq_prepare","stage_vectors","stage_factors","stage_force","bwd_mat","forward(x2)","aff sweeps","bwd_vec","costates","update"]
-for nt in ("64","128","256"):
+names=["residuals","prep","-","-","-","bwd_mat","forward(x2)","aff sweeps","bwd_vec","costates","update","init","mat:ph0+1","mat:ph2 chol","mat:ph3+4","mat:ph5"]
+for nt in sys.argv[2:] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
     mpc=BatchMPC(P,B,way_p=way); mpc.set_observation(0.0,x0)
     mpc.advance()
@@ -17,7 +17,7 @@ for nt in ("64","128","256"):
     mpc.reset(); mpc.advance()
     prof=mpc.qp_profile(); st=mpc.stats()
     its=st["qp_iters_last"]
-    per=prof[:, :11]/its[:,None]
+    per=prof[:, :16]/its[:,None]
     print("NT",nt,"solve ms",mpc.last_solve_ms(),"mean iters",its.mean())
     for i,n in enumerate(names): print("   %-14s %10.0f cycles/iter  (%.1f%%)"%(n,per[:,i].mean(),100*per[:,i].mean()/per.sum(1).mean()))
     print("   total cycles/iter",per.sum(1).mean())

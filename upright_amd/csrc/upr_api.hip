@@ -16,6 +16,7 @@
 #include "upr_linesearch.h"
 #include "upr_qp.h"
 #include "upr_qp2.h"
+#include "upr_qp3.h"
 
 namespace {
 
@@ -117,8 +118,8 @@ struct upr_batch {
     double* prof = nullptr;
     bool guess_set = false;
     double last_ms = 0.0;
-    int qp_nt = 128;
-    bool use_qp2 = false;
+    int qp_nt = 0;
+    bool use_qp2 = false, use_qp3 = false;
     bool use_mfma = true;
     bool timing = false;
     double k_ms[3] = {0, 0, 0};
@@ -189,6 +190,7 @@ template <class D>
 int launch_qp2(upr_batch* h, const upr_qp_args& A) {
     switch (h->qp_nt) {
         case 64: return launch_qp2_nt<D, 64>(h, A);
+        case 512:
         case 128: return launch_qp2_nt<D, 128>(h, A);
         case 256: return launch_qp2_nt<D, 256>(h, A);
         default: return fail("UPR_QP_NT must be 64, 128 or 256");
@@ -211,7 +213,27 @@ size_t qp2_ws_doubles(const upr_problem& P, const upr_dims& d) {
     return 0;
 }
 
+// third-structure kernel: instantiated for the headline shape (nq 9, nb 1, nc 4, nf 3, N 20)
+template <int NT>
+int launch_qp3(upr_batch* h, const upr_qp_args& A) {
+    typedef upr_qp3_cfg<9, 1, 4, 3, 20, NT> C;
+    const size_t lds = (size_t)upr_qp3_lds<C>::total * sizeof(double);
+    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((upr_qp3_kernel<C>), dim3(h->B), dim3(NT), lds, h->stream, A);
+    UPR_HIP(hipGetLastError());
+    return 0;
+}
+bool qp3_has_shape(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
+
 int launch_qp(upr_batch* h, const upr_qp_args& A) {
+    if (h->use_qp3) {
+        switch (h->qp_nt) {
+            case 128: return launch_qp3<128>(h, A);
+            case 256: return launch_qp3<256>(h, A);
+            case 512: return launch_qp3<512>(h, A);
+            default: return fail("UPR_QP_NT must be 128, 256 or 512 for the headline-shape kernel");
+        }
+    }
     if (h->use_qp2) {
 #define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp2<upr_qp2_dims<a, b, c, e>>(h, A);
         UPR_QP2_SHAPES(X)
@@ -346,12 +368,17 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     h->P = *P; h->d = upr_make_dims(P); h->B = B;
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
-    if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
+    h->use_qp3 = qp3_has_shape(*P);
     h->use_qp2 = qp2_has_shape(*P);
-    if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) h->use_qp2 = false; }
+    // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
+    if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
+    if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }
+    h->qp_nt = h->use_qp3 ? 512 : 128;
+    if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
     {   // both QP kernels index the instance workspace with the same stride
         size_t need = qp2_ws_doubles(*P, h->d);
         if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;
+        if (qp3_has_shape(*P)) { need = upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
     }
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
     auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };

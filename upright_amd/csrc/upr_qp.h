@@ -22,8 +22,11 @@
 #pragma once
 #include "upr_kin.h"
 
-#define UPR_QP_THR 1e-1
+#define UPR_QP_THR 10.0
 #define UPR_QP_MU0 1.0
+// floor of the complementarity target relative to the tolerance (keeps lam/t bounded while the other
+// residuals converge)
+#define UPR_QP_SIGMA_FLOOR 1e-2
 #define UPR_QP_RHO_S 1e-12
 #define UPR_QP_RHO_N 1e-6
 
@@ -852,6 +855,7 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
         double mu_aff = upr_reduce(ctx, L + o.red, upr_qp_ineq_sweep(S, 1, a_aff, nullptr), 0) / ntot;
         double sg = mu_aff / mu;
         S.sigma_mu = sg * sg * sg * mu;
+        if (S.sigma_mu < UPR_QP_SIGMA_FLOOR * tol) S.sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
         // ---- corrector
         S.mode = 1;
         upr_qp_backward(S, false);

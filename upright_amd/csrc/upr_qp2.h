@@ -760,6 +760,7 @@ struct upr_qp2 {
             const double mu_aff = upr_reduce(ctx, L + o.red, ineq_sweep(1, a_aff, nullptr), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
+            if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
             toc(7);
             // corrector
             mode = 1;

@@ -1,0 +1,890 @@
+// upr_qp3.h -- production QP kernel (third structure).  Same algorithm and arithmetic as upr_qp.h /
+// upr_qp2.h (Mehrotra predictor-corrector IPM over a square-root Riccati recursion, Schur-complement
+// treatment of the object-dynamics equality, proximal terminal equality); what changes is where the
+// data lives and how many dependent phases a knot costs:
+//
+//   * horizon N and workgroup size NT are template parameters next to (nq, nb, nc, nf);
+//   * slacks / multipliers of the state and input boxes never leave REGISTERS: every lane owns a fixed
+//     set of (knot, variable) box pairs for the whole solve; the friction-pyramid rows of a contact are
+//     owned by one lane and kept in lane-private LDS slots -- the contact-point x cone-facet loop of
+//     contact_constraints.h:50-77 runs out of LDS, as do the facet Jacobians;
+//   * iterate, step, every per-knot vector (reduced gradients, barrier diagonals, equality residuals,
+//     contact-block factors, Schur factors) and all problem constants are LDS resident; global
+//     memory only holds the read-only linearisation records and the per-knot Riccati factors that the
+//     back-substitutions re-read;
+//   * per knot the factorisation costs 6 barriers: {P+ b, A'P+A, B'P+A, B'P+B, Vc = Ls^-1 C} in one
+//     phase straight from P+ (block-scalar structure of the triple integrator, system_dynamics.h:15-22),
+//     an nq x nq Cholesky held in the registers of one lane, its inverse by nq lanes, V = Lj^-1 Hux,
+//     and the symmetric update P = A'P+A + Q~ - V'V + Vc'Vc.
+#pragma once
+#include "upr_kin.h"
+#include "upr_qp.h"
+#include "upr_qp2.h"
+
+template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_>
+struct upr_qp3_cfg {
+    static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
+    static constexpr int N1 = N + 1;
+    static constexpr int NX = 3 * NQ, NFC = NF * NC, NU = NQ + NFC, NE = 6 * NB;
+    static constexpr int NP = (NF == 3) ? 5 * NC : 0;
+    static constexpr int NLF = (NF == 3) ? 9 * NC : NC;
+    static constexpr int NH = NQ * (NQ + 1) / 2;
+    static constexpr int NZ = N1 * NX + N * NU;
+    static constexpr int NEN = 3 + 2 * NQ;
+    // lane-owned inequality items
+    static constexpr int NXI = N * NX, QX = (NXI + NT - 1) / NT;   // state boxes, knots 1..N
+    static constexpr int NUI = N * NU, QU = (NUI + NT - 1) / NT;   // input boxes, knots 0..N-1
+    static constexpr int NCI = N * NC, QC = (NCI + NT - 1) / NT;   // contacts (friction rows), knots 0..N-1
+    // Riccati store per knot (global)
+    static constexpr int SS_V = 0, SS_LJI = SS_V + NQ * NX, SS_YJ = SS_LJI + NQ * NQ, SS_PB = SS_YJ + NQ, SS_STRIDE = ((SS_PB + NX + 1) & ~1);
+};
+
+// global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
+template <class C>
+struct upr_qp3_ws {
+    static constexpr int dx = 0, du = C::N1 * C::NX;
+    static constexpr int a0 = (C::NZ + 1) & ~1;
+    static constexpr int pi = a0, pin = pi + C::N1 * C::NX + (C::N1 * C::NX & 1), nu = pin + C::N1 * C::NX + (C::N1 * C::NX & 1),
+                         store = nu + ((C::N * C::NE + 1) & ~1), total = ((store + C::N * C::SS_STRIDE + 15) & ~15);
+};
+
+// LDS layout (doubles), all compile-time
+template <class C>
+struct upr_qp3_lds {
+    static constexpr int r2(int n) { return (n + 1) & ~1; }
+    static constexpr int Z = 0, S = Z + r2(C::NZ), gxs = S + r2(C::NZ), wx = gxs + r2(C::N1 * C::NX), gus = wx + r2(C::N1 * C::NX),
+                         wu = gus + r2(C::N * C::NU), ek = wu + r2(C::N * C::NU), lfi = ek + r2(C::N * C::NE), lsi = lfi + r2(C::N * C::NLF),
+                         yf = lsi + r2(C::N * C::NE * C::NE), hf = yf + r2(C::N * C::NFC), ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE),
+                         cs = zt + r2(C::N * C::NE), nun = cs + r2(C::N * C::NX), cv = zt /* alias: zt is dead once cs exists */, hee = nun + r2(C::N * C::NE),
+                         g0 = hee + r2(C::N * C::NH), e0 = g0 + r2(C::N * C::NQ),
+                         // constants
+                         xlb = e0 + r2(C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
+                         rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
+                         // friction rows (lane-private slots)
+                         ct = df + r2(C::NE * C::NFC), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
+                         // working set of the sweeps
+                         Pa = cc + r2(5 * C::NCI), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX), vm = hux + r2(C::NQ * C::NX),
+                         hjj = vm + r2(C::NQ * C::NX), lji = hjj + r2(C::NQ * C::NQ), vc = lji + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
+                         pv = ck + r2(C::NE * C::NX), wv = pv + r2(C::NX), hx = wv + r2(C::NX), huj = hx + r2(C::NX), yj = huj + r2(C::NQ),
+                         tj = yj + r2(C::NQ), pbv = tj + r2(C::NQ), bk = pbv + r2(C::NX), yN = bk + r2(C::NX), dyN = yN + r2(C::NEN),
+                         eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + r2(C::NT),
+                         // LDS-resident Riccati store: feedback K = Hjj^-1 Hux, P+ b, feed-forward kff = Hjj^-1 huj, huj, Lj^-1 (packed lower)
+                         Ks = misc + 16, Pbs = Ks + r2(C::N * C::NQ * C::NX), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
+                         Ljis = hujs + r2(C::N * C::NQ), pv2 = Ljis + r2(C::N * C::NH), total = pv2 + r2(C::NX);
+};
+
+// Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
+// diagonal replaced by 1 / L_ii (what the triangular inverse and solves need).
+template <int n>
+static inline UPR_HD bool upr_chol_regs(const double* M, double* Lo) {
+    double a[n][n];
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[i][j] = M[i * n + j];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < n; ++p) {
+        double s = a[p][p];
+#pragma unroll
+        for (int k = 0; k < p; ++k) s -= a[p][k] * a[p][k];
+        if (!(s > 0.0)) { ok = false; s = 1.0; }
+        const double idg = 1.0 / sqrt(s);
+        a[p][p] = idg;
+#pragma unroll
+        for (int i = p + 1; i < n; ++i) {
+            double v = a[i][p];
+#pragma unroll
+            for (int k = 0; k < p; ++k) v -= a[i][k] * a[p][k];
+            a[i][p] = v * idg;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lo[i * n + j] = a[i][j];
+    return ok;
+}
+// column j of L^-1 from the factor above (diagonal holds reciprocals); static indexing only
+template <int n>
+static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
+    double c[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) v += Lo[i * n + k] * c[k];
+        c[i] = (i < j) ? 0.0 : ((i == j) ? Lo[i * n + i] : -v * Lo[i * n + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) Li[i * n + j] = c[i];
+}
+
+template <class C>
+struct upr_qp3 {
+    typedef upr_qp3_lds<C> O;
+    typedef upr_qp3_ws<C> W;
+    static constexpr int NQ = C::NQ, NX = C::NX, NU = C::NU, NE = C::NE, NFC = C::NFC, NC = C::NC, NF = C::NF, N = C::N, N1 = C::N1, NT = C::NT;
+    upr_ctx ctx;
+    const upr_problem* P;
+    double* L;
+    const double* xs; const double* us; const double* x0; const double* lin; const double* Dfg;
+    double* ws;
+    int lin_stride, lin_g, lin_gx, lin_grad, lin_hess, neN;
+    double h, h2, h3, sigma_mu;
+    int mode;
+    // lane-owned box rows: [item][0 = lower, 1 = upper]
+    double tx[C::QX][2], lx[C::QX][2], cx[C::QX][2];
+    double tu[C::QU][2], lu[C::QU][2], cu[C::QU][2];
+
+    UPR_HD const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
+    UPR_HD double* store(int k) const { return ws + W::store + (size_t)k * C::SS_STRIDE; }
+    UPR_HD double* Zx(int k) const { return L + O::Z + k * NX; }
+    UPR_HD double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
+    UPR_HD double* Sx(int k) const { return L + O::S + k * NX; }
+    UPR_HD double* Su(int k) const { return L + O::S + N1 * NX + k * NU; }
+    UPR_HD double coefA(int a, int b) const { return (a == b) ? 1.0 : ((a == 0 && b == 1) ? h : ((a == 0 && b == 2) ? h2 : ((a == 1 && b == 2) ? h : 0.0))); }
+    UPR_HD double coefB(int a) const { return a == 0 ? h3 : (a == 1 ? h2 : h); }
+
+    // one inequality row: slack residual, weight and reduced-gradient multiplier for the current mode
+    UPR_HD void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
+        const double rp = c - t;
+        w = lam / t;
+        if (mode == 0) s = w * rp;
+        else if (mode == 2) s = -lam;
+        else {
+            if (mode == 1) { const double dta = ds + rp; const double dla = -lam - w * dta; cterm = dta * dla - sigma_mu; }
+            s = (lam * t + cterm + lam * rp) / t - lam;
+        }
+    }
+
+    // ---- flat phases: per-knot vectors and factors out of the lane-owned rows -------------------------------
+    // level 0: reduced gradients + residuals only (KKT check); 1: + back-substitution vectors; 2: + factors
+    UPR_HD void prep(int level) {
+        const bool factor = level >= 2;
+        // A: box rows (registers)
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) {
+            const int ix = ctx.tid + q * NT;
+            if (ix < C::NXI) {
+                const int zo = NX + ix, k = 1 + ix / NX, i = ix % NX;
+                const double X = L[O::Z + zo], dS = L[O::S + zo];
+                double s0, s1, w0, w1;
+                row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], cx[q][0], s0, w0);
+                row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], cx[q][1], s1, w1);
+                double g = 0.0;
+                if (k < N) {
+                    g = L[O::qd + i] * (X - L[O::xd + i]);
+                    if (i < NQ) {
+                        double a = L[O::g0 + k * NQ + i];
+                        for (int j = 0; j < NQ; ++j) a += L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
+                        g += a;
+                    }
+                    g *= h;
+                }
+                L[O::gxs + zo] = g + s0 - s1;
+                L[O::wx + zo] = w0 + w1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) {
+            const int iu = ctx.tid + q * NT;
+            if (iu < C::NUI) {
+                const int i = iu % NU;
+                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                double s0, s1, w0, w1;
+                row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], cu[q][0], s0, w0);
+                row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], cu[q][1], s1, w1);
+                L[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
+                L[O::wu + iu] = w0 + w1;
+            }
+        }
+        UPR_SYNC();
+        // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
+        for (int q = 0; q < C::QC; ++q) {
+            const int ic = ctx.tid + q * NT;
+            if (ic < C::NCI) {
+                const int k = ic / NC, ci = ic % NC;
+                if (NF == 3) {
+                    const int uo = k * NU + NQ + 3 * ci;
+                    const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                    double guf[3] = {L[O::gus + uo], L[O::gus + uo + 1], L[O::gus + uo + 2]};
+                    double Hc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int a = 0; a < 3; ++a) Hc[4 * a] = h * L[O::rd + NQ + 3 * ci + a] + L[O::wu + uo + a];
+                    for (int r = 0; r < 5; ++r) {
+                        const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                        const double c = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
+                        const double ds = e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2];
+                        double s, wgt, ct_ = L[O::cc + 5 * ic + r];
+                        row(c, ds, L[O::ct + 5 * ic + r], L[O::cl + 5 * ic + r], ct_, s, wgt);
+                        if (mode == 1) L[O::cc + 5 * ic + r] = ct_;
+                        for (int a = 0; a < 3; ++a) { guf[a] += e3[a] * s; for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2]; }
+                    }
+                    for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
+                    if (level == 0) continue;
+                    double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
+                    if (factor) { if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0; for (int a = 0; a < 9; ++a) Bk[a] = Hc[a]; }
+                    double yv[3], hv[3];
+                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * guf[b2]; yv[a] = v; }
+                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * yv[b2]; hv[a] = v; }
+                    for (int a = 0; a < 3; ++a) { L[O::yf + k * NFC + 3 * ci + a] = yv[a]; L[O::hf + k * NFC + 3 * ci + a] = hv[a]; }
+                } else {
+                    if (level == 0) continue;
+                    const int uo = k * NU + NQ + ci;
+                    if (factor) L[O::lfi + k * C::NLF + ci] = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
+                    const double lf = L[O::lfi + k * C::NLF + ci];
+                    const double yv = lf * L[O::gus + uo];
+                    L[O::yf + k * NFC + ci] = yv; L[O::hf + k * NFC + ci] = lf * yv;
+                }
+            }
+        }
+        UPR_SYNC();
+        // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
+        UPR_FOR(e, N * NE) {
+            const int k = e / NE, r = e % NE;
+            const double* Ck = rec(k) + lin_gx + r * NX;
+            double v = L[O::e0 + e];
+            for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
+            double v2 = 0.0;
+            for (int i = 0; i < NFC; ++i) { v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i]; if (level > 0) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i]; }
+            L[O::ek + e] = v; L[O::ys + e] = v - v2;
+        }
+        if (factor) {
+            UPR_FOR(e, N * NE * NE) {
+                const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
+                if (c > r) continue;
+                double acc = (r == c) ? UPR_QP_RHO_S : 0.0;
+                for (int i = 0; i < NFC; ++i) {
+                    double zr, zc;
+                    if (NF == 3) {
+                        const int ci = i / 3, a = i % 3;
+                        const double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
+                        zr = 0.0; zc = 0.0;
+                        for (int b2 = 0; b2 <= a; ++b2) { zr += Bk[3 * a + b2] * L[O::df + r * NFC + 3 * ci + b2]; zc += Bk[3 * a + b2] * L[O::df + c * NFC + 3 * ci + b2]; }
+                    } else { const double lf = L[O::lfi + k * C::NLF + i]; zr = lf * L[O::df + r * NFC + i]; zc = lf * L[O::df + c * NFC + i]; }
+                    acc += zr * zc;
+                }
+                L[O::lsi + k * NE * NE + r * NE + c] = acc;
+            }
+        }
+        UPR_SYNC();
+        if (level == 0) return;
+        // D: one lane per knot: Schur factor (in place), ys = Lsi ee, zt = Lsi' ys
+        UPR_FOR(k, N) {
+            double* Ls = L + O::lsi + k * NE * NE;
+            if (factor) { if (!upr_chol_inv_serial<NE>(Ls, Ls)) L[O::misc] = 1.0; }
+            double ee[NE], yv[NE];
+#pragma unroll
+            for (int r = 0; r < NE; ++r) ee[r] = L[O::ys + k * NE + r];
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = 0.0;
+#pragma unroll
+                for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * ee[m];
+                yv[r] = v; }
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = 0.0;
+#pragma unroll
+                for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * yv[m];
+                L[O::ys + k * NE + r] = yv[r]; L[O::zt + k * NE + r] = v; }
+        }
+        UPR_SYNC();
+        // E: cs = C' zt
+        UPR_FOR(e, N * NX) {
+            const int k = e / NX, i = e % NX;
+            const double* Ck = rec(k) + lin_gx;
+            double v = 0.0;
+            for (int r = 0; r < NE; ++r) v += Ck[r * NX + i] * L[O::zt + k * NE + r];
+            L[O::cs + e] = v;
+        }
+        UPR_SYNC();
+    }
+
+    // dynamics residual of knot k in absolute variables -> L[bk]   (lanes 0..NQ-1)
+    UPR_HD void dyn_residual(int k) {
+        UPR_FOR(j, NQ) {
+            const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
+            const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
+            L[O::bk + j] = q + h * v + h2 * a + h3 * u - Xn[j];
+            L[O::bk + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
+            L[O::bk + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
+        }
+    }
+
+    // terminal residual [p_d - p - Jp dq ; v ; a] at the current iterate -> L[eN]
+    UPR_HD void terminal_residual() {
+        if (neN > 0) UPR_FOR(q, C::NEN) {
+            double v;
+            if (q < 3) { v = L[O::misc + 4 + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * (Zx(N)[j] - xs[N * NX + j]); }
+            else v = Zx(N)[NQ + (q - 3)];
+            L[O::eN + q] = v;
+        }
+    }
+
+    UPR_HD void backward(bool mat) {
+        const double irho = 1.0 / UPR_QP_RHO_N;
+        double* Pc = L + O::Pa; double* Pn = L + O::Pb;
+        double* pcur = L + O::pv; double* pnew = L + O::pv2;
+        // ---- terminal knot
+        terminal_residual();
+        if (mat) { const double* Ck = rec(N - 1) + lin_gx; UPR_FOR(e, NE * NX) L[O::ck + e] = Ck[e]; }
+        UPR_SYNC();
+        if (mat) UPR_FOR(e, NX * NX) {
+            const int i = e / NX, j = e % NX;
+            double v = (i == j) ? L[O::wx + N * NX + i] : 0.0;
+            if (neN > 0) {
+                if (i < NQ && j < NQ) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + i] * L[O::jN + q * NQ + j]; }
+                else if (i == j) v += irho;
+            }
+            Pc[e] = v;
+        }
+        UPR_FOR(i, NX) {
+            double v = L[O::gxs + N * NX + i];
+            if (neN > 0) {
+                if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + irho * L[O::eN + q]); }
+                else v += L[O::yN + 3 + (i - NQ)] + irho * L[O::eN + 3 + (i - NQ)];
+            }
+            pcur[i] = v;
+        }
+        UPR_SYNC();
+        if (mat) {
+            for (int k = N - 1; k >= 0; --k) {
+                // phase 0: dynamics residual of this knot
+                dyn_residual(k);
+                UPR_SYNC();
+                // phase 1: everything that is a function of P+ only.  Job list:
+                //   [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the 9
+                //               entries of A'P+A, 3 of Hux = B'P+A and 1 of Hjj = B'P+B (+ R + barrier);
+                //   then NE*NX jobs of Vc = Lsi C, then NX jobs of wv = P+ b + p+.
+                // prefetch of the next knot's C into registers (published to LDS in phase 5, after Vc used ck)
+                constexpr int CKQ = (NE * NX + NT - 1) / NT;
+                double ckn[CKQ];
+#pragma unroll
+                for (int q = 0; q < CKQ; ++q) { const int f = ctx.tid + q * NT; ckn[q] = (k > 0 && f < NE * NX) ? rec(k - 1)[lin_gx + f] : 0.0; }
+                UPR_FOR(e, NQ * NQ + NE * NX + NX) {
+                    if (e < NQ * NQ) {
+                        const int ii = e / NQ, jj = e % NQ;
+                        double p[3][3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) p[a][c] = Pc[(a * NQ + ii) * NX + c * NQ + jj];
+                        // T = P A (columns), then A' T (rows); A = [[1,h,h2],[0,1,h],[0,0,1]]
+                        double t[3][3], o2[3][3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { t[a][0] = p[a][0]; t[a][1] = h * p[a][0] + p[a][1]; t[a][2] = h2 * p[a][0] + h * p[a][1] + p[a][2]; }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { o2[0][c] = t[0][c]; o2[1][c] = h * t[0][c] + t[1][c]; o2[2][c] = h2 * t[0][c] + h * t[1][c] + t[2][c]; }
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) Pn[(a * NQ + ii) * NX + c * NQ + jj] = o2[a][c];
+                        // B' (P A) = h3 t[0] + h2 t[1] + h t[2]
+                        double bt[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { bt[c] = h3 * t[0][c] + h2 * t[1][c] + h * t[2][c]; L[O::hux + ii * NX + c * NQ + jj] = bt[c]; }
+                        // B' P B
+                        double v = 0.0;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) v += coefB(a) * (h3 * p[a][0] + h2 * p[a][1] + h * p[a][2]);
+                        if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
+                        L[O::hjj + e] = v;
+                    } else if (e < NQ * NQ + NE * NX) {
+                        const int f = e - NQ * NQ, r = f / NX, c = f % NX;
+                        const double* Ls = L + O::lsi + k * NE * NE;
+                        double v = 0.0;
+                        for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * L[O::ck + m * NX + c];
+                        L[O::vc + f] = v;
+                    } else {
+                        const int i = e - NQ * NQ - NE * NX;
+                        double pb = 0.0;
+                        for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bk + j];
+                        L[O::Pbs + k * NX + i] = pb; L[O::wv + i] = pcur[i] + pb;
+                    }
+                }
+                UPR_SYNC();
+                toc(12);
+                // phase 2: one lane factors Hjj in registers; others: hx, huj
+                if (ctx.tid == NT - 1) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
+                hx_huj(k);
+                UPR_SYNC();
+                toc(13);
+                // phase 3: Lji columns
+                UPR_FOR(j, NQ) upr_tri_inv_col<NQ>(L + O::hjj, L + O::lji, j);
+                UPR_SYNC();
+                // phase 4: V = Lji Hux, yj = Lji huj
+                UPR_FOR(e, NQ * NX + NQ) {
+                    if (e < NQ * NX) {
+                        const int i = e / NX, c = e % NX;
+                        double v = 0.0;
+                        for (int m = 0; m <= i; ++m) v += L[O::lji + i * NQ + m] * L[O::hux + m * NX + c];
+                        L[O::vm + e] = v;
+                    } else {
+                        const int j = e - NQ * NX;
+                        double v = 0.0;
+                        for (int m = 0; m <= j; ++m) v += L[O::lji + j * NQ + m] * L[O::huj + m];
+                        L[O::yj + j] = v;
+                    }
+                }
+                UPR_SYNC();
+                toc(14);
+                // phase 5: P = sym(A'P+A) + Q~ - V'V + Vc'Vc (upper triangle, mirrored) ; p = hx - V'yj + cs ;
+                //          K = Lji'V ; kff = Lji'yj ; packed Lji ; next knot's C
+                UPR_FOR(e, NX * NX + NX + NQ * NX + NQ + C::NH) {
+                    if (e < NX * NX) {
+                        const int i = e / NX, j = e % NX;
+                        if (i <= j) {
+                            double v = 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
+                            if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
+                            if (j < NQ) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)];
+                            for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::vm + m * NX + j];
+                            for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
+                            Pc[i * NX + j] = v; Pc[j * NX + i] = v;
+                        }
+                    } else if (e < NX * NX + NX) {
+                        const int i = e - NX * NX;
+                        double v = L[O::hx + i] + L[O::cs + k * NX + i];
+                        for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::yj + m];
+                        pcur[i] = v;
+                    } else if (e < NX * NX + NX + NQ * NX) {
+                        const int f = e - NX * NX - NX, i = f / NX, c = f % NX;
+                        double v = 0.0;
+                        for (int m = i; m < NQ; ++m) v += L[O::lji + m * NQ + i] * L[O::vm + m * NX + c];
+                        L[O::Ks + k * NQ * NX + f] = v;
+                    } else if (e < NX * NX + NX + NQ * NX + NQ) {
+                        const int i = e - NX * NX - NX - NQ * NX;
+                        double v = 0.0;
+                        for (int m = i; m < NQ; ++m) v += L[O::lji + m * NQ + i] * L[O::yj + m];
+                        L[O::kffs + k * NQ + i] = v;
+                    } else {
+                        const int f = e - NX * NX - NX - NQ * NX - NQ;
+                        int i = 0; while ((i + 1) * (i + 2) / 2 <= f) ++i;   // packed lower: f = i(i+1)/2 + j
+                        const int j = f - i * (i + 1) / 2;
+                        L[O::Ljis + k * C::NH + f] = L[O::lji + i * NQ + j];
+                    }
+                }
+                if (k > 0) {
+#pragma unroll
+                    for (int q = 0; q < CKQ; ++q) { const int f = ctx.tid + q * NT; if (f < NE * NX) L[O::ck + f] = ckn[q]; }
+                }
+                UPR_SYNC();
+                toc(15);
+            }
+        } else {
+            // vector pass: one phase per knot.  Every lane i < NX rebuilds the nq jerk gradients it needs.
+            for (int k = N - 1; k >= 0; --k) {
+                UPR_FOR(i, NX) {
+                    double w[NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) w[a] = pcur[a] + L[O::Pbs + k * NX + a];
+                    const int b = i / NQ, j = i % NQ;
+                    double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
+                    for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m) {
+                        const double hm = L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m];
+                        v -= L[O::Ks + k * NQ * NX + m * NX + i] * hm;
+                        if (i == m) L[O::hujs + k * NQ + m] = hm;
+                    }
+                    pnew[i] = v;
+                }
+                UPR_SYNC();
+                double* tsw = pcur; pcur = pnew; pnew = tsw;
+            }
+            // feed-forward of every knot: kff = Lji' (Lji huj)
+            UPR_FOR(k, N) {
+                const double* Lp = L + O::Ljis + k * C::NH;
+                double y[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= i; ++m) v += Lp[i * (i + 1) / 2 + m] * L[O::hujs + k * NQ + m];
+                    y[i] = v; }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { double v = 0.0;
+#pragma unroll
+                    for (int m = i; m < NQ; ++m) v += Lp[m * (m + 1) / 2 + i] * y[m];
+                    L[O::kffs + k * NQ + i] = v; }
+            }
+            UPR_SYNC();
+        }
+    }
+    // hx = gxs_k + A' wv ; huj = gus_k[j] + B' wv
+    UPR_HD void hx_huj(int k) {
+        UPR_FOR(e, NX + NQ) {
+            if (e < NX) {
+                const int b = e / NQ, j = e % NQ;
+                double v = L[O::gxs + k * NX + e];
+                for (int a = 0; a <= b; ++a) v += coefA(a, b) * L[O::wv + a * NQ + j];
+                L[O::hx + e] = v;
+            } else {
+                const int j = e - NX;
+                L[O::huj + j] = L[O::gus + k * NU + j] + h3 * L[O::wv + j] + h2 * L[O::wv + NQ + j] + h * L[O::wv + 2 * NQ + j];
+            }
+        }
+    }
+
+    // forward sweep: one phase per knot, closed-loop form  sx+ = A sx + b - B (K sx + kff)
+    UPR_HD void forward() {
+        UPR_FOR(i, NX) Sx(0)[i] = 0.0;
+        UPR_SYNC();
+        for (int k = 0; k < N; ++k) {
+            const double* sx = Sx(k); double* sn = Sx(k + 1);
+            UPR_FOR(i, NX) {
+                const int b = i / NQ, j = i % NQ;
+                const double* Kr = L + O::Ks + k * NQ * NX + j * NX;
+                double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
+                const double uj = -(d0 + d1 + d2);
+                const double* X = Zx(k); const double* Xn = Zx(k + 1); const double U = Zu(k)[j];
+                const double q = sx[j], v = sx[NQ + j], a = sx[2 * NQ + j];
+                const double Q = X[j], V = X[NQ + j], Ac = X[2 * NQ + j];
+                double r;
+                if (b == 0) { r = q + h * v + h2 * a + h3 * uj + (Q + h * V + h2 * Ac + h3 * U - Xn[j]); Su(k)[j] = uj; }
+                else if (b == 1) r = v + h * a + h2 * uj + (V + h * Ac + h2 * U - Xn[NQ + j]);
+                else r = a + h * uj + (Ac + h * U - Xn[2 * NQ + j]);
+                sn[i] = r;
+            }
+            UPR_SYNC();
+        }
+        // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
+        UPR_FOR(e, N * NE) {
+            const int k = e / NE, r = e % NE;
+            const double* Ck = rec(k) + lin_gx + r * NX; const double* sx = Sx(k);
+            double v = 0.0;
+            for (int c = 0; c < NX; ++c) v += Ck[c] * sx[c];
+            L[O::cv + e] = v;
+        }
+        UPR_SYNC();
+        UPR_FOR(k, N) {
+            const double* Ls = L + O::lsi + k * NE * NE;
+            double t1[NE];
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = L[O::ys + k * NE + r];
+#pragma unroll
+                for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * L[O::cv + k * NE + m];
+                t1[r] = v; }
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = 0.0;
+#pragma unroll
+                for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * t1[m];
+                L[O::nun + k * NE + r] = v; }
+        }
+        UPR_SYNC();
+        for (int q = 0; q < C::QC; ++q) {
+            const int ic = ctx.tid + q * NT;
+            if (ic < C::NCI) {
+                const int k = ic / NC, ci = ic % NC;
+                if (NF == 3) {
+                    double dfn[3], tf[3];
+                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * L[O::nun + k * NE + r]; dfn[a] = v; }
+                    const double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
+                    for (int a = 0; a < 3; ++a) { double v = L[O::yf + k * NFC + 3 * ci + a]; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * dfn[b2]; tf[a] = v; }
+                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * tf[b2]; Su(k)[NQ + 3 * ci + a] = -v; }
+                } else {
+                    double dfn = 0.0;
+                    for (int r = 0; r < NE; ++r) dfn += L[O::df + r * NFC + ci] * L[O::nun + k * NE + r];
+                    const double lf = L[O::lfi + k * C::NLF + ci];
+                    Su(k)[NQ + ci] = -lf * (L[O::yf + k * NFC + ci] + lf * dfn);
+                }
+            }
+        }
+        if (neN > 0) UPR_FOR(q, C::NEN) {
+            double v;
+            if (q < 3) { v = L[O::eN + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * Sx(N)[j]; }
+            else v = L[O::eN + q] + Sx(N)[NQ + (q - 3)];
+            L[O::dyN + q] = v / UPR_QP_RHO_N;
+        }
+        UPR_SYNC();
+    }
+
+    // costates of the full step (into global pin)
+    UPR_HD void costates() {
+        double* pin = ws + W::pin;
+        UPR_FOR(e, N1 * NX) {
+            const int k = e / NX, i = e % NX;
+            const double* sx = Sx(k);
+            double v = L[O::gxs + e] + L[O::wx + e] * sx[i];
+            if (k < N) {
+                v += h * L[O::qd + i] * sx[i];
+                if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
+                const double* Ck = rec(k) + lin_gx;
+                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * L[O::nun + k * NE + q];
+            } else if (neN > 0) {
+                if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
+                else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
+            }
+            pin[e] = v;
+        }
+        UPR_SYNC();
+        UPR_FOR(j, NQ) {
+            double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
+            for (int k = N - 1; k >= 1; --k) {
+                const double nq_ = pin[k * NX + j] + pq;
+                const double nv_ = pin[k * NX + NQ + j] + h * pq + pvv;
+                const double na_ = pin[k * NX + 2 * NQ + j] + h2 * pq + h * pvv + pa;
+                pq = nq_; pvv = nv_; pa = na_;
+                pin[k * NX + j] = pq; pin[k * NX + NQ + j] = pvv; pin[k * NX + 2 * NQ + j] = pa;
+            }
+        }
+        UPR_SYNC();
+    }
+
+    // ---- sweeps over the lane-owned rows with the current step ------------------------------------------------
+    //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t
+    UPR_HD void sweep_row(int what, double alpha, double c, double ds, double& t, double& lam, double cterm, double& acc, double* aux) const {
+        const double rp = c - t;
+        if (what == 3) { const double a = fabs(rp); if (a > acc) acc = a; *aux += lam * t; return; }
+        const double dt = ds + rp;
+        const double rc = (mode == 0) ? lam * t : lam * t + cterm;
+        const double dl = -(rc + lam * dt) / t;
+        if (what == 0) {
+            if (dt < 0.0) { const double a = -t / dt; if (a < acc) acc = a; }
+            if (dl < 0.0) { const double a = -lam / dl; if (a < acc) acc = a; }
+        } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
+        else { t += alpha * dt; lam += alpha * dl; }
+    }
+    UPR_HD double ineq_sweep(int what, double alpha, double* aux) {
+        double acc = (what == 0) ? 1e30 : 0.0;
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) {
+            const int ix = ctx.tid + q * NT;
+            if (ix < C::NXI) {
+                const int zo = NX + ix, i = ix % NX;
+                const double X = L[O::Z + zo], dS = L[O::S + zo];
+                sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], cx[q][0], acc, aux);
+                sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], cx[q][1], acc, aux);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) {
+            const int iu = ctx.tid + q * NT;
+            if (iu < C::NUI) {
+                const int i = iu % NU;
+                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], cu[q][0], acc, aux);
+                sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], cu[q][1], acc, aux);
+            }
+        }
+        if (NF == 3) for (int q = 0; q < C::QC; ++q) {
+            const int ic = ctx.tid + q * NT;
+            if (ic < C::NCI) {
+                const int k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
+                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                for (int r = 0; r < 5; ++r) {
+                    const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                    double t = L[O::ct + 5 * ic + r], lam = L[O::cl + 5 * ic + r];
+                    sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam,
+                              L[O::cc + 5 * ic + r], acc, aux);
+                    if (what == 2) { L[O::ct + 5 * ic + r] = t; L[O::cl + 5 * ic + r] = lam; }
+                }
+            }
+        }
+        return acc;
+    }
+
+    UPR_HD void residuals(int ntot, double* res) {
+        const double* pi = ws + W::pi; const double* nu = ws + W::nu;
+        const int save = mode;
+        mode = 2;
+        prep(0);
+        mode = save;
+        double r_stat = 0.0, r_eq = 0.0;
+        UPR_FOR(e, N * NX) {
+            const int k = 1 + e / NX, i = e % NX;
+            double v = L[O::gxs + k * NX + i] - pi[k * NX + i];
+            if (k < N) {
+                const double* pn = pi + (k + 1) * NX; const double* Ck = rec(k) + lin_gx;
+                const int blk = i / NQ, j = i % NQ;
+                for (int a = 0; a <= blk; ++a) v += coefA(a, blk) * pn[a * NQ + j];
+                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * nu[k * NE + q];
+            } else if (neN > 0) {
+                if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * L[O::yN + q]; }
+                else v += L[O::yN + 3 + (i - NQ)];
+            }
+            r_stat = fmax(r_stat, fabs(v));
+        }
+        UPR_FOR(e, N * NU) {
+            const int k = e / NU, i = e % NU;
+            double v = L[O::gus + e];
+            if (i < NQ) { const double* pn = pi + (k + 1) * NX; v += h3 * pn[i] + h2 * pn[NQ + i] + h * pn[2 * NQ + i]; }
+            else for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q];
+            r_stat = fmax(r_stat, fabs(v));
+        }
+        UPR_FOR(e, N * NQ) {
+            const int k = e / NQ, j = e % NQ;
+            const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
+            const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
+            r_eq = fmax(r_eq, fabs(q + h * v + h2 * a + h3 * u - Xn[j]));
+            r_eq = fmax(r_eq, fabs(v + h * a + h2 * u - Xn[NQ + j]));
+            r_eq = fmax(r_eq, fabs(a + h * u - Xn[2 * NQ + j]));
+        }
+        UPR_FOR(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e]));
+        terminal_residual();
+        UPR_SYNC();
+        if (neN > 0) UPR_FOR(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
+        double lt = 0.0;
+        const double r_in = ineq_sweep(3, 0.0, &lt);
+        res[0] = upr_reduce(ctx, L + O::red, r_stat, 1);
+        res[1] = upr_reduce(ctx, L + O::red, r_eq, 1);
+        res[2] = upr_reduce(ctx, L + O::red, r_in, 1);
+        res[3] = upr_reduce(ctx, L + O::red, lt, 0) / (ntot > 0 ? ntot : 1);
+    }
+
+    double* prof; long long tlast;
+    UPR_HD void tic() {
+#ifndef UPR_HOST_EMU
+        if (prof && ctx.tid == 0) tlast = (long long)__builtin_readcyclecounter();
+#endif
+    }
+    UPR_HD void toc(int id) {
+#ifndef UPR_HOST_EMU
+        if (prof && ctx.tid == 0) { long long t = (long long)__builtin_readcyclecounter(); prof[id] += (double)(t - tlast); tlast = t; }
+#endif
+    }
+
+    UPR_HD void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
+        ctx = c; P = A.P; L = lds;
+        xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
+        lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride;
+        lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
+        h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0;
+        prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
+        tic();
+        // ---- constants and linearisation-point data into LDS
+        UPR_FOR(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
+        UPR_FOR(i, NU) { L[O::ulb + i] = P->u_lb[i]; L[O::uub + i] = P->u_ub[i]; L[O::rd + i] = P->Rdiag[i]; }
+        if (NF == 3) UPR_FOR(e, C::NP) { double e3[3]; upr_friction_row_jac(P, e / 5, e % 5, e3); L[O::erow + 3 * e] = e3[0]; L[O::erow + 3 * e + 1] = e3[1]; L[O::erow + 3 * e + 2] = e3[2]; }
+        UPR_FOR(e, NE * NFC) L[O::df + e] = Dfg[e];
+        UPR_FOR(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
+        UPR_FOR(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
+        UPR_FOR(e, N * C::NH) { const int k = e / C::NH; L[O::hee + e] = rec(k)[lin_hess + e % C::NH]; }
+        UPR_FOR(e, 3 * NQ) L[O::jN + e] = rec(N)[lin_hess + e];
+        UPR_FOR(q, 3) L[O::misc + 4 + q] = rec(N)[lin_grad + q];
+        UPR_FOR(q, C::NEN) { L[O::yN + q] = 0.0; L[O::dyN + q] = 0.0; }
+        if (ctx.tid == 0) L[O::misc] = 0.0;
+        UPR_FOR(i, W::store) ws[i] = 0.0;
+        UPR_SYNC();
+        // g0 = gradEE - Hee xs_q ; e0 = g - C xs - Df us_f   (affine parts at the linearisation point)
+        UPR_FOR(e, N * NQ) {
+            const int k = e / NQ, i = e % NQ;
+            double v = rec(k)[lin_grad + i];
+            for (int j = 0; j < NQ; ++j) v -= L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * xs[k * NX + j];
+            L[O::g0 + e] = v;
+        }
+        UPR_FOR(e, N * NE) {
+            const int k = e / NE, r = e % NE;
+            const double* Ck = rec(k) + lin_gx + r * NX;
+            double v = rec(k)[lin_g + r];
+            for (int j = 0; j < NX; ++j) v -= Ck[j] * xs[k * NX + j];
+            for (int i = 0; i < NFC; ++i) v -= L[O::df + r * NFC + i] * us[k * NU + NQ + i];
+            L[O::e0 + e] = v;
+        }
+        // ---- initial slacks / multipliers
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) {
+            const int ix = ctx.tid + q * NT;
+            for (int s = 0; s < 2; ++s) { tx[q][s] = 1.0; lx[q][s] = 0.0; cx[q][s] = 0.0; }
+            if (ix < C::NXI) {
+                const int i = ix % NX; const double X = L[O::Z + NX + ix];
+                const double c0 = X - L[O::xlb + i], c1 = L[O::xub + i] - X;
+                tx[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tx[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
+                lx[q][0] = UPR_QP_MU0 / tx[q][0]; lx[q][1] = UPR_QP_MU0 / tx[q][1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) {
+            const int iu = ctx.tid + q * NT;
+            for (int s = 0; s < 2; ++s) { tu[q][s] = 1.0; lu[q][s] = 0.0; cu[q][s] = 0.0; }
+            if (iu < C::NUI) {
+                const int i = iu % NU; const double U = L[O::Z + N1 * NX + iu];
+                const double c0 = U - L[O::ulb + i], c1 = L[O::uub + i] - U;
+                tu[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tu[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
+                lu[q][0] = UPR_QP_MU0 / tu[q][0]; lu[q][1] = UPR_QP_MU0 / tu[q][1];
+            }
+        }
+        if (NF == 3) for (int q = 0; q < C::QC; ++q) {
+            const int ic = ctx.tid + q * NT;
+            if (ic < C::NCI) {
+                const int k = ic / NC, ci = ic % NC;
+                const double* f = L + O::Z + N1 * NX + k * NU + NQ + 3 * ci;
+                for (int r = 0; r < 5; ++r) {
+                    const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                    const double c0 = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
+                    const double t = c0 > UPR_QP_THR ? c0 : UPR_QP_THR;
+                    L[O::ct + 5 * ic + r] = t; L[O::cl + 5 * ic + r] = UPR_QP_MU0 / t; L[O::cc + 5 * ic + r] = 0.0;
+                }
+            }
+        }
+        UPR_SYNC();
+        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX;
+        double res[4] = {0, 0, 0, 0};
+        int it = 0, status = 1;
+        const double tol = P->qp_tol;
+        toc(11);
+        for (;; ++it) {
+            residuals(ntot, res);
+            toc(0);
+#ifdef UPR_HOST_EMU
+            if (getenv("UPR_EMU_DEBUG")) printf("v3 it %d res %.3e %.3e %.3e %.3e\n", it, res[0], res[1], res[2], res[3]);
+#endif
+            if (it > 0 && res[0] < tol && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
+            if (it >= P->qp_iter_max) break;
+            const double mu = res[3];
+            mode = 0;
+            prep(2); toc(1);
+            backward(true); toc(5);
+            if (L[O::misc] != 0.0) { status = 2; break; }
+            forward(); toc(6);
+            double a_aff = upr_reduce(ctx, L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            if (a_aff > 1.0) a_aff = 1.0;
+            const double mu_aff = upr_reduce(ctx, L + O::red, ineq_sweep(1, a_aff, nullptr), 0) / ntot;
+            const double sg = mu_aff / mu;
+            sigma_mu = sg * sg * sg * mu;
+            if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
+            toc(7);
+            mode = 1;
+            prep(1); toc(1);
+            backward(false); toc(8);
+            forward(); toc(6);
+            mode = 3;
+            costates(); toc(9);
+            double a = 0.995 * upr_reduce(ctx, L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            if (a > 1.0) a = 1.0;
+            ineq_sweep(2, a, nullptr);
+            UPR_SYNC();
+            UPR_FOR(e, N1 * NX) {
+                if (e >= NX) L[O::Z + e] += a * L[O::S + e];
+                ws[W::pi + e] += a * (ws[W::pin + e] - ws[W::pi + e]);
+            }
+            UPR_FOR(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
+            UPR_FOR(e, N * NE) ws[W::nu + e] += a * (L[O::nun + e] - ws[W::nu + e]);
+            UPR_FOR(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
+            UPR_SYNC();
+            toc(10);
+        }
+        // ---- result: step from the linearisation point
+        UPR_FOR(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
+        UPR_FOR(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
+        if (ctx.tid == 0) {
+            double* st = A.stats + (size_t)b * UPR_NSTATS;
+            st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];
+        }
+        UPR_SYNC();
+    }
+};
+
+template <class C>
+static inline UPR_HD void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int b, double* L) {
+    upr_qp3<C> S;
+    S.solve(ctx, A, b, L);
+}
+
+#ifndef UPR_HOST_EMU
+template <class C>
+__global__ void __launch_bounds__(C::NT) upr_qp3_kernel(upr_qp_args A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
+    upr_qp3_solve<C>(ctx, A, blockIdx.x, smem);
+}
+#endif
