@@ -109,10 +109,10 @@ long emu_qp2(const upr_problem* P, int B, const double* xs, const double* us, co
 }
 
 void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const double* x0, const double* t0,
-                    const double* body_params, const double* way_p, const double* lin, const double* ws, double* stats,
+                    const double* body_params, const double* way_p, const double* lin, const double* ws, long ws_stride, double* stats,
                     int* done, int iter) {
     upr_ls_args A;
-    A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
+    A.P = P; A.d = upr_make_dims(P); if (ws_stride > 0) A.d.ws_stride = (int)ws_stride; A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
     A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter;
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
     std::vector<double> L(64);

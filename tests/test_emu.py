@@ -1,0 +1,154 @@
+"""CPU tests of the HIP kernel SOURCE through the test-only host emulation (tests/emu/upr_emu.cpp: one
+thread per workgroup, same headers as the GPU build) against the oracle.  They validate index arithmetic
+and the mathematics of every kernel body before any GPU time is spent; the GPU execution itself is
+checked by tests/test_gpu_parity.py."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from upright_amd import _capi
+from upright_amd.problem import thing_problem
+from upright_amd.sampling import level_tray_states, stationary_guess, waypoints_for
+
+EMU = Path(__file__).resolve().parent / "emu" / "libupr_emu.so"
+p = _capi.ptr
+
+
+class Emu:
+    def __init__(self, P, B):
+        self.P, self.B = P, B
+        self.E = C.CDLL(str(EMU))
+        for f in ("emu_qp2", "emu_qp3"):
+            getattr(self.E, f).restype = C.c_long
+        self.cp = _capi.problem_to_c(P)
+        d = (C.c_int * 16)()
+        self.E.emu_dims(C.byref(self.cp), d)
+        (self.nx, self.nu, self.ne, self.np_, self.lin_stride, self.ws_stride, self.ws_dx, self.ws_du, self.lin_g, self.lin_gx,
+         self.lin_cost, self.lin_grad, self.lin_hess, self.nfc) = list(d)[:14]
+        self.bp = np.ascontiguousarray(np.broadcast_to(P.body_params, (B,) + P.body_params.shape))
+        self.Df = np.zeros((B, self.ne, self.nfc))
+        self.E.emu_make_Df(C.byref(self.cp), B, p(self.bp), p(self.Df))
+
+    def linearize(self, way, t0, xs, us):
+        lin = np.zeros((self.B, self.P.N + 1, self.lin_stride))
+        self.E.emu_linearize(C.byref(self.cp), self.B, p(self.bp), p(way), p(t0), p(xs), p(us), p(lin))
+        return lin
+
+    def qp(self, kernel, xs, us, x0, lin):
+        stats = np.zeros((self.B, 12))
+        if kernel == 1:
+            ws = np.zeros((self.B, self.ws_stride))
+            self.E.emu_qp(C.byref(self.cp), self.B, p(xs), p(us), p(x0), p(lin), p(self.Df), p(ws), p(stats))
+        else:
+            f = self.E.emu_qp2 if kernel == 2 else self.E.emu_qp3
+            need = f(C.byref(self.cp), self.B, None, None, None, None, None, None, C.c_long(0), None)
+            assert need > 0
+            ws = np.zeros((self.B, need))
+            assert f(C.byref(self.cp), self.B, p(xs), p(us), p(x0), p(lin), p(self.Df), p(ws), C.c_long(need), p(stats)) == 0
+        n1, N = self.P.N + 1, self.P.N
+        dx = ws[:, :n1 * self.nx].reshape(self.B, n1, self.nx)
+        du = ws[:, n1 * self.nx:n1 * self.nx + N * self.nu].reshape(self.B, N, self.nu)
+        return dx, du, stats, ws
+
+    def linesearch(self, xs, us, x0, t0, way, lin, ws, stats):
+        done = np.zeros(self.B, dtype=np.int32)
+        xs, us = xs.copy(), us.copy()
+        self.E.emu_linesearch(C.byref(self.cp), self.B, p(xs), p(us), p(x0), p(t0), p(self.bp), p(way), p(lin), p(ws), C.c_long(ws.shape[1]), p(stats),
+                              done.ctypes.data_as(C.POINTER(C.c_int)), 0)
+        return xs, us, done
+
+
+def _case(arrangements, B, seed, **kw):
+    P = thing_problem(arrangements["pink_bottle"], **kw)
+    x0 = level_tray_states(B, seed=seed)
+    way = waypoints_for(P, x0)
+    xs, us = stationary_guess(x0, P.N, P.nu)
+    return P, x0, way, np.ascontiguousarray(xs), np.ascontiguousarray(us)
+
+
+def test_linearize_kernel_source(arrangements):
+    B = 3
+    P, x0, way, xs, us = _case(arrangements, B, 2)
+    rng = np.random.default_rng(0)
+    xs = xs + rng.uniform(-0.1, 0.1, xs.shape); us = rng.uniform(-1, 1, us.shape)
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    for b in range(B):
+        P.way_p = way[b]
+        O = Oracle(P)
+        for k in range(P.N):
+            r = lin[b, k]
+            g, gx, _ = O.eq_constraint(xs[b, k], us[b, k])
+            assert np.abs(r[e.lin_g:e.lin_g + 6] - g).max() < 1e-13 and np.abs(r[e.lin_gx:e.lin_gx + 162].reshape(6, 27) - gx).max() < 1e-12
+            c, cgx, _, H, _ = O.stage_cost(0.1 * k, xs[b, k], us[b, k])
+            cj = 0.5 * np.sum(P.Qdiag * xs[b, k] ** 2) + 0.5 * np.sum(P.Rdiag * us[b, k] ** 2)
+            assert abs(r[e.lin_cost] - (c - cj)) < 1e-13
+            assert np.abs(r[e.lin_grad:e.lin_grad + 9] - (cgx - P.Qdiag * xs[b, k])[:9]).max() < 1e-13
+            Hm = np.zeros((9, 9)); Hm[np.triu_indices(9)] = r[e.lin_hess:e.lin_hess + 45]; Hm = Hm + np.triu(Hm, 1).T
+            assert np.abs(Hm - (H - np.diag(P.Qdiag))[:9, :9]).max() < 1e-13
+        cN, CN = O.terminal_constraint(0.1 * P.N, xs[b, P.N])
+        r = lin[b, P.N]
+        assert np.abs(r[e.lin_grad:e.lin_grad + 3] - cN[:3]).max() < 1e-13
+        assert np.abs(r[e.lin_hess:e.lin_hess + 27].reshape(3, 9) + CN[:3, :9]).max() < 1e-13
+        gu = O.eq_constraint(xs[b, 0], us[b, 0])[2]
+        assert np.abs(e.Df[b] - gu[:, 9:]).max() < 1e-15
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_qp_kernel_source(arrangements, kernel):
+    """All three QP kernel structures follow the oracle's iterate path: identical steps after a fixed
+    number of IPM iterations (tol = 0), and at convergence the same iteration count and the same minimiser
+    up to the ball the 1e-8 KKT tolerance allows (the last iterations are ill-conditioned: weights 1e8+)."""
+    B = 3
+    P, x0, way, xs, us = _case(arrangements, B, 11, qp_tol=0.0, qp_iter_max=7)
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(kernel, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert stats[b, 1] == 7 == so.qp_iters_last
+        assert np.abs(dx[b] - dxo).max() < 1e-7 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 1e-7 * max(1, np.abs(duo).max())
+        assert np.allclose(stats[b, 6:10], list(so.qp_res), rtol=5e-2, atol=1e-9)
+    P, x0, way, xs, us = _case(arrangements, B, 11)
+    e = Emu(P, B)
+    dx, du, stats, ws = e.qp(kernel, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert rc == 0 and stats[b, 2] == 0 and stats[b, 1] == so.qp_iters_last
+        assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max())
+        assert max(stats[b, 6:10]) < P.qp_tol
+
+
+def test_qp_kernels_agree_on_short_horizon_without_terminal_constraint(arrangements):
+    B = 2
+    P, x0, way, xs, us = _case(arrangements, B, 5, N=6, terminal_constraint=False)
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    d1 = e.qp(1, xs, us, x0, lin); d2 = e.qp(2, xs, us, x0, lin)
+    assert np.abs(d1[0] - d2[0]).max() < 2e-5 and np.abs(d1[1] - d2[1]).max() < 2e-4
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert np.abs(d1[0][b] - dxo).max() < 2e-5 and np.abs(d1[1][b] - duo).max() < 2e-4
+
+
+def test_linesearch_kernel_source_and_full_step(arrangements):
+    B = 3
+    P, x0, way, xs, us = _case(arrangements, B, 21)
+    e = Emu(P, B)
+    t0 = np.zeros(B)
+    lin = e.linearize(way, t0, xs, us)
+    dx, du, stats, ws = e.qp(3, xs, us, x0, lin)
+    xs2, us2, done = e.linesearch(xs, us, x0, t0, way, lin, ws, stats)
+    for b in range(B):
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs[b], us[b])
+        assert np.abs(xs2[b] - xo).max() < 2e-5 and np.abs(us2[b] - uo).max() < 2e-4
+        assert stats[b, 3] == so.step_alpha_last and abs(stats[b, 4] - so.cost) < 1e-7 and abs(stats[b, 5] - so.constraint_violation) < 1e-6

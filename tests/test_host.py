@@ -1,0 +1,160 @@
+"""CPU tests of the host side: config front-end against the golden outputs of the reference's parser, the
+bindings mirror, and the C-ABI library (loads, exports every declared symbol; no compute without a GPU)."""
+import ctypes as C
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from upright_amd import _capi, config, control, control_bindings, core_bindings, robots
+from upright_amd.distributed import shard_range
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden"
+
+
+def test_number_and_array_dsl_against_reference_outputs():
+    g = json.load(open(GOLD / "parse_dsl.json"))
+    for s, v in g["numbers"]:
+        assert np.isclose(config.parse_number(s), v, rtol=0, atol=0)
+    for a, v in g["arrays"]:
+        assert np.array_equal(config.parse_array(a), np.array(v))
+    with pytest.raises(ValueError):
+        config.parse_array(["abc"])
+    with pytest.raises(ValueError):
+        config.parse_support_offset({"r": 1})
+    assert np.allclose(config.parse_support_offset({"x": 1, "y": 2, "r": 1, "θ": "0.5pi"}), [1, 3])
+
+
+def test_include_resolution(tmp_path):
+    """docs/configuration.md:6-44: includes first and in order, includer overrides, `key` nests, depth cap."""
+    (tmp_path / "pkg").mkdir()
+    (tmp_path / "pkg" / "base.yaml").write_text("a: 1\nb: {c: 2, d: 3}\n")
+    (tmp_path / "pkg" / "mid.yaml").write_text("include:\n  - {package: pkg, path: base.yaml}\nb: {c: 20}\ne: 5\n")
+    (tmp_path / "pkg" / "top.yaml").write_text(
+        "include:\n  - {package: pkg, path: mid.yaml}\n  - {key: sub, package: pkg, path: base.yaml}\nb: {d: 30}\n")
+    config.register_package("pkg", tmp_path / "pkg")
+    d = config.load_config(tmp_path / "pkg" / "top.yaml")
+    assert d == {"a": 1, "b": {"c": 20, "d": 30}, "e": 5, "sub": {"a": 1, "b": {"c": 2, "d": 3}}}
+    (tmp_path / "pkg" / "loop.yaml").write_text("include:\n  - {package: pkg, path: loop.yaml}\n")
+    with pytest.raises(Exception, match="inclusion depth"):
+        config.load_config(tmp_path / "pkg" / "loop.yaml")
+
+
+@pytest.mark.parametrize("name,arr", [("full_bottle_point1", "pink_bottle"), ("thing_demo", "pink_bottle"), ("ur10_demo", "pink_bottle")])
+def test_controller_settings_match_reference_parse(arrangements, name, arr):
+    """Row P of SURVEY.md section 8a: the merged controller dict of the reference (golden) through our
+    ControllerSettings gives field-for-field the numbers the reference's wrappers.py computes."""
+    g = json.load(open(GOLD / "configs.json"))[name]
+    c, par = g["controller"], g["parsed"]
+    bodies, contacts = control.objects_from_fixture(arrangements[arr])
+    s = control.ControllerSettings(c, bodies=bodies, contacts=contacts)
+    assert np.array_equal(s.initial_state, np.array(par["x0"]))
+    for k in ("input_weight", "state_weight", "end_effector_weight", "input_limit_lower", "input_limit_upper",
+              "state_limit_lower", "state_limit_upper"):
+        assert np.array_equal(getattr(s, k), np.array(par[k])), k
+    assert s.mpc.time_horizon == par["time_horizon"] and s.sqp.dt == par["dt"]
+    assert s.dims.c == par["n_contacts"] and len(s.balancing_settings.bodies) == par["n_bodies"]
+    assert s.dims.nf == (1 if c["balancing"]["frictionless"] else 3)
+    assert s.dims.x() == c["robot"]["dims"]["x"] and s.dims.u() == c["robot"]["dims"]["u"] + s.dims.nf * s.dims.c
+    assert s.sqp.hpipm.iter_max == 30 and s.sqp.sqp_iteration == 1 and s.tracking.min_policy_update_time == 0.01
+
+
+def test_problem_from_settings_and_unsupported_terms(arrangements):
+    g = json.load(open(GOLD / "configs.json"))["full_bottle_point1"]["controller"]
+    bodies, contacts = control.objects_from_fixture(arrangements["pink_bottle"])
+    s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
+    P = control_bindings.problem_from_settings(s)
+    assert (P.nx, P.nu, P.N, P.nf, P.nb, P.nc) == (27, 21, 20, 3, 1, 4)
+    assert np.all(P.u_lb[9:] == -100) and np.all(P.u_ub[9:] == 100) and np.all(P.Rdiag[9:] == 0.001)
+    assert np.allclose(P.body_params[0], arrangements["pink_bottle"]["bodies"][0]["params"])
+    s.obstacle_settings.enabled = True
+    with pytest.raises(RuntimeError, match="obstacle"):
+        control_bindings.problem_from_settings(s)
+    s.obstacle_settings.enabled = False
+    s.balancing_settings.enabled = False
+    with pytest.raises(RuntimeError):
+        control_bindings.problem_from_settings(s)
+    with pytest.raises(RuntimeError):
+        control_bindings.robot_base_type_from_string("hovering")
+    with pytest.raises(NotImplementedError):
+        control.ControllerSettings(g)  # arrangement parser is a 'next' row
+
+
+def test_target_trajectories_and_dimensions():
+    d = control_bindings.OptimizationDimensions()
+    d.robot.q = d.robot.v = 9; d.robot.x = 27; d.robot.u = 9; d.c = 4; d.nf = 3; d.o = 1
+    assert (d.q(), d.v(), d.x(), d.f(), d.u()) == (12, 12, 36, 12, 21)
+    r, Q = np.array([1.0, 2, 3]), np.array([0, 0, np.sin(0.3), np.cos(0.3)])
+    cfg = {"waypoints": [{"time": 0, "position": [-2.0, 1.0, 0], "orientation": [0, 0, 0, 1]}, {"time": 2, "position": [0, 0, 1], "orientation": [0, 0, 0, 1]}]}
+    t = control.TargetTrajectories.from_config(cfg, r, Q, np.zeros(3))
+    assert np.allclose(t.xs[0], np.concatenate([r + [-2, 1, 0], Q, [0]])) and list(t.ts) == [0.0, 2.0]
+    assert np.allclose(t.get_desired_state(1.0)[:3], r + [-1, 0.5, 0.5])   # midway between the waypoints
+    assert np.allclose(t.get_desired_state(5.0)[:3], r + [0, 0, 1])
+    a = control_bindings.vector_array(); a.push_back([1, 2]); assert a[0].dtype == np.float64
+
+
+def test_core_bindings_data_model():
+    b = core_bindings.RigidBody(2.0, np.diag([1.0, 2, 3]), [0.1, 0.2, 0.3])
+    pvec = b.get_parameters()
+    assert np.allclose(pvec, [2, 0.2, 0.4, 0.6, 1, 0, 0, 2, 0, 3])          # rigid_body.h:47-51
+    b2 = core_bindings.RigidBody.from_parameters(pvec)
+    assert np.allclose(b2.com, b.com) and np.allclose(b2.inertia, b.inertia)
+    s = core_bindings.RigidBodyState.Zero()
+    assert np.array_equal(s.pose.orientation, np.eye(3))
+    c = core_bindings.ContactPoint(); c.object1_name, c.object2_name = "ee", "missing"
+    with pytest.raises(IndexError):
+        core_bindings.contact_tables({"box": b}, [c])
+
+
+def test_chains():
+    th = robots.thing()
+    assert th.nq == 9 and [j.kind for j in th.joints[:3]] == [robots.PRISMATIC, robots.PRISMATIC, robots.REVOLUTE]
+    ur = robots.ur10((-1.0, 1.0, 0.0))
+    q = np.array([-1.0, 1.0, 0.0, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, 0.417 * np.pi])
+    p9, C9 = th.forward(q)
+    p6, C6 = ur.forward(q[3:])
+    assert np.allclose(p9, p6) and np.allclose(C9, C6)    # fixed base locked at base_pose (util.h:35-47)
+    assert C9[2, 2] > 0.9998                               # tray level at home
+    with pytest.raises(ValueError):
+        robots.from_config({"base_type": "nonholonomic", "dims": {"q": 9}})
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "upright_mi.h").read_text()
+    declared = set(re.findall(r"\b(upr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"upr_batch", "upr_problem"}
+    lib = _capi.lib()
+    bound = {name for name, _, _ in _capi.PROTOTYPES}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert C.sizeof(_capi.UprProblem) > 0
+    if not lib.upr_device_available():
+        # no GPU in this container: compute entry points must fail loudly, not fall back
+        P = _capi.UprProblem(); P.nb = 1; P.nc = 1; P.nf = 3
+        z = np.zeros(16)
+        assert lib.upr_core_friction_rows(C.byref(P), 1, _capi.ptr(z), _capi.ptr(z)) != 0
+        assert b"no HIP device" in lib.upr_last_error()
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirror and C struct agree on the total size (field-order drift shows up here)."""
+    src = '#include "include/upright_mi.h"\n#include <stdio.h>\nint main(){printf("%zu", sizeof(upr_problem));return 0;}\n'
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f = Path(td) / "s.c"; f.write_text(src)
+        subprocess.check_call(["gcc", "-I", str(ROOT), "-o", str(Path(td) / "s"), str(f)], cwd=ROOT)
+        size = int(subprocess.check_output([str(Path(td) / "s")]))
+    assert size == C.sizeof(_capi.UprProblem)
+
+
+def test_shard_range_partitions():
+    for total, world in ((1024, 8), (8192, 8), (10, 3), (5, 8), (0, 2)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

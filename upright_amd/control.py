@@ -1,0 +1,222 @@
+"""Host-side mirror of `upright_control/src/upright_control/{wrappers,manager}.py`:
+same dict in, same settings out; `ControllerManager.step()` keeps the reference's replan cadence."""
+import time
+
+import numpy as np
+
+from . import config as cfg
+from . import control_bindings as bindings
+from . import robots
+
+
+def quat_multiply_xyzw(q0, q1):
+    x0, y0, z0, w0 = q0
+    x1, y1, z1, w1 = q1
+    return np.array([
+        w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+        w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1,
+        w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1,
+        w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1,
+    ])
+
+
+def rot_to_quat_xyzw(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    return q / np.linalg.norm(q)
+
+
+class TargetTrajectories(bindings.TargetTrajectories):
+    """wrappers.py:13-75."""
+
+    @classmethod
+    def from_config(cls, config, r_ew_w, Q_we, u):
+        ts, xs, us = [], [], []
+        for waypoint in config["waypoints"]:
+            r_d = np.asarray(r_ew_w) + np.asarray(waypoint["position"], dtype=np.float64)
+            Q_d = quat_multiply_xyzw(np.asarray(Q_we, dtype=np.float64), np.asarray(waypoint["orientation"], dtype=np.float64))
+            ts.append(waypoint["time"])
+            xs.append(np.concatenate((r_d, Q_d, [0])))
+            us.append(np.copy(u))
+        return cls(ts, xs, us)
+
+    def poses(self):
+        for x in self.xs:
+            yield x[:3], x[3:7]
+
+    def get_desired_pose(self, t):
+        x = self.get_desired_state(t)
+        return x[:3], x[3:7]
+
+
+class ControllerSettings(bindings.ControllerSettings):
+    """wrappers.py:78-399: controller config dict -> settings struct.  `bodies` / `contacts` replace the
+    arrangement parser (`parsing.py:351-410`), which is not re-implemented yet."""
+
+    def __init__(self, config, x0=None, bodies=None, contacts=None):
+        super().__init__()
+        pn, pa = cfg.parse_number, cfg.parse_array
+        self.mpc.time_horizon = pn(config["mpc"]["time_horizon"])
+        self.mpc.debug_print = config["mpc"]["debug_print"]
+        self.mpc.cold_start = config["mpc"]["cold_start"]
+        r = config["rollout"]
+        self.rollout.abs_tol_ode = pn(r["abs_tol_ode"]); self.rollout.rel_tol_ode = pn(r["rel_tol_ode"])
+        self.rollout.timestep = pn(r["timestep"]); self.rollout.max_num_steps_per_second = pn(r["max_num_steps_per_second"], dtype=int)
+        self.rollout.check_numerical_stability = r["check_numerical_stability"]
+        q = config["sqp"]
+        self.sqp.dt = pn(q["dt"]); self.sqp.sqp_iteration = q["sqp_iteration"]; self.sqp.init_sqp_iteration = q["init_sqp_iteration"]
+        self.sqp.delta_tol = pn(q["delta_tol"]); self.sqp.cost_tol = pn(q["cost_tol"])
+        self.sqp.use_feedback_policy = q["use_feedback_policy"]
+        self.sqp.project_state_input_equality_constraints = q["project_state_input_equality_constraints"]
+        self.sqp.print_solver_status = q["print_solver_status"]; self.sqp.print_solver_statistics = q["print_solver_statistics"]
+        self.sqp.print_line_search = q["print_line_search"]
+        hp = q["hpipm"]; sl = hp["slacks"]
+        self.sqp.hpipm.warm_start = hp["warm_start"]; self.sqp.hpipm.iter_max = hp["iter_max"]
+        s = self.sqp.hpipm.slacks
+        s.enabled = sl["enabled"]; s.input_box = sl.get("input_box", True); s.state_box = sl.get("state_box", True); s.poly_ineq = sl.get("poly_ineq", True)
+        s.upper_L2_penalty = sl.get("upper_L2_penalty", 100); s.lower_L2_penalty = sl.get("lower_L2_penalty", 100)
+        s.upper_L1_penalty = sl.get("upper_L1_penalty", 0); s.lower_L1_penalty = sl.get("lower_L1_penalty", 0)
+        s.upper_low_bound = sl.get("upper_low_bound", 0); s.lower_low_bound = sl.get("lower_low_bound", 0)
+        self.end_effector_link_name = config["robot"]["tool_link_name"]
+        self.robot_base_type = bindings.robot_base_type_from_string(config["robot"]["base_type"])
+        e = config["estimation"]
+        self.estimation.robot_init_variance = e["robot_init_variance"]; self.estimation.robot_process_variance = e["robot_process_variance"]
+        self.estimation.robot_measurement_variance = e["robot_measurement_variance"]
+        t = config["tracking"]
+        for k in ("rate", "min_policy_update_time", "kp", "kv", "ka", "enforce_state_limits", "enforce_input_limits",
+                  "enforce_ee_position_limits", "use_projectile", "state_violation_margin", "input_violation_margin",
+                  "ee_position_violation_margin"):
+            setattr(self.tracking, k, t[k])
+        self.gravity = np.array(config["gravity"], dtype=np.float64)
+        self.recompile_libraries = config.get("recompile_libraries", True)
+        self.debug = config["debug"]
+        d = config["robot"]["dims"]
+        self.dims.robot.q, self.dims.robot.v, self.dims.robot.x, self.dims.robot.u = d["q"], d["v"], d["x"], d["u"]
+        w = config["weights"]
+        self.input_weight = cfg.parse_diag_matrix_dict(w["input"]); self.state_weight = cfg.parse_diag_matrix_dict(w["state"])
+        self.end_effector_weight = cfg.parse_diag_matrix_dict(w["end_effector"])
+        assert self.input_weight.shape == (self.dims.robot.u, self.dims.robot.u)
+        assert self.state_weight.shape == (self.dims.robot.x, self.dims.robot.x)
+        assert self.end_effector_weight.shape == (6, 6)
+        lim = config["limits"]
+        self.input_limit_lower = pa(lim["input"]["lower"]); self.input_limit_upper = pa(lim["input"]["upper"])
+        self.state_limit_lower = pa(lim["state"]["lower"]); self.state_limit_upper = pa(lim["state"]["upper"])
+        assert self.input_limit_lower.shape == (self.dims.robot.u,) and self.input_limit_upper.shape == (self.dims.robot.u,)
+        assert self.state_limit_lower.shape == (self.dims.robot.x,) and self.state_limit_upper.shape == (self.dims.robot.x,)
+        b = config["end_effector_box_constraint"]
+        self.end_effector_box_constraint_enabled = b["enabled"]
+        self.xyz_lower = pa(b["xyz_lower"]); self.xyz_upper = pa(b["xyz_upper"])
+        if "projectile_path_constraint" in config:
+            p = config["projectile_path_constraint"]
+            self.projectile_path_constraint_enabled = p["enabled"]
+            self.projectile_path_distances = np.array(p["distances"]); self.projectile_path_scale = p["scale"]
+            self.projectile_path_collision_links = p["collision_links"]
+        for name, value in config["robot"].get("locked_joints", {}).items():
+            self.locked_joints[name] = pn(value)
+        self.base_pose = np.array(config["robot"].get("base_pose", [0.0, 0.0, 0.0]), dtype=np.float64)
+        assert self.base_pose.shape == (3,)
+        if config["operating_points"]["enabled"]:
+            self.use_operating_points = True
+        bal = config["balancing"]
+        self.balancing_settings.enabled = bal["enabled"]
+        self.balancing_settings.arrangement_name = bal["arrangement"]
+        self.balancing_settings.force_weight = bal["force_weight"]
+        if bodies is None or contacts is None:
+            raise NotImplementedError(
+                "arrangement -> contact-point parsing is not re-implemented yet (SURVEY.md 8f.4): pass bodies= and contacts= "
+                "(e.g. from tests/golden/arrangements.json via upright_amd.control.objects_from_fixture)")
+        self.balancing_settings.bodies = bodies
+        self.balancing_settings.contacts = contacts
+        if self.balancing_settings.enabled:
+            self.dims.c = len(contacts)
+            self.dims.nf = 1 if bal["frictionless"] else 3
+        else:
+            self.dims.c = 0
+            self.dims.nf = 0
+        ia = config["inertial_alignment"]
+        self.inertial_alignment_settings.cost_enabled = ia["cost_enabled"]
+        self.inertial_alignment_settings.constraint_enabled = ia["constraint_enabled"]
+        self.obstacle_settings.enabled = config["obstacles"]["enabled"]
+        if x0 is None:
+            x0 = pa(config["robot"]["x0"])
+            assert x0.shape == (self.dims.robot.x,)
+        self.initial_state = np.array(x0, dtype=np.float64)
+        assert self.initial_state.shape == (self.dims.x(),)
+        self.xd = np.array(config.get("desired_state", np.zeros_like(self.initial_state)), dtype=np.float64)
+
+
+def objects_from_fixture(arr):
+    """(bodies dict, contacts list) of bindings objects from one entry of tests/golden/arrangements.json."""
+    from .core_bindings import ContactPoint, RigidBody
+
+    bodies = {b["name"]: RigidBody.from_parameters(b["params"]) for b in arr["bodies"]}
+    contacts = []
+    for c in arr["contacts"]:
+        p = ContactPoint()
+        p.object1_name, p.object2_name, p.mu = c["object1_name"], c["object2_name"], c["mu"]
+        p.normal, p.span = np.array(c["normal"]), np.array(c["span"])
+        p.r_co_o1, p.r_co_o2 = np.array(c["r_co_o1"]), np.array(c["r_co_o2"])
+        contacts.append(p)
+    return bodies, contacts
+
+
+class ControllerManager:
+    """manager.py:100-209."""
+
+    def __init__(self, settings, ref_trajectory, timestep):
+        self.settings = settings
+        self.ref = ref_trajectory
+        self.timestep = timestep
+        self.mpc = bindings.ControllerInterface(settings)
+        self.mpc.reset(self.ref)
+        self.last_planning_time = -np.inf
+        self.x_opt = np.zeros(settings.dims.x())
+        self.u_opt = np.zeros(settings.dims.u())
+        self.replanning_times = []
+        self.replanning_durations = []
+
+    @classmethod
+    def from_config(cls, config, x0=None, bodies=None, contacts=None):
+        settings = ControllerSettings(config, x0=x0, bodies=bodies, contacts=contacts)
+        timestep = config["tracking"]["min_policy_update_time"]
+        chain = robots.from_config(config["robot"])
+        r_ew_w, C_we = chain.forward(settings.initial_state[: settings.dims.robot.q])
+        ref = TargetTrajectories.from_config(config, r_ew_w, rot_to_quat_xyzw(C_we), np.zeros(settings.dims.u()))
+        return cls(settings, ref, timestep)
+
+    def update(self, ref):
+        self.ref = ref
+        self.mpc.reset(self.ref)
+
+    def warmstart(self):
+        self.mpc.setObservation(0, self.settings.initial_state, np.zeros(self.settings.dims.u()))
+        self.mpc.advanceMpc()
+        self.last_planning_time = 0
+
+    def step(self, t, x):
+        self.mpc.setObservation(t, x, self.u_opt)
+        if t >= self.last_planning_time + self.timestep:
+            t0 = time.time()
+            self.mpc.advanceMpc()
+            t1 = time.time()
+            self.last_planning_time = t
+            self.replanning_times.append(t)
+            self.replanning_durations.append(t1 - t0)
+        self.mpc.evaluateMpcSolution(t, x, self.x_opt, self.u_opt)
+        return self.x_opt, self.u_opt
+
+    def get_mpc_trajectory(self):
+        ts, xs, us = bindings.scalar_array(), bindings.vector_array(), bindings.vector_array()
+        self.mpc.getMpcSolution(ts, xs, us)
+        return np.array(ts), np.array(xs), np.array(us)

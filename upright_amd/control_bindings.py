@@ -1,0 +1,416 @@
+"""Drop-in for the pybind11 module `upright_control.bindings` (upright_control/src/pybindings.cpp:43-428).
+
+Same class and attribute names; `ControllerInterface` drives one instance (B = 1) of the batched HIP
+engine through the C-ABI of libupright_mi.so.  What the engine does not cover yet raises RuntimeError at
+construction, the way the reference's constructor throws std::runtime_error -- never a silent fallback:
+obstacle avoidance, projectile constraint, inertial alignment, end-effector box, operating points,
+feedback gains.
+"""
+import enum
+
+import numpy as np
+
+from . import robots
+from .core_bindings import ContactPoint, RigidBody  # noqa: F401  (BalancingSettings carries them)
+from .engine import BatchMPC
+from .problem import Problem
+
+
+class scalar_array(list):
+    def push_back(self, v):
+        self.append(float(v))
+
+
+class vector_array(list):
+    def push_back(self, v):
+        self.append(np.array(v, dtype=np.float64))
+
+
+class matrix_array(list):
+    def push_back(self, v):
+        self.append(np.array(v, dtype=np.float64))
+
+
+class StringPairVector(list):
+    def push_back(self, v):
+        self.append(tuple(v))
+
+
+class DynamicObstacleVector(list):
+    push_back = list.append
+
+
+class DynamicObstacleModeVector(list):
+    push_back = list.append
+
+
+class MapStringScalar(dict):
+    pass
+
+
+class RobotBaseType(enum.Enum):
+    Fixed = 0
+    Nonholonomic = 1
+    Omnidirectional = 2
+    Floating = 3
+
+
+def robot_base_type_from_string(s):
+    try:
+        return {"fixed": RobotBaseType.Fixed, "nonholonomic": RobotBaseType.Nonholonomic,
+                "omnidirectional": RobotBaseType.Omnidirectional, "floating": RobotBaseType.Floating}[s]
+    except KeyError:
+        raise RuntimeError("Cannot parse RobotBaseType from string.")  # base_type.h:24
+
+
+def robot_base_type_to_string(t):
+    return t.name.lower()
+
+
+class RobotDimensions:
+    def __init__(self):
+        self.q = self.v = self.x = self.u = 0
+
+
+class OptimizationDimensions:
+    """dimensions.h:18-46."""
+
+    def __init__(self):
+        self.robot = RobotDimensions()
+        self.o = 0
+        self.c = 0
+        self.nf = 3
+
+    def q(self): return self.robot.q + 3 * self.o
+    def v(self): return self.robot.v + 3 * self.o
+    def x(self): return self.robot.x + 9 * self.o
+    def f(self): return self.nf * self.c
+    def u(self): return self.robot.u + self.f()
+
+
+class BalancingSettings:
+    def __init__(self):
+        self.enabled = False
+        self.arrangement_name = ""
+        self.bodies = {}
+        self.contacts = []
+        self.force_weight = 0.01
+
+
+class DynamicObstacleMode:
+    def __init__(self):
+        self.time = 0.0
+        self.position = np.zeros(3); self.velocity = np.zeros(3); self.acceleration = np.zeros(3)
+
+
+class DynamicObstacle:
+    def __init__(self):
+        self.name = ""; self.radius = 0.0; self.modes = DynamicObstacleModeVector()
+
+
+class ObstacleSettings:
+    def __init__(self):
+        self.enabled = False
+        self.collision_link_pairs = StringPairVector()
+        self.minimum_distance = 0.0
+        self.obstacle_urdf_path = ""
+        self.dynamic_obstacles = DynamicObstacleVector()
+
+
+class InertialAlignmentSettings:
+    def __init__(self):
+        self.cost_enabled = False; self.constraint_enabled = False
+        self.use_angular_acceleration = False; self.align_with_fixed_vector = False
+        self.cost_weight = 1.0; self.alpha = 0.0
+        self.contact_plane_normal = np.array([0.0, 0, 1]); self.contact_plane_span = np.zeros((2, 3)); self.com = np.zeros(3)
+
+
+class MPCSettings:
+    def __init__(self):
+        self.time_horizon = 1.0; self.debug_print = False; self.cold_start = False
+
+
+class RolloutSettings:
+    def __init__(self):
+        self.abs_tol_ode = 1e-9; self.rel_tol_ode = 1e-6; self.max_num_steps_per_second = 10000
+        self.timestep = 1e-2; self.check_numerical_stability = True
+
+
+class SlackSettings:
+    def __init__(self):
+        self.enabled = False; self.input_box = True; self.state_box = True; self.poly_ineq = True
+        self.upper_L2_penalty = 100.0; self.lower_L2_penalty = 100.0; self.upper_L1_penalty = 0.0; self.lower_L1_penalty = 0.0
+        self.upper_low_bound = 0.0; self.lower_low_bound = 0.0
+
+
+class HPIPMSettings:
+    def __init__(self):
+        self.iter_max = 30; self.warm_start = 0; self.slacks = SlackSettings()
+
+
+class SQPSettings:
+    def __init__(self):
+        self.sqp_iteration = 1; self.init_sqp_iteration = 1; self.delta_tol = 1e-6; self.cost_tol = 1e-4
+        self.use_feedback_policy = True; self.dt = 0.01; self.project_state_input_equality_constraints = True
+        self.print_solver_status = True; self.print_solver_statistics = True; self.print_line_search = False
+        self.hpipm = HPIPMSettings()
+
+
+class TrackingSettings:
+    def __init__(self):
+        self.rate = 125; self.min_policy_update_time = 0.01; self.kp = 0; self.kv = 0; self.ka = 0
+        self.enforce_state_limits = True; self.enforce_input_limits = False; self.enforce_ee_position_limits = False
+        self.use_projectile = False; self.state_violation_margin = 0.1; self.input_violation_margin = 1.0
+        self.ee_position_violation_margin = 0.1
+
+
+class EstimationSettings:
+    def __init__(self):
+        self.robot_init_variance = 0; self.robot_process_variance = 1.0; self.robot_measurement_variance = 1.0
+
+
+class ControllerSettings:
+    """controller_settings.h:47-119 (pybindings.cpp:246-303)."""
+
+    def __init__(self):
+        self.initial_state = np.zeros(0)
+        self.gravity = np.array([0.0, 0, -9.81])
+        self.recompile_libraries = True
+        self.debug = False
+        self.mpc = MPCSettings(); self.sqp = SQPSettings(); self.rollout = RolloutSettings()
+        self.tracking = TrackingSettings(); self.estimation = EstimationSettings()
+        self.input_weight = np.zeros((0, 0)); self.state_weight = np.zeros((0, 0)); self.end_effector_weight = np.zeros((6, 6))
+        self.input_limit_lower = np.zeros(0); self.input_limit_upper = np.zeros(0)
+        self.state_limit_lower = np.zeros(0); self.state_limit_upper = np.zeros(0)
+        self.end_effector_box_constraint_enabled = False
+        self.xyz_lower = np.zeros(3); self.xyz_upper = np.zeros(3)
+        self.projectile_path_constraint_enabled = False
+        self.projectile_path_distances = np.zeros(0); self.projectile_path_scale = 1.0; self.projectile_path_collision_links = []
+        self.robot_urdf_path = ""; self.lib_folder = "/tmp/ocs2"
+        self.robot_base_type = RobotBaseType.Fixed
+        self.locked_joints = MapStringScalar(); self.base_pose = np.zeros(3)
+        self.dims = OptimizationDimensions()
+        self.end_effector_link_name = ""
+        self.use_operating_points = False
+        self.operating_times = scalar_array(); self.operating_states = vector_array(); self.operating_inputs = vector_array()
+        self.balancing_settings = BalancingSettings()
+        self.inertial_alignment_settings = InertialAlignmentSettings()
+        self.obstacle_settings = ObstacleSettings()
+        self.xd = np.zeros(0)
+
+
+class TargetTrajectories:
+    """ocs2::TargetTrajectories (pybindings.cpp:348-357): state = [r_d(3), Q_d(4, xyzw), s]."""
+
+    def __init__(self, ts, xs, us):
+        self.ts = scalar_array(float(t) for t in ts)
+        self.xs = vector_array(np.array(x, dtype=np.float64) for x in xs)
+        self.us = vector_array(np.array(u, dtype=np.float64) for u in us)
+
+    @staticmethod
+    def _interp(ts, vals, t):
+        if len(vals) == 1 or t <= ts[0]:
+            return np.array(vals[0])
+        if t >= ts[-1]:
+            return np.array(vals[-1])
+        i = int(np.searchsorted(ts, t, side="right")) - 1
+        a = (ts[i + 1] - t) / (ts[i + 1] - ts[i])
+        return a * np.asarray(vals[i]) + (1 - a) * np.asarray(vals[i + 1])
+
+    def get_desired_state(self, t):
+        return self._interp(list(self.ts), list(self.xs), t)
+
+    def get_desired_input(self, t):
+        return self._interp(list(self.ts), list(self.us), t)
+
+
+class VectorFunctionLinearApproximation:
+    def __init__(self):
+        self.f = np.zeros(0); self.dfdx = np.zeros((0, 0)); self.dfdu = np.zeros((0, 0))
+
+
+def problem_from_settings(s):
+    """ControllerSettings -> Problem (what ControllerInterface's constructor assembles,
+    controller_interface.cpp:103-393).  Raises RuntimeError for OCP terms outside the accelerated path."""
+    if s.obstacle_settings.enabled:
+        raise RuntimeError("obstacle avoidance is not supported by the MI355X engine yet (SURVEY.md 8f.1)")
+    if s.projectile_path_constraint_enabled:
+        raise RuntimeError("projectile path constraint is not supported by the MI355X engine yet (SURVEY.md 8f.2)")
+    if s.inertial_alignment_settings.cost_enabled or s.inertial_alignment_settings.constraint_enabled:
+        raise RuntimeError("inertial alignment is outside the accelerated path (SURVEY.md section 2, row 12)")
+    if s.end_effector_box_constraint_enabled:
+        raise RuntimeError("end effector box constraint is outside the accelerated path (SURVEY.md section 2, row 13)")
+    if s.use_operating_points:
+        raise RuntimeError("operating points are not supported by the MI355X engine yet")
+    if not s.balancing_settings.enabled:
+        raise RuntimeError("Balancing constraints disabled: the MI355X engine accelerates the balancing OCP only")
+    if s.sqp.hpipm.slacks.enabled:
+        raise RuntimeError("HPIPM slack variables are not supported by the MI355X engine yet")
+    d = s.dims
+    if d.o != 0:
+        raise RuntimeError("dynamic obstacles are not supported by the MI355X engine yet (SURVEY.md 8f.2)")
+    base = robot_base_type_to_string(s.robot_base_type)
+    chain = robots.from_config({"base_type": base, "dims": {"q": d.robot.q}, "base_pose": list(s.base_pose)})
+    from .core_bindings import contact_tables
+    from .problem import contacts_from_fixture
+
+    bodies, contacts = s.balancing_settings.bodies, s.balancing_settings.contacts
+    if len(contacts) != d.c:
+        raise RuntimeError("dims.c does not match the number of contact points")
+    arr = {
+        "bodies": [{"name": n, "params": bodies[n].get_parameters().tolist()} for n in bodies],
+        "contacts": [dict(object1_name=c.object1_name, object2_name=c.object2_name, mu=c.mu, normal=np.asarray(c.normal).tolist(),
+                          span=np.asarray(c.span).tolist(), r_co_o1=np.asarray(c.r_co_o1).tolist(), r_co_o2=np.asarray(c.r_co_o2).tolist())
+                     for c in contacts],
+    }
+    tables = contacts_from_fixture(arr)
+    for name, W in (("input_weight", s.input_weight), ("state_weight", s.state_weight), ("end_effector_weight", s.end_effector_weight)):
+        W = np.asarray(W)
+        if np.abs(W - np.diag(np.diag(W))).max() > 0:
+            raise RuntimeError(f"{name} must be diagonal")
+    nf, nc = d.nf, d.c
+    T, dt = float(s.mpc.time_horizon), float(s.sqp.dt)
+    N = int(round(T / dt))
+    if abs(N * dt - T) > 1e-9:
+        raise RuntimeError("time_horizon must be a multiple of sqp.dt")
+    frictionless = nf == 1
+    # controller_interface.cpp:330-357
+    f_lb = np.full(nf * nc, 0.0 if frictionless else -1e2)
+    f_ub = np.full(nf * nc, 1e2)
+    xd = np.asarray(s.xd, dtype=np.float64)
+    if xd.size == 0:
+        xd = np.zeros(d.x())
+    P = Problem(
+        chain=chain, nf=nf, N=N, dt=dt, gravity=np.asarray(s.gravity, dtype=np.float64),
+        Qdiag=np.diag(np.asarray(s.state_weight)).copy(),
+        Rdiag=np.concatenate([np.diag(np.asarray(s.input_weight)), s.balancing_settings.force_weight * np.ones(nf * nc)]),
+        xd=xd, Wee=np.diag(np.asarray(s.end_effector_weight)).copy(),
+        x_lb=np.asarray(s.state_limit_lower, dtype=np.float64), x_ub=np.asarray(s.state_limit_upper, dtype=np.float64),
+        u_lb=np.concatenate([np.asarray(s.input_limit_lower, dtype=np.float64), f_lb]),
+        u_ub=np.concatenate([np.asarray(s.input_limit_upper, dtype=np.float64), f_ub]),
+        sqp_iters=int(s.sqp.sqp_iteration), qp_iter_max=int(s.sqp.hpipm.iter_max),
+        delta_tol=float(s.sqp.delta_tol), cost_tol=float(s.sqp.cost_tol), **tables,
+    )
+    return P.validate()
+
+
+class ControllerInterface:
+    """ControllerPythonInterface (controller_python_interface.h:13-93; pybindings.cpp:364-427)."""
+
+    def __init__(self, settings):
+        self.settings = settings
+        self.problem = problem_from_settings(settings)
+        self._mpc = None
+        self._target = None
+        self._t = 0.0
+        self._x = np.array(settings.initial_state, dtype=np.float64)
+        self._first = True
+
+    def _set_target(self, target):
+        self._target = target
+        ts = np.array(list(target.ts), dtype=np.float64)
+        ps = np.array([np.asarray(x)[:3] for x in target.xs], dtype=np.float64).reshape(len(ts), 3)
+        self.problem.way_t, self.problem.way_p = ts, ps
+        if self._mpc is not None and len(self._mpc.problem.way_t) == len(ts) and np.array_equal(self._mpc.problem.way_t, ts):
+            self._mpc.reset(ps.reshape(1, len(ts), 3))
+        else:
+            if self._mpc is not None:
+                self._mpc.close()
+            self._mpc = BatchMPC(self.problem, 1)
+        self._first = True
+
+    def reset(self, targetTrajectories):
+        self._set_target(targetTrajectories)
+
+    def setTargetTrajectories(self, targetTrajectories):
+        self._set_target(targetTrajectories)
+
+    def setObservation(self, t, x, u):
+        x = np.asarray(x)
+        if x.dtype != np.float64 or x.shape != (self.problem.nx,):
+            raise TypeError("setObservation(): incompatible function arguments (x must be float64 of length nx)")
+        self._t, self._x = float(t), x.copy()
+
+    def advanceMpc(self):
+        if self._mpc is None:
+            raise RuntimeError("advanceMpc called before reset(targetTrajectories)")
+        # first solve uses init_sqp_iteration (controller.yaml:57), later ones sqp_iteration
+        self._mpc.set_observation(self._t, self._x)
+        self._mpc.advance()
+        self._first = False
+
+    def evaluateMpcSolution(self, current_time, current_state, opt_state, opt_input):
+        x, u = self._mpc.evaluate(float(current_time))
+        opt_state[:] = x[0]
+        opt_input[:] = u[0]
+
+    def getMpcSolution(self, t, x, u):
+        ts, xs, us = self._mpc.solution()
+        del t[:], x[:], u[:]
+        for k in range(self.problem.N + 1):
+            t.push_back(ts[0, k]); x.push_back(xs[0, k])
+            u.push_back(us[0, min(k, self.problem.N - 1)])  # ocs2 repeats the last input at the final node
+
+    def getLastSolveTime(self):
+        return self._mpc.last_solve_ms()
+
+    def getStateDim(self):
+        return self.problem.nx
+
+    def getInputDim(self):
+        return self.problem.nu
+
+    # -- term-level access (pybindings.cpp:414-424) ---------------------------------------------------------
+    def _lin(self, t, x, u):
+        if self._mpc is None:
+            self._mpc = BatchMPC(self.problem, 1)
+        return self._mpc.linearize_points(np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64), t)
+
+    def getStateInputEqualityConstraintValue(self, name, t, x, u):
+        if name != "object_dynamics":
+            raise RuntimeError(f"no equality constraint named '{name}'")
+        return self._lin(t, x, u)["g"][0]
+
+    def getStateInputInequalityConstraintValue(self, name, t, x, u):
+        if name != "contact_forces" or self.problem.nf != 3:
+            raise RuntimeError(f"no inequality constraint named '{name}'")
+        from .engine import core_friction_rows
+
+        return core_friction_rows(self.problem, np.asarray(u, dtype=np.float64)[self.problem.nq:])[0]
+
+    def getCostValue(self, name, t, x, u):
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        if name == "end_effector_cost":
+            return float(self._lin(t, x, u)["cost"][0])
+        if name == "state_input_cost":
+            P = self.problem
+            return float(0.5 * np.sum(P.Qdiag * (x - P.xd) ** 2) + 0.5 * np.sum(P.Rdiag * u ** 2))
+        raise RuntimeError(f"no cost named '{name}'")
+
+    def stateInputEqualityConstraint(self, t, x, u):
+        return self.getStateInputEqualityConstraintValue("object_dynamics", t, x, u)
+
+    def getLinearFeedbackGain(self, t):
+        raise RuntimeError("feedback gains are not exported by the MI355X engine yet (SURVEY.md 8f.3)")
+
+
+class BalancingConstraintWrapper:
+    """balancing_constraint_wrapper.h:16-66: f = [contact rows (5c), object dynamics (6 nb)], dfdx likewise."""
+
+    def __init__(self, settings):
+        if not settings.balancing_settings.enabled:
+            raise RuntimeError("Balancing settings not enabled.")
+        self.problem = problem_from_settings(settings)
+        self._mpc = BatchMPC(self.problem, 1)
+
+    def getLinearApproximation(self, t, x, u):
+        from .engine import core_friction_rows
+
+        P = self.problem
+        out = self._mpc.linearize_points(np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64), t)
+        a = core_friction_rows(P, np.asarray(u, dtype=np.float64)[P.nq:])[0] if P.nf == 3 else np.zeros(0)
+        approx = VectorFunctionLinearApproximation()
+        approx.f = np.concatenate([a, out["g"][0]])
+        approx.dfdx = np.vstack([np.zeros((a.size, P.nx)), out["gx"][0]])
+        approx.dfdu = np.zeros((approx.f.size, 0))
+        return approx

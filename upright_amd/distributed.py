@@ -1,0 +1,42 @@
+"""Multi-GPU layer: independent problem instances are sharded over ranks (one process per GPU); the only
+exchange step is an all-gather of the solved trajectories.  No collective touches
+the solve itself.  Works with backend "nccl" (RCCL over xGMI, GPU tensors) and "gloo" (CPU tensors, tests).
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous block of instances owned by `rank`: sizes differ by at most one, earlier ranks take the
+    remainder (ragged totals are allowed)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def all_gather_solutions(xs_local, us_local, counts=None, group=None):
+    """All-gather per-rank solution blocks [B_r, ...] into [sum B_r, ...] on every rank.
+    Tensors may be torch CPU (gloo) or CUDA (nccl) tensors; ragged B_r is handled by padding to the
+    largest shard (all_gather needs equal sizes) and trimming afterwards."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if counts is None:
+        n = torch.tensor([xs_local.shape[0]], dtype=torch.int64, device=xs_local.device)
+        allc = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(allc, n, group=group)
+        counts = [int(c.item()) for c in allc]
+    bmax = max(counts)
+
+    def gather(t):
+        pad = torch.zeros((bmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        out = torch.empty((world * bmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+        parts = [out[r * bmax: r * bmax + counts[r]] for r in range(world)]
+        return torch.cat(parts, dim=0)
+
+    return gather(xs_local), gather(us_local), counts
