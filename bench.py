@@ -42,6 +42,30 @@ def qp_flops_per_iter(P):
     return ric + bar
 
 
+def pmc_traffic():
+    """Per-launch HBM bytes of the two kernels from the committed rocprofv3 PMC passes (profiles/):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  They are measured at
+    the default workload (B = 1024); None when no profile is committed."""
+    import csv
+
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_hbm.csv")):
+        best = f
+    if best is None:
+        return {}, None
+    vals = {}
+    for row in csv.reader(l for l in open(best) if not l.startswith("#")):
+        if len(row) == 4 and row[0] != "kernel":
+            vals[(row[0], row[1])] = float(row[3])
+    out = {}
+    for key, tag in (("upr_qp", "qp"), ("upr_linearize_kernel", "linearize")):
+        fe = [v for (k, c), v in vals.items() if key in k and c == "FETCH_SIZE"]
+        wr = [v for (k, c), v in vals.items() if key in k and c == "WRITE_SIZE"]
+        if fe and wr:
+            out[tag] = (2.0 * fe[0] + wr[0]) * 1024.0
+    return out, best.name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +158,7 @@ def main():
         lin_gbs = lin_bytes / (kt["linearize_ms"] * 1e-3) / 1e9 if kt["linearize_ms"] > 0 else 0.0
         qp_flops = qp_flops_per_iter(P) * iters
         qp_tflops = qp_flops / (kt["qp_ms"] * 1e-3) / 1e12 if kt["qp_ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic() if B == 1024 else ({}, None)
         out = {
             "metric": "batched MPC solves/sec (Thing + 1 object, horizon 20)",
             "value": value,
@@ -165,7 +190,8 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": qp_tflops / PEAK_FP64_TFLOPS,
-                "traffic": None,
+                "traffic": traffic.get("qp"),
+                "traffic_source": traffic_src,
                 "avg_launch_ms": kt["qp_ms"],
             },
             # the constraint / linearisation kernel the north_star asks HBM GB/s for
@@ -176,7 +202,8 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": lin_gbs / PEAK_HBM_GBS,
-                "traffic": None,
+                "traffic": traffic.get("linearize"),
+                "algorithmic_bytes": lin_bytes,
                 "avg_launch_ms": kt["linearize_ms"],
                 "bytes_per_knot": bytes_per_knot(P),
             },
