@@ -144,8 +144,9 @@ def test_qp_kernel_vs_host_emulation(arrangements, kernel, nt, monkeypatch):
                      _capi.ptr(ws), C.c_long(need), _capi.ptr(stats)) == 0
     n1 = P.N + 1
     dxe = ws[:, :n1 * P.nx].reshape(B, n1, P.nx); due = ws[:, n1 * P.nx:n1 * P.nx + P.N * P.nu].reshape(B, P.N, P.nu)
-    assert np.abs(dxs - dxe).max() < 1e-9 * max(1.0, np.abs(dxe).max())
-    assert np.abs(dus - due).max() < 1e-9 * max(1.0, np.abs(due).max())
+    # a race shows up at 1e-3 and above; 1e-8 leaves room for FMA contraction / rsqrt rounding differences
+    assert np.abs(dxs - dxe).max() < 1e-8 * max(1.0, np.abs(dxe).max())
+    assert np.abs(dus - due).max() < 1e-8 * max(1.0, np.abs(due).max())
     mpc.close()
 
 
@@ -194,6 +195,31 @@ def test_mpc_solve_one_iteration(arrangements, kernel, nt, monkeypatch):
         # north_star tolerance on norms
         assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4
         assert abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
+    mpc.close()
+
+
+@pytest.mark.parametrize("name,offset", [("foam_die2", (-0.5, 0.5, 0.0)), ("box_arch", (-0.5, 0.5, 0.0)), ("blue_cups", (-0.5, 0.5, 0.0))])
+def test_mpc_solve_other_arrangements(arrangements, name, offset):
+    """Multi-body arrangements (2 / 3 / 7 bodies, 8 / 16 / 28 contact points: BASELINE config 3's object set):
+    stacked objects couple several bodies through shared contact forces.  foam_die2 runs the compile-time
+    kernel structure, the larger ones the generic (runtime-dimension) QP kernel."""
+    B = 3
+    P = thing_problem(arrangements[name])
+    x0 = level_tray_states(B, seed=17)
+    way = waypoints_for(P, x0, offset=offset)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] == 0)
+    for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
+        assert rc == 0
+        assert np.abs(xs[b] - xo).max() < 5e-5 and np.abs(us[b] - uo).max() < 5e-4
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4
+        assert abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
+        assert st["step_alpha_last"][b] == so.step_alpha_last
     mpc.close()
 
 

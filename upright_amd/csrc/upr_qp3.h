@@ -70,8 +70,21 @@ struct upr_qp3_lds {
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + r2(C::NT),
                          // LDS-resident Riccati store: feedback K = Hjj^-1 Hux, P+ b, feed-forward kff = Hjj^-1 huj, huj, Lj^-1 (packed lower)
                          Ks = misc + 16, Pbs = Ks + r2(C::N * C::NQ * C::NX), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
-                         Ljis = hujs + r2(C::N * C::NQ), pv2 = Ljis + r2(C::N * C::NH), total = pv2 + r2(C::NX);
+                         Ljis = hujs + r2(C::N * C::NQ), pv2 = Ljis + r2(C::N * C::NH), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
 };
+
+// 1/sqrt(x) without the IEEE division / square-root sequences (they cost ~300 cycles per pivot on the
+// critical path): hardware estimate + two Newton steps, relative error < 1e-15.
+static inline UPR_HD double upr_rsqrt(double x) {
+#ifdef UPR_HOST_EMU
+    return 1.0 / sqrt(x);
+#else
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+#endif
+}
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
 // diagonal replaced by 1 / L_ii (what the triangular inverse and solves need).
@@ -89,7 +102,7 @@ static inline UPR_HD bool upr_chol_regs(const double* M, double* Lo) {
 #pragma unroll
         for (int k = 0; k < p; ++k) s -= a[p][k] * a[p][k];
         if (!(s > 0.0)) { ok = false; s = 1.0; }
-        const double idg = 1.0 / sqrt(s);
+        const double idg = upr_rsqrt(s);
         a[p][p] = idg;
 #pragma unroll
         for (int i = p + 1; i < n; ++i) {
@@ -198,6 +211,15 @@ struct upr_qp3 {
                 L[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
                 L[O::wu + iu] = w0 + w1;
             }
+        }
+        // dynamics residual of every knot in absolute variables (multiple-shooting defect of the iterate)
+        UPR_FOR(e, N * NQ) {
+            const int k = e / NQ, j = e % NQ;
+            const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
+            const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
+            L[O::bks + k * NX + j] = q + h * v + h2 * a + h3 * u - Xn[j];
+            L[O::bks + k * NX + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
+            L[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
         }
         UPR_SYNC();
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
@@ -348,9 +370,6 @@ struct upr_qp3 {
         UPR_SYNC();
         if (mat) {
             for (int k = N - 1; k >= 0; --k) {
-                // phase 0: dynamics residual of this knot
-                dyn_residual(k);
-                UPR_SYNC();
                 // phase 1: everything that is a function of P+ only.  Job list:
                 //   [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the 9
                 //               entries of A'P+A, 3 of Hux = B'P+A and 1 of Hjj = B'P+B (+ R + barrier);
@@ -379,9 +398,8 @@ struct upr_qp3 {
 #pragma unroll
                             for (int c = 0; c < 3; ++c) Pn[(a * NQ + ii) * NX + c * NQ + jj] = o2[a][c];
                         // B' (P A) = h3 t[0] + h2 t[1] + h t[2]
-                        double bt[3];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { bt[c] = h3 * t[0][c] + h2 * t[1][c] + h * t[2][c]; L[O::hux + ii * NX + c * NQ + jj] = bt[c]; }
+                        for (int c = 0; c < 3; ++c) L[O::hux + ii * NX + c * NQ + jj] = h3 * t[0][c] + h2 * t[1][c] + h * t[2][c];
                         // B' P B
                         double v = 0.0;
 #pragma unroll
@@ -397,33 +415,34 @@ struct upr_qp3 {
                     } else {
                         const int i = e - NQ * NQ - NE * NX;
                         double pb = 0.0;
-                        for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bk + j];
+                        for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bks + k * NX + j];
                         L[O::Pbs + k * NX + i] = pb; L[O::wv + i] = pcur[i] + pb;
                     }
                 }
                 UPR_SYNC();
                 toc(12);
-                // phase 2: one lane factors Hjj in registers; others: hx, huj
-                if (ctx.tid == NT - 1) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
-                hx_huj(k);
-                UPR_SYNC();
-                toc(13);
-                // phase 3: Lji columns
-                UPR_FOR(j, NQ) upr_tri_inv_col<NQ>(L + O::hjj, L + O::lji, j);
-                UPR_SYNC();
-                // phase 4: V = Lji Hux, yj = Lji huj
-                UPR_FOR(e, NQ * NX + NQ) {
-                    if (e < NQ * NX) {
-                        const int i = e / NX, c = e % NX;
-                        double v = 0.0;
-                        for (int m = 0; m <= i; ++m) v += L[O::lji + i * NQ + m] * L[O::hux + m * NX + c];
-                        L[O::vm + e] = v;
-                    } else {
-                        const int j = e - NQ * NX;
+                // phases 2-3 inside the first wave only (no workgroup barrier): lane 0 factors Hjj in registers while
+                // lanes 1.. build hx / huj; then nq lanes invert the factor column by column and form yj
+                if (ctx.tid < 64) {
+                    upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
+                    if (wc.tid == 0) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
+                    hx_huj_w(wc, k);
+                    UPR_WSYNC();
+                    { const upr_ctx& ctx = wc; UPR_FOR(j, NQ) upr_tri_inv_col<NQ>(L + O::hjj, L + O::lji, j); }
+                    UPR_WSYNC();
+                    { const upr_ctx& ctx = wc; UPR_FOR(j, NQ) {
                         double v = 0.0;
                         for (int m = 0; m <= j; ++m) v += L[O::lji + j * NQ + m] * L[O::huj + m];
-                        L[O::yj + j] = v;
-                    }
+                        L[O::yj + j] = v; } }
+                }
+                UPR_SYNC();
+                toc(13);
+                // phase 4: V = Lji Hux
+                UPR_FOR(e, NQ * NX) {
+                    const int i = e / NX, c = e % NX;
+                    double v = 0.0;
+                    for (int m = 0; m <= i; ++m) v += L[O::lji + i * NQ + m] * L[O::hux + m * NX + c];
+                    L[O::vm + e] = v;
                 }
                 UPR_SYNC();
                 toc(14);
@@ -470,26 +489,32 @@ struct upr_qp3 {
                 toc(15);
             }
         } else {
-            // vector pass: one phase per knot.  Every lane i < NX rebuilds the nq jerk gradients it needs.
-            for (int k = N - 1; k >= 0; --k) {
-                UPR_FOR(i, NX) {
-                    double w[NX];
+            // vector pass: one wave-local phase per knot (first wave only, no workgroup barrier).  Every lane
+            // i < NX rebuilds the nq jerk gradients it needs.
+            if (ctx.tid < 64) {
+                upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
+                const upr_ctx& ctx = wc;
+                for (int k = N - 1; k >= 0; --k) {
+                    UPR_FOR(i, NX) {
+                        double w[NX];
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) w[a] = pcur[a] + L[O::Pbs + k * NX + a];
-                    const int b = i / NQ, j = i % NQ;
-                    double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
-                    for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
+                        for (int a = 0; a < NX; ++a) w[a] = pcur[a] + L[O::Pbs + k * NX + a];
+                        const int b = i / NQ, j = i % NQ;
+                        double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
+                        for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
 #pragma unroll
-                    for (int m = 0; m < NQ; ++m) {
-                        const double hm = L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m];
-                        v -= L[O::Ks + k * NQ * NX + m * NX + i] * hm;
-                        if (i == m) L[O::hujs + k * NQ + m] = hm;
+                        for (int m = 0; m < NQ; ++m) {
+                            const double hm = L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m];
+                            v -= L[O::Ks + k * NQ * NX + m * NX + i] * hm;
+                            if (i == m) L[O::hujs + k * NQ + m] = hm;
+                        }
+                        pnew[i] = v;
                     }
-                    pnew[i] = v;
+                    UPR_WSYNC();
+                    double* tsw = pcur; pcur = pnew; pnew = tsw;
                 }
-                UPR_SYNC();
-                double* tsw = pcur; pcur = pnew; pnew = tsw;
             }
+            UPR_SYNC();
             // feed-forward of every knot: kff = Lji' (Lji huj)
             UPR_FOR(k, N) {
                 const double* Lp = L + O::Ljis + k * C::NH;
@@ -508,9 +533,10 @@ struct upr_qp3 {
             UPR_SYNC();
         }
     }
-    // hx = gxs_k + A' wv ; huj = gus_k[j] + B' wv
-    UPR_HD void hx_huj(int k) {
-        UPR_FOR(e, NX + NQ) {
+    // hx = gxs_k + A' wv ; huj = gus_k[j] + B' wv   (lanes 1.. of the given context; lane 0 may be busy)
+    UPR_HD void hx_huj_w(const upr_ctx& wc, int k) {
+        const int lanes = wc.nt > 1 ? wc.nt - 1 : 1, me = wc.nt > 1 ? wc.tid - 1 : 0;
+        if (me >= 0) for (int e = me; e < NX + NQ; e += lanes) {
             if (e < NX) {
                 const int b = e / NQ, j = e % NQ;
                 double v = L[O::gxs + k * NX + e];
@@ -525,28 +551,32 @@ struct upr_qp3 {
 
     // forward sweep: one phase per knot, closed-loop form  sx+ = A sx + b - B (K sx + kff)
     UPR_HD void forward() {
-        UPR_FOR(i, NX) Sx(0)[i] = 0.0;
-        UPR_SYNC();
-        for (int k = 0; k < N; ++k) {
-            const double* sx = Sx(k); double* sn = Sx(k + 1);
-            UPR_FOR(i, NX) {
-                const int b = i / NQ, j = i % NQ;
-                const double* Kr = L + O::Ks + k * NQ * NX + j * NX;
-                double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
+        // wave-local sweep (first wave, no workgroup barrier): sx+ = A sx + b - B (K sx + kff)
+        if (ctx.tid < 64) {
+            upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
+            const upr_ctx& ctx = wc;
+            UPR_FOR(i, NX) Sx(0)[i] = 0.0;
+            UPR_WSYNC();
+            for (int k = 0; k < N; ++k) {
+                const double* sx = Sx(k); double* sn = Sx(k + 1);
+                UPR_FOR(i, NX) {
+                    const int b = i / NQ, j = i % NQ;
+                    const double* Kr = L + O::Ks + k * NQ * NX + j * NX;
+                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
 #pragma unroll
-                for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
-                const double uj = -(d0 + d1 + d2);
-                const double* X = Zx(k); const double* Xn = Zx(k + 1); const double U = Zu(k)[j];
-                const double q = sx[j], v = sx[NQ + j], a = sx[2 * NQ + j];
-                const double Q = X[j], V = X[NQ + j], Ac = X[2 * NQ + j];
-                double r;
-                if (b == 0) { r = q + h * v + h2 * a + h3 * uj + (Q + h * V + h2 * Ac + h3 * U - Xn[j]); Su(k)[j] = uj; }
-                else if (b == 1) r = v + h * a + h2 * uj + (V + h * Ac + h2 * U - Xn[NQ + j]);
-                else r = a + h * uj + (Ac + h * U - Xn[2 * NQ + j]);
-                sn[i] = r;
+                    for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
+                    const double uj = -(d0 + d1 + d2);
+                    const double q = sx[j], v = sx[NQ + j], a = sx[2 * NQ + j];
+                    double r;
+                    if (b == 0) { r = q + h * v + h2 * a + h3 * uj; Su(k)[j] = uj; }
+                    else if (b == 1) r = v + h * a + h2 * uj;
+                    else r = a + h * uj;
+                    sn[i] = r + L[O::bks + k * NX + i];
+                }
+                UPR_WSYNC();
             }
-            UPR_SYNC();
         }
+        UPR_SYNC();
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
         UPR_FOR(e, N * NE) {
             const int k = e / NE, r = e % NE;
