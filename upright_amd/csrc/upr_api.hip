@@ -373,7 +373,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
     if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }
-    h->qp_nt = h->use_qp3 ? 512 : 128;
+    h->qp_nt = h->use_qp3 ? 256 : 128;
     if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
     {   // both QP kernels index the instance workspace with the same stride
         size_t need = qp2_ws_doubles(*P, h->d);

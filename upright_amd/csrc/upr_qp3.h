@@ -421,34 +421,99 @@ struct upr_qp3 {
                 }
                 UPR_SYNC();
                 toc(12);
-                // phases 2-3 inside the first wave only (no workgroup barrier): lane 0 factors Hjj in registers while
-                // lanes 1.. build hx / huj; then nq lanes invert the factor column by column and form yj
+                // phases 2-4 inside the first wave only (no workgroup barrier): lane 0 factors Hjj in registers while
+                // lanes 1.. build hx / huj; then one lane per column does the forward substitution V = Lj^-1 Hux and,
+                // without leaving its registers, the back substitution K = Lj^-T V (lane NX: yj and kff).
                 if (ctx.tid < 64) {
                     upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
                     if (wc.tid == 0) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
                     hx_huj_w(wc, k);
                     UPR_WSYNC();
-                    { const upr_ctx& ctx = wc; UPR_FOR(j, NQ) upr_tri_inv_col<NQ>(L + O::hjj, L + O::lji, j); }
-                    UPR_WSYNC();
-                    { const upr_ctx& ctx = wc; UPR_FOR(j, NQ) {
-                        double v = 0.0;
-                        for (int m = 0; m <= j; ++m) v += L[O::lji + j * NQ + m] * L[O::huj + m];
-                        L[O::yj + j] = v; } }
+                    const double* Lo = L + O::hjj;   // lower factor, reciprocal diagonal
+                    for (int e = wc.tid; e < NX + 1 + C::NH; e += wc.nt) {
+                        if (e <= NX) {
+                            double v[NQ];
+#pragma unroll
+                            for (int i = 0; i < NQ; ++i) {
+                                double t = (e < NX) ? L[O::hux + i * NX + e] : L[O::huj + i];
+#pragma unroll
+                                for (int m = 0; m < i; ++m) t -= Lo[i * NQ + m] * v[m];
+                                v[i] = t * Lo[i * NQ + i];
+                            }
+                            if (e < NX) {
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) L[O::vm + i * NX + e] = v[i];
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) L[O::yj + i] = v[i];
+                            }
+                            double kk[NQ];
+#pragma unroll
+                            for (int i = NQ - 1; i >= 0; --i) {
+                                double t = v[i];
+#pragma unroll
+                                for (int m = i + 1; m < NQ; ++m) t -= Lo[m * NQ + i] * kk[m];
+                                kk[i] = t * Lo[i * NQ + i];
+                            }
+                            if (e < NX) {
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) L[O::Ks + k * NQ * NX + i * NX + e] = kk[i];
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
+                            }
+                        } else {
+                            const int f = e - NX - 1;
+                            int i = 0; while ((i + 1) * (i + 2) / 2 <= f) ++i;   // packed lower: f = i(i+1)/2 + j
+                            L[O::Ljis + k * C::NH + f] = Lo[i * NQ + (f - i * (i + 1) / 2)];
+                        }
+                    }
                 }
                 UPR_SYNC();
                 toc(13);
-                // phase 4: V = Lji Hux
-                UPR_FOR(e, NQ * NX) {
-                    const int i = e / NX, c = e % NX;
-                    double v = 0.0;
-                    for (int m = 0; m <= i; ++m) v += L[O::lji + i * NQ + m] * L[O::hux + m * NX + c];
-                    L[O::vm + e] = v;
-                }
-                UPR_SYNC();
-                toc(14);
-                // phase 5: P = sym(A'P+A) + Q~ - V'V + Vc'Vc (upper triangle, mirrored) ; p = hx - V'yj + cs ;
-                //          K = Lji'V ; kff = Lji'yj ; packed Lji ; next knot's C
-                UPR_FOR(e, NX * NX + NX + NQ * NX + NQ + C::NH) {
+                // phase 5: P = sym(A'P+A) + Q~ - V'V + Vc'Vc (upper triangle, mirrored) ; p = hx - V'yj + cs ; next knot's C
+#ifndef UPR_HOST_EMU
+                if (NX <= 32 && NQ + NE <= 16) {
+                    // Matrix-core path: the rank-(nq + ne) update M' diag(-1.., +1..) M with M = [V; Vc] (<= 16 x nx) is
+                    // three 16x16 output tiles of v_mfma_f64_16x16x4_f64 (tiles (0,0), (0,1), (1,1) of the 32x32 padded
+                    // result; the lower triangle is mirrored).  Lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and
+                    // receives D[(l >> 4) + 4 r][l & 15].
+                    typedef double v4d __attribute__((ext_vector_type(4)));
+                    const int wave = ctx.tid >> 6, lane = ctx.tid & 63, nwaves = NT >> 6;
+                    for (int tile = wave; tile < 3; tile += nwaves) {
+                        const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
+                        const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
+                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int r = 4 * s4 + kk;   // row of M
+                            double a = 0.0, b = 0.0;
+                            if (r < NQ) { if (ci < NX) a = -L[O::vm + r * NX + ci]; if (cj < NX) b = L[O::vm + r * NX + cj]; }
+                            else if (r < NQ + NE) { if (ci < NX) a = L[O::vc + (r - NQ) * NX + ci]; if (cj < NX) b = L[O::vc + (r - NQ) * NX + cj]; }
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
+                            if (i < NX && j < NX && i <= j) {
+                                double v = acc[r] + 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
+                                if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
+                                if (j < NQ) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)];
+                                Pc[i * NX + j] = v; Pc[j * NX + i] = v;
+                            }
+                        }
+                    }
+                    // the affine term on the last wave (free of tile work whenever the workgroup has >= 4 waves)
+                    if (ctx.tid >= NT - 64) {
+                        for (int i = ctx.tid - (NT - 64); i < NX; i += 64) {
+                            double v = L[O::hx + i] + L[O::cs + k * NX + i];
+                            for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::yj + m];
+                            pcur[i] = v;
+                        }
+                    }
+                } else
+#endif
+                UPR_FOR(e, NX * NX + NX) {
                     if (e < NX * NX) {
                         const int i = e / NX, j = e % NX;
                         if (i <= j) {
@@ -459,26 +524,11 @@ struct upr_qp3 {
                             for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
                             Pc[i * NX + j] = v; Pc[j * NX + i] = v;
                         }
-                    } else if (e < NX * NX + NX) {
+                    } else {
                         const int i = e - NX * NX;
                         double v = L[O::hx + i] + L[O::cs + k * NX + i];
                         for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::yj + m];
                         pcur[i] = v;
-                    } else if (e < NX * NX + NX + NQ * NX) {
-                        const int f = e - NX * NX - NX, i = f / NX, c = f % NX;
-                        double v = 0.0;
-                        for (int m = i; m < NQ; ++m) v += L[O::lji + m * NQ + i] * L[O::vm + m * NX + c];
-                        L[O::Ks + k * NQ * NX + f] = v;
-                    } else if (e < NX * NX + NX + NQ * NX + NQ) {
-                        const int i = e - NX * NX - NX - NQ * NX;
-                        double v = 0.0;
-                        for (int m = i; m < NQ; ++m) v += L[O::lji + m * NQ + i] * L[O::yj + m];
-                        L[O::kffs + k * NQ + i] = v;
-                    } else {
-                        const int f = e - NX * NX - NX - NQ * NX - NQ;
-                        int i = 0; while ((i + 1) * (i + 2) / 2 <= f) ++i;   // packed lower: f = i(i+1)/2 + j
-                        const int j = f - i * (i + 1) / 2;
-                        L[O::Ljis + k * C::NH + f] = L[O::lji + i * NQ + j];
                     }
                 }
                 if (k > 0) {
@@ -495,40 +545,46 @@ struct upr_qp3 {
                 upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
                 const upr_ctx& ctx = wc;
                 for (int k = N - 1; k >= 0; --k) {
-                    UPR_FOR(i, NX) {
-                        double w[NX];
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) w[a] = pcur[a] + L[O::Pbs + k * NX + a];
-                        const int b = i / NQ, j = i % NQ;
-                        double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
-                        for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) {
-                            const double hm = L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m];
-                            v -= L[O::Ks + k * NQ * NX + m * NX + i] * hm;
-                            if (i == m) L[O::hujs + k * NQ + m] = hm;
+                    UPR_FOR(a, NX) L[O::wv + a] = pcur[a] + L[O::Pbs + k * NX + a];
+                    UPR_WSYNC();
+                    UPR_FOR(e, NX + NQ) {
+                        if (e < NQ) {
+                            const double hm = L[O::gus + k * NU + e] + h3 * L[O::wv + e] + h2 * L[O::wv + NQ + e] + h * L[O::wv + 2 * NQ + e];
+                            L[O::huj + e] = hm; L[O::hujs + k * NQ + e] = hm;
+                        } else {
+                            const int i = e - NQ, b = i / NQ, j = i % NQ;
+                            double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
+                            for (int a = 0; a <= b; ++a) v += coefA(a, b) * L[O::wv + a * NQ + j];
+                            L[O::hx + i] = v;
                         }
-                        pnew[i] = v;
                     }
                     UPR_WSYNC();
-                    double* tsw = pcur; pcur = pnew; pnew = tsw;
+                    UPR_FOR(i, NX) {
+                        double v = L[O::hx + i];
+#pragma unroll
+                        for (int m = 0; m < NQ; ++m) v -= L[O::Ks + k * NQ * NX + m * NX + i] * L[O::huj + m];
+                        pcur[i] = v;
+                    }
+                    UPR_WSYNC();
                 }
             }
             UPR_SYNC();
-            // feed-forward of every knot: kff = Lji' (Lji huj)
+            // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
             UPR_FOR(k, N) {
                 const double* Lp = L + O::Ljis + k * C::NH;
-                double y[NQ];
+                double y[NQ], kk[NQ];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) { double v = 0.0;
+                for (int i = 0; i < NQ; ++i) { double t = L[O::hujs + k * NQ + i];
 #pragma unroll
-                    for (int m = 0; m <= i; ++m) v += Lp[i * (i + 1) / 2 + m] * L[O::hujs + k * NQ + m];
-                    y[i] = v; }
+                    for (int m = 0; m < i; ++m) t -= Lp[i * (i + 1) / 2 + m] * y[m];
+                    y[i] = t * Lp[i * (i + 1) / 2 + i]; }
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) { double v = 0.0;
+                for (int i = NQ - 1; i >= 0; --i) { double t = y[i];
 #pragma unroll
-                    for (int m = i; m < NQ; ++m) v += Lp[m * (m + 1) / 2 + i] * y[m];
-                    L[O::kffs + k * NQ + i] = v; }
+                    for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
+                    kk[i] = t * Lp[i * (i + 1) / 2 + i]; }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
             }
             UPR_SYNC();
         }
@@ -559,13 +615,18 @@ struct upr_qp3 {
             UPR_WSYNC();
             for (int k = 0; k < N; ++k) {
                 const double* sx = Sx(k); double* sn = Sx(k + 1);
+                UPR_FOR(i, NX) {   // partial dot products of K sx over one nq-block each
+                    const int b = i / NQ, j = i % NQ;
+                    const double* Kr = L + O::Ks + k * NQ * NX + j * NX + b * NQ;
+                    double d = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) d += Kr[c] * sx[b * NQ + c];
+                    L[O::hx + i] = d;
+                }
+                UPR_WSYNC();
                 UPR_FOR(i, NX) {
                     const int b = i / NQ, j = i % NQ;
-                    const double* Kr = L + O::Ks + k * NQ * NX + j * NX;
-                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
-                    const double uj = -(d0 + d1 + d2);
+                    const double uj = -(L[O::kffs + k * NQ + j] + L[O::hx + j] + L[O::hx + NQ + j] + L[O::hx + 2 * NQ + j]);
                     const double q = sx[j], v = sx[NQ + j], a = sx[2 * NQ + j];
                     double r;
                     if (b == 0) { r = q + h * v + h2 * a + h3 * uj; Su(k)[j] = uj; }
