@@ -39,13 +39,26 @@ struct upr_qp3_cfg {
     static constexpr int SS_V = 0, SS_LJI = SS_V + NQ * NX, SS_YJ = SS_LJI + NQ * NQ, SS_PB = SS_YJ + NQ, SS_STRIDE = ((SS_PB + NX + 1) & ~1);
 };
 
+// "far" arrays: per-instance data that only the flat (stage-parallel) phases touch, plus the Riccati feedback
+// store that the back-substitutions stream with a one-knot register prefetch.  They live in global memory
+// (L2-resident) so that two workgroups fit the 160 KB of LDS of a CU.
+template <class C>
+struct upr_qp3_far {
+    static constexpr int r2(int n) { return (n + 1) & ~1; }
+    static constexpr int g0 = 0, e0 = g0 + r2(C::N * C::NQ), ek = e0 + r2(C::N * C::NE), yf = ek + r2(C::N * C::NE), hf = yf + r2(C::N * C::NFC),
+                         ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE), cv = zt, nun = zt + r2(C::N * C::NE), lfi = nun + r2(C::N * C::NE),
+                         Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * C::NH), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
+                         hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NE * C::NE),
+                         total = Ks + r2(C::N * C::NQ * C::NX);
+};
+
 // global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
 template <class C>
 struct upr_qp3_ws {
     static constexpr int dx = 0, du = C::N1 * C::NX;
     static constexpr int a0 = (C::NZ + 1) & ~1;
     static constexpr int pi = a0, pin = pi + C::N1 * C::NX + (C::N1 * C::NX & 1), nu = pin + C::N1 * C::NX + (C::N1 * C::NX & 1),
-                         store = nu + ((C::N * C::NE + 1) & ~1), total = ((store + C::N * C::SS_STRIDE + 15) & ~15);
+                         store = nu + ((C::N * C::NE + 1) & ~1), far = store /* the old per-knot store is gone */, total = ((far + upr_qp3_far<C>::total + 15) & ~15);
 };
 
 // LDS layout (doubles), all compile-time
@@ -53,24 +66,20 @@ template <class C>
 struct upr_qp3_lds {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
     static constexpr int Z = 0, S = Z + r2(C::NZ), gxs = S + r2(C::NZ), wx = gxs + r2(C::N1 * C::NX), gus = wx + r2(C::N1 * C::NX),
-                         wu = gus + r2(C::N * C::NU), ek = wu + r2(C::N * C::NU), lfi = ek + r2(C::N * C::NE), lsi = lfi + r2(C::N * C::NLF),
-                         yf = lsi + r2(C::N * C::NE * C::NE), hf = yf + r2(C::N * C::NFC), ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE),
-                         cs = zt + r2(C::N * C::NE), nun = cs + r2(C::N * C::NX), cv = zt /* alias: zt is dead once cs exists */, hee = nun + r2(C::N * C::NE),
-                         g0 = hee + r2(C::N * C::NH), e0 = g0 + r2(C::N * C::NQ),
+                         wu = gus + r2(C::N * C::NU), cs = wu + r2(C::N * C::NU), hf = cs + r2(C::N * C::NX), ys = hf + r2(C::N * C::NFC),
+                         zt = ys + r2(C::N * C::NE), cv = zt, ek = zt + r2(C::N * C::NE),
                          // constants
-                         xlb = e0 + r2(C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
+                         xlb = ek + r2(C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
                          rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
-                         // friction rows (lane-private slots)
-                         ct = df + r2(C::NE * C::NFC), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
                          // working set of the sweeps
-                         Pa = cc + r2(5 * C::NCI), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX), vm = hux + r2(C::NQ * C::NX),
-                         hjj = vm + r2(C::NQ * C::NX), lji = hjj + r2(C::NQ * C::NQ), vc = lji + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
+                         Pa = df + r2(C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX), vm = hux + r2(C::NQ * C::NX),
+                         hjj = vm + r2(C::NQ * C::NX), vc = hjj + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
                          pv = ck + r2(C::NE * C::NX), wv = pv + r2(C::NX), hx = wv + r2(C::NX), huj = hx + r2(C::NX), yj = huj + r2(C::NQ),
-                         tj = yj + r2(C::NQ), pbv = tj + r2(C::NQ), bk = pbv + r2(C::NX), yN = bk + r2(C::NX), dyN = yN + r2(C::NEN),
+                         bk = yj + r2(C::NQ), yN = bk + r2(C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + r2(C::NT),
                          // LDS-resident Riccati store: feedback K = Hjj^-1 Hux, P+ b, feed-forward kff = Hjj^-1 huj, huj, Lj^-1 (packed lower)
-                         Ks = misc + 16, Pbs = Ks + r2(C::N * C::NQ * C::NX), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
-                         Ljis = hujs + r2(C::N * C::NQ), pv2 = Ljis + r2(C::N * C::NH), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
+                         lsik = misc + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
+                         pv2 = hujs + r2(C::N * C::NQ), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
 };
 
 // 1/sqrt(x) without the IEEE division / square-root sequences (they cost ~300 cycles per pivot on the
@@ -137,10 +146,12 @@ template <class C>
 struct upr_qp3 {
     typedef upr_qp3_lds<C> O;
     typedef upr_qp3_ws<C> W;
+    typedef upr_qp3_far<C> F;
     static constexpr int NQ = C::NQ, NX = C::NX, NU = C::NU, NE = C::NE, NFC = C::NFC, NC = C::NC, NF = C::NF, N = C::N, N1 = C::N1, NT = C::NT;
     upr_ctx ctx;
     const upr_problem* P;
     double* L;
+    double* G;   // far arrays (global)
     const double* xs; const double* us; const double* x0; const double* lin; const double* Dfg;
     double* ws;
     int lin_stride, lin_g, lin_gx, lin_grad, lin_hess, neN;
@@ -151,7 +162,6 @@ struct upr_qp3 {
     double tu[C::QU][2], lu[C::QU][2], cu[C::QU][2];
 
     UPR_HD const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
-    UPR_HD double* store(int k) const { return ws + W::store + (size_t)k * C::SS_STRIDE; }
     UPR_HD double* Zx(int k) const { return L + O::Z + k * NX; }
     UPR_HD double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
     UPR_HD double* Sx(int k) const { return L + O::S + k * NX; }
@@ -189,8 +199,8 @@ struct upr_qp3 {
                 if (k < N) {
                     g = L[O::qd + i] * (X - L[O::xd + i]);
                     if (i < NQ) {
-                        double a = L[O::g0 + k * NQ + i];
-                        for (int j = 0; j < NQ; ++j) a += L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
+                        double a = G[F::g0 + k * NQ + i];
+                        for (int j = 0; j < NQ; ++j) a += G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
                         g += a;
                     }
                     g *= h;
@@ -237,26 +247,26 @@ struct upr_qp3 {
                         const double* e3 = L + O::erow + 3 * (5 * ci + r);
                         const double c = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
                         const double ds = e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2];
-                        double s, wgt, ct_ = L[O::cc + 5 * ic + r];
-                        row(c, ds, L[O::ct + 5 * ic + r], L[O::cl + 5 * ic + r], ct_, s, wgt);
-                        if (mode == 1) L[O::cc + 5 * ic + r] = ct_;
+                        double s, wgt, ct_ = G[F::cc + 5 * ic + r];
+                        row(c, ds, G[F::ct + 5 * ic + r], G[F::cl + 5 * ic + r], ct_, s, wgt);
+                        if (mode == 1) G[F::cc + 5 * ic + r] = ct_;
                         for (int a = 0; a < 3; ++a) { guf[a] += e3[a] * s; for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2]; }
                     }
                     for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
                     if (level == 0) continue;
-                    double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
+                    double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
                     if (factor) { if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0; for (int a = 0; a < 9; ++a) Bk[a] = Hc[a]; }
                     double yv[3], hv[3];
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * guf[b2]; yv[a] = v; }
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * yv[b2]; hv[a] = v; }
-                    for (int a = 0; a < 3; ++a) { L[O::yf + k * NFC + 3 * ci + a] = yv[a]; L[O::hf + k * NFC + 3 * ci + a] = hv[a]; }
+                    for (int a = 0; a < 3; ++a) { G[F::yf + k * NFC + 3 * ci + a] = yv[a]; L[O::hf + k * NFC + 3 * ci + a] = hv[a]; }
                 } else {
                     if (level == 0) continue;
                     const int uo = k * NU + NQ + ci;
-                    if (factor) L[O::lfi + k * C::NLF + ci] = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
-                    const double lf = L[O::lfi + k * C::NLF + ci];
+                    if (factor) G[F::lfi + k * C::NLF + ci] = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
+                    const double lf = G[F::lfi + k * C::NLF + ci];
                     const double yv = lf * L[O::gus + uo];
-                    L[O::yf + k * NFC + ci] = yv; L[O::hf + k * NFC + ci] = lf * yv;
+                    G[F::yf + k * NFC + ci] = yv; L[O::hf + k * NFC + ci] = lf * yv;
                 }
             }
         }
@@ -265,7 +275,7 @@ struct upr_qp3 {
         UPR_FOR(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
-            double v = L[O::e0 + e];
+            double v = G[F::e0 + e];
             for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
             double v2 = 0.0;
             for (int i = 0; i < NFC; ++i) { v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i]; if (level > 0) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i]; }
@@ -280,20 +290,20 @@ struct upr_qp3 {
                     double zr, zc;
                     if (NF == 3) {
                         const int ci = i / 3, a = i % 3;
-                        const double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
+                        const double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
                         zr = 0.0; zc = 0.0;
                         for (int b2 = 0; b2 <= a; ++b2) { zr += Bk[3 * a + b2] * L[O::df + r * NFC + 3 * ci + b2]; zc += Bk[3 * a + b2] * L[O::df + c * NFC + 3 * ci + b2]; }
-                    } else { const double lf = L[O::lfi + k * C::NLF + i]; zr = lf * L[O::df + r * NFC + i]; zc = lf * L[O::df + c * NFC + i]; }
+                    } else { const double lf = G[F::lfi + k * C::NLF + i]; zr = lf * L[O::df + r * NFC + i]; zc = lf * L[O::df + c * NFC + i]; }
                     acc += zr * zc;
                 }
-                L[O::lsi + k * NE * NE + r * NE + c] = acc;
+                G[F::lsi + k * NE * NE + r * NE + c] = acc;
             }
         }
         UPR_SYNC();
         if (level == 0) return;
         // D: one lane per knot: Schur factor (in place), ys = Lsi ee, zt = Lsi' ys
         UPR_FOR(k, N) {
-            double* Ls = L + O::lsi + k * NE * NE;
+            double* Ls = G + F::lsi + k * NE * NE;
             if (factor) { if (!upr_chol_inv_serial<NE>(Ls, Ls)) L[O::misc] = 1.0; }
             double ee[NE], yv[NE];
 #pragma unroll
@@ -348,7 +358,12 @@ struct upr_qp3 {
         double* pcur = L + O::pv; double* pnew = L + O::pv2;
         // ---- terminal knot
         terminal_residual();
-        if (mat) { const double* Ck = rec(N - 1) + lin_gx; UPR_FOR(e, NE * NX) L[O::ck + e] = Ck[e]; }
+        if (mat) {
+            const double* Ck = rec(N - 1) + lin_gx;
+            UPR_FOR(e, NE * NX) L[O::ck + e] = Ck[e];
+            UPR_FOR(e, NE * NE) L[O::lsik + e] = G[F::lsi + (N - 1) * NE * NE + e];
+            UPR_FOR(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[F::hee + (N - 1) * C::NH + e];
+        }
         UPR_SYNC();
         if (mat) UPR_FOR(e, NX * NX) {
             const int i = e / NX, j = e % NX;
@@ -375,10 +390,19 @@ struct upr_qp3 {
                 //               entries of A'P+A, 3 of Hux = B'P+A and 1 of Hjj = B'P+B (+ R + barrier);
                 //   then NE*NX jobs of Vc = Lsi C, then NX jobs of wv = P+ b + p+.
                 // prefetch of the next knot's C into registers (published to LDS in phase 5, after Vc used ck)
-                constexpr int CKQ = (NE * NX + NT - 1) / NT;
+                constexpr int NPF = NE * NX + NE * NE + C::NH, CKQ = (NPF + NT - 1) / NT;
                 double ckn[CKQ];
 #pragma unroll
-                for (int q = 0; q < CKQ; ++q) { const int f = ctx.tid + q * NT; ckn[q] = (k > 0 && f < NE * NX) ? rec(k - 1)[lin_gx + f] : 0.0; }
+                for (int q = 0; q < CKQ; ++q) {
+                    const int f = ctx.tid + q * NT;
+                    double v = 0.0;
+                    if (k > 0) {
+                        if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
+                        else if (f < NE * NX + NE * NE) v = G[F::lsi + (k - 1) * NE * NE + (f - NE * NX)];
+                        else if (f < NPF) v = G[F::hee + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
+                    }
+                    ckn[q] = v;
+                }
                 UPR_FOR(e, NQ * NQ + NE * NX + NX) {
                     if (e < NQ * NQ) {
                         const int ii = e / NQ, jj = e % NQ;
@@ -408,7 +432,7 @@ struct upr_qp3 {
                         L[O::hjj + e] = v;
                     } else if (e < NQ * NQ + NE * NX) {
                         const int f = e - NQ * NQ, r = f / NX, c = f % NX;
-                        const double* Ls = L + O::lsi + k * NE * NE;
+                        const double* Ls = L + O::lsik;
                         double v = 0.0;
                         for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * L[O::ck + m * NX + c];
                         L[O::vc + f] = v;
@@ -457,7 +481,7 @@ struct upr_qp3 {
                             }
                             if (e < NX) {
 #pragma unroll
-                                for (int i = 0; i < NQ; ++i) L[O::Ks + k * NQ * NX + i * NX + e] = kk[i];
+                                for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + e] = kk[i];
                             } else {
 #pragma unroll
                                 for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
@@ -465,7 +489,7 @@ struct upr_qp3 {
                         } else {
                             const int f = e - NX - 1;
                             int i = 0; while ((i + 1) * (i + 2) / 2 <= f) ++i;   // packed lower: f = i(i+1)/2 + j
-                            L[O::Ljis + k * C::NH + f] = Lo[i * NQ + (f - i * (i + 1) / 2)];
+                            G[F::Ljis + k * C::NH + f] = Lo[i * NQ + (f - i * (i + 1) / 2)];
                         }
                     }
                 }
@@ -498,7 +522,7 @@ struct upr_qp3 {
                             if (i < NX && j < NX && i <= j) {
                                 double v = acc[r] + 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
                                 if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
-                                if (j < NQ) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)];
+                                if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
                                 Pc[i * NX + j] = v; Pc[j * NX + i] = v;
                             }
                         }
@@ -519,7 +543,7 @@ struct upr_qp3 {
                         if (i <= j) {
                             double v = 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
                             if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
-                            if (j < NQ) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)];
+                            if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
                             for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::vm + m * NX + j];
                             for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
                             Pc[i * NX + j] = v; Pc[j * NX + i] = v;
@@ -533,7 +557,12 @@ struct upr_qp3 {
                 }
                 if (k > 0) {
 #pragma unroll
-                    for (int q = 0; q < CKQ; ++q) { const int f = ctx.tid + q * NT; if (f < NE * NX) L[O::ck + f] = ckn[q]; }
+                    for (int q = 0; q < CKQ; ++q) {
+                        const int f = ctx.tid + q * NT;
+                        if (f < NE * NX) L[O::ck + f] = ckn[q];
+                        else if (f < NE * NX + NE * NE) L[O::lsik + (f - NE * NX)] = ckn[q];
+                        else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
+                    }
                 }
                 UPR_SYNC();
                 toc(15);
@@ -544,6 +573,13 @@ struct upr_qp3 {
             if (ctx.tid < 64) {
                 upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
                 const upr_ctx& ctx = wc;
+#ifndef UPR_HOST_EMU
+                double kc[NQ];   // column ctx.tid of K_k, loaded one knot ahead
+                if (ctx.tid < NX) {
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (N - 1) * NQ * NX + m * NX + ctx.tid];
+                }
+#endif
                 for (int k = N - 1; k >= 0; --k) {
                     UPR_FOR(a, NX) L[O::wv + a] = pcur[a] + L[O::Pbs + k * NX + a];
                     UPR_WSYNC();
@@ -561,8 +597,16 @@ struct upr_qp3 {
                     UPR_WSYNC();
                     UPR_FOR(i, NX) {
                         double v = L[O::hx + i];
+#ifdef UPR_HOST_EMU
+                        for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * L[O::huj + m];
+#else
 #pragma unroll
-                        for (int m = 0; m < NQ; ++m) v -= L[O::Ks + k * NQ * NX + m * NX + i] * L[O::huj + m];
+                        for (int m = 0; m < NQ; ++m) v -= kc[m] * L[O::huj + m];
+                        if (k > 0) {
+#pragma unroll
+                            for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (k - 1) * NQ * NX + m * NX + i];
+                        }
+#endif
                         pcur[i] = v;
                     }
                     UPR_WSYNC();
@@ -571,7 +615,7 @@ struct upr_qp3 {
             UPR_SYNC();
             // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
             UPR_FOR(k, N) {
-                const double* Lp = L + O::Ljis + k * C::NH;
+                const double* Lp = G + F::Ljis + k * C::NH;
                 double y[NQ], kk[NQ];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) { double t = L[O::hujs + k * NQ + i];
@@ -613,14 +657,31 @@ struct upr_qp3 {
             const upr_ctx& ctx = wc;
             UPR_FOR(i, NX) Sx(0)[i] = 0.0;
             UPR_WSYNC();
+#ifndef UPR_HOST_EMU
+            double kq[NQ];   // block (b, j) of row j of K_k, loaded one knot ahead
+            if (ctx.tid < NX) {
+                const double* Kr = G + F::Ks + (ctx.tid % NQ) * NX + (ctx.tid / NQ) * NQ;
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) kq[c] = Kr[c];
+            }
+#endif
             for (int k = 0; k < N; ++k) {
                 const double* sx = Sx(k); double* sn = Sx(k + 1);
                 UPR_FOR(i, NX) {   // partial dot products of K sx over one nq-block each
                     const int b = i / NQ, j = i % NQ;
-                    const double* Kr = L + O::Ks + k * NQ * NX + j * NX + b * NQ;
                     double d = 0.0;
-#pragma unroll
+#ifdef UPR_HOST_EMU
+                    const double* Kr = G + F::Ks + k * NQ * NX + j * NX + b * NQ;
                     for (int c = 0; c < NQ; ++c) d += Kr[c] * sx[b * NQ + c];
+#else
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) d += kq[c] * sx[b * NQ + c];
+                    if (k + 1 < N) {
+                        const double* Kr = G + F::Ks + (k + 1) * NQ * NX + j * NX + b * NQ;
+#pragma unroll
+                        for (int c = 0; c < NQ; ++c) kq[c] = Kr[c];
+                    }
+#endif
                     L[O::hx + i] = d;
                 }
                 UPR_WSYNC();
@@ -648,7 +709,7 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         UPR_FOR(k, N) {
-            const double* Ls = L + O::lsi + k * NE * NE;
+            const double* Ls = G + F::lsi + k * NE * NE;
             double t1[NE];
 #pragma unroll
             for (int r = 0; r < NE; ++r) { double v = L[O::ys + k * NE + r];
@@ -659,7 +720,7 @@ struct upr_qp3 {
             for (int r = 0; r < NE; ++r) { double v = 0.0;
 #pragma unroll
                 for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * t1[m];
-                L[O::nun + k * NE + r] = v; }
+                G[F::nun + k * NE + r] = v; }
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
@@ -668,15 +729,15 @@ struct upr_qp3 {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
                     double dfn[3], tf[3];
-                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * L[O::nun + k * NE + r]; dfn[a] = v; }
-                    const double* Bk = L + O::lfi + k * C::NLF + 9 * ci;
-                    for (int a = 0; a < 3; ++a) { double v = L[O::yf + k * NFC + 3 * ci + a]; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * dfn[b2]; tf[a] = v; }
+                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * G[F::nun + k * NE + r]; dfn[a] = v; }
+                    const double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
+                    for (int a = 0; a < 3; ++a) { double v = G[F::yf + k * NFC + 3 * ci + a]; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * dfn[b2]; tf[a] = v; }
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * tf[b2]; Su(k)[NQ + 3 * ci + a] = -v; }
                 } else {
                     double dfn = 0.0;
-                    for (int r = 0; r < NE; ++r) dfn += L[O::df + r * NFC + ci] * L[O::nun + k * NE + r];
-                    const double lf = L[O::lfi + k * C::NLF + ci];
-                    Su(k)[NQ + ci] = -lf * (L[O::yf + k * NFC + ci] + lf * dfn);
+                    for (int r = 0; r < NE; ++r) dfn += L[O::df + r * NFC + ci] * G[F::nun + k * NE + r];
+                    const double lf = G[F::lfi + k * C::NLF + ci];
+                    Su(k)[NQ + ci] = -lf * (G[F::yf + k * NFC + ci] + lf * dfn);
                 }
             }
         }
@@ -698,9 +759,9 @@ struct upr_qp3 {
             double v = L[O::gxs + e] + L[O::wx + e] * sx[i];
             if (k < N) {
                 v += h * L[O::qd + i] * sx[i];
-                if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
+                if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
                 const double* Ck = rec(k) + lin_gx;
-                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * L[O::nun + k * NE + q];
+                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * G[F::nun + k * NE + q];
             } else if (neN > 0) {
                 if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
                 else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
@@ -764,10 +825,10 @@ struct upr_qp3 {
                 const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
-                    double t = L[O::ct + 5 * ic + r], lam = L[O::cl + 5 * ic + r];
+                    double t = G[F::ct + 5 * ic + r], lam = G[F::cl + 5 * ic + r];
                     sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam,
-                              L[O::cc + 5 * ic + r], acc, aux);
-                    if (what == 2) { L[O::ct + 5 * ic + r] = t; L[O::cl + 5 * ic + r] = lam; }
+                              G[F::cc + 5 * ic + r], acc, aux);
+                    if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
                 }
             }
         }
@@ -837,7 +898,7 @@ struct upr_qp3 {
     UPR_HD void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
         ctx = c; P = A.P; L = lds;
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
-        lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride;
+        lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0;
         prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
@@ -849,7 +910,7 @@ struct upr_qp3 {
         UPR_FOR(e, NE * NFC) L[O::df + e] = Dfg[e];
         UPR_FOR(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
         UPR_FOR(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
-        UPR_FOR(e, N * C::NH) { const int k = e / C::NH; L[O::hee + e] = rec(k)[lin_hess + e % C::NH]; }
+        UPR_FOR(e, N * C::NH) { const int k = e / C::NH; G[F::hee + e] = rec(k)[lin_hess + e % C::NH]; }
         UPR_FOR(e, 3 * NQ) L[O::jN + e] = rec(N)[lin_hess + e];
         UPR_FOR(q, 3) L[O::misc + 4 + q] = rec(N)[lin_grad + q];
         UPR_FOR(q, C::NEN) { L[O::yN + q] = 0.0; L[O::dyN + q] = 0.0; }
@@ -860,8 +921,8 @@ struct upr_qp3 {
         UPR_FOR(e, N * NQ) {
             const int k = e / NQ, i = e % NQ;
             double v = rec(k)[lin_grad + i];
-            for (int j = 0; j < NQ; ++j) v -= L[O::hee + k * C::NH + upr_tri(NQ, i, j)] * xs[k * NX + j];
-            L[O::g0 + e] = v;
+            for (int j = 0; j < NQ; ++j) v -= G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * xs[k * NX + j];
+            G[F::g0 + e] = v;
         }
         UPR_FOR(e, N * NE) {
             const int k = e / NE, r = e % NE;
@@ -869,7 +930,7 @@ struct upr_qp3 {
             double v = rec(k)[lin_g + r];
             for (int j = 0; j < NX; ++j) v -= Ck[j] * xs[k * NX + j];
             for (int i = 0; i < NFC; ++i) v -= L[O::df + r * NFC + i] * us[k * NU + NQ + i];
-            L[O::e0 + e] = v;
+            G[F::e0 + e] = v;
         }
         // ---- initial slacks / multipliers
 #pragma unroll
@@ -903,7 +964,7 @@ struct upr_qp3 {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
                     const double c0 = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
                     const double t = c0 > UPR_QP_THR ? c0 : UPR_QP_THR;
-                    L[O::ct + 5 * ic + r] = t; L[O::cl + 5 * ic + r] = UPR_QP_MU0 / t; L[O::cc + 5 * ic + r] = 0.0;
+                    G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = UPR_QP_MU0 / t; G[F::cc + 5 * ic + r] = 0.0;
                 }
             }
         }
@@ -949,7 +1010,7 @@ struct upr_qp3 {
                 ws[W::pi + e] += a * (ws[W::pin + e] - ws[W::pi + e]);
             }
             UPR_FOR(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
-            UPR_FOR(e, N * NE) ws[W::nu + e] += a * (L[O::nun + e] - ws[W::nu + e]);
+            UPR_FOR(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
             UPR_FOR(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
             toc(10);
@@ -973,7 +1034,7 @@ static inline UPR_HD void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A
 
 #ifndef UPR_HOST_EMU
 template <class C>
-__global__ void __launch_bounds__(C::NT) upr_qp3_kernel(upr_qp_args A) {
+__global__ void __launch_bounds__(C::NT, (C::NT <= 256) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
     upr_qp3_solve<C>(ctx, A, blockIdx.x, smem);
