@@ -320,3 +320,60 @@ def test_full_size_properties(arrangements):
     _, xs_b, us_b = mpc2.solution()
     assert np.array_equal(xs, xs_b) and np.array_equal(us, us_b)
     mpc.close(); mpc2.close()
+
+
+def test_closed_loop_mpc(arrangements):
+    """Closed loop at the reference's cadence (re-solve every 10 ms, tracking.min_policy_update_time,
+    controller.yaml:33; one SQP iteration per solve, warm start from the previous plan).  The plant is the
+    exact triple integrator driven by the planned jerk (mrt_node.cpp:337-345 integrates the same way), so the
+    observed state is dynamically consistent.  The end effector moves toward the target, every QP converges,
+    the executed trajectory keeps the object balanced."""
+    B = 4
+    P, x0, way = _setup(arrangements, B, seed=51)
+    mpc = BatchMPC(P, B, way_p=way)
+    x = x0.copy()
+    d0 = None
+    t, dt = 0.0, 0.01
+    for tick in range(60):
+        mpc.set_observation(t, x)
+        mpc.advance()
+        st = mpc.stats()
+        assert np.all(st["qp_status_last"] == 0), (tick, st["qp_status_last"])
+        assert np.all(st["step_alpha_last"] > 0)
+        _, u = mpc.evaluate(t)
+        j = u[:, :9]
+        q, v, a = x[:, :9], x[:, 9:18], x[:, 18:]
+        x = np.concatenate([q + dt * v + dt ** 2 / 2 * a + dt ** 3 / 6 * j, v + dt * a + dt ** 2 / 2 * j, a + dt * j], axis=1)
+        t += dt
+        out = mpc.linearize_points(x, u, t=np.full(B, t), inst=np.arange(B))
+        d = np.linalg.norm(out["ee"] - way[:, 0, :], axis=1)
+        d0 = d if d0 is None else d0
+        if tick >= 10:   # after a few SQP iterations the plan is dynamically consistent
+            assert core_friction_rows(P, u[:, 9:]).min() > -1e-6
+    assert np.all(d < d0)                      # moved toward the target
+    assert np.all(st["constraint_violation"] < 1e-2)
+    mpc.close()
+
+
+def test_infeasible_instance_is_flagged_not_propagated(arrangements):
+    """A start state whose base acceleration exceeds the friction cone makes the QP infeasible at the fixed first knot
+    (hard constraints, no slacks -- the reference's HPIPM run ends at its iteration cap in the same situation).
+    The engine must report it per instance (status != 0), keep the neighbours unaffected and never emit NaN."""
+    B = 4
+    P, x0, way = _setup(arrangements, B, seed=61)
+    x0[2, 18] = 5.0                             # base x acceleration 5 m/s^2 > mu g = 0.234 * 9.81
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    st = mpc.stats()
+    _, xs, us = mpc.solution()
+    assert st["qp_status_last"][2] != 0
+    ok = [0, 1, 3]
+    assert np.all(st["qp_status_last"][ok] == 0) and np.all(st["step_alpha_last"][ok] > 0)
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b in ok:
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        assert np.abs(xs[b] - xo).max() < 2e-5
+    mpc.close()

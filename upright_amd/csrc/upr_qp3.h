@@ -453,6 +453,7 @@ struct upr_qp3 {
                     if (wc.tid == 0) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
                     hx_huj_w(wc, k);
                     UPR_WSYNC();
+                    toc(13);
                     const double* Lo = L + O::hjj;   // lower factor, reciprocal diagonal
                     for (int e = wc.tid; e < NX + 1 + C::NH; e += wc.nt) {
                         if (e <= NX) {
@@ -494,7 +495,7 @@ struct upr_qp3 {
                     }
                 }
                 UPR_SYNC();
-                toc(13);
+                toc(14);
                 // phase 5: P = sym(A'P+A) + Q~ - V'V + Vc'Vc (upper triangle, mirrored) ; p = hx - V'yj + cs ; next knot's C
 #ifndef UPR_HOST_EMU
                 if (NX <= 32 && NQ + NE <= 16) {
