@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #define UPR_HD
+#define UPR_HDI inline
 #define UPR_D
 #define UPR_SYNC() ((void)0)
 #define UPR_WSYNC() ((void)0)
@@ -21,6 +22,7 @@ struct upr_ctx { int tid; int nt; };
 #else
 #include <hip/hip_runtime.h>
 #define UPR_HD __host__ __device__
+#define UPR_HDI __host__ __device__ __forceinline__
 #define UPR_D __device__ __forceinline__
 #define UPR_SYNC() __syncthreads()
 // wave-level ordering point: LDS operations of one wave are executed in program order, so only the
@@ -29,7 +31,15 @@ struct upr_ctx { int tid; int nt; };
 struct upr_ctx { int tid; int nt; };
 #endif
 
-#define UPR_FOR(i, n) for (int i = ctx.tid; i < (n); i += ctx.nt)
+// Block-strided loop.  On the device the start index passes through an empty asm: everything derived from it
+// (addresses above all) is recomputed where the loop stands instead of being hoisted to the top of the
+// kernel and kept alive -- spilled to scratch -- across the whole interior-point iteration.
+#ifdef UPR_HOST_EMU
+static inline int upr_opq(int x) { return x; }
+#else
+static __device__ __forceinline__ int upr_opq(int x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+#define UPR_FOR(i, n) for (int i = upr_opq(ctx.tid); i < (n); i += ctx.nt)
 
 // derived dimensions
 struct upr_dims {

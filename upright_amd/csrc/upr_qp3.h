@@ -170,7 +170,7 @@ struct upr_qp3 {
     UPR_HD double coefB(int a) const { return a == 0 ? h3 : (a == 1 ? h2 : h); }
 
     // one inequality row: slack residual, weight and reduced-gradient multiplier for the current mode
-    UPR_HD void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
+    UPR_HDI void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
         const double rp = c - t;
         w = lam / t;
         if (mode == 0) s = w * rp;
@@ -183,12 +183,13 @@ struct upr_qp3 {
 
     // ---- flat phases: per-knot vectors and factors out of the lane-owned rows -------------------------------
     // level 0: reduced gradients + residuals only (KKT check); 1: + back-substitution vectors; 2: + factors
-    UPR_HD void prep(int level) {
+    UPR_HDI void prep(int level) {
         const bool factor = level >= 2;
+        const int tid_ = upr_opq(ctx.tid);
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
-            const int ix = ctx.tid + q * NT;
+            const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, k = 1 + ix / NX, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
@@ -211,7 +212,7 @@ struct upr_qp3 {
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
-            const int iu = ctx.tid + q * NT;
+            const int iu = tid_ + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
@@ -234,7 +235,7 @@ struct upr_qp3 {
         UPR_SYNC();
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         for (int q = 0; q < C::QC; ++q) {
-            const int ic = ctx.tid + q * NT;
+            const int ic = upr_opq(ctx.tid) + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
@@ -343,7 +344,7 @@ struct upr_qp3 {
     }
 
     // terminal residual [p_d - p - Jp dq ; v ; a] at the current iterate -> L[eN]
-    UPR_HD void terminal_residual() {
+    UPR_HDI void terminal_residual() {
         if (neN > 0) UPR_FOR(q, C::NEN) {
             double v;
             if (q < 3) { v = L[O::misc + 4 + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * (Zx(N)[j] - xs[N * NX + j]); }
@@ -352,7 +353,7 @@ struct upr_qp3 {
         }
     }
 
-    UPR_HD void backward(bool mat) {
+    UPR_HDI void backward(bool mat) {
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
         double* pcur = L + O::pv; double* pnew = L + O::pv2;
@@ -392,9 +393,10 @@ struct upr_qp3 {
                 // prefetch of the next knot's C into registers (published to LDS in phase 5, after Vc used ck)
                 constexpr int NPF = NE * NX + NE * NE + C::NH, CKQ = (NPF + NT - 1) / NT;
                 double ckn[CKQ];
+                const int tid_ = upr_opq(ctx.tid);
 #pragma unroll
                 for (int q = 0; q < CKQ; ++q) {
-                    const int f = ctx.tid + q * NT;
+                    const int f = tid_ + q * NT;
                     double v = 0.0;
                     if (k > 0) {
                         if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
@@ -559,7 +561,7 @@ struct upr_qp3 {
                 if (k > 0) {
 #pragma unroll
                     for (int q = 0; q < CKQ; ++q) {
-                        const int f = ctx.tid + q * NT;
+                        const int f = tid_ + q * NT;
                         if (f < NE * NX) L[O::ck + f] = ckn[q];
                         else if (f < NE * NX + NE * NE) L[O::lsik + (f - NE * NX)] = ckn[q];
                         else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
@@ -635,7 +637,7 @@ struct upr_qp3 {
         }
     }
     // hx = gxs_k + A' wv ; huj = gus_k[j] + B' wv   (lanes 1.. of the given context; lane 0 may be busy)
-    UPR_HD void hx_huj_w(const upr_ctx& wc, int k) {
+    UPR_HDI void hx_huj_w(const upr_ctx& wc, int k) {
         const int lanes = wc.nt > 1 ? wc.nt - 1 : 1, me = wc.nt > 1 ? wc.tid - 1 : 0;
         if (me >= 0) for (int e = me; e < NX + NQ; e += lanes) {
             if (e < NX) {
@@ -651,7 +653,7 @@ struct upr_qp3 {
     }
 
     // forward sweep: one phase per knot, closed-loop form  sx+ = A sx + b - B (K sx + kff)
-    UPR_HD void forward() {
+    UPR_HDI void forward() {
         // wave-local sweep (first wave, no workgroup barrier): sx+ = A sx + b - B (K sx + kff)
         if (ctx.tid < 64) {
             upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
@@ -725,7 +727,7 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
-            const int ic = ctx.tid + q * NT;
+            const int ic = upr_opq(ctx.tid) + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
@@ -752,7 +754,7 @@ struct upr_qp3 {
     }
 
     // costates of the full step (into global pin)
-    UPR_HD void costates() {
+    UPR_HDI void costates() {
         double* pin = ws + W::pin;
         UPR_FOR(e, N1 * NX) {
             const int k = e / NX, i = e % NX;
@@ -785,7 +787,7 @@ struct upr_qp3 {
 
     // ---- sweeps over the lane-owned rows with the current step ------------------------------------------------
     //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t
-    UPR_HD void sweep_row(int what, double alpha, double c, double ds, double& t, double& lam, double cterm, double& acc, double* aux) const {
+    UPR_HDI void sweep_row(int what, double alpha, double c, double ds, double& t, double& lam, double cterm, double& acc, double* aux) const {
         const double rp = c - t;
         if (what == 3) { const double a = fabs(rp); if (a > acc) acc = a; *aux += lam * t; return; }
         const double dt = ds + rp;
@@ -797,11 +799,12 @@ struct upr_qp3 {
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
         else { t += alpha * dt; lam += alpha * dl; }
     }
-    UPR_HD double ineq_sweep(int what, double alpha, double* aux) {
+    UPR_HDI double ineq_sweep(int what, double alpha, double* aux) {
         double acc = (what == 0) ? 1e30 : 0.0;
+        const int tid_ = upr_opq(ctx.tid);
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
-            const int ix = ctx.tid + q * NT;
+            const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
@@ -811,7 +814,7 @@ struct upr_qp3 {
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
-            const int iu = ctx.tid + q * NT;
+            const int iu = tid_ + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
@@ -820,7 +823,7 @@ struct upr_qp3 {
             }
         }
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
-            const int ic = ctx.tid + q * NT;
+            const int ic = tid_ + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
                 const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
@@ -836,7 +839,7 @@ struct upr_qp3 {
         return acc;
     }
 
-    UPR_HD void residuals(int ntot, double* res) {
+    UPR_HDI void residuals(int ntot, double* res) {
         const double* pi = ws + W::pi; const double* nu = ws + W::nu;
         const int save = mode;
         mode = 2;
