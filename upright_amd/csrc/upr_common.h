@@ -17,6 +17,7 @@
 #define UPR_HDI inline
 #define UPR_D
 #define UPR_SYNC() ((void)0)
+#define UPR_SYNC_LDS() ((void)0)
 #define UPR_WSYNC() ((void)0)
 struct upr_ctx { int tid; int nt; };
 #else
@@ -25,6 +26,9 @@ struct upr_ctx { int tid; int nt; };
 #define UPR_HDI __host__ __device__ __forceinline__
 #define UPR_D __device__ __forceinline__
 #define UPR_SYNC() __syncthreads()
+// workgroup barrier that orders LDS traffic only: global loads in flight (register prefetches) and global
+// stores that nobody reads before the next full UPR_SYNC are NOT waited for, unlike __syncthreads()
+#define UPR_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // wave-level ordering point: LDS operations of one wave are executed in program order, so only the
 // compiler has to be kept from moving code across it
 #define UPR_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -38,6 +42,11 @@ struct upr_ctx { int tid; int nt; };
 static inline int upr_opq(int x) { return x; }
 #else
 static __device__ __forceinline__ int upr_opq(int x) { asm volatile("" : "+v"(x)); return x; }
+// value of lane `lane` (compile-time constant after unrolling) broadcast through scalar registers
+static __device__ __forceinline__ double upr_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 #endif
 #define UPR_FOR(i, n) for (int i = upr_opq(ctx.tid); i < (n); i += ctx.nt)
 

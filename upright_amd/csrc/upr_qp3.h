@@ -143,12 +143,48 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 }
 
 template <class C>
+#define UPR_FORT(i, n) for (int i = tid(); i < (n); i += stride())
+
 struct upr_qp3 {
     typedef upr_qp3_lds<C> O;
     typedef upr_qp3_ws<C> W;
     typedef upr_qp3_far<C> F;
     static constexpr int NQ = C::NQ, NX = C::NX, NU = C::NU, NE = C::NE, NFC = C::NFC, NC = C::NC, NF = C::NF, N = C::N, N1 = C::N1, NT = C::NT;
     upr_ctx ctx;
+    int wb;   // first lane of this wave (uniform; lives in a scalar register)
+    // Lane / work-item index recomputed from the hardware where it is needed: a work-item id kept in a vector
+    // register for the whole solve gets spilled, and every reload from scratch waits for ALL global loads in
+    // flight (s_waitcnt vmcnt(0)), which serialises the register prefetches of the sweeps.
+    UPR_HDI int lane() const {
+#ifdef UPR_HOST_EMU
+        return ctx.tid;
+#else
+        int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+#endif
+    }
+    UPR_HDI int tid() const {
+#ifdef UPR_HOST_EMU
+        return ctx.tid;
+#else
+        return wb + lane();
+#endif
+    }
+    UPR_HDI bool wave0() const {
+#ifdef UPR_HOST_EMU
+        return ctx.tid < 64;
+#else
+        return wb == 0;
+#endif
+    }
+    UPR_HDI int stride() const {
+#ifdef UPR_HOST_EMU
+        return ctx.nt;
+#else
+        return NT;
+#endif
+    }
+    UPR_HDI upr_ctx ctxv() const { upr_ctx c; c.tid = tid(); c.nt = stride(); return c; }
     const upr_problem* P;
     double* L;
     double* G;   // far arrays (global)
@@ -161,13 +197,15 @@ struct upr_qp3 {
     double tx[C::QX][2], lx[C::QX][2], cx[C::QX][2];
     double tu[C::QU][2], lu[C::QU][2], cu[C::QU][2];
 
-    UPR_HD const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
-    UPR_HD double* Zx(int k) const { return L + O::Z + k * NX; }
-    UPR_HD double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
-    UPR_HD double* Sx(int k) const { return L + O::S + k * NX; }
-    UPR_HD double* Su(int k) const { return L + O::S + N1 * NX + k * NU; }
-    UPR_HD double coefA(int a, int b) const { return (a == b) ? 1.0 : ((a == 0 && b == 1) ? h : ((a == 0 && b == 2) ? h2 : ((a == 1 && b == 2) ? h : 0.0))); }
-    UPR_HD double coefB(int a) const { return a == 0 ? h3 : (a == 1 ? h2 : h); }
+    UPR_HDI const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
+    UPR_HDI double* Zx(int k) const { return L + O::Z + k * NX; }
+    UPR_HDI double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
+    UPR_HDI double* Sx(int k) const { return L + O::S + k * NX; }
+    UPR_HDI double* Su(int k) const { return L + O::S + N1 * NX + k * NU; }
+    // entries of A = [[1,h,h2],[0,1,h],[0,0,1]] and B = [h3;h2;h] in arithmetic form: a select between the members
+    // h, h2, h3 on a lane-dependent index would be turned into an indexed load and pin the whole object in scratch
+    UPR_HDI double coefA(int a, int b) const { return ((a == b) ? 1.0 : 0.0) + (((a == 0 && b == 1) || (a == 1 && b == 2)) ? 1.0 : 0.0) * h + ((a == 0 && b == 2) ? 1.0 : 0.0) * h2; }
+    UPR_HDI double coefB(int a) const { return ((a == 0) ? 1.0 : 0.0) * h3 + ((a == 1) ? 1.0 : 0.0) * h2 + ((a == 2) ? 1.0 : 0.0) * h; }
 
     // one inequality row: slack residual, weight and reduced-gradient multiplier for the current mode
     UPR_HDI void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
@@ -185,7 +223,7 @@ struct upr_qp3 {
     // level 0: reduced gradients + residuals only (KKT check); 1: + back-substitution vectors; 2: + factors
     UPR_HDI void prep(int level) {
         const bool factor = level >= 2;
-        const int tid_ = upr_opq(ctx.tid);
+        const int tid_ = tid();
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -224,7 +262,7 @@ struct upr_qp3 {
             }
         }
         // dynamics residual of every knot in absolute variables (multiple-shooting defect of the iterate)
-        UPR_FOR(e, N * NQ) {
+        UPR_FORT(e, N * NQ) {
             const int k = e / NQ, j = e % NQ;
             const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
             const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
@@ -235,7 +273,7 @@ struct upr_qp3 {
         UPR_SYNC();
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         for (int q = 0; q < C::QC; ++q) {
-            const int ic = upr_opq(ctx.tid) + q * NT;
+            const int ic = tid() + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
@@ -273,7 +311,7 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
-        UPR_FOR(e, N * NE) {
+        UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
             double v = G[F::e0 + e];
@@ -283,7 +321,7 @@ struct upr_qp3 {
             L[O::ek + e] = v; L[O::ys + e] = v - v2;
         }
         if (factor) {
-            UPR_FOR(e, N * NE * NE) {
+            UPR_FORT(e, N * NE * NE) {
                 const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
                 if (c > r) continue;
                 double acc = (r == c) ? UPR_QP_RHO_S : 0.0;
@@ -303,7 +341,7 @@ struct upr_qp3 {
         UPR_SYNC();
         if (level == 0) return;
         // D: one lane per knot: Schur factor (in place), ys = Lsi ee, zt = Lsi' ys
-        UPR_FOR(k, N) {
+        UPR_FORT(k, N) {
             double* Ls = G + F::lsi + k * NE * NE;
             if (factor) { if (!upr_chol_inv_serial<NE>(Ls, Ls)) L[O::misc] = 1.0; }
             double ee[NE], yv[NE];
@@ -322,7 +360,7 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         // E: cs = C' zt
-        UPR_FOR(e, N * NX) {
+        UPR_FORT(e, N * NX) {
             const int k = e / NX, i = e % NX;
             const double* Ck = rec(k) + lin_gx;
             double v = 0.0;
@@ -332,20 +370,9 @@ struct upr_qp3 {
         UPR_SYNC();
     }
 
-    // dynamics residual of knot k in absolute variables -> L[bk]   (lanes 0..NQ-1)
-    UPR_HD void dyn_residual(int k) {
-        UPR_FOR(j, NQ) {
-            const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
-            const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
-            L[O::bk + j] = q + h * v + h2 * a + h3 * u - Xn[j];
-            L[O::bk + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
-            L[O::bk + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
-        }
-    }
-
     // terminal residual [p_d - p - Jp dq ; v ; a] at the current iterate -> L[eN]
     UPR_HDI void terminal_residual() {
-        if (neN > 0) UPR_FOR(q, C::NEN) {
+        if (neN > 0) UPR_FORT(q, C::NEN) {
             double v;
             if (q < 3) { v = L[O::misc + 4 + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * (Zx(N)[j] - xs[N * NX + j]); }
             else v = Zx(N)[NQ + (q - 3)];
@@ -353,20 +380,22 @@ struct upr_qp3 {
         }
     }
 
-    UPR_HDI void backward(bool mat) {
+    // ---- backward sweep, matrix part: P_k, the factor of Hjj_k and V_k = Lj^-1 Hux_k for k = N-1 .. 0 ------------
+    // Per knot: phase 1 (everything that is a function of P+ only) | barrier | wave 0: Cholesky of Hjj in the
+    // registers of lane 0, then one lane per column of V by forward substitution -- meanwhile the other waves
+    // preload the matrix-core accumulators with sym(A'P+A) + Q~ + Vc'Vc | barrier | P = acc - V'V | barrier.
+    // The feedback K = Lj^-T V is not on this critical path: it is formed for all knots at once afterwards.
+    // Knot 0 needs only the factor of Hjj_0 (the first state is fixed: no P_0, no K_0).
+    UPR_HDI void backward_mat() {
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
-        double* pcur = L + O::pv; double* pnew = L + O::pv2;
-        // ---- terminal knot
-        terminal_residual();
-        if (mat) {
+        {
             const double* Ck = rec(N - 1) + lin_gx;
-            UPR_FOR(e, NE * NX) L[O::ck + e] = Ck[e];
-            UPR_FOR(e, NE * NE) L[O::lsik + e] = G[F::lsi + (N - 1) * NE * NE + e];
-            UPR_FOR(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[F::hee + (N - 1) * C::NH + e];
+            UPR_FORT(e, NE * NX) L[O::ck + e] = Ck[e];
+            UPR_FORT(e, NE * NE) L[O::lsik + e] = G[F::lsi + (N - 1) * NE * NE + e];
+            UPR_FORT(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[F::hee + (N - 1) * C::NH + e];
         }
-        UPR_SYNC();
-        if (mat) UPR_FOR(e, NX * NX) {
+        UPR_FORT(e, NX * NX) {
             const int i = e / NX, j = e % NX;
             double v = (i == j) ? L[O::wx + N * NX + i] : 0.0;
             if (neN > 0) {
@@ -375,335 +404,376 @@ struct upr_qp3 {
             }
             Pc[e] = v;
         }
-        UPR_FOR(i, NX) {
-            double v = L[O::gxs + N * NX + i];
-            if (neN > 0) {
-                if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + irho * L[O::eN + q]); }
-                else v += L[O::yN + 3 + (i - NQ)] + irho * L[O::eN + 3 + (i - NQ)];
-            }
-            pcur[i] = v;
-        }
         UPR_SYNC();
-        if (mat) {
-            for (int k = N - 1; k >= 0; --k) {
-                // phase 1: everything that is a function of P+ only.  Job list:
-                //   [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the 9
-                //               entries of A'P+A, 3 of Hux = B'P+A and 1 of Hjj = B'P+B (+ R + barrier);
-                //   then NE*NX jobs of Vc = Lsi C, then NX jobs of wv = P+ b + p+.
-                // prefetch of the next knot's C into registers (published to LDS in phase 5, after Vc used ck)
-                constexpr int NPF = NE * NX + NE * NE + C::NH, CKQ = (NPF + NT - 1) / NT;
-                double ckn[CKQ];
-                const int tid_ = upr_opq(ctx.tid);
+        constexpr int NPAIR = (NE / 2) * NX;   // Vc = Lsi C by row pairs (r, NE-1-r): equal work per job
+        for (int k = N - 1; k >= 0; --k) {
+            // next knot's C, Lsi, Hee: global -> registers now, -> LDS after the barrier (their readers are in phase 1 /
+            // in the accumulator preload of the NEXT knot)
+            constexpr int NPF = NE * NX + NE * NE + C::NH, CKQ = (NPF + NT - 1) / NT;
+            double ckn[CKQ];
+            const int tid_ = tid();
 #pragma unroll
-                for (int q = 0; q < CKQ; ++q) {
-                    const int f = tid_ + q * NT;
-                    double v = 0.0;
-                    if (k > 0) {
-                        if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
-                        else if (f < NE * NX + NE * NE) v = G[F::lsi + (k - 1) * NE * NE + (f - NE * NX)];
-                        else if (f < NPF) v = G[F::hee + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
-                    }
-                    ckn[q] = v;
+            for (int q = 0; q < CKQ; ++q) {
+                const int f = tid_ + q * NT;
+                double v = 0.0;
+                if (k > 0) {
+                    if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
+                    else if (f < NE * NX + NE * NE) v = G[F::lsi + (k - 1) * NE * NE + (f - NE * NX)];
+                    else if (f < NPF) v = G[F::hee + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
                 }
-                UPR_FOR(e, NQ * NQ + NE * NX + NX) {
-                    if (e < NQ * NQ) {
-                        const int ii = e / NQ, jj = e % NQ;
-                        double p[3][3];
+                ckn[q] = v;
+            }
+            // phase 1.  Jobs [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the
+            // entries of A'P+A it owns (upper triangle of the result), 3 of Hux = B'P+A and 1 of Hjj = B'P+B + R + W;
+            // then NPAIR jobs of Vc = Lsi C and NX jobs of P+ b.
+            UPR_FORT(e, NQ * NQ + NPAIR + NX) {
+                if (e < NQ * NQ) {
+                    const int ii = e / NQ, jj = e % NQ;
+                    double p[3][3];
 #pragma unroll
-                        for (int a = 0; a < 3; ++a)
+                    for (int a = 0; a < 3; ++a)
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) p[a][c] = Pc[(a * NQ + ii) * NX + c * NQ + jj];
-                        // T = P A (columns), then A' T (rows); A = [[1,h,h2],[0,1,h],[0,0,1]]
-                        double t[3][3], o2[3][3];
+                        for (int c = 0; c < 3; ++c) p[a][c] = Pc[(a * NQ + ii) * NX + c * NQ + jj];
+                    // T = P A (columns), then A' T (rows); A = [[1,h,h2],[0,1,h],[0,0,1]]
+                    double t[3][3], o2[3][3];
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) { t[a][0] = p[a][0]; t[a][1] = h * p[a][0] + p[a][1]; t[a][2] = h2 * p[a][0] + h * p[a][1] + p[a][2]; }
+                    for (int a = 0; a < 3; ++a) { t[a][0] = p[a][0]; t[a][1] = h * p[a][0] + p[a][1]; t[a][2] = h2 * p[a][0] + h * p[a][1] + p[a][2]; }
+                    if (k > 0) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) { o2[0][c] = t[0][c]; o2[1][c] = h * t[0][c] + t[1][c]; o2[2][c] = h2 * t[0][c] + h * t[1][c] + t[2][c]; }
+                        // only the upper triangle of A'P+A is read back (and mirrored): rounding cannot make P asymmetric
 #pragma unroll
                         for (int a = 0; a < 3; ++a)
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) Pn[(a * NQ + ii) * NX + c * NQ + jj] = o2[a][c];
+                            for (int c = 0; c < 3; ++c) if (a < c || (a == c && ii <= jj)) Pn[(a * NQ + ii) * NX + c * NQ + jj] = o2[a][c];
                         // B' (P A) = h3 t[0] + h2 t[1] + h t[2]
 #pragma unroll
                         for (int c = 0; c < 3; ++c) L[O::hux + ii * NX + c * NQ + jj] = h3 * t[0][c] + h2 * t[1][c] + h * t[2][c];
-                        // B' P B
-                        double v = 0.0;
+                    }
+                    // B' P B
+                    double v = 0.0;
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) v += coefB(a) * (h3 * p[a][0] + h2 * p[a][1] + h * p[a][2]);
-                        if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
-                        L[O::hjj + e] = v;
-                    } else if (e < NQ * NQ + NE * NX) {
-                        const int f = e - NQ * NQ, r = f / NX, c = f % NX;
+                    for (int a = 0; a < 3; ++a) v += coefB(a) * (h3 * p[a][0] + h2 * p[a][1] + h * p[a][2]);
+                    if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
+                    L[O::hjj + e] = v;
+                } else if (e < NQ * NQ + NPAIR) {
+                    if (k > 0) {
+                        const int f = e - NQ * NQ, pr = f / NX, c = f % NX, r2 = NE - 1 - pr;
                         const double* Ls = L + O::lsik;
-                        double v = 0.0;
-                        for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * L[O::ck + m * NX + c];
-                        L[O::vc + f] = v;
-                    } else {
-                        const int i = e - NQ * NQ - NE * NX;
-                        double pb = 0.0;
-                        for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bks + k * NX + j];
-                        L[O::Pbs + k * NX + i] = pb; L[O::wv + i] = pcur[i] + pb;
+                        double v1 = 0.0, v2 = 0.0;
+                        for (int m = 0; m <= r2; ++m) { const double cm = L[O::ck + m * NX + c]; if (m <= pr) v1 += Ls[pr * NE + m] * cm; v2 += Ls[r2 * NE + m] * cm; }
+                        L[O::vc + pr * NX + c] = v1; L[O::vc + r2 * NX + c] = v2;
                     }
+                } else {
+                    const int i = e - NQ * NQ - NPAIR;
+                    double pb = 0.0;
+                    for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bks + k * NX + j];
+                    L[O::Pbs + k * NX + i] = pb;
                 }
-                UPR_SYNC();
-                toc(12);
-                // phases 2-4 inside the first wave only (no workgroup barrier): lane 0 factors Hjj in registers while
-                // lanes 1.. build hx / huj; then one lane per column does the forward substitution V = Lj^-1 Hux and,
-                // without leaving its registers, the back substitution K = Lj^-T V (lane NX: yj and kff).
-                if (ctx.tid < 64) {
-                    upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
-                    if (wc.tid == 0) { if (!upr_chol_regs<NQ>(L + O::hjj, L + O::hjj)) L[O::misc] = 1.0; }
-                    hx_huj_w(wc, k);
-                    UPR_WSYNC();
-                    toc(13);
-                    const double* Lo = L + O::hjj;   // lower factor, reciprocal diagonal
-                    for (int e = wc.tid; e < NX + 1 + C::NH; e += wc.nt) {
-                        if (e <= NX) {
-                            double v[NQ];
-#pragma unroll
-                            for (int i = 0; i < NQ; ++i) {
-                                double t = (e < NX) ? L[O::hux + i * NX + e] : L[O::huj + i];
-#pragma unroll
-                                for (int m = 0; m < i; ++m) t -= Lo[i * NQ + m] * v[m];
-                                v[i] = t * Lo[i * NQ + i];
-                            }
-                            if (e < NX) {
-#pragma unroll
-                                for (int i = 0; i < NQ; ++i) L[O::vm + i * NX + e] = v[i];
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < NQ; ++i) L[O::yj + i] = v[i];
-                            }
-                            double kk[NQ];
-#pragma unroll
-                            for (int i = NQ - 1; i >= 0; --i) {
-                                double t = v[i];
-#pragma unroll
-                                for (int m = i + 1; m < NQ; ++m) t -= Lo[m * NQ + i] * kk[m];
-                                kk[i] = t * Lo[i * NQ + i];
-                            }
-                            if (e < NX) {
-#pragma unroll
-                                for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + e] = kk[i];
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
-                            }
-                        } else {
-                            const int f = e - NX - 1;
-                            int i = 0; while ((i + 1) * (i + 2) / 2 <= f) ++i;   // packed lower: f = i(i+1)/2 + j
-                            G[F::Ljis + k * C::NH + f] = Lo[i * NQ + (f - i * (i + 1) / 2)];
-                        }
-                    }
-                }
-                UPR_SYNC();
-                toc(14);
-                // phase 5: P = sym(A'P+A) + Q~ - V'V + Vc'Vc (upper triangle, mirrored) ; p = hx - V'yj + cs ; next knot's C
+            }
+            UPR_SYNC_LDS();
+            toc(12);
 #ifndef UPR_HOST_EMU
-                if (NX <= 32 && NQ + NE <= 16) {
-                    // Matrix-core path: the rank-(nq + ne) update M' diag(-1.., +1..) M with M = [V; Vc] (<= 16 x nx) is
-                    // three 16x16 output tiles of v_mfma_f64_16x16x4_f64 (tiles (0,0), (0,1), (1,1) of the 32x32 padded
-                    // result; the lower triangle is mirrored).  Lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and
-                    // receives D[(l >> 4) + 4 r][l & 15].
-                    typedef double v4d __attribute__((ext_vector_type(4)));
-                    const int wave = ctx.tid >> 6, lane = ctx.tid & 63, nwaves = NT >> 6;
-                    for (int tile = wave; tile < 3; tile += nwaves) {
-                        const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
-                        const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
-                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+            // Matrix-core path.  The 32 x 32 padded result is three 16 x 16 tiles ((0,0), (0,1), (1,1); the lower
+            // triangle is mirrored) of v_mfma_f64_16x16x4_f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and
+            // receives D[(l >> 4) + 4 r][l & 15].  Tile t belongs to wave 1 + t % (nwaves - 1) (wave 0 is busy
+            // with the factorisation), which keeps the accumulator in registers across the barrier.
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            constexpr bool MFMA = (NX <= 32 && NQ <= 12 && NE <= 8);
+            constexpr int nwaves = NT >> 6;
+            const int wave = wb >> 6, lane = this->lane();
+            v4d acc[3];
+            if (MFMA && k > 0) {
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const int r = 4 * s4 + kk;   // row of M
-                            double a = 0.0, b = 0.0;
-                            if (r < NQ) { if (ci < NX) a = -L[O::vm + r * NX + ci]; if (cj < NX) b = L[O::vm + r * NX + cj]; }
-                            else if (r < NQ + NE) { if (ci < NX) a = L[O::vc + (r - NQ) * NX + ci]; if (cj < NX) b = L[O::vc + (r - NQ) * NX + cj]; }
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                        }
+                for (int tile = 0; tile < 3; ++tile) {
+                    if (wave != ((nwaves > 1) ? 1 + tile % (nwaves - 1) : 0)) continue;
+                    const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
+                    const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
+                    v4d a4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
-                            if (i < NX && j < NX && i <= j) {
-                                double v = acc[r] + 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
-                                if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
-                                if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
-                                Pc[i * NX + j] = v; Pc[j * NX + i] = v;
-                            }
-                        }
+                    for (int s4 = 0; s4 < (NE + 3) / 4; ++s4) {
+                        const int r = 4 * s4 + kk;   // row of Vc
+                        double a = 0.0, b = 0.0;
+                        if (r < NE) { if (ci < NX) a = L[O::vc + r * NX + ci]; if (cj < NX) b = L[O::vc + r * NX + cj]; }
+                        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
                     }
-                    // the affine term on the last wave (free of tile work whenever the workgroup has >= 4 waves)
-                    if (ctx.tid >= NT - 64) {
-                        for (int i = ctx.tid - (NT - 64); i < NX; i += 64) {
-                            double v = L[O::hx + i] + L[O::cs + k * NX + i];
-                            for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::yj + m];
-                            pcur[i] = v;
-                        }
-                    }
-                } else
-#endif
-                UPR_FOR(e, NX * NX + NX) {
-                    if (e < NX * NX) {
-                        const int i = e / NX, j = e % NX;
-                        if (i <= j) {
-                            double v = 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
+                        if (i < NX && j < NX && i <= j) {
+                            double v = Pn[i * NX + j];
                             if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
                             if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
-                            for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::vm + m * NX + j];
-                            for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
-                            Pc[i * NX + j] = v; Pc[j * NX + i] = v;
+                            a4[r] += v;
                         }
-                    } else {
-                        const int i = e - NX * NX;
-                        double v = L[O::hx + i] + L[O::cs + k * NX + i];
-                        for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::yj + m];
-                        pcur[i] = v;
                     }
+                    acc[tile] = a4;
                 }
-                if (k > 0) {
-#pragma unroll
-                    for (int q = 0; q < CKQ; ++q) {
-                        const int f = tid_ + q * NT;
-                        if (f < NE * NX) L[O::ck + f] = ckn[q];
-                        else if (f < NE * NX + NE * NE) L[O::lsik + (f - NE * NX)] = ckn[q];
-                        else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
-                    }
-                }
-                UPR_SYNC();
-                toc(15);
             }
-        } else {
-            // vector pass: one wave-local phase per knot (first wave only, no workgroup barrier).  Every lane
-            // i < NX rebuilds the nq jerk gradients it needs.
-            if (ctx.tid < 64) {
-                upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
-                const upr_ctx& ctx = wc;
+#endif
+            // wave 0: Cholesky of the augmented matrix M = [Hjj | Hux] (nq x (nq + nx)), one lane per COLUMN, all
+            // columns in lock step: at pivot p every lane scales its entry of row p (lane c < nq obtains L[c][p],
+            // lane nq + c' obtains V[p][c'] = (Lj^-1 Hux)[p][c']) and eliminates it from the rows below with the
+            // multipliers L[j][p] read from lanes j through scalar registers -- the factorisation and the forward
+            // substitution are one pass of nq dependent pivots, without LDS traffic in between.
+            if (wave0()) {
 #ifndef UPR_HOST_EMU
-                double kc[NQ];   // column ctx.tid of K_k, loaded one knot ahead
-                if (ctx.tid < NX) {
+                static_assert(NQ + NX <= 64, "one lane per column of [Hjj | Hux]");
+                const int c = tid();
+                double x[NQ];
 #pragma unroll
-                    for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (N - 1) * NQ * NX + m * NX + ctx.tid];
+                for (int j = 0; j < NQ; ++j) x[j] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((c < NQ + NX && k > 0) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                bool ok = true;
+#pragma unroll
+                for (int p2 = 0; p2 < NQ; ++p2) {
+                    double piv = upr_readlane(x[p2], p2);
+                    if (!(piv > 0.0)) { ok = false; piv = 1.0; }
+                    const double idg = upr_rsqrt(piv);
+                    const double y = x[p2] * idg;
+                    x[p2] = (c == p2) ? idg : y;   // the diagonal keeps its reciprocal (what the solves need)
+#pragma unroll
+                    for (int j = p2 + 1; j < NQ; ++j) x[j] -= y * upr_readlane(y, j);
                 }
-#endif
-                for (int k = N - 1; k >= 0; --k) {
-                    UPR_FOR(a, NX) L[O::wv + a] = pcur[a] + L[O::Pbs + k * NX + a];
-                    UPR_WSYNC();
-                    UPR_FOR(e, NX + NQ) {
-                        if (e < NQ) {
-                            const double hm = L[O::gus + k * NU + e] + h3 * L[O::wv + e] + h2 * L[O::wv + NQ + e] + h * L[O::wv + 2 * NQ + e];
-                            L[O::huj + e] = hm; L[O::hujs + k * NQ + e] = hm;
-                        } else {
-                            const int i = e - NQ, b = i / NQ, j = i % NQ;
-                            double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
-                            for (int a = 0; a <= b; ++a) v += coefA(a, b) * L[O::wv + a * NQ + j];
-                            L[O::hx + i] = v;
-                        }
-                    }
-                    UPR_WSYNC();
-                    UPR_FOR(i, NX) {
-                        double v = L[O::hx + i];
-#ifdef UPR_HOST_EMU
-                        for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * L[O::huj + m];
+                if (!ok && c == 0) L[O::misc] = 1.0;
+                toc(13);
+                if (c < NQ) {
+#pragma unroll
+                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2];
+                } else if (c < NQ + NX && k > 0) {
+#pragma unroll
+                    for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + (c - NQ)] = x[p2]; G[F::Ks + k * NQ * NX + p2 * NX + (c - NQ)] = x[p2]; }
+                }
 #else
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) v -= kc[m] * L[O::huj + m];
-                        if (k > 0) {
-#pragma unroll
-                            for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (k - 1) * NQ * NX + m * NX + i];
-                        }
-#endif
-                        pcur[i] = v;
+                if (tid() == 0) {
+                    constexpr int NM = NQ + NX;
+                    double M[NQ][NM];
+                    for (int j = 0; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] = (c < NQ) ? L[O::hjj + j * NQ + c] : (k > 0 ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                    for (int p2 = 0; p2 < NQ; ++p2) {
+                        double piv = M[p2][p2];
+                        if (!(piv > 0.0)) { L[O::misc] = 1.0; piv = 1.0; }
+                        const double idg = upr_rsqrt(piv);
+                        double y[NM];
+                        for (int c = 0; c < NM; ++c) y[c] = M[p2][c] * idg;
+                        for (int j = p2 + 1; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] -= y[c] * y[j];
+                        for (int c = 0; c < NM; ++c) M[p2][c] = (c == p2) ? idg : y[c];
                     }
-                    UPR_WSYNC();
+                    for (int c = 0; c < NQ; ++c) for (int p2 = 0; p2 <= c; ++p2) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = M[p2][c];
+                    if (k > 0) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + c] = M[p2][NQ + c]; G[F::Ks + k * NQ * NX + p2 * NX + c] = M[p2][NQ + c]; }
+                }
+#endif
+            }
+            if (k == 0) break;
+            UPR_SYNC_LDS();
+            toc(14);
+            // P = sym(A'P+A) + Q~ + Vc'Vc - V'V (upper triangle, mirrored)
+#ifndef UPR_HOST_EMU
+            if (MFMA) {
+#pragma unroll
+                for (int tile = 0; tile < 3; ++tile) {
+                    if (wave != ((nwaves > 1) ? 1 + tile % (nwaves - 1) : 0)) continue;
+                    const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
+                    const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
+                    v4d a4 = acc[tile];
+#pragma unroll
+                    for (int s4 = 0; s4 < (NQ + 3) / 4; ++s4) {
+                        const int r = 4 * s4 + kk;   // row of V
+                        double a = 0.0, b = 0.0;
+                        if (r < NQ) { if (ci < NX) a = -L[O::vm + r * NX + ci]; if (cj < NX) b = L[O::vm + r * NX + cj]; }
+                        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
+                        if (i < NX && j < NX && i <= j) { Pc[i * NX + j] = a4[r]; Pc[j * NX + i] = a4[r]; }
+                    }
+                }
+            } else
+#endif
+            UPR_FORT(e, NX * NX) {
+                const int i = e / NX, j = e % NX;
+                if (i <= j) {
+                    double v = Pn[i * NX + j];
+                    if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
+                    if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
+                    for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
+                    for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::vm + m * NX + j];
+                    Pc[i * NX + j] = v; Pc[j * NX + i] = v;
                 }
             }
-            UPR_SYNC();
-            // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
-            UPR_FOR(k, N) {
-                const double* Lp = G + F::Ljis + k * C::NH;
-                double y[NQ], kk[NQ];
+            {
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) { double t = L[O::hujs + k * NQ + i];
-#pragma unroll
-                    for (int m = 0; m < i; ++m) t -= Lp[i * (i + 1) / 2 + m] * y[m];
-                    y[i] = t * Lp[i * (i + 1) / 2 + i]; }
-#pragma unroll
-                for (int i = NQ - 1; i >= 0; --i) { double t = y[i];
-#pragma unroll
-                    for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
-                    kk[i] = t * Lp[i * (i + 1) / 2 + i]; }
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
+                for (int q = 0; q < CKQ; ++q) {
+                    const int f = tid_ + q * NT;
+                    if (f < NE * NX) L[O::ck + f] = ckn[q];
+                    else if (f < NE * NX + NE * NE) L[O::lsik + (f - NE * NX)] = ckn[q];
+                    else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
+                }
             }
-            UPR_SYNC();
+            UPR_SYNC_LDS();
+            toc(15);
         }
-    }
-    // hx = gxs_k + A' wv ; huj = gus_k[j] + B' wv   (lanes 1.. of the given context; lane 0 may be busy)
-    UPR_HDI void hx_huj_w(const upr_ctx& wc, int k) {
-        const int lanes = wc.nt > 1 ? wc.nt - 1 : 1, me = wc.nt > 1 ? wc.tid - 1 : 0;
-        if (me >= 0) for (int e = me; e < NX + NQ; e += lanes) {
-            if (e < NX) {
-                const int b = e / NQ, j = e % NQ;
-                double v = L[O::gxs + k * NX + e];
-                for (int a = 0; a <= b; ++a) v += coefA(a, b) * L[O::wv + a * NQ + j];
-                L[O::hx + e] = v;
-            } else {
-                const int j = e - NX;
-                L[O::huj + j] = L[O::gus + k * NU + j] + h3 * L[O::wv + j] + h2 * L[O::wv + NQ + j] + h * L[O::wv + 2 * NQ + j];
+        UPR_SYNC();
+        // feedback of knots 1 .. N-1, all at once: column e of K_k = Lj^-T V_k by back substitution, in place
+        UPR_FORT(e, (N - 1) * NX) {
+            const int k = 1 + e / NX, c = e % NX;
+            const double* Lp = G + F::Ljis + k * C::NH;
+            double* Kc = G + F::Ks + k * NQ * NX + c;
+            double kk[NQ];
+#pragma unroll
+            for (int i = NQ - 1; i >= 0; --i) {
+                double t = Kc[i * NX];
+#pragma unroll
+                for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
+                kk[i] = t * Lp[i * (i + 1) / 2 + i];
             }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) Kc[i * NX] = kk[i];
         }
+        UPR_SYNC();
     }
 
-    // forward sweep: one phase per knot, closed-loop form  sx+ = A sx + b - B (K sx + kff)
-    UPR_HDI void forward() {
-        // wave-local sweep (first wave, no workgroup barrier): sx+ = A sx + b - B (K sx + kff)
-        if (ctx.tid < 64) {
-            upr_ctx wc; wc.tid = ctx.tid; wc.nt = ctx.nt < 64 ? ctx.nt : 64;
-            const upr_ctx& ctx = wc;
-            UPR_FOR(i, NX) Sx(0)[i] = 0.0;
+    // ---- backward sweep, vector part, for the current right-hand side ----------------------------------------
+    // With w_k = p_{k+1} + P_{k+1} b_k the recursion is  p_k = c_k + A'w_k - K_k'(B'w_k),  c_k = gx_k + C_k'zt_k -
+    // K_k' gu_k[jerk]: one wave-local phase per knot (lane i < nx owns p_k[i] and column i of K_k, prefetched one
+    // knot ahead).  w_k is kept (in the step array, which the forward sweep overwrites afterwards) for the
+    // feed-forward  kff_k = Hjj_k^-1 (gu_k[jerk] + B'w_k)  of all knots at once.
+    UPR_HDI double* Wk(int k) const { return L + O::S + (k + 1) * NX; }
+    UPR_HDI void backward_vec() {
+        const double irho = 1.0 / UPR_QP_RHO_N;
+        terminal_residual();
+        UPR_FORT(e, (N - 1) * NX) {
+            const int k = 1 + e / NX, i = e % NX;
+            double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
+            for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * L[O::gus + k * NU + m];
+            L[O::cs + k * NX + i] = v;
+        }
+        UPR_SYNC();
+        if (wave0()) {
+            UPR_FORT(i, NX) {
+                double v = L[O::gxs + N * NX + i];
+                if (neN > 0) {
+                    if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + irho * L[O::eN + q]); }
+                    else v += L[O::yN + 3 + (i - NQ)] + irho * L[O::eN + 3 + (i - NQ)];
+                }
+                Wk(N - 1)[i] = v + L[O::Pbs + (N - 1) * NX + i];
+            }
             UPR_WSYNC();
 #ifndef UPR_HOST_EMU
-            double kq[NQ];   // block (b, j) of row j of K_k, loaded one knot ahead
-            if (ctx.tid < NX) {
-                const double* Kr = G + F::Ks + (ctx.tid % NQ) * NX + (ctx.tid / NQ) * NQ;
+            static_assert(NX <= 64, "one lane per state component");
+            const int i = tid();
+            if (i < NX) {
+                const int b = i / NQ, j = i % NQ;
+                double kc[NQ];   // column i of K_k
 #pragma unroll
-                for (int c = 0; c < NQ; ++c) kq[c] = Kr[c];
-            }
-#endif
-            for (int k = 0; k < N; ++k) {
-                const double* sx = Sx(k); double* sn = Sx(k + 1);
-                UPR_FOR(i, NX) {   // partial dot products of K sx over one nq-block each
-                    const int b = i / NQ, j = i % NQ;
-                    double d = 0.0;
-#ifdef UPR_HOST_EMU
-                    const double* Kr = G + F::Ks + k * NQ * NX + j * NX + b * NQ;
-                    for (int c = 0; c < NQ; ++c) d += Kr[c] * sx[b * NQ + c];
-#else
+                for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (N - 1) * NQ * NX + m * NX + i];
+                for (int k = N - 1; k >= 1; --k) {
+                    const double* w = Wk(k);
+                    const double ck_ = L[O::cs + k * NX + i], pbn = L[O::Pbs + (k - 1) * NX + i];
+                    double v = ck_;
+                    for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c) d += kq[c] * sx[b * NQ + c];
-                    if (k + 1 < N) {
-                        const double* Kr = G + F::Ks + (k + 1) * NQ * NX + j * NX + b * NQ;
+                    for (int m = 0; m < NQ; ++m) v -= kc[m] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
+                    if (k > 1) {
 #pragma unroll
-                        for (int c = 0; c < NQ; ++c) kq[c] = Kr[c];
+                        for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (k - 1) * NQ * NX + m * NX + i];
                     }
-#endif
-                    L[O::hx + i] = d;
+                    Wk(k - 1)[i] = v + pbn;
+                    UPR_WSYNC();
                 }
-                UPR_WSYNC();
-                UPR_FOR(i, NX) {
-                    const int b = i / NQ, j = i % NQ;
-                    const double uj = -(L[O::kffs + k * NQ + j] + L[O::hx + j] + L[O::hx + NQ + j] + L[O::hx + 2 * NQ + j]);
-                    const double q = sx[j], v = sx[NQ + j], a = sx[2 * NQ + j];
-                    double r;
-                    if (b == 0) { r = q + h * v + h2 * a + h3 * uj; Su(k)[j] = uj; }
-                    else if (b == 1) r = v + h * a + h2 * uj;
-                    else r = a + h * uj;
-                    sn[i] = r + L[O::bks + k * NX + i];
-                }
-                UPR_WSYNC();
             }
+#else
+            for (int k = N - 1; k >= 1; --k) {
+                const double* w = Wk(k);
+                UPR_FORT(i, NX) {
+                    const int b = i / NQ, j = i % NQ;
+                    double v = L[O::cs + k * NX + i];
+                    for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
+                    for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
+                    Wk(k - 1)[i] = v + L[O::Pbs + (k - 1) * NX + i];
+                }
+            }
+#endif
+        }
+        UPR_SYNC();
+        // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
+        UPR_FORT(k, N) {
+            const double* Lp = G + F::Ljis + k * C::NH;
+            const double* w = Wk(k);
+            double y[NQ], kk[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { double t = L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+#pragma unroll
+                for (int m = 0; m < i; ++m) t -= Lp[i * (i + 1) / 2 + m] * y[m];
+                y[i] = t * Lp[i * (i + 1) / 2 + i]; }
+#pragma unroll
+            for (int i = NQ - 1; i >= 0; --i) { double t = y[i];
+#pragma unroll
+                for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
+                kk[i] = t * Lp[i * (i + 1) / 2 + i]; }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
+        }
+        UPR_SYNC();
+    }
+
+    // forward sweep, closed-loop form  sx+ = A sx + b - B (K sx + kff): one wave-local phase per knot, lane
+    // (block b, joint j) owns sx+[b nq + j] and row j of K_k (prefetched one knot ahead)
+    UPR_HDI void forward() {
+        if (wave0()) {
+            // knot 0: sx_0 = 0
+            UPR_FORT(i, NX) {
+                const int b = i / NQ, j = i % NQ;
+                const double uj = -L[O::kffs + j];
+                Sx(0)[i] = 0.0;
+                Sx(1)[i] = coefB(b) * uj + L[O::bks + i];
+                if (b == 0) Su(0)[j] = uj;
+            }
+            UPR_WSYNC();
+#ifndef UPR_HOST_EMU
+            const int i = tid();
+            if (i < NX) {
+                const int b = i / NQ, j = i % NQ;
+                double kq[NX];   // row j of K_k
+#pragma unroll
+                for (int c = 0; c < NX; ++c) kq[c] = G[F::Ks + 1 * NQ * NX + j * NX + c];
+                for (int k = 1; k < N; ++k) {
+                    const double* sx = Sx(k);
+                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
+                    const double bk_ = L[O::bks + k * NX + i];
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) { d0 += kq[c] * sx[c]; d1 += kq[NQ + c] * sx[NQ + c]; d2 += kq[2 * NQ + c] * sx[2 * NQ + c]; }
+                    if (k + 1 < N) {
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) kq[c] = G[F::Ks + (k + 1) * NQ * NX + j * NX + c];
+                    }
+                    const double uj = -(d0 + d1 + d2);
+                    double r = coefB(b) * uj + bk_;
+                    for (int a = b; a < 3; ++a) r += coefA(b, a) * sx[a * NQ + j];
+                    Sx(k + 1)[i] = r;
+                    if (b == 0) Su(k)[j] = uj;
+                    UPR_WSYNC();
+                }
+            }
+#else
+            for (int k = 1; k < N; ++k) {
+                const double* sx = Sx(k);
+                UPR_FORT(i, NX) {
+                    const int b = i / NQ, j = i % NQ;
+                    const double* Kr = G + F::Ks + k * NQ * NX + j * NX;
+                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
+                    for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
+                    const double uj = -(d0 + d1 + d2);
+                    double r = coefB(b) * uj + L[O::bks + k * NX + i];
+                    for (int a = b; a < 3; ++a) r += coefA(b, a) * sx[a * NQ + j];
+                    Sx(k + 1)[i] = r;
+                    if (b == 0) Su(k)[j] = uj;
+                }
+            }
+#endif
         }
         UPR_SYNC();
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
-        UPR_FOR(e, N * NE) {
+        UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX; const double* sx = Sx(k);
             double v = 0.0;
@@ -711,7 +781,7 @@ struct upr_qp3 {
             L[O::cv + e] = v;
         }
         UPR_SYNC();
-        UPR_FOR(k, N) {
+        UPR_FORT(k, N) {
             const double* Ls = G + F::lsi + k * NE * NE;
             double t1[NE];
 #pragma unroll
@@ -727,7 +797,7 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
-            const int ic = upr_opq(ctx.tid) + q * NT;
+            const int ic = tid() + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
@@ -744,7 +814,7 @@ struct upr_qp3 {
                 }
             }
         }
-        if (neN > 0) UPR_FOR(q, C::NEN) {
+        if (neN > 0) UPR_FORT(q, C::NEN) {
             double v;
             if (q < 3) { v = L[O::eN + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * Sx(N)[j]; }
             else v = L[O::eN + q] + Sx(N)[NQ + (q - 3)];
@@ -756,7 +826,7 @@ struct upr_qp3 {
     // costates of the full step (into global pin)
     UPR_HDI void costates() {
         double* pin = ws + W::pin;
-        UPR_FOR(e, N1 * NX) {
+        UPR_FORT(e, N1 * NX) {
             const int k = e / NX, i = e % NX;
             const double* sx = Sx(k);
             double v = L[O::gxs + e] + L[O::wx + e] * sx[i];
@@ -772,7 +842,7 @@ struct upr_qp3 {
             pin[e] = v;
         }
         UPR_SYNC();
-        UPR_FOR(j, NQ) {
+        UPR_FORT(j, NQ) {
             double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
             for (int k = N - 1; k >= 1; --k) {
                 const double nq_ = pin[k * NX + j] + pq;
@@ -801,7 +871,7 @@ struct upr_qp3 {
     }
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux) {
         double acc = (what == 0) ? 1e30 : 0.0;
-        const int tid_ = upr_opq(ctx.tid);
+        const int tid_ = tid();
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
@@ -846,7 +916,7 @@ struct upr_qp3 {
         prep(0);
         mode = save;
         double r_stat = 0.0, r_eq = 0.0;
-        UPR_FOR(e, N * NX) {
+        UPR_FORT(e, N * NX) {
             const int k = 1 + e / NX, i = e % NX;
             double v = L[O::gxs + k * NX + i] - pi[k * NX + i];
             if (k < N) {
@@ -860,14 +930,14 @@ struct upr_qp3 {
             }
             r_stat = fmax(r_stat, fabs(v));
         }
-        UPR_FOR(e, N * NU) {
+        UPR_FORT(e, N * NU) {
             const int k = e / NU, i = e % NU;
             double v = L[O::gus + e];
             if (i < NQ) { const double* pn = pi + (k + 1) * NX; v += h3 * pn[i] + h2 * pn[NQ + i] + h * pn[2 * NQ + i]; }
             else for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q];
             r_stat = fmax(r_stat, fabs(v));
         }
-        UPR_FOR(e, N * NQ) {
+        UPR_FORT(e, N * NQ) {
             const int k = e / NQ, j = e % NQ;
             const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
             const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
@@ -875,32 +945,37 @@ struct upr_qp3 {
             r_eq = fmax(r_eq, fabs(v + h * a + h2 * u - Xn[NQ + j]));
             r_eq = fmax(r_eq, fabs(a + h * u - Xn[2 * NQ + j]));
         }
-        UPR_FOR(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e]));
+        UPR_FORT(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e]));
         terminal_residual();
         UPR_SYNC();
-        if (neN > 0) UPR_FOR(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
+        if (neN > 0) UPR_FORT(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
         double lt = 0.0;
         const double r_in = ineq_sweep(3, 0.0, &lt);
-        res[0] = upr_reduce(ctx, L + O::red, r_stat, 1);
-        res[1] = upr_reduce(ctx, L + O::red, r_eq, 1);
-        res[2] = upr_reduce(ctx, L + O::red, r_in, 1);
-        res[3] = upr_reduce(ctx, L + O::red, lt, 0) / (ntot > 0 ? ntot : 1);
+        res[0] = upr_reduce(ctxv(), L + O::red, r_stat, 1);
+        res[1] = upr_reduce(ctxv(), L + O::red, r_eq, 1);
+        res[2] = upr_reduce(ctxv(), L + O::red, r_in, 1);
+        res[3] = upr_reduce(ctxv(), L + O::red, lt, 0) / (ntot > 0 ? ntot : 1);
     }
 
     double* prof; long long tlast;
-    UPR_HD void tic() {
+    UPR_HDI void tic() {
 #ifndef UPR_HOST_EMU
-        if (prof && ctx.tid == 0) tlast = (long long)__builtin_readcyclecounter();
+        if (prof && tid() == 0) tlast = (long long)__builtin_readcyclecounter();
 #endif
     }
-    UPR_HD void toc(int id) {
+    UPR_HDI void toc(int id) {
 #ifndef UPR_HOST_EMU
-        if (prof && ctx.tid == 0) { long long t = (long long)__builtin_readcyclecounter(); prof[id] += (double)(t - tlast); tlast = t; }
+        if (prof && tid() == 0) { long long t = (long long)__builtin_readcyclecounter(); prof[id] += (double)(t - tlast); tlast = t; }
 #endif
     }
 
-    UPR_HD void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
+    UPR_HDI void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
         ctx = c; P = A.P; L = lds;
+#ifdef UPR_HOST_EMU
+        wb = 0;
+#else
+        wb = __builtin_amdgcn_readfirstlane(c.tid & ~63);
+#endif
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
         lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
@@ -908,27 +983,27 @@ struct upr_qp3 {
         prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
         tic();
         // ---- constants and linearisation-point data into LDS
-        UPR_FOR(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
-        UPR_FOR(i, NU) { L[O::ulb + i] = P->u_lb[i]; L[O::uub + i] = P->u_ub[i]; L[O::rd + i] = P->Rdiag[i]; }
-        if (NF == 3) UPR_FOR(e, C::NP) { double e3[3]; upr_friction_row_jac(P, e / 5, e % 5, e3); L[O::erow + 3 * e] = e3[0]; L[O::erow + 3 * e + 1] = e3[1]; L[O::erow + 3 * e + 2] = e3[2]; }
-        UPR_FOR(e, NE * NFC) L[O::df + e] = Dfg[e];
-        UPR_FOR(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
-        UPR_FOR(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
-        UPR_FOR(e, N * C::NH) { const int k = e / C::NH; G[F::hee + e] = rec(k)[lin_hess + e % C::NH]; }
-        UPR_FOR(e, 3 * NQ) L[O::jN + e] = rec(N)[lin_hess + e];
-        UPR_FOR(q, 3) L[O::misc + 4 + q] = rec(N)[lin_grad + q];
-        UPR_FOR(q, C::NEN) { L[O::yN + q] = 0.0; L[O::dyN + q] = 0.0; }
-        if (ctx.tid == 0) L[O::misc] = 0.0;
-        UPR_FOR(i, W::store) ws[i] = 0.0;
+        UPR_FORT(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
+        UPR_FORT(i, NU) { L[O::ulb + i] = P->u_lb[i]; L[O::uub + i] = P->u_ub[i]; L[O::rd + i] = P->Rdiag[i]; }
+        if (NF == 3) UPR_FORT(e, C::NP) { double e3[3]; upr_friction_row_jac(P, e / 5, e % 5, e3); L[O::erow + 3 * e] = e3[0]; L[O::erow + 3 * e + 1] = e3[1]; L[O::erow + 3 * e + 2] = e3[2]; }
+        UPR_FORT(e, NE * NFC) L[O::df + e] = Dfg[e];
+        UPR_FORT(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
+        UPR_FORT(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
+        UPR_FORT(e, N * C::NH) { const int k = e / C::NH; G[F::hee + e] = rec(k)[lin_hess + e % C::NH]; }
+        UPR_FORT(e, 3 * NQ) L[O::jN + e] = rec(N)[lin_hess + e];
+        UPR_FORT(q, 3) L[O::misc + 4 + q] = rec(N)[lin_grad + q];
+        UPR_FORT(q, C::NEN) { L[O::yN + q] = 0.0; L[O::dyN + q] = 0.0; }
+        if (tid() == 0) L[O::misc] = 0.0;
+        UPR_FORT(i, W::store) ws[i] = 0.0;
         UPR_SYNC();
         // g0 = gradEE - Hee xs_q ; e0 = g - C xs - Df us_f   (affine parts at the linearisation point)
-        UPR_FOR(e, N * NQ) {
+        UPR_FORT(e, N * NQ) {
             const int k = e / NQ, i = e % NQ;
             double v = rec(k)[lin_grad + i];
             for (int j = 0; j < NQ; ++j) v -= G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * xs[k * NX + j];
             G[F::g0 + e] = v;
         }
-        UPR_FOR(e, N * NE) {
+        UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
             double v = rec(k)[lin_g + r];
@@ -939,8 +1014,8 @@ struct upr_qp3 {
         // ---- initial slacks / multipliers
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
-            const int ix = ctx.tid + q * NT;
-            for (int s = 0; s < 2; ++s) { tx[q][s] = 1.0; lx[q][s] = 0.0; cx[q][s] = 0.0; }
+            const int ix = tid() + q * NT;
+            tx[q][0] = tx[q][1] = 1.0; lx[q][0] = lx[q][1] = 0.0; cx[q][0] = cx[q][1] = 0.0;
             if (ix < C::NXI) {
                 const int i = ix % NX; const double X = L[O::Z + NX + ix];
                 const double c0 = X - L[O::xlb + i], c1 = L[O::xub + i] - X;
@@ -950,8 +1025,8 @@ struct upr_qp3 {
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
-            const int iu = ctx.tid + q * NT;
-            for (int s = 0; s < 2; ++s) { tu[q][s] = 1.0; lu[q][s] = 0.0; cu[q][s] = 0.0; }
+            const int iu = tid() + q * NT;
+            tu[q][0] = tu[q][1] = 1.0; lu[q][0] = lu[q][1] = 0.0; cu[q][0] = cu[q][1] = 0.0;
             if (iu < C::NUI) {
                 const int i = iu % NU; const double U = L[O::Z + N1 * NX + iu];
                 const double c0 = U - L[O::ulb + i], c1 = L[O::uub + i] - U;
@@ -960,7 +1035,7 @@ struct upr_qp3 {
             }
         }
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
-            const int ic = ctx.tid + q * NT;
+            const int ic = tid() + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
                 const double* f = L + O::Z + N1 * NX + k * NU + NQ + 3 * ci;
@@ -989,40 +1064,41 @@ struct upr_qp3 {
             const double mu = res[3];
             mode = 0;
             prep(2); toc(1);
-            backward(true); toc(5);
+            backward_mat(); toc(5);
+            backward_vec(); toc(8);
             if (L[O::misc] != 0.0) { status = 2; break; }
             forward(); toc(6);
-            double a_aff = upr_reduce(ctx, L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            double a_aff = upr_reduce(ctxv(), L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
             if (a_aff > 1.0) a_aff = 1.0;
-            const double mu_aff = upr_reduce(ctx, L + O::red, ineq_sweep(1, a_aff, nullptr), 0) / ntot;
+            const double mu_aff = upr_reduce(ctxv(), L + O::red, ineq_sweep(1, a_aff, nullptr), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
             toc(7);
             mode = 1;
             prep(1); toc(1);
-            backward(false); toc(8);
+            backward_vec(); toc(8);
             forward(); toc(6);
             mode = 3;
             costates(); toc(9);
-            double a = 0.995 * upr_reduce(ctx, L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            double a = 0.995 * upr_reduce(ctxv(), L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
             if (a > 1.0) a = 1.0;
             ineq_sweep(2, a, nullptr);
             UPR_SYNC();
-            UPR_FOR(e, N1 * NX) {
+            UPR_FORT(e, N1 * NX) {
                 if (e >= NX) L[O::Z + e] += a * L[O::S + e];
                 ws[W::pi + e] += a * (ws[W::pin + e] - ws[W::pi + e]);
             }
-            UPR_FOR(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
-            UPR_FOR(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
-            UPR_FOR(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
+            UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
+            UPR_FORT(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
+            UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
             toc(10);
         }
         // ---- result: step from the linearisation point
-        UPR_FOR(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
-        UPR_FOR(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
-        if (ctx.tid == 0) {
+        UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
+        UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
+        if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;
             st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];
         }
@@ -1031,7 +1107,7 @@ struct upr_qp3 {
 };
 
 template <class C>
-static inline UPR_HD void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int b, double* L) {
+static UPR_HDI void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int b, double* L) {
     upr_qp3<C> S;
     S.solve(ctx, A, b, L);
 }
