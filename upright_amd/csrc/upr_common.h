@@ -42,6 +42,14 @@ struct upr_ctx { int tid; int nt; };
 static inline int upr_opq(int x) { return x; }
 #else
 static __device__ __forceinline__ int upr_opq(int x) { asm volatile("" : "+v"(x)); return x; }
+// quad permutation of a double by DPP (CTRL = quad_perm encoding: 0xB1 swaps neighbours, 0x4E swaps pairs); all
+// four lanes of the quad must be active
+template <int CTRL>
+static __device__ __forceinline__ double upr_dpp_quad(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // value of lane `lane` (compile-time constant after unrolling) broadcast through scalar registers
 static __device__ __forceinline__ double upr_readlane(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

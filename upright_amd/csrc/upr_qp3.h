@@ -78,20 +78,20 @@ struct upr_qp3_lds {
                          bk = yj + r2(C::NQ), yN = bk + r2(C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + r2(C::NT),
                          // LDS-resident Riccati store: feedback K = Hjj^-1 Hux, P+ b, feed-forward kff = Hjj^-1 huj, huj, Lj^-1 (packed lower)
-                         lsik = misc + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
+                         prf = misc + 16, lsik = prf + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
                          pv2 = hujs + r2(C::N * C::NQ), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
 };
 
 // 1/sqrt(x) without the IEEE division / square-root sequences (they cost ~300 cycles per pivot on the
-// critical path): hardware estimate + two Newton steps, relative error < 1e-15.
+// critical path): hardware estimate (relative error 5e-8 on gfx950, tools/rsq_test.hip) + ONE third-order
+// step y (1 + e/2 + 3e^2/8), e = 1 - x y^2: 5 dependent operations, relative error < 3e-16.
 static inline UPR_HD double upr_rsqrt(double x) {
 #ifdef UPR_HOST_EMU
     return 1.0 / sqrt(x);
 #else
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y, e * fma(0.375, e, 0.5), y);
 #endif
 }
 
@@ -206,6 +206,50 @@ struct upr_qp3 {
     // h, h2, h3 on a lane-dependent index would be turned into an indexed load and pin the whole object in scratch
     UPR_HDI double coefA(int a, int b) const { return ((a == b) ? 1.0 : 0.0) + (((a == 0 && b == 1) || (a == 1 && b == 2)) ? 1.0 : 0.0) * h + ((a == 0 && b == 2) ? 1.0 : 0.0) * h2; }
     UPR_HDI double coefB(int a) const { return ((a == 0) ? 1.0 : 0.0) * h3 + ((a == 1) ? 1.0 : 0.0) * h2 + ((a == 2) ? 1.0 : 0.0) * h; }
+
+    // workgroup reductions: butterfly inside each wave (ds_bpermute), one LDS slot per wave, two LDS-only barriers
+    UPR_HDI static double comb(double a, double b, int op) { return (op == 0) ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
+    UPR_HDI double reduce(double v, int op /*0 sum 1 max 2 min*/) {
+#ifdef UPR_HOST_EMU
+        return upr_reduce(ctx, L + O::red, v, op);
+#else
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = comb(v, __shfl_xor(v, off), op);
+        if (lane() == 0) L[O::red + (wb >> 6)] = v;
+        UPR_SYNC_LDS();
+        double r = L[O::red];
+#pragma unroll
+        for (int w = 1; w < (NT >> 6); ++w) r = comb(r, L[O::red + w], op);
+        UPR_SYNC_LDS();
+        return r;
+#endif
+    }
+    // three maxima and one sum at once
+    UPR_HDI void reduce4(double* v) {
+#ifdef UPR_HOST_EMU
+        v[0] = upr_reduce(ctx, L + O::red, v[0], 1); v[1] = upr_reduce(ctx, L + O::red, v[1], 1);
+        v[2] = upr_reduce(ctx, L + O::red, v[2], 1); v[3] = upr_reduce(ctx, L + O::red, v[3], 0);
+#else
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = comb(v[q], __shfl_xor(v[q], off), q < 3 ? 1 : 0);
+        }
+        if (lane() == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) L[O::red + 4 * (wb >> 6) + q] = v[q];
+        }
+        UPR_SYNC_LDS();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double r = L[O::red + q];
+#pragma unroll
+            for (int w = 1; w < (NT >> 6); ++w) r = comb(r, L[O::red + 4 * w + q], q < 3 ? 1 : 0);
+            v[q] = r;
+        }
+        UPR_SYNC_LDS();
+#endif
+    }
 
     // one inequality row: slack residual, weight and reduced-gradient multiplier for the current mode
     UPR_HDI void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
@@ -648,6 +692,7 @@ struct upr_qp3 {
             L[O::cs + k * NX + i] = v;
         }
         UPR_SYNC();
+        toc(2);
         if (wave0()) {
             UPR_FORT(i, NX) {
                 double v = L[O::gxs + N * NX + i];
@@ -663,23 +708,24 @@ struct upr_qp3 {
             const int i = tid();
             if (i < NX) {
                 const int b = i / NQ, j = i % NQ;
-                double kc[NQ];   // column i of K_k
-#pragma unroll
-                for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (N - 1) * NQ * NX + m * NX + i];
-                for (int k = N - 1; k >= 1; --k) {
-                    const double* w = Wk(k);
-                    const double ck_ = L[O::cs + k * NX + i], pbn = L[O::Pbs + (k - 1) * NX + i];
-                    double v = ck_;
-                    for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
-#pragma unroll
-                    for (int m = 0; m < NQ; ++m) v -= kc[m] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
-                    if (k > 1) {
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) kc[m] = G[F::Ks + (k - 1) * NQ * NX + m * NX + i];
-                    }
-                    Wk(k - 1)[i] = v + pbn;
-                    UPR_WSYNC();
+                // column i of K_k, K_{k-1}, K_{k-2}: three knots of register prefetch cover the L2 / fabric latency
+                double kc0[NQ], kc1[NQ], kc2[NQ];
+#define UPR_LOADKC(dst, kk) do { if ((kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
+#define UPR_VECSTEP(kcx, kk) do { \
+                    const double* w = Wk(kk); const int b_ = upr_opq(b); \
+                    double v = L[O::cs + (kk) * NX + i]; const double pbn = L[O::Pbs + ((kk) - 1) * NX + i]; \
+                    for (int a = 0; a <= b_; ++a) v += coefA(a, b_) * w[a * NQ + j]; \
+                    _Pragma("unroll") for (int m = 0; m < NQ; ++m) v -= kcx[m] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]); \
+                    Wk((kk) - 1)[i] = v + pbn; \
+                    UPR_WSYNC(); } while (0)
+                UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
+                for (int k = N - 1; k >= 1; k -= 3) {
+                    UPR_VECSTEP(kc0, k); UPR_LOADKC(kc0, k - 3);
+                    if (k - 1 >= 1) { UPR_VECSTEP(kc1, k - 1); UPR_LOADKC(kc1, k - 4); }
+                    if (k - 2 >= 1) { UPR_VECSTEP(kc2, k - 2); UPR_LOADKC(kc2, k - 5); }
                 }
+#undef UPR_LOADKC
+#undef UPR_VECSTEP
             }
 #else
             for (int k = N - 1; k >= 1; --k) {
@@ -695,6 +741,7 @@ struct upr_qp3 {
 #endif
         }
         UPR_SYNC();
+        toc(3);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
         UPR_FORT(k, N) {
             const double* Lp = G + F::Ljis + k * C::NH;
@@ -730,29 +777,35 @@ struct upr_qp3 {
             }
             UPR_WSYNC();
 #ifndef UPR_HOST_EMU
-            const int i = tid();
-            if (i < NX) {
-                const int b = i / NQ, j = i % NQ;
-                double kq[NX];   // row j of K_k
-#pragma unroll
-                for (int c = 0; c < NX; ++c) kq[c] = G[F::Ks + 1 * NQ * NX + j * NX + c];
-                for (int k = 1; k < N; ++k) {
-                    const double* sx = Sx(k);
-                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
-                    const double bk_ = L[O::bks + k * NX + i];
-#pragma unroll
-                    for (int c = 0; c < NQ; ++c) { d0 += kq[c] * sx[c]; d1 += kq[NQ + c] * sx[NQ + c]; d2 += kq[2 * NQ + c] * sx[2 * NQ + c]; }
-                    if (k + 1 < N) {
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) kq[c] = G[F::Ks + (k + 1) * NQ * NX + j * NX + c];
-                    }
-                    const double uj = -(d0 + d1 + d2);
-                    double r = coefB(b) * uj + bk_;
-                    for (int a = b; a < 3; ++a) r += coefA(b, a) * sx[a * NQ + j];
-                    Sx(k + 1)[i] = r;
-                    if (b == 0) Su(k)[j] = uj;
-                    UPR_WSYNC();
+            // lane 4 j + b (b < 3) owns sx+[b nq + j] and the nq entries K_k[j][b nq ..] (three knots of register
+            // prefetch); the three partial dot products of a joint are summed inside its quad by DPP
+            static_assert(4 * NQ <= 64, "one quad per joint");
+            {
+                const int l = lane(), j = l >> 2, b = l & 3;
+                const bool act = (b < 3) && (j < NQ);
+                const int i = act ? b * NQ + j : 0;
+                double kq0[NQ], kq1[NQ], kq2[NQ];
+#define UPR_LOADKQ(dst, kk) do { if (act && (kk) < N) { _Pragma("unroll") for (int c = 0; c < NQ; ++c) dst[c] = G[F::Ks + (kk) * NQ * NX + j * NX + b * NQ + c]; } } while (0)
+#define UPR_FWDSTEP(kqx, kk) do { \
+                    const double* sx = Sx(kk); const int b_ = upr_opq(b); \
+                    double d = 0.0, r = 0.0; \
+                    if (act) { \
+                        d = (b_ == 0) ? L[O::kffs + (kk) * NQ + j] : 0.0; \
+                        _Pragma("unroll") for (int c = 0; c < NQ; ++c) d += kqx[c] * sx[b_ * NQ + c]; \
+                        r = L[O::bks + (kk) * NX + i]; \
+                        for (int a = b_; a < 3; ++a) r += coefA(b_, a) * sx[a * NQ + j]; \
+                    } \
+                    d += upr_dpp_quad<0xB1>(d); d += upr_dpp_quad<0x4E>(d); \
+                    if (act) { Sx((kk) + 1)[i] = r - coefB(b_) * d; if (b_ == 0) Su(kk)[j] = -d; } \
+                    UPR_WSYNC(); } while (0)
+                UPR_LOADKQ(kq0, 1); UPR_LOADKQ(kq1, 2); UPR_LOADKQ(kq2, 3);
+                for (int k = 1; k < N; k += 3) {
+                    UPR_FWDSTEP(kq0, k); UPR_LOADKQ(kq0, k + 3);
+                    if (k + 1 < N) { UPR_FWDSTEP(kq1, k + 1); UPR_LOADKQ(kq1, k + 4); }
+                    if (k + 2 < N) { UPR_FWDSTEP(kq2, k + 2); UPR_LOADKQ(kq2, k + 5); }
                 }
+#undef UPR_LOADKQ
+#undef UPR_FWDSTEP
             }
 #else
             for (int k = 1; k < N; ++k) {
@@ -772,6 +825,7 @@ struct upr_qp3 {
 #endif
         }
         UPR_SYNC();
+        toc(4);
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
@@ -909,7 +963,18 @@ struct upr_qp3 {
         return acc;
     }
 
-    UPR_HDI void residuals(int ntot, double* res) {
+    // full == false: only the inequality residual and the complementarity average (what the step needs and what
+    // decides whether the expensive stationarity / equality residuals can matter at all)
+    UPR_HDI void residuals(int ntot, double* res, bool full) {
+        if (!full) {
+            double lt0 = 0.0;
+            const double r_in0 = ineq_sweep(3, 0.0, &lt0);
+            res[0] = 0.0; res[1] = 0.0; res[2] = r_in0; res[3] = lt0;
+            reduce4(res);
+            res[0] = 1e300; res[1] = 1e300;
+            res[3] /= (ntot > 0 ? ntot : 1);
+            return;
+        }
         const double* pi = ws + W::pi; const double* nu = ws + W::nu;
         const int save = mode;
         mode = 2;
@@ -951,10 +1016,9 @@ struct upr_qp3 {
         if (neN > 0) UPR_FORT(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
         double lt = 0.0;
         const double r_in = ineq_sweep(3, 0.0, &lt);
-        res[0] = upr_reduce(ctxv(), L + O::red, r_stat, 1);
-        res[1] = upr_reduce(ctxv(), L + O::red, r_eq, 1);
-        res[2] = upr_reduce(ctxv(), L + O::red, r_in, 1);
-        res[3] = upr_reduce(ctxv(), L + O::red, lt, 0) / (ntot > 0 ? ntot : 1);
+        res[0] = r_stat; res[1] = r_eq; res[2] = r_in; res[3] = lt;
+        reduce4(res);
+        res[3] /= (ntot > 0 ? ntot : 1);
     }
 
     double* prof; long long tlast;
@@ -965,7 +1029,7 @@ struct upr_qp3 {
     }
     UPR_HDI void toc(int id) {
 #ifndef UPR_HOST_EMU
-        if (prof && tid() == 0) { long long t = (long long)__builtin_readcyclecounter(); prof[id] += (double)(t - tlast); tlast = t; }
+        if (prof && tid() == 0) { long long t = (long long)__builtin_readcyclecounter(); L[O::prf + id] += (double)(t - tlast); tlast = t; }
 #endif
     }
 
@@ -981,6 +1045,7 @@ struct upr_qp3 {
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0;
         prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
+        if (prof) UPR_FORT(i, 16) L[O::prf + i] = 0.0;
         tic();
         // ---- constants and linearisation-point data into LDS
         UPR_FORT(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
@@ -1054,7 +1119,13 @@ struct upr_qp3 {
         const double tol = P->qp_tol;
         toc(11);
         for (;; ++it) {
-            residuals(ntot, res);
+            // the KKT test can only pass once the complementarity average and the inequality residual are below the
+            // tolerance: until then the stationarity / equality residuals are not evaluated
+#pragma nounroll
+            for (int pass = 0; pass < 2; ++pass) {
+                residuals(ntot, res, pass == 1);
+                if (!((it > 0 && res[2] < tol && res[3] < tol) || it >= P->qp_iter_max)) break;
+            }
             toc(0);
 #ifdef UPR_HOST_EMU
             if (getenv("UPR_EMU_DEBUG")) printf("v3 it %d res %.3e %.3e %.3e %.3e\n", it, res[0], res[1], res[2], res[3]);
@@ -1068,9 +1139,9 @@ struct upr_qp3 {
             backward_vec(); toc(8);
             if (L[O::misc] != 0.0) { status = 2; break; }
             forward(); toc(6);
-            double a_aff = upr_reduce(ctxv(), L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            double a_aff = reduce(ineq_sweep(0, 0.0, nullptr), 2);
             if (a_aff > 1.0) a_aff = 1.0;
-            const double mu_aff = upr_reduce(ctxv(), L + O::red, ineq_sweep(1, a_aff, nullptr), 0) / ntot;
+            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
@@ -1081,7 +1152,7 @@ struct upr_qp3 {
             forward(); toc(6);
             mode = 3;
             costates(); toc(9);
-            double a = 0.995 * upr_reduce(ctxv(), L + O::red, ineq_sweep(0, 0.0, nullptr), 2);
+            double a = 0.995 * reduce(ineq_sweep(0, 0.0, nullptr), 2);
             if (a > 1.0) a = 1.0;
             ineq_sweep(2, a, nullptr);
             UPR_SYNC();
@@ -1098,6 +1169,7 @@ struct upr_qp3 {
         // ---- result: step from the linearisation point
         UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
         UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
+        if (prof) UPR_FORT(i, 16) prof[i] += L[O::prf + i];
         if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;
             st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];
