@@ -338,7 +338,7 @@ struct StageQP {
     vec Gu, d;               // np rows on du
 };
 struct QP {
-    int N, nx, nu, ne, np, neN;
+    int N, nx, nu, ne, np, neN, nfc;
     vec A, B;
     std::vector<StageQP> st;  // N stages
     vec QN, qN, CN, eN, xlN, xuN;
@@ -557,7 +557,9 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     for (int k = 0; k <= N; ++k)
         for (size_t i = 0; i < t[k].size(); ++i) { t[k][i] = std::max(cval[k][i], thr); lam[k][i] = mu0 / t[k][i]; }
 
-    Riccati ric; ric.qp = &qp; ric.rho_s = 1e-12; ric.rhoN = 1e-6;
+    // forces are the tail of u: the force block spans the equality rows iff nu - nq >= ne
+    const double rho_prox = (qp.nfc < ne) ? 1e-6 : 0.0;
+    Riccati ric; ric.qp = &qp; ric.rho_s = (qp.nfc < ne) ? 1e-6 : 1e-12; ric.rhoN = 1e-6;
     std::vector<vec> Hxx_add(N + 1, vec(nx, 0.0)), Huu_add(N, vec((size_t)nu * nu, 0.0));
     std::vector<vec> gx(N + 1, vec(nx)), gu(N, vec(nu)), bres(N, vec(nx)), eres(N, vec(ne));
     std::vector<vec> rp(N + 1), rc(N + 1);
@@ -674,7 +676,11 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
             std::vector<vec> hxN = hx;
             for (int i = 0; i < nx; ++i) for (int r = 0; r < neN; ++r) hxN[N][i] += qp.CN[r * nx + i] * yN[r];
             ddx[0].assign(nx, 0.0);  // dx[0] is fixed -> zero step
-            ric.solve(hxN, hu, bres, eres, eNres, ddx, ddu, pi_new, nu_new, dyN);
+            // rank-deficient force block (frictionless arrangements): proximal form of the stage equality,
+            // C dz + e = rho_s (nu+ - nu); the IPM iterations double as the proximal iterations
+            std::vector<vec> eprox = eres;
+            if (rho_prox > 0.0) for (int k = 0; k < N; ++k) for (int r = 0; r < ne; ++r) eprox[k][r] += rho_prox * nu_[k][r];
+            ric.solve(hxN, hu, bres, eprox, eNres, ddx, ddu, pi_new, nu_new, dyN);
             for (int k = 0; k <= N; ++k) {
                 int o = 0;
                 if (k >= 1) {
@@ -730,7 +736,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 // intermediate cost and its derivatives scaled by dt, defects b = f(x_k,u_k) - x_{k+1}).
 void build_qp(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us, QP& qp) {
     const int nx = orc_nx(P), nu = orc_nu(P), N = P->N, ne = 6 * P->nb, np = (P->nf == 3 ? 5 * P->nc : 0);
-    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np;
+    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq;
     Dyn dyn{P->nq, nx, nu, P->dt};
     dyn.dense(qp.A, qp.B);
     qp.st.assign(N, StageQP());

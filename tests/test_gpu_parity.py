@@ -377,3 +377,77 @@ def test_infeasible_instance_is_flagged_not_propagated(arrangements):
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert np.abs(xs[b] - xo).max() < 2e-5
     mpc.close()
+
+
+def _manager_from_golden(name, arrangements, arr="pink_bottle", x0=None, **override):
+    import copy
+    import json
+    from pathlib import Path
+
+    from upright_amd import control
+
+    cfg = copy.deepcopy(json.load(open(Path(__file__).parent / "golden" / "configs.json"))[name]["controller"])
+    for k, v in override.items():
+        d = cfg
+        ks = k.split(".")
+        for kk in ks[:-1]:
+            d = d[kk]
+        d[ks[-1]] = v
+    bodies, contacts = control.objects_from_fixture(arrangements[arr])
+    return control.ControllerManager.from_config(cfg, x0=x0, bodies=bodies, contacts=contacts)
+
+
+def _level_tool(chain, q_home):
+    """Rotate the tool frame so that the tray normal is EXACTLY vertical at q_home.  With the calibrated transforms
+    (tray_transforms_real.yaml) the tray is level to 1 degree only; frictionless contacts (nf = 1) cannot hold any
+    tangential load, so the fixed first knot of a frictionless problem is feasible only on an exactly level tray."""
+    _, C = chain.forward(q_home)
+    ez = np.array([0.0, 0.0, 1.0])
+    v = C.T @ ez
+    ax = np.cross(ez, v)
+    s, c = np.linalg.norm(ax), ez @ v
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    chain.tool_R = chain.tool_R @ (np.eye(3) + K + K @ K * ((1 - c) / (s * s)))
+    return chain
+
+
+@pytest.mark.parametrize("name,override,level", [
+    ("ur10_demo", {}, True),                                       # BASELINE configs[0]: fixed-base UR10, frictionless (nx 18, nu 10)
+    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, True),    # configs 2': Thing, frictionless (nx 27, nu 13); HPIPM slacks are not in the engine
+    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, False),   # as configured (tray 1 degree off level): infeasible first knot
+    ("full_bottle_point1", {}, False),                             # headline H through the manager
+])
+def test_reference_call_sequence_other_configs(arrangements, name, override, level):
+    """The reference's own call sequence (mpc_sim.py:68-176: ControllerManager.from_config -> warmstart -> step ->
+    get_mpc_trajectory) on the merged configs the reference parses (tests/golden/configs.json), against the oracle
+    on the Problem the settings produce.  Covers the frictionless (nf = 1) constraint layout, whose force block does
+    not span the object-dynamics rows (proximal treatment, upr_qp.h), and the 6-joint chain."""
+    m = _manager_from_golden(name, arrangements, **override)
+    P = m.mpc.problem
+    x0 = np.array(m.settings.initial_state)
+    if level:
+        _level_tool(P.chain, x0[:P.nq])
+        m.mpc._mpc.close(); m.mpc._mpc = None
+        m.mpc.reset(m.ref)   # new handle with the levelled chain
+    m.warmstart()
+    ts, xs, us = m.get_mpc_trajectory()
+    assert xs.shape == (P.N + 1, P.nx) and us.shape == (P.N + 1, P.nu) and np.allclose(ts, P.dt * np.arange(P.N + 1))
+    xs0, us0 = stationary_guess(x0[None], P.N, P.nu)
+    xo, uo, so, rc = Oracle(P).solve(0.0, x0, xs0[0], us0[0])
+    st = m.mpc._mpc.stats()
+    if P.nf == 1 and not level:
+        # hard constraints, no slacks: both solvers stop at the iteration cap (as HPIPM does in the reference), the
+        # plans agree to the accuracy an unconverged QP allows and stay usable
+        assert so.qp_status_last == 1 and st["qp_status_last"][0] == 1
+        assert np.abs(xs - xo).max() < 1e-3 and np.all(np.isfinite(us))
+    else:
+        assert rc == 0 and so.qp_status_last == 0 and st["qp_status_last"][0] == 0
+        assert np.abs(xs - xo).max() < 2e-5 and np.abs(us[:-1] - uo).max() < 2e-4
+        assert abs(np.linalg.norm(xs) - np.linalg.norm(xo)) < 1e-4 and abs(np.linalg.norm(us[:-1]) - np.linalg.norm(uo)) < 1e-4
+    # replan cadence (manager.py:158-168): no new solve before min_policy_update_time has passed
+    n0 = len(m.replanning_times)
+    m.step(0.004, x0)
+    assert len(m.replanning_times) == n0
+    xd, u = m.step(0.012, x0)
+    assert len(m.replanning_times) == n0 + 1 and xd.shape == (P.nx,) and u.shape == (P.nu,)
+    assert np.all(np.isfinite(u))

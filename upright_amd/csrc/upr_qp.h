@@ -28,6 +28,13 @@
 // residuals converge)
 #define UPR_QP_SIGMA_FLOOR 1e-2
 #define UPR_QP_RHO_S 1e-12
+// When the contact-force block cannot span the equality rows (frictionless arrangements: nf nc < 6 nb) the
+// Schur complement S = Df Hff^-1 Df' is rank deficient: part of the equality constrains the state alone.  It is
+// then treated by the proximal method of multipliers,  C dx + Df df + e = rho (nu+ - nu),  with a rho that keeps
+// the Riccati recursion conditioned; the interior-point iterations double as the proximal iterations.
+#define UPR_QP_RHO_S_PROX 1e-6
+static inline UPR_HD double upr_qp_rho_s(int ne, int nfc) { return (nfc < ne) ? UPR_QP_RHO_S_PROX : UPR_QP_RHO_S; }
+static inline UPR_HD double upr_qp_rho_prox(int ne, int nfc) { return (nfc < ne) ? UPR_QP_RHO_S_PROX : 0.0; }
 #define UPR_QP_RHO_N 1e-6
 
 struct upr_qp_args {
@@ -465,7 +472,7 @@ static inline UPR_HD void upr_qp_backward(upr_qp_state& S, bool mat) {
             UPR_SYNC();
             UPR_FOR(e, ne * ne) {
                 int r = e / ne, c = e % ne;
-                double v = (r == c) ? UPR_QP_RHO_S : 0.0;
+                double v = (r == c) ? upr_qp_rho_s(ne, nfc) : 0.0;
                 for (int i = 0; i < nfc; ++i) v += L[o.Yf + i * ne + r] * L[o.Yf + i * ne + c];
                 L[o.Sm + e] = v;
             }
@@ -523,7 +530,7 @@ static inline UPR_HD void upr_qp_backward(upr_qp_state& S, bool mat) {
         UPR_FOR(i, nfc) L[o.huf + i] = upr_blk_up(d, L + o.Hff, L + o.uf0, i);
         UPR_SYNC();
         UPR_FOR(r, ne) {
-            double v = L[o.nuv + r];
+            double v = L[o.nuv + r] + upr_qp_rho_prox(ne, nfc) * S.ws[d.ws_nu + k * ne + r];
             for (int i = 0; i < nfc; ++i) v -= L[o.Df + r * nfc + i] * L[o.huf + i];
             L[o.ee + r] = v;
         }

@@ -314,7 +314,7 @@ struct upr_qp2 {
             const int k = e / (D::NE * D::NE), r = (e % (D::NE * D::NE)) / D::NE, c = e % D::NE;
             if (c > r) continue;
             double* pr = pre(k);
-            double acc = (r == c) ? UPR_QP_RHO_S : 0.0;
+            double acc = (r == c) ? upr_qp_rho_s(D::NE, D::NFC) : 0.0;
             for (int i = 0; i < D::NFC; ++i) {
                 double zr, zc;
                 if (D::NF == 3) {
@@ -355,7 +355,7 @@ struct upr_qp2 {
             for (int i = 0; i < D::NFC; ++i) hf[i] = upr_blk_up(dd, pr + D::PR_LFI, yf, i);
             double ee[D::NE], ys[D::NE];
             for (int r = 0; r < D::NE; ++r) {
-                double v = pr[D::PR_EK + r];
+                double v = pr[D::PR_EK + r] + upr_qp_rho_prox(D::NE, D::NFC) * ws[w.nu + k * D::NE + r];
                 for (int i = 0; i < D::NFC; ++i) v -= Dfg[r * D::NFC + i] * hf[i];
                 ee[r] = v;
             }
