@@ -219,6 +219,24 @@ def main():
     for name in ("box", "cylinder_box", "wedge_box"):
         arrangements["tests/" + name] = dump_arrangement(core, tcfg, name)
 
+    # BASELINE config 4 (upright_robust): the arrangement planning_sim_loop.py:454-534 assembles at run time --
+    # one 0.15 x 0.15 x h cuboid of mass 1 per vertex of the CoM box (+-0.06, +-0.06, +-h/2), all at the same place
+    # on the tray, mu = 0.2, no support-area inset.  The dicts below carry the same VALUES that script writes
+    # into the config (h = 0.30 m); bodies / contacts come out of the reference's own parser.
+    h = 0.30
+    rcfg = copy.deepcopy(cfg)
+    names = []
+    for i, (sx, sy, sz) in enumerate((a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)):
+        n = f"sim_block_{i + 1}"
+        names.append(n)
+        rcfg["objects"][n] = {"mass": 1.0, "shape": "cuboid", "side_lengths": [0.15, 0.15, h], "color": [1, 0, 0, 1],
+                              "com_offset": [0.06 * sx, 0.06 * sy, 0.5 * h * sz]}
+    rcfg["arrangements"]["robust_8corner"] = {
+        "objects": [{"name": n, "type": n, "parent": "ee", "offset": {"x": 0}} for n in names],
+        "contacts": [{"first": "ee", "second": n, "mu": 0.2, "support_area_inset": 0.0} for n in names],
+    }
+    arrangements["robust_8corner"] = dump_arrangement(core, rcfg, "robust_8corner")
+
     with open(OUT / "arrangements.json", "w") as f:
         json.dump(arrangements, f, indent=1)
 

@@ -451,3 +451,64 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
     xd, u = m.step(0.012, x0)
     assert len(m.replanning_times) == n0 + 1 and xd.shape == (P.nx,) and u.shape == (P.nu,)
     assert np.all(np.isfinite(u))
+
+
+def test_robust_arrangement_per_instance_parameters(arrangements):
+    """BASELINE config 4 (upright_robust, planning_sim_loop.py:454-534): eight copies of one cuboid, one per vertex of
+    the CoM box, 32 frictionless contact points (nx 27, nu 41, 48 equality rows / knot), and a DIFFERENT inertial
+    parameter vector per instance of the batch (CoM in the box, inertia scaled by {1, 0.5, 0.1}: the batch axis of
+    planning_sim_loop.py:559,613-655).  Constraint values and Jacobians of every instance, and the QP iterate after
+    a fixed number of interior-point iterations, against the oracle run with that instance's parameters."""
+    import copy
+
+    from upright_amd.problem import THING_HOME
+
+    arr = arrangements["robust_8corner"]
+    P = thing_problem(arr, nf=1, force_weight=0.0, qp_tol=0.0, qp_iter_max=4)
+    _level_tool(P.chain, THING_HOME)
+    assert (P.nx, P.nu, P.nb, P.nc) == (27, 41, 8, 32)
+    B = 5
+    rng = np.random.default_rng(2)
+    bp = np.zeros((B, P.nb, 10))
+    for b in range(B):
+        scale = (1.0, 0.5, 0.1)[b % 3]
+        for i in range(P.nb):
+            com = rng.uniform([-0.06, -0.06, -0.15], [0.06, 0.06, 0.15])
+            I = scale * np.diag([0.009375, 0.009375, 0.00375])
+            bp[b, i] = [1.0, *com, I[0, 0], 0, 0, I[1, 1], 0, I[2, 2]]
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, :3] += rng.uniform(-0.25, 0.25, (B, 3))       # base pose: keeps the tray level
+    way = waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0))
+    mpc = BatchMPC(P, B, body_params=bp, way_p=way)
+    n = 11
+    x = np.tile(x0[0], (n, 1)) + rng.uniform(-0.1, 0.1, (n, 27))
+    u = rng.uniform(0, 3, (n, P.nu))
+    for b in range(B):
+        out = mpc.linearize_points(x, u, np.zeros(n), inst=np.full(n, b))
+        Pb = copy.copy(P); Pb.body_params = bp[b]
+        O = Oracle(Pb)
+        for i in range(n):
+            g, gx, _ = O.eq_constraint(x[i], u[i])
+            assert np.abs(out["g"][i] - g).max() < 1e-11 * max(1, np.abs(g).max())
+            assert np.abs(out["gx"][i] - gx).max() < 1e-10 * max(1, np.abs(gx).max())
+    # the same instance parameters must NOT give the same constraint (the per-instance vector is really used)
+    o0 = mpc.linearize_points(x[:1], u[:1], np.zeros(1), inst=np.zeros(1, dtype=int))["g"]
+    o1 = mpc.linearize_points(x[:1], u[:1], np.zeros(1), inst=np.ones(1, dtype=int))["g"]
+    assert np.abs(o0 - o1).max() > 1e-3
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    st = mpc.stats()
+    assert np.all(st["qp_iters_last"] == 4)
+    for b in range(B):
+        Pb = copy.copy(P); Pb.body_params = bp[b]; Pb.way_p = way[b]
+        dxo, duo, so, rc = Oracle(Pb).qp_step(0.0, x0[b], xs0[b], us0[b])
+        # two 1e6 penalties (proximal stage equality, terminal equality) amplify the 1e-11 linearisation differences
+        assert np.abs(dxs[b] - dxo).max() < 2e-4 * max(1, np.abs(dxo).max())
+        assert np.abs(dus[b][:, :9] - duo[:, :9]).max() < 2e-4 * max(1, np.abs(duo[:, :9]).max())
+        # force_weight = 0 and four normal forces per body for three wrench equations: the split of the load between
+        # the contact points is fixed by the barrier alone; what is determined is the wrench on every body
+        gu = mpc.eq_input_jacobian(b)
+        assert np.abs((dus[b] - duo) @ gu.T).max() < 2e-4 * max(1, np.abs(duo @ gu.T).max())
+    mpc.close()
