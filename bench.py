@@ -99,7 +99,8 @@ def main():
     from upright_amd.sampling import level_tray_states, stationary_guess, waypoints_for
 
     arr = json.load(open(ROOT / "tests" / "golden" / "arrangements.json"))["pink_bottle"]
-    P = thing_problem(arr)  # nx 27, nu 21, 6 equality + 20 friction rows per knot, N = 20
+    # nx 27, nu 21, 6 equality + 20 friction rows per knot, N = 20; sqp.use_feedback_policy as in controller.yaml:60
+    P = thing_problem(arr, use_feedback_policy=True)
     B = args.batch
     # shard: rank r owns instances [r*B, (r+1)*B) of the global sample (weak scaling: B per GPU)
     x0_all = level_tray_states(B * world, seed=0)

@@ -76,6 +76,8 @@ typedef struct upr_problem {
     double delta_tol;
     double cost_tol;
     int terminal_constraint; /* stationary_desired_position_constraint at knot N */
+    int use_feedback_policy; /* sqp.use_feedback_policy (controller.yaml:60; pybindings.cpp:199): keep the Riccati gains of
+                                the last QP and apply them in upr_batch_evaluate_policy */
 } upr_problem;
 
 const char* upr_last_error(void);
@@ -132,6 +134,18 @@ int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us);
 /* ControllerInterface.evaluateMpcSolution (pybindings.cpp:378-381): interpolate the stored solution
  * at time t[B] -> x_out[B][nx], u_out[B][nu] (feed-forward policy). */
 int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out);
+
+/* Linear feedback policy of the last solve (sqp.use_feedback_policy = true: the primal solution carries an
+ * ocs2::LinearController, evaluated by ControllerPythonInterface::evaluateMpcSolution with the CURRENT state,
+ * controller_python_interface.h:46-55):
+ *     u(t, x) = (1 - a) [u_j + K_j (x - x_j)] + a [u_j+1 + K_j+1 (x - x_j+1)],   t = t_j + a dt
+ * K_j are the Riccati gains of the last QP (sign convention of ocs2: u = bias + K x).  x_obs[B][nx], outputs as
+ * upr_batch_evaluate.  Needs use_feedback_policy != 0 at creation. */
+int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out);
+/* ControllerInterface.getLinearFeedbackGain (pybindings.cpp:382-384) at the knots: K[B][N][nu][nx]; jerk rows from the
+ * Riccati recursion, contact-force rows from the elimination of the object-dynamics equality
+ * (f = f* - Hff^-1 Df' S^-1 C dx). */
+int upr_batch_get_feedback(upr_batch* h, double* K);
 
 /* ControllerInterface.getLastSolveTime (pybindings.cpp:366), milliseconds of the last advance */
 double upr_batch_last_solve_ms(const upr_batch* h);

@@ -167,6 +167,12 @@ class Oracle:
         rc = self.L.orc_qp_step(C.byref(self.o), d(t0), _p(_c(x0)), _p(_c(xs)), _p(_c(us)), _p(dxs), _p(dus), C.byref(st))
         return dxs, dus, st, rc
 
+    def qp_feedback(self, t0, x0, xs, us):
+        P = self.P
+        dxs = np.zeros((P.N + 1, self.nx)); dus = np.zeros((P.N, self.nu)); K = np.zeros((P.N, self.nu, self.nx)); st = OrcStats()
+        rc = self.L.orc_qp_feedback(C.byref(self.o), d(t0), _p(_c(x0)), _p(_c(xs)), _p(_c(us)), _p(dxs), _p(dus), _p(K), C.byref(st))
+        return dxs, dus, K, st, rc
+
     def solve(self, t0, x0, xs, us):
         xs = _c(xs).copy(); us = _c(us).copy(); st = OrcStats()
         rc = self.L.orc_solve(C.byref(self.o), d(t0), _p(_c(x0)), _p(xs), _p(us), C.byref(st))

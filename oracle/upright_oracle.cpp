@@ -347,6 +347,7 @@ struct QP {
 
 struct QPSol {
     std::vector<vec> dx, du, pi, nu_;  // dx[0..N], du[0..N-1], pi[0..N], nu_[0..N-1]
+    std::vector<vec> K;                // feedback gains of the last factorisation, ocs2 sign (du = K ddx + ...), [N][nu*nx]
     vec yN;
     int iters, status;
     double res[4];
@@ -728,6 +729,20 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
         for (int r = 0; r < neN; ++r) yN[r] += alpha * dyN[r];
     }
     sol.iters = it; sol.dx = dx; sol.du = du; sol.pi = pi; sol.nu_ = nu_; sol.yN = yN;
+    // linear policy of the last Riccati factorisation: du = -(Kx + Y S^-1 Cbar) dx - (feed-forward)
+    // ([UPSTREAM] hpipm_interface getRiccatiFeedback; consumed through ocs2::LinearController when
+    // sqp.use_feedback_policy is set, upright_control/src/pybindings.cpp:199)
+    sol.K.assign(N, vec());
+    if (!ric.Kx.empty()) for (int k = 0; k < N; ++k) {
+        if (ric.Kx[k].empty()) continue;
+        vec Kt = ric.Kx[k];
+        if (ne > 0 && !ric.Ls[k].empty()) {
+            vec SC = ric.Cbar[k]; chol_solve(ric.Ls[k].data(), ne, SC.data(), nx);
+            for (int i = 0; i < nu; ++i) for (int j = 0; j < nx; ++j) { double t = 0; for (int r = 0; r < ne; ++r) t += ric.Y[k][i * ne + r] * SC[r * nx + j]; Kt[i * nx + j] += t; }
+        }
+        for (double& v : Kt) v = -v;
+        sol.K[k] = Kt;
+    }
     return sol.status;
 }
 
@@ -927,6 +942,19 @@ int orc_qp_step(const orc_problem* P, double t0, const double* x0, const double*
     const int nx = qp.nx, nu = qp.nu;
     for (int k = 0; k <= qp.N; ++k) for (int i = 0; i < nx; ++i) dxs[(size_t)k * nx + i] = sol.dx[k][i];
     for (int k = 0; k < qp.N; ++k) for (int i = 0; i < nu; ++i) dus[(size_t)k * nu + i] = sol.du[k][i];
+    if (stats) { stats->qp_iters_last = sol.iters; stats->qp_status_last = st; for (int i = 0; i < 4; ++i) stats->qp_res[i] = sol.res[i]; }
+    return st;
+}
+
+// QP step + feedback gains K[N][nu][nx] of its last factorisation
+int orc_qp_feedback(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us,
+                    double* dxs, double* dus, double* K, orc_stats* stats) {
+    QP qp; build_qp(P, t0, x0, xs, us, qp);
+    QPSol sol; int st = ipm_solve(qp, P->qp_iter_max, P->qp_tol, sol);
+    const int nx = qp.nx, nu = qp.nu;
+    for (int k = 0; k <= qp.N; ++k) for (int i = 0; i < nx; ++i) dxs[(size_t)k * nx + i] = sol.dx[k][i];
+    for (int k = 0; k < qp.N; ++k) for (int i = 0; i < nu; ++i) dus[(size_t)k * nu + i] = sol.du[k][i];
+    for (int k = 0; k < qp.N; ++k) for (int e = 0; e < nu * nx; ++e) K[(size_t)k * nu * nx + e] = sol.K[k].empty() ? 0.0 : sol.K[k][e];
     if (stats) { stats->qp_iters_last = sol.iters; stats->qp_status_last = st; for (int i = 0; i < 4; ++i) stats->qp_res[i] = sol.res[i]; }
     return st;
 }

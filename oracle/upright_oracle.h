@@ -137,6 +137,9 @@ int orc_solve(const orc_problem* P, double t0, const double* x0, double* xs, dou
  * Exposed for QP-level parity tests. */
 int orc_qp_step(const orc_problem* P, double t0, const double* x0, const double* xs,
                 const double* us, double* dxs, double* dus, orc_stats* stats);
+/* same + the feedback gains K[N][nu][nx] (u = bias + K x) of the last Riccati factorisation */
+int orc_qp_feedback(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us,
+                    double* dxs, double* dus, double* K, orc_stats* stats);
 
 /* merit terms at a trajectory: out = [cost, dyn_sse, eq_sse, ineq_sse] */
 void orc_performance(const orc_problem* P, double t0, const double* x0, const double* xs,

@@ -512,3 +512,55 @@ def test_robust_arrangement_per_instance_parameters(arrangements):
         gu = mpc.eq_input_jacobian(b)
         assert np.abs((dus[b] - duo) @ gu.T).max() < 2e-4 * max(1, np.abs(duo @ gu.T).max())
     mpc.close()
+
+
+@pytest.mark.parametrize("kernel", ["3", "2", "1"])
+def test_feedback_gains_and_policy(arrangements, kernel, monkeypatch):
+    """sqp.use_feedback_policy (controller.yaml:60, default true): the solution carries the linear policy
+    u = u* + K (x - x*) whose gains are the Riccati feedback of the last QP (ocs2::LinearController,
+    controller_python_interface.h:46-55).  (a) gains against the oracle's dense-stage Riccati; (b) the gain of
+    the first knot is the sensitivity of the QP solution to the observed state; (c) policy evaluation."""
+    monkeypatch.setenv("UPR_QP_KERNEL", kernel)
+    B = 3
+    P, x0, way = _setup(arrangements, B, seed=71, use_feedback_policy=True)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    K = mpc.feedback_gains()
+    _, xs, us = mpc.solution()
+    assert K.shape == (B, P.N, P.nu, P.nx) and np.all(np.isfinite(K))
+    for b in range(B):
+        P.way_p = way[b]
+        _, _, Ko, so, rc = Oracle(P).qp_feedback(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0
+        # same algorithm, different elimination order, barrier weights up to 1e8: relative agreement of the gains
+        scale = np.abs(Ko).max(axis=(1, 2), keepdims=True)
+        assert np.abs(K[b] - Ko).max() < 1e-4 * np.abs(Ko).max()
+        assert (np.abs(K[b] - Ko) / scale).max() < 2e-3
+    # (b) sensitivity: solve again from a perturbed observation; du_0 = K_0 dx_0 to first order wherever no
+    # inequality of the first knots changes its activity (the barrier weights enter K, so this holds at the solution)
+    dx0 = np.zeros_like(x0)
+    dx0[:, 9:18] = 1e-5 * np.random.default_rng(3).standard_normal((B, 9))      # joint velocities
+    mpc2 = BatchMPC(P, B, way_p=way)
+    mpc2.set_observation(0.0, x0 + dx0)
+    xs1 = xs0.copy(); xs1[:, 0] = x0 + dx0      # same linearisation points for knots 1..N: only the observation moves
+    mpc2.set_guess(xs1, us0)
+    mpc2.advance()
+    _, xs2, us2 = mpc2.solution()
+    for b in range(B):
+        pred = K[b, 0, :9] @ dx0[b]
+        got = us2[b, 0, :9] - us[b, 0, :9]
+        assert np.abs(got - pred).max() < 0.05 * np.abs(pred).max() + 1e-7
+    # (c) policy: at the planned state the feed-forward input comes back; off the plan the gain acts
+    t = 0.03
+    xp, uff = mpc.evaluate(t)
+    x1, u1 = mpc.evaluate(t, x_obs=xp)
+    a = t / P.dt
+    expect = (1 - a) * (us[:, 0] + np.einsum("bij,bj->bi", K[:, 0], xp - xs[:, 0])) + a * (us[:, 1] + np.einsum("bij,bj->bi", K[:, 1], xp - xs[:, 1]))
+    assert np.abs(u1 - expect).max() < 1e-9 and np.abs(x1 - xp).max() == 0
+    dx = 1e-3 * np.random.default_rng(4).standard_normal(xp.shape)
+    _, u2 = mpc.evaluate(t, x_obs=xp + dx)
+    Kt = (1 - a) * K[:, 0] + a * K[:, 1]
+    assert np.abs((u2 - u1) - np.einsum("bij,bj->bi", Kt, dx)).max() < 1e-9
+    mpc.close(); mpc2.close()

@@ -36,6 +36,7 @@ class UprProblem(C.Structure):
         ("n_way", C.c_int), ("way_t", d * MAXW),
         ("sqp_iters", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", d), ("delta_tol", d), ("cost_tol", d),
         ("terminal_constraint", C.c_int),
+        ("use_feedback_policy", C.c_int),
     ]
 
 
@@ -74,6 +75,7 @@ def problem_to_c(P):
     _fill(o.way_t, P.way_t)
     o.sqp_iters, o.qp_iter_max, o.qp_tol = int(P.sqp_iters), int(P.qp_iter_max), float(P.qp_tol)
     o.delta_tol, o.cost_tol, o.terminal_constraint = float(P.delta_tol), float(P.cost_tol), int(bool(P.terminal_constraint))
+    o.use_feedback_policy = int(bool(getattr(P, "use_feedback_policy", False)))
     return o
 
 
@@ -93,6 +95,8 @@ PROTOTYPES = [
     ("upr_batch_sync", C.c_int, [C.c_void_p]),
     ("upr_batch_get_solution", C.c_int, [C.c_void_p, dp, dp, dp]),
     ("upr_batch_evaluate", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp]),
+    ("upr_batch_evaluate_policy", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp, dp]),
+    ("upr_batch_get_feedback", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
     ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_linearize_points", C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp]),

@@ -288,7 +288,7 @@ def problem_from_settings(s):
         x_lb=np.asarray(s.state_limit_lower, dtype=np.float64), x_ub=np.asarray(s.state_limit_upper, dtype=np.float64),
         u_lb=np.concatenate([np.asarray(s.input_limit_lower, dtype=np.float64), f_lb]),
         u_ub=np.concatenate([np.asarray(s.input_limit_upper, dtype=np.float64), f_ub]),
-        sqp_iters=int(s.sqp.sqp_iteration), qp_iter_max=int(s.sqp.hpipm.iter_max),
+        sqp_iters=int(s.sqp.sqp_iteration), qp_iter_max=int(s.sqp.hpipm.iter_max), use_feedback_policy=bool(s.sqp.use_feedback_policy),
         delta_tol=float(s.sqp.delta_tol), cost_tol=float(s.sqp.cost_tol), **tables,
     )
     return P.validate()
@@ -340,7 +340,10 @@ class ControllerInterface:
         self._first = False
 
     def evaluateMpcSolution(self, current_time, current_state, opt_state, opt_input):
-        x, u = self._mpc.evaluate(float(current_time))
+        # controller_python_interface.h:46-55: the policy is evaluated at the CURRENT state (a LinearController when
+        # sqp.use_feedback_policy is set, the feed-forward input otherwise)
+        xo = np.asarray(current_state, dtype=np.float64).reshape(1, -1) if self.problem.use_feedback_policy else None
+        x, u = self._mpc.evaluate(float(current_time), xo)
         opt_state[:] = x[0]
         opt_input[:] = u[0]
 
@@ -391,7 +394,16 @@ class ControllerInterface:
         return self.getStateInputEqualityConstraintValue("object_dynamics", t, x, u)
 
     def getLinearFeedbackGain(self, t):
-        raise RuntimeError("feedback gains are not exported by the MI355X engine yet (SURVEY.md 8f.3)")
+        """pybindings.cpp:382-384: gain of the linear policy at time t (linear interpolation between knots)."""
+        if not self.problem.use_feedback_policy:
+            raise RuntimeError("sqp.use_feedback_policy is false: the solution carries a feed-forward controller")
+        K = self._mpc.feedback_gains()[0]
+        ts = self._mpc.solution()[0][0]
+        P = self.problem
+        s = min(max((float(t) - ts[0]) / P.dt, 0.0), P.N - 1)
+        j = min(int(s), P.N - 1)
+        a = s - j
+        return (1 - a) * K[j] + a * K[min(j + 1, P.N - 1)]
 
 
 class BalancingConstraintWrapper:

@@ -102,6 +102,91 @@ __global__ void evaluate_kernel(const upr_problem* P, upr_dims d, int B, const d
         upr_interp(d, P->dt, tsol[b], xs + (size_t)b * (N + 1) * nx, us + (size_t)b * N * nu, tau, 0, i, nullptr, u_out + (size_t)b * nu + i);
 }
 
+// Where the QP kernel that ran left its per-knot factors (doubles, relative to the instance workspace)
+struct upr_fb_src {
+    int kind;                       // 3: K stored; 1, 2: V = Lj^-1 Hux and Lji = Lj^-1 stored
+    long k_base; int k_stride;      // kind 3: K_k ; kinds 1, 2: V_k
+    long lji_base; int lji_stride;  // kinds 1, 2
+    long lfi_base; int lfi_stride;  // inverse Cholesky factor of the contact-force blocks of Hff
+    long lsi_base; int lsi_stride;  // inverse Cholesky factor of S = Df Hff^-1 Df'
+};
+
+// Linear feedback gains of the last QP, ocs2 sign convention (u = bias + K x): fb[B][N][nu][nx].
+// Jerk rows: -Hjj^-1 Hux from the Riccati recursion; contact-force rows: -Hff^-1 Df' S^-1 C (the forces
+// follow the state through the object-dynamics equality).
+__global__ void feedback_kernel(const upr_problem* P, upr_dims d, upr_fb_src src, const double* ws, const double* lin,
+                                const double* Df, double* fb) {
+    const int b = blockIdx.x;
+    const int N = d.N, nq = d.nq, nx = d.nx, nu = d.nu, ne = d.ne, nfc = d.nfc, nf = d.nf;
+    const double* w = ws + (size_t)b * d.ws_stride;
+    double* out = fb + (size_t)b * N * nu * nx;
+    for (int e = threadIdx.x; e < N * nq * nx; e += blockDim.x) {
+        const int k = e / (nq * nx), j = (e % (nq * nx)) / nx, c = e % nx;
+        double v;
+        if (src.kind == 3) v = w[src.k_base + (long)k * src.k_stride + j * nx + c];
+        else {
+            const double* V = w + src.k_base + (long)k * src.k_stride;
+            const double* Lji = w + src.lji_base + (long)k * src.lji_stride;
+            v = 0.0;
+            for (int m = j; m < nq; ++m) v += Lji[m * nq + j] * V[m * nx + c];
+        }
+        out[((size_t)k * nu + j) * nx + c] = -v;
+    }
+    const double* Dfb = Df + (size_t)b * ne * nfc;
+    for (int e = threadIdx.x; e < N * nx; e += blockDim.x) {
+        const int k = e / nx, c = e % nx;
+        const double* Ck = lin + ((size_t)b * (N + 1) + k) * d.lin_stride + d.lin_gx;
+        const double* Lsi = w + src.lsi_base + (long)k * src.lsi_stride;
+        const double* Lfi = w + src.lfi_base + (long)k * src.lfi_stride;
+        double t1[6 * UPR_MAX_BODIES], t2[6 * UPR_MAX_BODIES], t3[3 * UPR_MAX_CONTACTS];
+        for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = 0; m <= r; ++m) v += Lsi[r * ne + m] * Ck[m * nx + c]; t1[r] = v; }
+        for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = r; m < ne; ++m) v += Lsi[m * ne + r] * t1[m]; t2[r] = v; }
+        for (int i = 0; i < nfc; ++i) { double v = 0.0; for (int r = 0; r < ne; ++r) v += Dfb[r * nfc + i] * t2[r]; t3[i] = v; }
+        for (int ci = 0; ci < d.nc; ++ci) {
+            if (nf == 3) {
+                const double* Bk = Lfi + 9 * ci; const double* x3 = t3 + 3 * ci;
+                double y[3], z[3];
+                for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * x3[b2]; y[a] = v; }
+                for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * y[b2]; z[a] = v; }
+                for (int a = 0; a < 3; ++a) out[((size_t)k * nu + nq + 3 * ci + a) * nx + c] = -z[a];
+            } else {
+                const double lf = Lfi[ci];
+                out[((size_t)k * nu + nq + ci) * nx + c] = -lf * lf * t3[ci];
+            }
+        }
+    }
+}
+
+// u(t, x) = (1 - a) [u_j + K_j (x - x_j)] + a [u_j+1 + K_j+1 (x - x_j+1)]   (ocs2::LinearController with
+// bias_j = u_j - K_j x_j, both arrays interpolated linearly); the last interval keeps u_{N-1}, K_{N-1}.
+__global__ void evaluate_policy_kernel(const upr_problem* P, upr_dims d, int B, const double* tsol, const double* xs,
+                                       const double* us, const double* fb, const double* t, const double* x_obs,
+                                       double* x_out, double* u_out) {
+    const int b = blockIdx.x;
+    const int N = d.N, nx = d.nx, nu = d.nu;
+    const double* X = xs + (size_t)b * (N + 1) * nx; const double* U = us + (size_t)b * N * nu;
+    const double* K = fb + (size_t)b * N * nu * nx; const double* xo = x_obs + (size_t)b * nx;
+    double s = (t[b] - tsol[b]) / P->dt;
+    if (s < 0.0) s = 0.0;
+    for (int i = threadIdx.x; i < nx; i += blockDim.x)
+        upr_interp(d, P->dt, tsol[b], X, U, t[b], i, 0, x_out + (size_t)b * nx + i, nullptr);
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
+        double v = 0.0;
+        if (s <= N) {
+            int j = (int)s; if (j > N - 1) j = N - 1;
+            const double a = (s >= N - 1) ? 0.0 : s - j;
+            const int j1 = (j + 1 < N) ? j + 1 : N - 1;
+            double v0 = U[j * nu + i], v1 = U[j1 * nu + i];
+            for (int c = 0; c < nx; ++c) {
+                v0 += K[((size_t)j * nu + i) * nx + c] * (xo[c] - X[j * nx + c]);
+                if (a > 0.0) v1 += K[((size_t)j1 * nu + i) * nx + c] * (xo[c] - X[j1 * nx + c]);
+            }
+            v = (1.0 - a) * v0 + a * v1;
+        }
+        u_out[(size_t)b * nu + i] = v;
+    }
+}
+
 }  // namespace
 
 // ========================================================================================================
@@ -116,6 +201,7 @@ struct upr_batch {
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr, *has_prev = nullptr;
     double* prof = nullptr;
+    double *fb = nullptr, *xs_lin = nullptr;   // feedback gains of the last solve
     bool guess_set = false;
     double last_ms = 0.0;
     int qp_nt = 0;
@@ -282,6 +368,28 @@ struct KernelTimer {
     void stop() { if (h->timing) (void)hipEventRecord(h->ev_pool[idx + 1], h->stream); }
 };
 
+// where the QP kernel selected for this handle keeps its per-knot factors
+upr_fb_src fb_source(const upr_batch* h) {
+    upr_fb_src s;
+    const upr_dims& d = h->d;
+    if (h->use_qp3) {
+        typedef upr_qp3_cfg<9, 1, 4, 3, 20, 256> C; typedef upr_qp3_ws<C> W; typedef upr_qp3_far<C> F;
+        s.kind = 3; s.k_base = W::far + F::Ks; s.k_stride = C::NQ * C::NX; s.lji_base = 0; s.lji_stride = 0;
+        s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NE * C::NE;
+        return s;
+    }
+    if (h->use_qp2) {
+#define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) { typedef upr_qp2_dims<a, b, c, e> D; upr_qp2_ws<D> w(d.N, d.neN); \
+        s.kind = 2; s.k_base = w.store + D::SS_V; s.k_stride = D::SS_STRIDE; s.lji_base = w.store + D::SS_LJI; s.lji_stride = D::SS_STRIDE; \
+        s.lfi_base = w.pre + D::PR_LFI; s.lfi_stride = D::PR_STRIDE; s.lsi_base = w.pre + D::PR_LSI; s.lsi_stride = D::PR_STRIDE; return s; }
+        UPR_QP2_SHAPES(X)
+#undef X
+    }
+    s.kind = 1; s.k_base = d.ws_store + d.ss_kx; s.k_stride = d.ss_stride; s.lji_base = d.ws_store + d.ss_hjj; s.lji_stride = d.ss_stride;
+    s.lfi_base = d.ws_store + d.ss_hff; s.lfi_stride = d.ss_stride; s.lsi_base = d.ws_store + d.ss_sinv; s.lsi_stride = d.ss_stride;
+    return s;
+}
+
 int advance_impl(upr_batch* h) {
     const upr_dims& d = h->d;
     if (!h->guess_set) {
@@ -300,6 +408,10 @@ int advance_impl(upr_batch* h) {
         L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
         L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it;
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
+    }
+    if (h->fb) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
+        hipLaunchKernelGGL(feedback_kernel, dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
+        UPR_HIP(hipGetLastError());
     }
     // remember the solution for the next warm start / policy evaluation
     UPR_HIP(hipMemcpyAsync(h->xs_prev, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
@@ -391,7 +503,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
         dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) ||
-        dev_alloc(&h->has_prev, B))
+        dev_alloc(&h->has_prev, B) || (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)))
         return bad();
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
     hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
@@ -418,6 +530,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
 void upr_batch_destroy(upr_batch* h) {
     if (!h) return;
     hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
+    if (h->fb) hipFree(h->fb);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
     hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -502,6 +615,34 @@ int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_ou
     UPR_HIP(hipMemcpy(x_out, dx, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost));
     UPR_HIP(hipMemcpy(u_out, du, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost));
     hipFree(dt_); hipFree(dx); hipFree(du);
+    return 0;
+}
+
+int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
+    if (!h) return fail("null batch");
+    if (!h->fb) return fail("upr_batch_evaluate_policy: the batch was created with use_feedback_policy = 0");
+    const upr_dims& d = h->d;
+    double *dt_ = nullptr, *dxo = nullptr, *dx = nullptr, *du = nullptr;
+    if (dev_alloc(&dt_, h->B) || dev_alloc(&dxo, (size_t)h->B * d.nx) || dev_alloc(&dx, (size_t)h->B * d.nx) || dev_alloc(&du, (size_t)h->B * d.nu)) return 1;
+    std::vector<double> tt(h->B);
+    for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
+    UPR_HIP(hipMemcpy(dt_, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(dxo, x_obs, sizeof(double) * h->B * d.nx, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, dt_, dxo, dx, du);
+    UPR_HIP(hipGetLastError());
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    UPR_HIP(hipMemcpy(x_out, dx, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost));
+    UPR_HIP(hipMemcpy(u_out, du, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost));
+    hipFree(dt_); hipFree(dxo); hipFree(dx); hipFree(du);
+    return 0;
+}
+
+int upr_batch_get_feedback(upr_batch* h, double* K) {
+    if (!h) return fail("null batch");
+    if (!h->fb) return fail("upr_batch_get_feedback: the batch was created with use_feedback_policy = 0");
+    const upr_dims& d = h->d;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    UPR_HIP(hipMemcpy(K, h->fb, sizeof(double) * h->B * d.N * d.nu * d.nx, hipMemcpyDeviceToHost));
     return 0;
 }
 

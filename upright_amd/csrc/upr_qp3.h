@@ -193,6 +193,7 @@ struct upr_qp3 {
     int lin_stride, lin_g, lin_gx, lin_grad, lin_hess, neN;
     double h, h2, h3, sigma_mu;
     int mode;
+    bool fbk;   // the feedback gain of the first knot is wanted (use_feedback_policy)
     // lane-owned box rows: [item][0 = lower, 1 = upper]
     double tx[C::QX][2], lx[C::QX][2], cx[C::QX][2];
     double tu[C::QU][2], lu[C::QU][2], cu[C::QU][2];
@@ -490,7 +491,9 @@ struct upr_qp3 {
                         for (int a = 0; a < 3; ++a)
 #pragma unroll
                             for (int c = 0; c < 3; ++c) if (a < c || (a == c && ii <= jj)) Pn[(a * NQ + ii) * NX + c * NQ + jj] = o2[a][c];
-                        // B' (P A) = h3 t[0] + h2 t[1] + h t[2]
+                    }
+                    // B' (P A) = h3 t[0] + h2 t[1] + h t[2]   (knot 0: only for the feedback gain K_0)
+                    if (k > 0 || fbk) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) L[O::hux + ii * NX + c * NQ + jj] = h3 * t[0][c] + h2 * t[1][c] + h * t[2][c];
                     }
@@ -566,7 +569,7 @@ struct upr_qp3 {
                 const int c = tid();
                 double x[NQ];
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) x[j] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((c < NQ + NX && k > 0) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                for (int j = 0; j < NQ; ++j) x[j] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((c < NQ + NX && (k > 0 || fbk)) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
                 bool ok = true;
 #pragma unroll
                 for (int p2 = 0; p2 < NQ; ++p2) {
@@ -583,7 +586,7 @@ struct upr_qp3 {
                 if (c < NQ) {
 #pragma unroll
                     for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2];
-                } else if (c < NQ + NX && k > 0) {
+                } else if (c < NQ + NX && (k > 0 || fbk)) {
 #pragma unroll
                     for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + (c - NQ)] = x[p2]; G[F::Ks + k * NQ * NX + p2 * NX + (c - NQ)] = x[p2]; }
                 }
@@ -591,7 +594,7 @@ struct upr_qp3 {
                 if (tid() == 0) {
                     constexpr int NM = NQ + NX;
                     double M[NQ][NM];
-                    for (int j = 0; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] = (c < NQ) ? L[O::hjj + j * NQ + c] : (k > 0 ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                    for (int j = 0; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((k > 0 || fbk) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
                     for (int p2 = 0; p2 < NQ; ++p2) {
                         double piv = M[p2][p2];
                         if (!(piv > 0.0)) { L[O::misc] = 1.0; piv = 1.0; }
@@ -602,7 +605,7 @@ struct upr_qp3 {
                         for (int c = 0; c < NM; ++c) M[p2][c] = (c == p2) ? idg : y[c];
                     }
                     for (int c = 0; c < NQ; ++c) for (int p2 = 0; p2 <= c; ++p2) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = M[p2][c];
-                    if (k > 0) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + c] = M[p2][NQ + c]; G[F::Ks + k * NQ * NX + p2 * NX + c] = M[p2][NQ + c]; }
+                    if (k > 0 || fbk) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + c] = M[p2][NQ + c]; G[F::Ks + k * NQ * NX + p2 * NX + c] = M[p2][NQ + c]; }
                 }
 #endif
             }
@@ -658,8 +661,9 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         // feedback of knots 1 .. N-1, all at once: column e of K_k = Lj^-T V_k by back substitution, in place
-        UPR_FORT(e, (N - 1) * NX) {
-            const int k = 1 + e / NX, c = e % NX;
+        UPR_FORT(e, N * NX) {
+            const int k = e / NX, c = e % NX;
+            if (k == 0 && !fbk) continue;
             const double* Lp = G + F::Ljis + k * C::NH;
             double* Kc = G + F::Ks + k * NQ * NX + c;
             double kk[NQ];
@@ -1043,7 +1047,7 @@ struct upr_qp3 {
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
         lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
-        h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0;
+        h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
         prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
         if (prof) UPR_FORT(i, 16) L[O::prf + i] = 0.0;
         tic();

@@ -73,12 +73,24 @@ class BatchMPC:
         check(self._lib.upr_batch_get_solution(self._h, ptr(ts), ptr(xs), ptr(us)))
         return ts, xs, us
 
-    def evaluate(self, t):
+    def evaluate(self, t, x_obs=None):
+        """Plan state and input at time t.  With x_obs (B, nx) and use_feedback_policy the input is the linear
+        policy u*(t) + K(t) (x_obs - x*(t)) of the last solve (ocs2::LinearController), else the feed-forward input."""
         t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
         x = np.zeros((self.B, self.nx))
         u = np.zeros((self.B, self.nu))
-        check(self._lib.upr_batch_evaluate(self._h, ptr(t), 1, ptr(x), ptr(u)))
+        if x_obs is not None and self.problem.use_feedback_policy:
+            xo = cont(x_obs).reshape(self.B, self.nx)
+            check(self._lib.upr_batch_evaluate_policy(self._h, ptr(t), 1, ptr(xo), ptr(x), ptr(u)))
+        else:
+            check(self._lib.upr_batch_evaluate(self._h, ptr(t), 1, ptr(x), ptr(u)))
         return x, u
+
+    def feedback_gains(self):
+        """K[B][N][nu][nx] at the knots of the last solve (u = bias + K x, ocs2 sign)."""
+        K = np.zeros((self.B, self.N, self.nu, self.nx))
+        check(self._lib.upr_batch_get_feedback(self._h, ptr(K)))
+        return K
 
     def last_solve_ms(self):
         return float(self._lib.upr_batch_last_solve_ms(self._h))

@@ -46,6 +46,7 @@ class Problem:
     delta_tol: float = 1e-3
     cost_tol: float = 1e-4
     terminal_constraint: bool = True
+    use_feedback_policy: bool = False  # sqp.use_feedback_policy (controller.yaml:60)
 
     @property
     def nq(self):
