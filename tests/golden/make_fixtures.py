@@ -178,6 +178,15 @@ def dump_arrangement(core, cfg, name):
     return out
 
 
+def arrangement_input(cfg, name):
+    """The INPUT side of one arrangement: the arrangement entry and the object-type entries it uses (plain data
+    out of the reference's YAML files), so that the arrangement parser of the build can be checked against
+    `dump_arrangement`'s output without reading the reference tree."""
+    arr = copy.deepcopy(cfg["arrangements"][name])
+    types = {"ee"} | {o["type"] for o in arr["objects"]}
+    return {"arrangement": arr, "objects": {t: copy.deepcopy(cfg["objects"][t]) for t in types}}
+
+
 def jsonable(x):
     if isinstance(x, dict):
         return {str(k): jsonable(v) for k, v in x.items()}
@@ -211,12 +220,15 @@ def main():
         arr = yaml.safe_load(f)
     cfg = core.parsing.recursive_dict_update(copy.deepcopy(arr), ctrl)
     arrangements = {}
+    inputs = {}
     for name in ("pink_bottle", "foam_die2", "box_arch", "blue_cups", "wedge", "simulation_box_with_fixture"):
+        inputs[name] = arrangement_input(cfg, name)
         arrangements[name] = dump_arrangement(core, cfg, name)
 
     with open(REF / "upright_core/tests/config.yaml") as f:
         tcfg = yaml.safe_load(f)
     for name in ("box", "cylinder_box", "wedge_box"):
+        inputs["tests/" + name] = arrangement_input(tcfg, name)
         arrangements["tests/" + name] = dump_arrangement(core, tcfg, name)
 
     # BASELINE config 4 (upright_robust): the arrangement planning_sim_loop.py:454-534 assembles at run time --
@@ -235,7 +247,10 @@ def main():
         "objects": [{"name": n, "type": n, "parent": "ee", "offset": {"x": 0}} for n in names],
         "contacts": [{"first": "ee", "second": n, "mu": 0.2, "support_area_inset": 0.0} for n in names],
     }
+    inputs["robust_8corner"] = arrangement_input(rcfg, "robust_8corner")
     arrangements["robust_8corner"] = dump_arrangement(core, rcfg, "robust_8corner")
+    with open(OUT / "arrangement_inputs.json", "w") as f:
+        json.dump(jsonable(inputs), f, indent=1)
 
     with open(OUT / "arrangements.json", "w") as f:
         json.dump(arrangements, f, indent=1)

@@ -79,8 +79,73 @@ def test_problem_from_settings_and_unsupported_terms(arrangements):
         control_bindings.problem_from_settings(s)
     with pytest.raises(RuntimeError):
         control_bindings.robot_base_type_from_string("hovering")
-    with pytest.raises(NotImplementedError):
-        control.ControllerSettings(g)  # arrangement parser is a 'next' row
+    # without bodies= / contacts= the arrangement named in the config is parsed (wrappers.py:303-305)
+    s2 = control.ControllerSettings(g)
+    P2 = control_bindings.problem_from_settings(s2)
+    assert np.allclose(P2.body_params, P.body_params, atol=1e-12) and np.allclose(P2.contact_r2, P.contact_r2, atol=1e-12)
+    assert np.array_equal(P2.contact_mu, P.contact_mu) and np.allclose(P2.contact_span, P.contact_span, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "foam_die2", "box_arch", "blue_cups", "wedge", "simulation_box_with_fixture",
+                                  "tests/box", "tests/cylinder_box", "tests/wedge_box", "robust_8corner"])
+def test_arrangement_parser_matches_reference_outputs(arrangements, name):
+    """the arrangement front-end (solids stacked on the tray -> bodies, contact polygons, insets)
+    against what the reference's parse_control_objects produced from the same YAML entries.  Contact ORDER matters:
+    it is the layout of the force block of u.  1e-9: the reference finds stacking heights with a linear programme."""
+    import copy
+
+    from upright_amd.arrangement import parse_control_objects
+
+    inp = json.load(open(GOLD / "arrangement_inputs.json"))[name]
+    cfg = {"objects": copy.deepcopy(inp["objects"]), "arrangements": {name: copy.deepcopy(inp["arrangement"])}, "balancing": {"arrangement": name}}
+    bodies, contacts = parse_control_objects(cfg)
+    exp = arrangements[name]
+    eb = {b["name"]: b for b in exp["bodies"]}
+    assert set(bodies) == set(eb) and len(contacts) == len(exp["contacts"])
+    for n, b in bodies.items():
+        assert abs(b.mass - eb[n]["mass"]) < 1e-12
+        assert np.abs(b.com - np.array(eb[n]["com"])).max() < 1e-9
+        assert np.abs(b.inertia - np.array(eb[n]["inertia"])).max() < 1e-12
+        assert np.abs(b.get_parameters() - np.array(eb[n]["params"])).max() < 1e-9
+    for c, e in zip(contacts, exp["contacts"]):
+        assert (c.object1_name, c.object2_name) == (e["object1_name"], e["object2_name"])
+        assert abs(c.mu - e["mu"]) < 1e-15
+        for k in ("normal", "span", "r_co_o1", "r_co_o2"):
+            assert np.abs(np.asarray(getattr(c, k)) - np.array(e[k])).max() < 1e-9, k
+
+
+def test_arrangement_parser_errors_and_geometry():
+    from upright_amd import arrangement as A
+
+    ee = {"shape": "cuboid", "side_lengths": [0.3, 0.3, 0.02], "position": [0, 0, -0.01]}
+    cube = {"mass": 1.0, "com_offset": [0, 0, 0], "shape": "cuboid", "side_lengths": [0.1, 0.1, 0.1]}
+
+    def cfg(objects, contacts):
+        return {"objects": {"ee": dict(ee), "cube": dict(cube)}, "arrangements": {"a": {"objects": objects, "contacts": contacts}}, "balancing": {"arrangement": "a"}}
+
+    one = [{"name": "c1", "type": "cube", "parent": "ee"}]
+    bodies, contacts = A.parse_control_objects(cfg(one, [{"first": "ee", "second": "c1", "mu": 0.5, "mu_margin": 0.1}]))
+    assert np.allclose(bodies["c1"].com, [0, 0, 0.05]) and len(contacts) == 4 and abs(contacts[0].mu - 0.4) < 1e-15
+    assert np.allclose(contacts[0].normal, [0, 0, -1])               # points into the first object (the tray)
+    assert {tuple(np.round(c.r_co_o2, 9)) for c in contacts} == {(0.05, 0.05, 0), (0.05, -0.05, 0), (-0.05, 0.05, 0), (-0.05, -0.05, 0)}
+    with pytest.raises(ValueError, match="too large"):             # math.py:149-158
+        A.parse_control_objects(cfg(one, [{"first": "ee", "second": "c1", "mu": 0.5, "support_area_inset": 0.2}]))
+    with pytest.raises(ValueError, match="Multiple control objects"):
+        A.parse_control_objects(cfg(one + one, []))
+    two = one + [{"name": "c2", "type": "cube", "parent": "ee", "offset": {"x": 0.2}}]
+    with pytest.raises(ValueError, match="No contact points"):     # parsing.py:169: objects 0.1 m apart
+        A.parse_control_objects(cfg(two, [{"first": "c1", "second": "c2", "mu": 0.5}]))
+    with pytest.raises(ValueError, match="both"):
+        A.support_offset({"r": 0.1})
+    assert np.allclose(A.support_offset({"x": 0.1, "r": 0.2, "θ": "0.5pi"}), [0.1, 0.2])
+    # stacking height of a tilted box: lowest corner touches the parent
+    tilted = A.solid_of(cube, rotation=A.quat_xyzs_to_rot([0, np.sin(0.2), 0, np.cos(0.2)]))
+    assert abs(tilted.exit_distance(np.array([0, 0, -1.0])) - 0.05 / np.cos(0.4)) < 1e-12
+    # overlap polygon of two offset squares
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1.0]])
+    ov = A.overlap_polygon(sq, sq + 0.5)
+    assert ov.shape == (4, 2) and np.allclose(sorted(map(tuple, ov)), [(0.5, 0.5), (0.5, 1), (1, 0.5), (1, 1)])
+    assert A.overlap_polygon(sq, sq + 2.0) is None
 
 
 def test_target_trajectories_and_dimensions():

@@ -133,9 +133,10 @@ class ControllerSettings(bindings.ControllerSettings):
         self.balancing_settings.arrangement_name = bal["arrangement"]
         self.balancing_settings.force_weight = bal["force_weight"]
         if bodies is None or contacts is None:
-            raise NotImplementedError(
-                "arrangement -> contact-point parsing is not re-implemented yet (SURVEY.md 8f.4): pass bodies= and contacts= "
-                "(e.g. from tests/golden/arrangements.json via upright_amd.control.objects_from_fixture)")
+            # wrappers.py:303-305: core.parsing.parse_control_objects(config)
+            from .arrangement import parse_control_objects
+
+            bodies, contacts = parse_control_objects(config)
         self.balancing_settings.bodies = bodies
         self.balancing_settings.contacts = contacts
         if self.balancing_settings.enabled:
