@@ -564,3 +564,28 @@ def test_feedback_gains_and_policy(arrangements, kernel, monkeypatch):
     Kt = (1 - a) * K[:, 0] + a * K[:, 1]
     assert np.abs((u2 - u1) - np.einsum("bij,bj->bi", Kt, dx)).max() < 1e-9
     mpc.close(); mpc2.close()
+
+
+def test_cpp_header_twin_matches_python_path(arrangements, tmp_path):
+    """The C++ face (include/upright_mi.hpp) driven by a stand-alone g++ program gives bit-identical trajectories,
+    policy outputs and gains to the Python shim: both are thin layers over the same C-ABI."""
+    import subprocess
+
+    from test_host import _build_hpp_demo, _write_cpp_inputs
+
+    B = 3
+    P, x0, way = _setup(arrangements, B, seed=91, use_feedback_policy=True)
+    exe = _build_hpp_demo(tmp_path)
+    _write_cpp_inputs(tmp_path, P, B, np.broadcast_to(P.body_params, (B, 1, 10)), way, x0)
+    r = subprocess.run([str(exe), str(tmp_path), str(B)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = {l.split()[0]: np.array(l.split()[1:], dtype=np.float64) for l in r.stdout.splitlines() if l and not l.startswith("nx ")}
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    _, up = mpc.evaluate(0.05, x_obs=x0)
+    assert np.array_equal(out["xs"], xs.ravel()) and np.array_equal(out["us"], us.ravel())
+    assert np.array_equal(out["upol"], up.ravel())
+    assert abs(out["Knorm2"][0] - np.sum(mpc.feedback_gains() ** 2)) < 1e-9 * out["Knorm2"][0]
+    mpc.close()

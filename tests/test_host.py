@@ -223,3 +223,47 @@ def test_shard_range_partitions():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _build_hpp_demo(tmp_path):
+    import subprocess
+
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "hpp_demo"
+    lib = root / "upright_amd"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "hpp_demo.cpp"),
+                    f"-L{lib}", "-lupright_mi", f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True)
+    return exe
+
+
+def _write_cpp_inputs(tmp_path, P, B, body_params, way, x0):
+    import ctypes as C
+
+    from upright_amd import _capi
+
+    c = _capi.problem_to_c(P)
+    (tmp_path / "problem.bin").write_bytes(bytes(memoryview((C.c_char * C.sizeof(c)).from_buffer(c))))
+    (tmp_path / "body_params.bin").write_bytes(np.ascontiguousarray(body_params, dtype=np.float64).tobytes())
+    (tmp_path / "way_p.bin").write_bytes(np.ascontiguousarray(way, dtype=np.float64).tobytes())
+    (tmp_path / "x0.bin").write_bytes(np.ascontiguousarray(x0, dtype=np.float64).tobytes())
+
+
+def test_cpp_header_twin_compiles_and_fails_loudly_without_gpu(arrangements, tmp_path):
+    """include/upright_mi.hpp (C++ face of the C-ABI for ROS-node style callers) builds with -Wall -Werror against
+    the in-tree library; on a machine without a GPU the constructor throws the library's error (no CPU path)."""
+    import subprocess
+
+    import torch
+
+    from upright_amd.problem import thing_problem
+    from upright_amd.sampling import level_tray_states, waypoints_for
+
+    exe = _build_hpp_demo(tmp_path)
+    P = thing_problem(arrangements["pink_bottle"], use_feedback_policy=True)
+    x0 = level_tray_states(2, seed=3)
+    _write_cpp_inputs(tmp_path, P, 2, np.broadcast_to(P.body_params, (2, 1, 10)), waypoints_for(P, x0), x0)
+    r = subprocess.run([str(exe), str(tmp_path), "2"], capture_output=True, text=True)
+    if not torch.cuda.is_available():
+        assert r.returncode == 1 and "runtime_error" in r.stdout and "no HIP device" in r.stdout
+    else:
+        assert r.returncode == 0, r.stdout + r.stderr
