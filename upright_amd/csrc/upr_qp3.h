@@ -471,7 +471,12 @@ struct upr_qp3 {
             // phase 1.  Jobs [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the
             // entries of A'P+A it owns (upper triangle of the result), 3 of Hux = B'P+A and 1 of Hjj = B'P+B + R + W;
             // then NPAIR jobs of Vc = Lsi C and NX jobs of P+ b.
-            UPR_FORT(e, NQ * NQ + NPAIR + NX) {
+            // job -> lane map: A'P+A blocks from lane 0, Vc row pairs behind them, P+ b on the LAST wave of the workgroup
+            // (a wave that holds two job kinds runs them one after the other: the 27-term dot products must not share
+            // a wave with anything else)
+            constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NPAIR;
+            static_assert(PB0 >= NQ * NQ + NPAIR, "P+ b jobs overlap the others");
+            UPR_FORT(e, PB0 + NX) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
                     double p[3][3];
@@ -511,11 +516,16 @@ struct upr_qp3 {
                         for (int m = 0; m <= r2; ++m) { const double cm = L[O::ck + m * NX + c]; if (m <= pr) v1 += Ls[pr * NE + m] * cm; v2 += Ls[r2 * NE + m] * cm; }
                         L[O::vc + pr * NX + c] = v1; L[O::vc + r2 * NX + c] = v2;
                     }
-                } else {
-                    const int i = e - NQ * NQ - NPAIR;
-                    double pb = 0.0;
-                    for (int j = 0; j < NX; ++j) pb += Pc[i * NX + j] * L[O::bks + k * NX + j];
-                    L[O::Pbs + k * NX + i] = pb;
+                } else if (e >= PB0) {
+                    const int i = e - PB0;
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0;   // three independent chains
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        p0 += Pc[i * NX + j] * L[O::bks + k * NX + j];
+                        p1 += Pc[i * NX + NQ + j] * L[O::bks + k * NX + NQ + j];
+                        p2 += Pc[i * NX + 2 * NQ + j] * L[O::bks + k * NX + 2 * NQ + j];
+                    }
+                    L[O::Pbs + k * NX + i] = (p0 + p1) + p2;
                 }
             }
             UPR_SYNC_LDS();
@@ -723,6 +733,8 @@ struct upr_qp3 {
                     Wk((kk) - 1)[i] = v + pbn; \
                     UPR_WSYNC(); } while (0)
                 UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
+                // fully unrolled: inside a loop the compiler's s_waitcnt bookkeeping collapses the three prefetch stages into one
+#pragma unroll
                 for (int k = N - 1; k >= 1; k -= 3) {
                     UPR_VECSTEP(kc0, k); UPR_LOADKC(kc0, k - 3);
                     if (k - 1 >= 1) { UPR_VECSTEP(kc1, k - 1); UPR_LOADKC(kc1, k - 4); }
@@ -803,6 +815,7 @@ struct upr_qp3 {
                     if (act) { Sx((kk) + 1)[i] = r - coefB(b_) * d; if (b_ == 0) Su(kk)[j] = -d; } \
                     UPR_WSYNC(); } while (0)
                 UPR_LOADKQ(kq0, 1); UPR_LOADKQ(kq1, 2); UPR_LOADKQ(kq2, 3);
+#pragma unroll
                 for (int k = 1; k < N; k += 3) {
                     UPR_FWDSTEP(kq0, k); UPR_LOADKQ(kq0, k + 3);
                     if (k + 1 < N) { UPR_FWDSTEP(kq1, k + 1); UPR_LOADKQ(kq1, k + 4); }
