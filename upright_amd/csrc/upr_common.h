@@ -58,6 +58,19 @@ static __device__ __forceinline__ double upr_readlane(double v, int lane) {
 #endif
 #define UPR_FOR(i, n) for (int i = upr_opq(ctx.tid); i < (n); i += ctx.nt)
 
+// 1/sqrt(x) without the IEEE division / square-root sequences (they cost ~300 cycles per pivot on the
+// critical path): hardware estimate (relative error 5e-8 on gfx950, tools/rsq_test.hip) + ONE third-order
+// step y (1 + e/2 + 3e^2/8), e = 1 - x y^2: 5 dependent operations, relative error < 3e-16.
+static inline UPR_HD double upr_rsqrt(double x) {
+#ifdef UPR_HOST_EMU
+    return 1.0 / sqrt(x);
+#else
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y, e * fma(0.375, e, 0.5), y);
+#endif
+}
+
 // derived dimensions
 struct upr_dims {
     int nq, nb, nc, nf, N, nx, nu, nfc, ne, np, neN;

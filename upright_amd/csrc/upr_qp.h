@@ -125,17 +125,16 @@ static inline UPR_HD void upr_chol_inv(const upr_ctx& ctx, double* M, double* Li
 
 // 3x3 SPD block: m <- L^-1 (lower triangular, row-major 3x3, upper entries 0). false if not PD.
 static inline UPR_HD bool upr_chol_inv3(double* m) {
-    double a = m[0], b = m[3], c = m[6], e = m[4], f = m[7], i = m[8];
+    const double a = m[0], b = m[3], c = m[6], e = m[4], f = m[7], i = m[8];
     if (!(a > 0.0)) return false;
-    double l00 = sqrt(a), l10 = b / l00, l20 = c / l00;
-    double d1 = e - l10 * l10;
+    const double n00 = upr_rsqrt(a), l10 = b * n00, l20 = c * n00;
+    const double d1 = e - l10 * l10;
     if (!(d1 > 0.0)) return false;
-    double l11 = sqrt(d1), l21 = (f - l20 * l10) / l11;
-    double d2 = i - l20 * l20 - l21 * l21;
+    const double n11 = upr_rsqrt(d1), l21 = (f - l20 * l10) * n11;
+    const double d2 = i - l20 * l20 - l21 * l21;
     if (!(d2 > 0.0)) return false;
-    double l22 = sqrt(d2);
-    double n00 = 1.0 / l00, n11 = 1.0 / l11, n22 = 1.0 / l22;
-    double n10 = -l10 * n00 * n11, n21 = -l21 * n11 * n22, n20 = -(l20 * n00 + l21 * n10) * n22;
+    const double n22 = upr_rsqrt(d2);
+    const double n10 = -l10 * n00 * n11, n21 = -l21 * n11 * n22, n20 = -(l20 * n00 + l21 * n10) * n22;
     m[0] = n00; m[1] = 0.0; m[2] = 0.0; m[3] = n10; m[4] = n11; m[5] = 0.0; m[6] = n20; m[7] = n21; m[8] = n22;
     return true;
 }

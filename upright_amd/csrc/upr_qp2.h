@@ -83,8 +83,8 @@ static inline UPR_HD bool upr_chol_inv_serial(const double* M, double* Li) {
 #pragma unroll
         for (int k = 0; k < p; ++k) s -= a[p][k] * a[p][k];
         if (!(s > 0.0)) { ok = false; s = 1.0; }
-        const double dg = sqrt(s), idg = 1.0 / dg;
-        a[p][p] = dg;
+        const double idg = upr_rsqrt(s);
+        a[p][p] = idg;   // the diagonal holds the reciprocal pivot
 #pragma unroll
         for (int i = p + 1; i < n; ++i) {
             double v = a[i][p];
@@ -97,13 +97,13 @@ static inline UPR_HD bool upr_chol_inv_serial(const double* M, double* Li) {
 #pragma unroll
     for (int j = 0; j < n; ++j) {
         double c[n];
-        c[j] = 1.0 / a[j][j];
+        c[j] = a[j][j];
 #pragma unroll
         for (int i = j + 1; i < n; ++i) {
             double v = 0.0;
 #pragma unroll
             for (int k = j; k < i; ++k) v += a[i][k] * c[k];
-            c[i] = -v / a[i][i];
+            c[i] = -v * a[i][i];
         }
 #pragma unroll
         for (int i = 0; i < n; ++i) Li[i * n + j] = (i >= j) ? c[i] : 0.0;

@@ -82,19 +82,6 @@ struct upr_qp3_lds {
                          pv2 = hujs + r2(C::N * C::NQ), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
 };
 
-// 1/sqrt(x) without the IEEE division / square-root sequences (they cost ~300 cycles per pivot on the
-// critical path): hardware estimate (relative error 5e-8 on gfx950, tools/rsq_test.hip) + ONE third-order
-// step y (1 + e/2 + 3e^2/8), e = 1 - x y^2: 5 dependent operations, relative error < 3e-16.
-static inline UPR_HD double upr_rsqrt(double x) {
-#ifdef UPR_HOST_EMU
-    return 1.0 / sqrt(x);
-#else
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y, y, 1.0);
-    return fma(y, e * fma(0.375, e, 0.5), y);
-#endif
-}
-
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
 // diagonal replaced by 1 / L_ii (what the triangular inverse and solves need).
 template <int n>
