@@ -22,6 +22,8 @@ extern "C" {
 #define UPR_MAX_WAYPOINTS 8
 #define UPR_MAX_NX 36  /* 3 * UPR_MAX_JOINTS */
 #define UPR_MAX_NU 108 /* UPR_MAX_JOINTS + 3 * UPR_MAX_CONTACTS */
+#define UPR_MAX_SPHERES 16
+#define UPR_MAX_PAIRS 32
 
 /* Problem family shared by all instances of a batch: what ControllerInterface's constructor reads
  * from ControllerSettings (upright_control/src/controller_interface.cpp:103-393;
@@ -78,6 +80,18 @@ typedef struct upr_problem {
     int terminal_constraint; /* stationary_desired_position_constraint at knot N */
     int use_feedback_policy; /* sqp.use_feedback_policy (controller.yaml:60; pybindings.cpp:199): keep the Riccati gains of
                                 the last QP and apply them in upr_batch_evaluate_policy */
+
+    /* collision avoidance (controller_interface.cpp:172-228,450-481; obstacles/simple.yaml:11-41): spheres rigidly
+     * attached to chain frames (sph_frame: -1 world, i < nq the link carried by joint i, nq the tool frame) and the
+     * pairs whose distance |c_a - c_b| - r_a - r_b - obs_min_dist stays >= 0 at knots 1..N-1 (hard state
+     * inequality "obstacle_avoidance"; replaces ocs2::SelfCollisionConstraintCppAd over hpp-fcl sphere pairs) */
+    int n_sph;
+    int sph_frame[UPR_MAX_SPHERES];
+    double sph_off[UPR_MAX_SPHERES][3];
+    double sph_r[UPR_MAX_SPHERES];
+    int n_pairs;
+    int pair_a[UPR_MAX_PAIRS], pair_b[UPR_MAX_PAIRS];
+    double obs_min_dist; /* controller.yaml:108 */
 } upr_problem;
 
 const char* upr_last_error(void);
@@ -169,6 +183,9 @@ int upr_batch_get_stats(upr_batch* h, double* stats);
 int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x,
                                const double* u, double* g, double* gx, double* cost, double* grad,
                                double* hess, double* ee);
+/* ControllerInterface.getStateInputInequalityConstraintValue("obstacle_avoidance", t, x, u) (pybindings.cpp:417-419;
+ * mpc_sim.py:191-219) at n states: d[n][n_pairs] and (may be NULL) dq[n][n_pairs][nq] = d d / d q */
+int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* d, double* dq);
 /* constant d(object_dynamics)/du of instance `inst`: gu[ne][nu] */
 int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu);
 

@@ -10,7 +10,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "_build" / "libupright_oracle.so"
 
-MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU = 16, 64, 16, 8, 64, 208
+MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU, MAXS, MAXP = 16, 64, 16, 8, 64, 208, 32, 64
 d = C.c_double
 
 
@@ -27,6 +27,8 @@ class OrcProblem(C.Structure):
         ("n_way", C.c_int), ("way_t", d * MAXW), ("way_p", d * 3 * MAXW),
         ("sqp_iters", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", d), ("delta_tol", d), ("cost_tol", d),
         ("terminal_constraint", C.c_int),
+        ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", d * 3 * MAXS), ("sph_r", d * MAXS),
+        ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", d),
     ]
 
 
@@ -92,6 +94,12 @@ def to_orc(P):
         _fill(o.way_p[i], P.way_p[i])
     o.sqp_iters, o.qp_iter_max, o.qp_tol = P.sqp_iters, P.qp_iter_max, P.qp_tol
     o.delta_tol, o.cost_tol, o.terminal_constraint = P.delta_tol, P.cost_tol, int(P.terminal_constraint)
+    ns, npair = len(getattr(P, "sph_r", ())), len(getattr(P, "pair_a", ()))
+    o.n_sph, o.n_pairs, o.obs_min_dist = ns, npair, float(getattr(P, "obs_min_dist", 0.0))
+    for i in range(ns):
+        o.sph_frame[i] = int(P.sph_frame[i]); o.sph_r[i] = float(P.sph_r[i]); _fill(o.sph_off[i], P.sph_off[i])
+    for i in range(npair):
+        o.pair_a[i], o.pair_b[i] = int(P.pair_a[i]), int(P.pair_b[i])
     return o
 
 
@@ -166,6 +174,17 @@ class Oracle:
         dxs = np.zeros((self.P.N + 1, self.nx)); dus = np.zeros((self.P.N, self.nu)); st = OrcStats()
         rc = self.L.orc_qp_step(C.byref(self.o), d(t0), _p(_c(x0)), _p(_c(xs)), _p(_c(us)), _p(dxs), _p(dus), C.byref(st))
         return dxs, dus, st, rc
+
+    def sphere_centers(self, x):
+        c = np.zeros((self.o.n_sph, 3))
+        self.L.orc_sphere_centers(C.byref(self.o), _p(_c(x)), _p(c))
+        return c
+
+    def obstacle_rows(self, x, jac=True):
+        n = self.o.n_pairs
+        dd = np.zeros(n); dq = np.zeros((n, self.P.nq))
+        self.L.orc_obstacle_rows(C.byref(self.o), _p(_c(x)), _p(dd), _p(dq) if jac else None)
+        return (dd, dq) if jac else dd
 
     def qp_feedback(self, t0, x0, xs, us):
         P = self.P

@@ -38,6 +38,8 @@ inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d
 inline Dual operator/(Dual a, Dual b) { return {a.v / b.v, (a.d * b.v - a.v * b.d) / (b.v * b.v)}; }
 inline Dual sin(Dual a) { return {std::sin(a.v), std::cos(a.v) * a.d}; }
 inline Dual cos(Dual a) { return {std::cos(a.v), -std::sin(a.v) * a.d}; }
+inline Dual sqrt(Dual a) { const double r = std::sqrt(a.v); return {r, 0.5 * a.d / r}; }
+inline double sqrt(double a) { return std::sqrt(a); }
 inline double sin(double a) { return std::sin(a); }
 inline double cos(double a) { return std::cos(a); }
 inline double val(double a) { return a; }
@@ -152,6 +154,39 @@ EEState<T> ee_kin(const orc_problem* P, const T* x) {
     EEState<T> S;
     S.p = o; S.C = R; S.v = v; S.w = w; S.a = a; S.al = al;
     return S;
+}
+
+// centres of the collision spheres: the same chain walk, positions only
+template <class T>
+void sphere_centers(const orc_problem* P, const T* x, std::vector<V3<T>>& c) {
+    const int nq = P->nq;
+    c.assign(P->n_sph, V3<T>{{T(0.0), T(0.0), T(0.0)}});
+    M3<T> R; for (int i = 0; i < 9; ++i) R.m[i] = T((i % 4 == 0) ? 1.0 : 0.0);
+    V3<T> o{{T(0.0), T(0.0), T(0.0)}};
+    auto place = [&](int frame) {
+        for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == frame) c[s] = add(o, mv(R, from_d3<T>(P->sph_off[s])));
+    };
+    place(-1);
+    for (int i = 0; i < nq; ++i) {
+        o = add(o, mv(R, from_d3<T>(P->joint_p[i])));
+        R = mm(R, from_d<T>(P->joint_R[i]));
+        if (P->joint_type[i] == 1) R = mm(R, axis_rot<T>(P->joint_axis[i], x[i]));
+        else o = add(o, scl(mv(R, from_d3<T>(P->joint_axis[i])), x[i]));
+        place(i);
+    }
+    o = add(o, mv(R, from_d3<T>(P->tool_p)));
+    R = mm(R, from_d<T>(P->tool_R));
+    place(nq);
+}
+template <class T>
+void obstacle_rows(const orc_problem* P, const T* x, T* d) {
+    std::vector<V3<T>> c;
+    sphere_centers<T>(P, x, c);
+    for (int r = 0; r < P->n_pairs; ++r) {
+        const int a = P->pair_a[r], b = P->pair_b[r];
+        V3<T> e = sub(c[a], c[b]);
+        d[r] = sqrt(dot(e, e)) - T(P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+    }
 }
 
 // rigid_body.h:36-43 from_parameters
@@ -336,9 +371,10 @@ struct StageQP {
     vec Ce, De, e;           // ne rows
     vec xl, xu, ul, uu;      // box on the step
     vec Gu, d;               // np rows on du
+    vec Gx, gd;              // no rows on dx: Gx dx + gd >= 0 (obstacle rows, stages 1..N-1)
 };
 struct QP {
-    int N, nx, nu, ne, np, neN, nfc;
+    int N, nx, nu, ne, np, neN, nfc, no = 0;
     vec A, B;
     std::vector<StageQP> st;  // N stages
     vec QN, qN, CN, eN, xlN, xuN;
@@ -364,7 +400,8 @@ struct Riccati {
     std::vector<vec> p, ku0, snu;
 
     bool factor(const std::vector<vec>& Hxx_add /*diag barrier on x, per k (0..N)*/,
-                const std::vector<vec>& Huu_add /*full nu*nu barrier on u per k*/) {
+                const std::vector<vec>& Huu_add /*full nu*nu barrier on u per k*/,
+                const std::vector<vec>& Hxx_dense /*full nx*nx barrier on x per k (may be empty)*/) {
         const int N = qp->N, nx = qp->nx, nu = qp->nu, ne = qp->ne;
         P.assign(N + 1, vec()); Lr.assign(N, vec()); Kx.assign(N, vec()); Y.assign(N, vec());
         Ls.assign(N, vec()); Cbar.assign(N, vec());
@@ -390,6 +427,7 @@ struct Riccati {
                     Hxx[i * nx + j] = t;
                 }
             for (int i = 0; i < nx; ++i) Hxx[i * nx + i] += Hxx_add[k][i];
+            if (!Hxx_dense.empty() && !Hxx_dense[k].empty()) for (size_t i = 0; i < Hxx.size(); ++i) Hxx[i] += Hxx_dense[k][i];
             for (int i = 0; i < nu; ++i)
                 for (int j = 0; j < nx; ++j) {
                     double t = 0; for (int l = 0; l < nx; ++l) t += B[l * nu + i] * W[l * nx + j];
@@ -522,7 +560,11 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     const int N = qp.N, nx = qp.nx, nu = qp.nu, ne = qp.ne, np = qp.np, neN = qp.neN;
     // inequality layout per stage k<N: [x lower nx][x upper nx] (k>=1 only) [u lower nu][u upper nu][poly np]
     // terminal: [x lower][x upper]
-    auto nik = [&](int k) { return (k >= 1 ? 2 * nx : 0) + (k < N ? 2 * nu + np : 0); };
+    // state-polytopic (obstacle) rows sit behind the others at stages 1..N-1
+    const int no = qp.no;
+    auto has_obs = [&](int k) { return no > 0 && k >= 1 && k < N; };
+    const int oo = 2 * nx + 2 * nu + np;
+    auto nik = [&](int k) { return (k >= 1 ? 2 * nx : 0) + (k < N ? 2 * nu + np : 0) + (has_obs(k) ? no : 0); };
     std::vector<vec> t(N + 1), lam(N + 1), dt_(N + 1), dlam(N + 1), dt_aff(N + 1), dlam_aff(N + 1), cval(N + 1);
     std::vector<vec> dx(N + 1, vec(nx, 0.0)), du(N, vec(nu, 0.0)), pi(N + 1, vec(nx, 0.0)), nu_(N, vec(ne, 0.0));
     std::vector<vec> ddx(N + 1, vec(nx, 0.0)), ddu(N, vec(nu, 0.0)), pi_new(N + 1, vec(nx, 0.0)), nu_new(N, vec(ne, 0.0));
@@ -548,6 +590,10 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                 o += 2 * nu;
                 for (int r = 0; r < np; ++r) { double v = s.d[r]; for (int j = 0; j < nu; ++j) v += s.Gu[r * nu + j] * U[k][j]; c[k][o + r] = v; }
             }
+            if (has_obs(k)) {
+                const StageQP& s = qp.st[k];
+                for (int r = 0; r < no; ++r) { double v = s.gd[r]; for (int j = 0; j < nx; ++j) v += s.Gx[r * nx + j] * X[k][j]; c[k][oo + r] = v; }
+            }
         }
     };
     // initial point: z = 0 (dx0 fixed), t = max(c, thr), lam = mu0 / t
@@ -561,7 +607,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     // forces are the tail of u: the force block spans the equality rows iff nu - nq >= ne
     const double rho_prox = (qp.nfc < ne) ? 1e-6 : 0.0;
     Riccati ric; ric.qp = &qp; ric.rho_s = (qp.nfc < ne) ? 1e-6 : 1e-12; ric.rhoN = 1e-6;
-    std::vector<vec> Hxx_add(N + 1, vec(nx, 0.0)), Huu_add(N, vec((size_t)nu * nu, 0.0));
+    std::vector<vec> Hxx_add(N + 1, vec(nx, 0.0)), Huu_add(N, vec((size_t)nu * nu, 0.0)), Hxx_dense(no > 0 ? N + 1 : 0);
     std::vector<vec> gx(N + 1, vec(nx)), gu(N, vec(nu)), bres(N, vec(nx)), eres(N, vec(ne));
     std::vector<vec> rp(N + 1), rc(N + 1);
     for (int k = 0; k <= N; ++k) { rp[k].assign(t[k].size(), 0); rc[k] = rp[k]; }
@@ -608,6 +654,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                 for (int i = 0; i < nu; ++i) gu[k][i] = s.Rd[i] * du[k][i] + s.r[i] - lam[k][o + i] + lam[k][o + nu + i];
                 for (int r = 0; r < np; ++r) for (int j = 0; j < nu; ++j) gu[k][j] -= s.Gu[r * nu + j] * lam[k][o + 2 * nu + r];
             }
+            if (has_obs(k)) for (int r = 0; r < no; ++r) for (int j = 0; j < nx; ++j) gx[k][j] -= qp.st[k].Gx[r * nx + j] * lam[k][oo + r];
         }
         // full stationarity residual with current multipliers
         for (int k = 0; k <= N; ++k) {
@@ -645,7 +692,18 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                 }
             }
         }
-        if (!ric.factor(Hxx_add, Huu_add)) { sol.status = 2; break; }
+        for (int k = 0; k <= N && no > 0; ++k) {
+            Hxx_dense[k].clear();
+            if (!has_obs(k)) continue;
+            Hxx_dense[k].assign((size_t)nx * nx, 0.0);
+            const StageQP& s = qp.st[k];
+            for (int r = 0; r < no; ++r) {
+                const double w = lam[k][oo + r] / t[k][oo + r];
+                for (int i = 0; i < nx; ++i) { const double gi = s.Gx[r * nx + i]; if (gi == 0.0) continue;
+                    for (int j = 0; j < nx; ++j) Hxx_dense[k][i * nx + j] += w * gi * s.Gx[r * nx + j]; }
+            }
+        }
+        if (!ric.factor(Hxx_add, Huu_add, Hxx_dense)) { sol.status = 2; break; }
 
         // solve the Newton system for a given complementarity target rc (per inequality):
         //   lam*dt + t*dlam = -rc ;  dt = G dz + rp ;  =>  dlam = -(rc + lam*(G dz + rp)) / t
@@ -672,6 +730,10 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                         for (int j = 0; j < nu; ++j) hu[k][j] += s.Gu[r * nu + j] * w;
                     }
                 }
+                if (has_obs(k)) for (int r = 0; r < no; ++r) {
+                    const int ii = oo + r; const double w = (rc[k][ii] + lam[k][ii] * rp[k][ii]) / t[k][ii];
+                    for (int j = 0; j < nx; ++j) hx[k][j] += qp.st[k].Gx[r * nx + j] * w;
+                }
             }
             // terminal multiplier enters the terminal gradient through the proximal term (true residual)
             std::vector<vec> hxN = hx;
@@ -693,6 +755,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                     for (int i = 0; i < nu; ++i) { dT[k][o + i] = ddu[k][i] + rp[k][o + i]; dT[k][o + nu + i] = -ddu[k][i] + rp[k][o + nu + i]; }
                     for (int r = 0; r < np; ++r) { double v = rp[k][o + 2 * nu + r]; for (int j = 0; j < nu; ++j) v += s.Gu[r * nu + j] * ddu[k][j]; dT[k][o + 2 * nu + r] = v; }
                 }
+                if (has_obs(k)) for (int r = 0; r < no; ++r) { double v = rp[k][oo + r]; for (int j = 0; j < nx; ++j) v += qp.st[k].Gx[r * nx + j] * ddx[k][j]; dT[k][oo + r] = v; }
                 for (size_t i = 0; i < t[k].size(); ++i) dL[k][i] = -(rc[k][i] + lam[k][i] * dT[k][i]) / t[k][i];
             }
         };
@@ -751,7 +814,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 // intermediate cost and its derivatives scaled by dt, defects b = f(x_k,u_k) - x_{k+1}).
 void build_qp(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us, QP& qp) {
     const int nx = orc_nx(P), nu = orc_nu(P), N = P->N, ne = 6 * P->nb, np = (P->nf == 3 ? 5 * P->nc : 0);
-    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq;
+    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq; qp.no = P->n_pairs;
     Dyn dyn{P->nq, nx, nu, P->dt};
     dyn.dense(qp.A, qp.B);
     qp.st.assign(N, StageQP());
@@ -782,6 +845,12 @@ void build_qp(const orc_problem* P, double t0, const double* x0, const double* x
         for (int i = 0; i < nx; ++i) { s.xl[i] = P->x_lb[i] - x[i]; s.xu[i] = P->x_ub[i] - x[i]; }
         for (int i = 0; i < nu; ++i) { s.ul[i] = P->u_lb[i] - u[i]; s.uu[i] = P->u_ub[i] - u[i]; }
         if (np > 0) { orc_ineq_constraint(P, u, h.data()); s.Gu = Gu; s.d.assign(h.begin(), h.begin() + np); }
+        if (qp.no > 0 && k >= 1) {   // collision rows: d(q) + dd/dq dq >= 0
+            s.gd.assign(qp.no, 0.0); s.Gx.assign((size_t)qp.no * nx, 0.0);
+            vec dq((size_t)qp.no * P->nq);
+            orc_obstacle_rows(P, x, s.gd.data(), dq.data());
+            for (int r = 0; r < qp.no; ++r) for (int j = 0; j < P->nq; ++j) s.Gx[r * nx + j] = dq[r * P->nq + j];
+        }
     }
     const double* xN = xs + (size_t)N * nx;
     qp.QN.assign((size_t)nx * nx, 0.0); qp.qN.assign(nx, 0.0);  // no final cost (controller_interface.cpp:138-148)
@@ -799,6 +868,25 @@ void build_qp(const orc_problem* P, double t0, const double* x0, const double* x
 extern "C" {
 
 int orc_nx(const orc_problem* P) { return 3 * P->nq; }
+
+void orc_sphere_centers(const orc_problem* P, const double* x, double* c) {
+    std::vector<V3<double>> cs;
+    sphere_centers<double>(P, x, cs);
+    for (int s = 0; s < P->n_sph; ++s) for (int i = 0; i < 3; ++i) c[3 * s + i] = cs[s][i];
+}
+
+void orc_obstacle_rows(const orc_problem* P, const double* x, double* d, double* dq) {
+    const int nq = P->nq, np = P->n_pairs;
+    if (np == 0) return;
+    obstacle_rows<double>(P, x, d);
+    if (!dq) return;
+    std::vector<Dual> xd(nq), dd(np);
+    for (int j = 0; j < nq; ++j) {
+        for (int i = 0; i < nq; ++i) xd[i] = Dual(x[i], i == j ? 1.0 : 0.0);
+        obstacle_rows<Dual>(P, xd.data(), dd.data());
+        for (int r = 0; r < np; ++r) dq[r * nq + j] = dd[r].d;
+    }
+}
 int orc_nu(const orc_problem* P) { return P->nq + P->nf * P->nc; }
 
 void orc_object_dynamics(const orc_problem* P, const double* forces, const double* C, const double* w,
@@ -924,6 +1012,7 @@ void orc_performance(const orc_problem* P, double t0, const double* x0, const do
         if (np > 0) { orc_ineq_constraint(P, u, h.data()); for (int r = 0; r < np; ++r) { double v = std::min(0.0, h[r]); ineq_sse += P->dt * v * v; } }
         for (int i = 0; i < nu; ++i) { double v = std::min(0.0, std::min(u[i] - P->u_lb[i], P->u_ub[i] - u[i])); ineq_sse += P->dt * v * v; }
         if (k >= 1) for (int i = 0; i < nx; ++i) { double v = std::min(0.0, std::min(x[i] - P->x_lb[i], P->x_ub[i] - x[i])); ineq_sse += P->dt * v * v; }
+        if (k >= 1 && P->n_pairs > 0) { vec dd(P->n_pairs); orc_obstacle_rows(P, x, dd.data(), nullptr); for (double v : dd) { v = std::min(0.0, v); ineq_sse += P->dt * v * v; } }
     }
     const double* xN = xs + (size_t)N * nx;
     for (int i = 0; i < nx; ++i) { double v = std::min(0.0, std::min(xN[i] - P->x_lb[i], P->x_ub[i] - xN[i])); ineq_sse += v * v; }

@@ -29,6 +29,8 @@ extern "C" {
 #define ORC_MAX_WAYPOINTS 8
 #define ORC_MAX_NX 64
 #define ORC_MAX_NU 208
+#define ORC_MAX_SPHERES 32
+#define ORC_MAX_PAIRS 64
 
 typedef struct {
     /* ---- dimensions (upright_control/include/upright_control/dimensions.h:18-46) ---- */
@@ -84,9 +86,25 @@ typedef struct {
     double delta_tol;    /* controller.yaml:58 */
     double cost_tol;     /* controller.yaml:59 */
     int terminal_constraint; /* 1: stationary_desired_position_constraint at knot N */
+
+    /* ---- collision avoidance (controller_interface.cpp:172-228,450-481): spheres rigidly attached to chain frames
+     *      (frame = -1 world, i < nq the link after joint i, nq the tool frame) and the pairs whose distance
+     *      |c_a - c_b| - r_a - r_b - obs_min_dist must stay >= 0 at knots 1..N-1 ([UPSTREAM]
+     *      ocs2::SelfCollisionConstraintCppAd over hpp-fcl sphere-sphere distances) ---- */
+    int n_sph;
+    int sph_frame[ORC_MAX_SPHERES];
+    double sph_off[ORC_MAX_SPHERES][3];
+    double sph_r[ORC_MAX_SPHERES];
+    int n_pairs;
+    int pair_a[ORC_MAX_PAIRS], pair_b[ORC_MAX_PAIRS];
+    double obs_min_dist;
 } orc_problem;
 
 int orc_nx(const orc_problem* P);
+/* obstacle rows at state x: d[n_pairs] and (if not NULL) dq[n_pairs][nq] = d d / d q */
+void orc_obstacle_rows(const orc_problem* P, const double* x, double* d, double* dq);
+/* sphere centres c[n_sph][3] at configuration q = x[0:nq] */
+void orc_sphere_centers(const orc_problem* P, const double* x, double* c);
 int orc_nu(const orc_problem* P);
 
 /* ---- upright_core.bindings twins (upright_core/src/pybindings.cpp:53-56), unnormalised ---- */

@@ -16,12 +16,16 @@
 
 template <int NQ>
 static void lin_all(const upr_lin_args& A) {
-    std::vector<double> sh(upr_lin_lds_doubles(A.d) + 8);
+    std::vector<double> sh(upr_lin_lds_doubles(A.d, A.P->n_sph) + 8);
     for (int p = 0; p < A.npoints; ++p) {
         upr_lin_point q = upr_lin_locate(A, p);
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0b(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ>(A, q, l, sh.data());
+        if (A.d.no > 0) {
+            for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_a<NQ>(A, q, l, sh.data());
+            for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_b<NQ>(A, q, l, sh.data());
+        }
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase2<NQ>(A, q, l, sh.data());
     }
 }

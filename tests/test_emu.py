@@ -152,3 +152,61 @@ def test_linesearch_kernel_source_and_full_step(arrangements):
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs[b], us[b])
         assert np.abs(xs2[b] - xo).max() < 2e-5 and np.abs(us2[b] - uo).max() < 2e-4
         assert stats[b, 3] == so.step_alpha_last and abs(stats[b, 4] - so.cost) < 1e-7 and abs(stats[b, 5] - so.constraint_violation) < 1e-6
+
+
+def _obstacle_case(arrangements, B, seed, **kw):
+    """Thing + bottle with a small collision model: a world sphere right in front of the mobile base (the base has
+    to give way while the arm still brings the tray to the target), the two self-collision pairs of
+    obstacles/simple.yaml:37-41 and a far tray-vs-obstacle pair."""
+    from upright_amd import robots
+
+    P, x0, way, xs, us = _case(arrangements, B, seed, **kw)
+    pairs = [("base_collision_link", "obs2"), ("wrist1_collision_link", "shoulder_collision_link"),
+             ("wrist1_collision_link", "base_collision_link"), ("balanced_object_collision_link", "obs3")]
+    cm = robots.collision_model(P.chain, pairs, spheres={"obs2": ("world", (0.0, 1.0, 0.25), 0.25), "obs3": ("world", (-0.3, 2.9, 0.9), 0.25)})
+    for k, v in cm.items():
+        setattr(P, k, v)
+    way = waypoints_for(P, x0, offset=(1.0, 0.0, 0.0))
+    return P, x0, way, xs, us
+
+
+def test_collision_rows_kernel_source(arrangements):
+    """sphere-pair distance rows of the linearisation kernel (values and d/dq through the same
+    forward-mode lanes) against the oracle, the generic QP kernel with these state-polytopic rows against the
+    oracle's IPM on the same iterate path, and the rows in the line-search merit."""
+    B = 2
+    P, x0, way, xs, us = _obstacle_case(arrangements, B, 4, qp_tol=0.0, qp_iter_max=6)
+    rng = np.random.default_rng(1)
+    e = Emu(P, B)
+    assert e.lin_stride == 223 + 4 * 10
+    xr = xs + rng.uniform(-0.2, 0.2, xs.shape)
+    lin = e.linearize(way, np.zeros(B), xr, us)
+    O = Oracle(P)
+    for b in range(B):
+        for k in range(P.N):
+            d, dq = O.obstacle_rows(xr[b, k])
+            r = lin[b, k, 223:]
+            assert np.abs(r[:4] - d).max() < 1e-13 and np.abs(r[4:].reshape(4, 9) - dq).max() < 1e-12
+    # the rows decide the step: same iterate path as the oracle after 6 IPM iterations
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert stats[b, 1] == 6 == so.qp_iters_last
+        assert np.abs(dx[b] - dxo).max() < 1e-6 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 1e-6 * max(1, np.abs(duo).max())
+    # ... and they matter: without them the base drives into the obstacle's margin
+    P2, _, _, _, _ = _case(arrangements, B, 4, qp_tol=0.0, qp_iter_max=6)
+    e2 = Emu(P2, B)
+    dx2 = e2.qp(1, xs, us, x0, e2.linearize(way, np.zeros(B), xs, us))[0]
+    assert np.abs(dx2 - dx).max() > 1e-2
+    # line-search merit sees a violated row
+    xs_bad = xs.copy(); xs_bad[:, 5, 0] += 0.6          # base 0.6 m towards the obstacle at knot 5
+    lin_bad = e.linearize(way, np.zeros(B), xs_bad, us)
+    ws0 = np.zeros_like(ws); st0 = np.zeros_like(stats)
+    _, _, _ = e.linesearch(xs_bad, us, x0, np.zeros(B), way, lin_bad, ws0, st0)
+    for b in range(B):
+        P.way_p = way[b]
+        perf = Oracle(P).performance(0.0, x0[b], xs_bad[b], us[b])
+        assert perf[3] > 1e-3 and abs(st0[b, 5] - np.sqrt(perf[1] + perf[2] + perf[3])) < 1e-10

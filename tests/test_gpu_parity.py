@@ -589,3 +589,81 @@ def test_cpp_header_twin_matches_python_path(arrangements, tmp_path):
     assert np.array_equal(out["upol"], up.ravel())
     assert abs(out["Knorm2"][0] - np.sum(mpc.feedback_gains() ** 2)) < 1e-9 * out["Knorm2"][0]
     mpc.close()
+
+
+def _with_collision_model(P):
+    from upright_amd import robots
+
+    pairs = [("base_collision_link", "obs2"), ("wrist1_collision_link", "shoulder_collision_link"),
+             ("wrist1_collision_link", "base_collision_link"), ("balanced_object_collision_link", "obs3")]
+    cm = robots.collision_model(P.chain, pairs, spheres={"obs2": ("world", (0.0, 1.0, 0.25), 0.25), "obs3": ("world", (-0.3, 2.9, 0.9), 0.25)})
+    for k, v in cm.items():
+        setattr(P, k, v)
+    return P
+
+
+def test_collision_avoidance(arrangements):
+    """SURVEY 8f.1 (controller_interface.cpp:172-228,450-481): hard state inequality "obstacle_avoidance" over
+    named sphere pairs -- a world sphere right in front of the mobile base, two self-collision pairs
+    (obstacles/simple.yaml:37-41) and a tray-vs-obstacle pair.  (a) rows and their joint Jacobian through the C-ABI
+    against the oracle and finite differences; (b) the QP with these state-polytopic rows on the oracle's iterate
+    path; (c) SQP to convergence: the base gives way (the row is active, not violated) while the tray reaches the
+    target; without the rows the same solve drives the base into the obstacle's margin."""
+    from upright_amd.problem import THING_HOME
+
+    B = 3
+    P = _with_collision_model(thing_problem(arrangements["pink_bottle"], qp_tol=0.0, qp_iter_max=6))
+    rng = np.random.default_rng(8)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] += rng.uniform(-0.1, 0.1, B)
+    way = waypoints_for(P, x0, offset=(1.0, 0.0, 0.0))
+    mpc = BatchMPC(P, B, way_p=way)
+    O = Oracle(P)
+    # (a)
+    xr = level_tray_states(9, seed=2) + rng.uniform(-0.3, 0.3, (9, 27))
+    d, dq = mpc.obstacle_rows(xr)
+    for i in range(9):
+        do, dqo = O.obstacle_rows(xr[i])
+        assert np.abs(d[i] - do).max() < 1e-13 and np.abs(dq[i] - dqo).max() < 1e-12
+        eps = 1e-6
+        for j in (0, 2, 4, 7):
+            xp = xr[i].copy(); xp[j] += eps; xm = xr[i].copy(); xm[j] -= eps
+            fd = (mpc.obstacle_rows(np.stack([xp, xm]), jac=False)[0] - mpc.obstacle_rows(np.stack([xp, xm]), jac=False)[1]) / (2 * eps)
+            assert np.abs(fd - dq[i][:, j]).max() < 1e-7
+    # (b)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    assert np.all(mpc.stats()["qp_iters_last"] == 6)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert np.abs(dxs[b] - dxo).max() < 1e-4 * max(1, np.abs(dxo).max())
+        assert np.abs(dus[b][:, :9] - duo[:, :9]).max() < 1e-4 * max(1, np.abs(duo).max())
+    mpc.close()
+    # (c)
+    P = _with_collision_model(thing_problem(arrangements["pink_bottle"], sqp_iters=12))
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    Pn = thing_problem(arrangements["pink_bottle"], sqp_iters=12)
+    free = BatchMPC(Pn, B, way_p=way)
+    free.set_observation(0.0, x0)
+    free.advance()
+    _, xf, _ = free.solution()
+    for b in range(B):
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and st["qp_status_last"][b] == 0 and st["sqp_iters_done"][b] == so.sqp_iters_done
+        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b][:, :9] - uo[:, :9]).max() < 1e-3
+        rows = np.array([O.obstacle_rows(xs[b, k], jac=False) for k in range(1, P.N)])
+        rows_free = np.array([O.obstacle_rows(xf[b, k], jac=False) for k in range(1, P.N)])
+        assert rows.min() > -1e-6 and rows[:, 0].min() < 1e-5       # base row active, nothing violated
+        assert rows_free[:, 0].min() < -0.05                         # without the rows: 5 cm and more inside the margin
+        assert st["constraint_violation"][b] < 1e-3
+        p_end = O.ee_kinematics(xs[b, P.N])[:3]
+        assert np.abs(p_end - way[b, 0]).max() < 1e-6               # the tray still reaches the target
+    mpc.close(); free.close()

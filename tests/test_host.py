@@ -70,9 +70,24 @@ def test_problem_from_settings_and_unsupported_terms(arrangements):
     assert (P.nx, P.nu, P.N, P.nf, P.nb, P.nc) == (27, 21, 20, 3, 1, 4)
     assert np.all(P.u_lb[9:] == -100) and np.all(P.u_ub[9:] == 100) and np.all(P.Rdiag[9:] == 0.001)
     assert np.allclose(P.body_params[0], arrangements["pink_bottle"]["bodies"][0]["params"])
+    # obstacle avoidance: named sphere pairs (obstacles/simple.yaml:11-41) become the collision model
     s.obstacle_settings.enabled = True
-    with pytest.raises(RuntimeError, match="obstacle"):
+    s.obstacle_settings.minimum_distance = 0.1
+    for pair in (("wrist1_collision_link_0", "sphere1_top_link_0"), ("base_collision_link_0", "sphere2_bottom_link_0"),
+                 ("wrist1_collision_link_0", "shoulder_collision_link_0")):
+        s.obstacle_settings.collision_link_pairs.push_back(pair)
+    Po = control_bindings.problem_from_settings(s)
+    assert len(Po.pair_a) == 3 and len(Po.sph_r) == 5 and Po.obs_min_dist == 0.1
+    assert list(Po.sph_frame) == [6, -1, 2, -1, 4]        # wrist_1 link, world, base link, world, upper arm link
+    assert np.allclose(Po.sph_off[1], [0, 0.25, 0.75]) and np.allclose(Po.sph_r, [0.15, 0.25, 0.5, 0.25, 0.15])
+    s.obstacle_settings.collision_link_pairs.push_back(("no_such_link_0", "sphere1_top_link_0"))
+    with pytest.raises(RuntimeError, match="unknown collision object"):
         control_bindings.problem_from_settings(s)
+    s.obstacle_settings.collision_link_pairs.pop()
+    s.obstacle_settings.dynamic_obstacles.append(object())
+    with pytest.raises(RuntimeError, match="dynamic obstacles"):
+        control_bindings.problem_from_settings(s)
+    s.obstacle_settings.dynamic_obstacles.pop()
     s.obstacle_settings.enabled = False
     s.balancing_settings.enabled = False
     with pytest.raises(RuntimeError):

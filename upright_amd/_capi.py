@@ -13,7 +13,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "libupright_mi.so"
 
-MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU = 12, 32, 8, 8, 36, 108
+MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU, MAXS, MAXP = 12, 32, 8, 8, 36, 108, 16, 32
 NSTATS = 12
 STAT_NAMES = (
     "sqp_iters_done", "qp_iters_last", "qp_status_last", "step_alpha_last", "cost", "constraint_violation",
@@ -37,6 +37,8 @@ class UprProblem(C.Structure):
         ("sqp_iters", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", d), ("delta_tol", d), ("cost_tol", d),
         ("terminal_constraint", C.c_int),
         ("use_feedback_policy", C.c_int),
+        ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", (C.c_double * 3) * MAXS), ("sph_r", C.c_double * MAXS),
+        ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", C.c_double),
     ]
 
 
@@ -76,6 +78,14 @@ def problem_to_c(P):
     o.sqp_iters, o.qp_iter_max, o.qp_tol = int(P.sqp_iters), int(P.qp_iter_max), float(P.qp_tol)
     o.delta_tol, o.cost_tol, o.terminal_constraint = float(P.delta_tol), float(P.cost_tol), int(bool(P.terminal_constraint))
     o.use_feedback_policy = int(bool(getattr(P, "use_feedback_policy", False)))
+    ns, npair = len(P.sph_r), len(P.pair_a)
+    if ns > MAXS or npair > MAXP:
+        raise ValueError(f"collision model too large for libupright_mi ({ns} spheres / {npair} pairs; max {MAXS} / {MAXP})")
+    o.n_sph, o.n_pairs, o.obs_min_dist = ns, npair, float(P.obs_min_dist)
+    for i in range(ns):
+        o.sph_frame[i] = int(P.sph_frame[i]); o.sph_r[i] = float(P.sph_r[i]); _fill(o.sph_off[i], P.sph_off[i])
+    for i in range(npair):
+        o.pair_a[i], o.pair_b[i] = int(P.pair_a[i]), int(P.pair_b[i])
     return o
 
 
@@ -100,6 +110,7 @@ PROTOTYPES = [
     ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
     ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_linearize_points", C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    ("upr_batch_obstacle_rows", C.c_int, [C.c_void_p, C.c_int, dp, dp, dp]),
     ("upr_batch_eq_input_jacobian", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("upr_batch_qp_step", C.c_int, [C.c_void_p, dp, dp]),
     ("upr_batch_device_ptrs", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -148,7 +148,18 @@ class ControllerSettings(bindings.ControllerSettings):
         ia = config["inertial_alignment"]
         self.inertial_alignment_settings.cost_enabled = ia["cost_enabled"]
         self.inertial_alignment_settings.constraint_enabled = ia["constraint_enabled"]
-        self.obstacle_settings.enabled = config["obstacles"]["enabled"]
+        # wrappers.py:347-376
+        obs = config["obstacles"]
+        self.obstacle_settings.enabled = obs["enabled"]
+        if self.obstacle_settings.enabled:
+            for pair in obs.get("collision_pairs") or []:
+                self.obstacle_settings.collision_link_pairs.push_back(tuple(pair))
+            self.obstacle_settings.minimum_distance = obs["minimum_distance"]
+            # obstacle geometry: the reference compiles obstacles.urdf from xacro includes; here the include names
+            # select the sphere table (upright_amd/robots.py documents the numbers and their xacro provenance)
+            self.obstacle_settings.obstacle_urdf_path = ";".join((obs.get("urdf") or {}).get("includes", []))
+            if obs.get("dynamic"):
+                self.dims.o = len(obs["dynamic"])
         if x0 is None:
             x0 = pa(config["robot"]["x0"])
             assert x0.shape == (self.dims.robot.x,)

@@ -232,8 +232,8 @@ class VectorFunctionLinearApproximation:
 def problem_from_settings(s):
     """ControllerSettings -> Problem (what ControllerInterface's constructor assembles,
     controller_interface.cpp:103-393).  Raises RuntimeError for OCP terms outside the accelerated path."""
-    if s.obstacle_settings.enabled:
-        raise RuntimeError("obstacle avoidance is not supported by the MI355X engine yet (SURVEY.md 8f.1)")
+    if s.obstacle_settings.enabled and len(s.obstacle_settings.dynamic_obstacles) > 0:
+        raise RuntimeError("dynamic obstacles are not supported by the MI355X engine yet (SURVEY.md 8f.2)")
     if s.projectile_path_constraint_enabled:
         raise RuntimeError("projectile path constraint is not supported by the MI355X engine yet (SURVEY.md 8f.2)")
     if s.inertial_alignment_settings.cost_enabled or s.inertial_alignment_settings.constraint_enabled:
@@ -291,6 +291,15 @@ def problem_from_settings(s):
         sqp_iters=int(s.sqp.sqp_iteration), qp_iter_max=int(s.sqp.hpipm.iter_max), use_feedback_policy=bool(s.sqp.use_feedback_policy),
         delta_tol=float(s.sqp.delta_tol), cost_tol=float(s.sqp.cost_tol), **tables,
     )
+    if s.obstacle_settings.enabled:
+        # controller_interface.cpp:172-228,450-481: sphere pairs by name, hard state inequality "obstacle_avoidance"
+        try:
+            cm = robots.collision_model(chain, [tuple(p) for p in s.obstacle_settings.collision_link_pairs])
+        except ValueError as e:
+            raise RuntimeError(str(e))
+        for k, v in cm.items():
+            setattr(P, k, v)
+        P.obs_min_dist = float(s.obstacle_settings.minimum_distance)
     return P.validate()
 
 
@@ -375,6 +384,10 @@ class ControllerInterface:
         return self._lin(t, x, u)["g"][0]
 
     def getStateInputInequalityConstraintValue(self, name, t, x, u):
+        if name == "obstacle_avoidance" and len(self.problem.pair_a) > 0:
+            if self._mpc is None:
+                self._mpc = BatchMPC(self.problem, 1)
+            return self._mpc.obstacle_rows(np.asarray(x, dtype=np.float64), jac=False)[0]
         if name != "contact_forces" or self.problem.nf != 3:
             raise RuntimeError(f"no inequality constraint named '{name}'")
         from .engine import core_friction_rows

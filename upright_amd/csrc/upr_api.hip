@@ -227,6 +227,11 @@ int check_problem(const upr_problem* P) {
     if (!(P->dt > 0)) return fail("dt must be positive");
     if (P->n_way < 1 || P->n_way > UPR_MAX_WAYPOINTS) return fail("n_way out of range");
     if (P->Wee[3] != 0 || P->Wee[4] != 0 || P->Wee[5] != 0) return fail("end-effector orientation weights are not supported");
+    if (P->n_sph < 0 || P->n_sph > UPR_MAX_SPHERES) return fail("n_sph out of range");
+    if (P->n_pairs < 0 || P->n_pairs > UPR_MAX_PAIRS) return fail("n_pairs out of range");
+    for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -1 || P->sph_frame[i] > P->nq) return fail("sph_frame out of range");
+    for (int i = 0; i < P->n_pairs; ++i)
+        if (P->pair_a[i] < 0 || P->pair_a[i] >= P->n_sph || P->pair_b[i] < 0 || P->pair_b[i] >= P->n_sph || P->pair_a[i] == P->pair_b[i]) return fail("collision pair out of range");
     for (int i = 0; i < P->nc; ++i) {
         if (P->contact_body2[i] < 0 || P->contact_body2[i] >= P->nb) return fail("contact_body2 must index a balanced body");
         if (P->contact_body1[i] >= P->nb) return fail("contact_body1 out of range");
@@ -244,7 +249,8 @@ int need_device() {
 template <int NQ>
 int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     const int blocks = (A.npoints + 7) / 8;
-    const size_t lds = (size_t)8 * upr_lin_lds_doubles(A.d) * sizeof(double);
+    const size_t lds = (size_t)8 * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double);
+    if (lds > 64 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
     if (h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true>), dim3(blocks), dim3(256), lds, h->stream, A);
     else hipLaunchKernelGGL((upr_linearize_kernel<NQ, false>), dim3(blocks), dim3(256), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
@@ -480,8 +486,9 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     h->P = *P; h->d = upr_make_dims(P); h->B = B;
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
-    h->use_qp3 = qp3_has_shape(*P);
-    h->use_qp2 = qp2_has_shape(*P);
+    // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
+    h->use_qp3 = qp3_has_shape(*P) && P->n_pairs == 0;
+    h->use_qp2 = qp2_has_shape(*P) && P->n_pairs == 0;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
     if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }
@@ -655,10 +662,9 @@ int upr_batch_get_stats(upr_batch* h, double* stats) {
     return 0;
 }
 
-int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
-                               double* g, double* gx, double* cost, double* grad, double* hess, double* ee) {
-    if (!h) return fail("null batch");
-    if (n <= 0) return 0;
+// points mode of the linearisation kernel: records of n arbitrary (x, u) pairs back on the host
+static int linearize_points_impl(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
+                                 std::vector<double>& rec, double* ee) {
     const upr_dims& d = h->d;
     for (int i = 0; i < n; ++i) if (inst[i] < 0 || inst[i] >= h->B) return fail("instance index out of range");
     int* dinst = nullptr; double *dt_, *dx, *du, *dlin, *dee;
@@ -673,9 +679,20 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
     A.lin = dlin; A.ee_out = dee; A.npoints = n;
     if (do_linearize(h, A)) return 1;
     UPR_HIP(hipStreamSynchronize(h->stream));
-    std::vector<double> rec((size_t)n * d.lin_stride);
+    rec.assign((size_t)n * d.lin_stride, 0.0);
     UPR_HIP(hipMemcpy(rec.data(), dlin, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
     if (ee) UPR_HIP(hipMemcpy(ee, dee, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
+    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee);
+    return 0;
+}
+
+int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
+                               double* g, double* gx, double* cost, double* grad, double* hess, double* ee) {
+    if (!h) return fail("null batch");
+    if (n <= 0) return 0;
+    const upr_dims& d = h->d;
+    std::vector<double> rec;
+    if (linearize_points_impl(h, n, inst, t, x, u, rec, ee)) return 1;
     for (int i = 0; i < n; ++i) {
         const double* r = rec.data() + (size_t)i * d.lin_stride;
         if (g) std::memcpy(g + (size_t)i * d.ne, r + d.lin_g, sizeof(double) * d.ne);
@@ -684,7 +701,22 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
         if (grad) std::memcpy(grad + (size_t)i * d.nq, r + d.lin_grad, sizeof(double) * d.nq);
         if (hess) for (int a = 0; a < d.nq; ++a) for (int c = 0; c < d.nq; ++c) hess[((size_t)i * d.nq + a) * d.nq + c] = r[d.lin_hess + upr_tri(d.nq, a, c)];
     }
-    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee);
+    return 0;
+}
+
+int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* dd, double* dq) {
+    if (!h) return fail("null batch");
+    const upr_dims& d = h->d;
+    if (d.no == 0) return fail("upr_batch_obstacle_rows: the problem has no collision pairs");
+    if (n <= 0) return 0;
+    std::vector<int> inst(n, 0);
+    std::vector<double> t(n, 0.0), u((size_t)n * d.nu, 0.0), rec;
+    if (linearize_points_impl(h, n, inst.data(), t.data(), x, u.data(), rec, nullptr)) return 1;
+    for (int i = 0; i < n; ++i) {
+        const double* r = rec.data() + (size_t)i * d.lin_stride + d.lin_obs;
+        std::memcpy(dd + (size_t)i * d.no, r, sizeof(double) * d.no);
+        if (dq) std::memcpy(dq + (size_t)i * d.no * d.nq, r + d.no, sizeof(double) * d.no * d.nq);
+    }
     return 0;
 }
 

@@ -73,9 +73,9 @@ static inline UPR_HD double upr_rsqrt(double x) {
 
 // derived dimensions
 struct upr_dims {
-    int nq, nb, nc, nf, N, nx, nu, nfc, ne, np, neN;
+    int nq, nb, nc, nf, N, nx, nu, nfc, ne, np, neN, no;   // no: collision pairs (state rows at knots 1..N-1)
     // per-knot linearisation record (doubles): [g ne][gx ne*nx][cost 1][grad nq][hess nq(nq+1)/2]
-    int lin_g, lin_gx, lin_cost, lin_grad, lin_hess, lin_stride;
+    int lin_g, lin_gx, lin_cost, lin_grad, lin_hess, lin_obs, lin_stride;   // lin_obs: [d no][dd/dq no*nq]
     // inequality layout per stage: [x lo nx][x hi nx] (k >= 1) [u lo nu][u hi nu][poly np] (k < N)
     int ni_stage;   // 2nx + 2nu + np  (slot size; stage 0 leaves the x part unused, stage N the u part)
     // Riccati stage store (doubles)
@@ -91,8 +91,9 @@ static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
     d.ne = 6 * P->nb; d.np = (P->nf == 3) ? 5 * P->nc : 0;
     d.neN = P->terminal_constraint ? 3 + 2 * P->nq : 0;
     d.lin_g = 0; d.lin_gx = d.ne; d.lin_cost = d.lin_gx + d.ne * d.nx; d.lin_grad = d.lin_cost + 1;
-    d.lin_hess = d.lin_grad + d.nq; d.lin_stride = d.lin_hess + d.nq * (d.nq + 1) / 2;
-    d.ni_stage = 2 * d.nx + 2 * d.nu + d.np;
+    d.no = P->n_pairs;
+    d.lin_hess = d.lin_grad + d.nq; d.lin_obs = d.lin_hess + d.nq * (d.nq + 1) / 2; d.lin_stride = d.lin_obs + d.no * (1 + d.nq);
+    d.ni_stage = 2 * d.nx + 2 * d.nu + d.np + d.no;
     d.ss_kx = 0; d.ss_hjj = d.ss_kx + d.nq * d.nx; d.ss_hff = d.ss_hjj + d.nq * d.nq;
     d.ss_sinv = d.ss_hff + ((d.nf == 3) ? 9 * d.nc : d.nc);
     d.ss_ku0 = d.ss_sinv + d.ne * d.ne; d.ss_uf0 = d.ss_ku0 + d.nq; d.ss_snu = d.ss_uf0 + d.nfc;

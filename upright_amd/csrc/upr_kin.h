@@ -129,6 +129,69 @@ static inline UPR_HD void upr_ee_kinematics(const upr_problem* P, const double* 
     upr_rmul_const(E.C, P->tool_R);
 }
 
+// Centres of the collision spheres (controller_interface.cpp:172-228: the spheres of
+// upright_assets/thing/xacro/collision_links.urdf.xacro ride on chain links, obstacle spheres are fixed in the
+// world): the same chain walk, positions only.  `put(s, c)` receives sphere s and its centre c[3].
+template <class T, int NQ, class F>
+static inline UPR_HD void upr_sphere_walk(const upr_problem* P, const double* x, int dir, F put) {
+    T* tag = nullptr;
+    T R[9], o[3];
+    for (int i = 0; i < 9; ++i) R[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
+    for (int i = 0; i < 3; ++i) o[i] = upr_lift(0.0, tag);
+    const int ns = P->n_sph;
+    auto place = [&](int frame) {
+        for (int s = 0; s < ns; ++s) if (P->sph_frame[s] == frame) {
+            T c[3];
+            upr_rot_const(R, P->sph_off[s], c);
+            for (int i = 0; i < 3; ++i) c[i] = c[i] + o[i];
+            put(s, c);
+        }
+    };
+    place(-1);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        T q = upr_seed(x[j], dir == j, tag);
+        T r[3];
+        upr_rot_const(R, P->joint_p[j], r);
+        for (int i = 0; i < 3; ++i) o[i] = o[i] + r[i];
+        upr_rmul_const(R, P->joint_R[j]);
+        if (P->joint_type[j] == 1) {
+            const double* ax = P->joint_axis[j];
+            T s, c;
+            upr_sincos(q, &s, &c);
+            T omc = upr_lift(1.0, tag) - c;
+            T M[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) M[3 * a + b] = (ax[a] * ax[b]) * omc + ((a == b) ? c : upr_lift(0.0, tag));
+            M[1] = M[1] - ax[2] * s; M[2] = M[2] + ax[1] * s;
+            M[3] = M[3] + ax[2] * s; M[5] = M[5] - ax[0] * s;
+            M[6] = M[6] - ax[1] * s; M[7] = M[7] + ax[0] * s;
+            upr_rmul(R, M);
+        } else {
+            T z[3];
+            upr_rot_const(R, P->joint_axis[j], z);
+            for (int i = 0; i < 3; ++i) o[i] = o[i] + z[i] * q;
+        }
+        place(j);
+    }
+    T r[3];
+    upr_rot_const(R, P->tool_p, r);
+    for (int i = 0; i < 3; ++i) o[i] = o[i] + r[i];
+    upr_rmul_const(R, P->tool_R);
+    place(NQ);
+}
+// values of the collision rows at a configuration (line search): d[n_pairs]
+template <int NQ>
+static inline UPR_HD void upr_obstacle_values(const upr_problem* P, const double* x, double* d) {
+    double c[UPR_MAX_SPHERES][3];
+    upr_sphere_walk<double, NQ>(P, x, -1, [&](int s, const double* cs) { c[s][0] = cs[0]; c[s][1] = cs[1]; c[s][2] = cs[2]; });
+    for (int r = 0; r < P->n_pairs; ++r) {
+        const int a = P->pair_a[r], b = P->pair_b[r];
+        const double e0 = c[a][0] - c[b][0], e1 = c[a][1] - c[b][1], e2 = c[a][2] - c[b][2];
+        d[r] = sqrt(e0 * e0 + e1 * e1 + e2 * e2) - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+    }
+}
+
 // Object-dynamics residual of body b (contact_constraints.h:80-102), unnormalised, given the summed
 // contact wrench (F, Tq) on the body (plain values: the wrench does not depend on the state).
 // bp = the body's 10 inertial parameters (rigid_body.h:36-51).

@@ -19,8 +19,9 @@
 
 #define UPR_LPK 32
 
-// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[3 nq] e[3]
-static inline UPR_HD int upr_lin_lds_doubles(const upr_dims& d) { return d.nx + d.nu + 6 * d.nb + 3 * d.nq + 3 + 1; }
+// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[3 nq] e[3] | sphere centres and their q-tangents [ns][3][1 + nq]
+static inline UPR_HD int upr_lin_lds_base(const upr_dims& d) { return (d.nx + d.nu + 6 * d.nb + 3 * d.nq + 3 + 1 + 1) & ~1; }
+static inline UPR_HD int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
 
 struct upr_lin_args {
     const upr_problem* P;
@@ -113,6 +114,40 @@ static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_po
     }
 }
 
+// collision rows (only when the problem has pairs), two sub-phases around a barrier:
+//   a: lane l < nq walks the chain with the tangent along q_l and leaves every sphere centre's tangent in LDS
+//      (lane 0 also the values);  b: lane r owns pair r: distance and its gradient n . (dc_a/dq - dc_b/dq)
+template <int NQ>
+static inline UPR_HD void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+    const upr_problem* P = A.P;
+    double* sc = sh + upr_lin_lds_base(A.d);
+    if (q.terminal || lane >= NQ) return;
+    upr_sphere_walk<upr_dd, NQ>(P, sh, lane, [&](int s, const upr_dd* c) {
+        for (int i = 0; i < 3; ++i) {
+            sc[(s * 3 + i) * (1 + NQ) + 1 + lane] = c[i].d;
+            if (lane == 0) sc[(s * 3 + i) * (1 + NQ)] = c[i].v;
+        }
+    });
+}
+template <int NQ>
+static inline UPR_HD void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
+    const upr_problem* P = A.P; const upr_dims& d = A.d;
+    const double* sc = sh + upr_lin_lds_base(d);
+    if (q.terminal) return;
+    for (int r = lane; r < d.no; r += UPR_LPK) {
+        const int a = P->pair_a[r], b = P->pair_b[r];
+        double e[3];
+        for (int i = 0; i < 3; ++i) e[i] = sc[(a * 3 + i) * (1 + NQ)] - sc[(b * 3 + i) * (1 + NQ)];
+        const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        q.out[d.lin_obs + r] = dist - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+        for (int j = 0; j < NQ; ++j) {
+            double v = 0.0;
+            for (int i = 0; i < 3; ++i) v += e[i] * (sc[(a * 3 + i) * (1 + NQ) + 1 + j] - sc[(b * 3 + i) * (1 + NQ) + 1 + j]);
+            q.out[d.lin_obs + d.no + r * NQ + j] = v / dist;
+        }
+    }
+}
+
 // phase 2 (VALU path): gradient, Gauss-Newton Hessian, cost from the LDS-staged position Jacobian
 template <int NQ>
 static inline UPR_HD void upr_lin_phase2(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
@@ -144,7 +179,7 @@ static inline UPR_HD void upr_lin_phase2(const upr_lin_args& A, const upr_lin_po
 template <int NQ, bool USE_MFMA>
 __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int per = upr_lin_lds_doubles(A.d);
+    const int per = upr_lin_lds_doubles(A.d, A.P->n_sph);
     const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int p = blockIdx.x * 8 + sub;
     const bool live = p < A.npoints;
@@ -155,6 +190,11 @@ __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
     if (live) upr_lin_phase0b(A, q, lane, sh);
     __syncthreads();
     if (live) upr_lin_phase1<NQ>(A, q, lane, sh);
+    if (A.d.no > 0) {
+        if (live) upr_lin_phase_obs_a<NQ>(A, q, lane, sh);
+        __syncthreads();
+        if (live) upr_lin_phase_obs_b<NQ>(A, q, lane, sh);
+    }
     __syncthreads();
     if (!USE_MFMA) {
         if (live) upr_lin_phase2<NQ>(A, q, lane, sh);

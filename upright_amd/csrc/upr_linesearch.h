@@ -44,6 +44,11 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
         double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
         iq += wt * v * v;
     }
+    if (d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1)
+        double dd[UPR_MAX_PAIRS];
+        upr_obstacle_values<NQ>(P, X, dd);
+        for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, dd[r]); iq += h * v * v; }
+    }
     upr_ee<double> E;
     upr_ee_kinematics<double, NQ>(P, X, -1, E);
     double pd[3];

@@ -54,7 +54,7 @@ struct upr_qp_args {
 struct upr_qp_lds {
     int Pm, Tm, Kx, Hjj, Lji, Cm, SC, Df, Yf, Sm, Lsi, Hff;
     int pv, wv, hx, bk, Xk, Xn, Uk, dxk, duk, sxk, suk, huj, huf, ku0, uf0, ee, snu, nuv, gxs, gus, Wx, Wu;
-    int tk, lk, sv, wq, gjr, gjc, grad, hess, red, misc, total;
+    int tk, lk, sv, wq, gjr, gjc, grad, hess, ob, hob, red, misc, total;   // ob: collision rows [d no][J no*nq]; hob: their barrier Hessian (packed)
 };
 static inline UPR_HD upr_qp_lds upr_qp_lds_layout(const upr_dims& d, int nt) {
     upr_qp_lds L; int o = 0;
@@ -70,6 +70,7 @@ static inline UPR_HD upr_qp_lds upr_qp_lds_layout(const upr_dims& d, int nt) {
     L.tk = take(d.ni_stage); L.lk = take(d.ni_stage); L.sv = take(d.ni_stage); L.wq = take(d.ni_stage);
     int gm = d.nq > d.ne ? d.nq : d.ne;
     L.gjr = take(gm); L.gjc = take(gm); L.grad = take(d.nq); L.hess = take(d.nq * (d.nq + 1) / 2 > 3 * d.nq ? d.nq * (d.nq + 1) / 2 : 3 * d.nq);
+    L.ob = take(d.no * (1 + d.nq)); L.hob = take(d.no > 0 ? d.nq * (d.nq + 1) / 2 : 0);
     L.red = take(nt); L.misc = take(16);
     L.total = o;
     return L;
@@ -161,13 +162,16 @@ static inline UPR_HD double upr_Bt_vec_j(int nq, double h, const double* w, int 
 }
 
 // ---- inequality bookkeeping ------------------------------------------------------------------------
-// slot j of stage k: is it a live inequality?
+// slot j of stage k: is it a live inequality?   Slot layout: [x lo nx][x hi nx][u lo nu][u hi nu][friction np][collision no]
 static inline UPR_HD bool upr_ineq_active(const upr_dims& d, int k, int j) {
     if (j < 2 * d.nx) return k >= 1;
+    if (j >= 2 * d.nx + 2 * d.nu + d.np) return k >= 1 && k < d.N;   // collision rows: knots 1..N-1
     return k < d.N;
 }
-// value c_j at absolute (X, U)
-static inline UPR_HD double upr_ineq_value(const upr_problem* P, const upr_dims& d, int j, const double* X, const double* U) {
+// value c_j at absolute (X, U); collision rows are linear in the step from the linearisation point:
+// ob = [d no][J no*nq] of this knot, dxq = dx_k[0:nq]
+static inline UPR_HD double upr_ineq_value(const upr_problem* P, const upr_dims& d, int j, const double* X, const double* U,
+                                           const double* ob, const double* dxq) {
     if (j < d.nx) return X[j] - P->x_lb[j];
     j -= d.nx;
     if (j < d.nx) return P->x_ub[j] - X[j];
@@ -176,14 +180,20 @@ static inline UPR_HD double upr_ineq_value(const upr_problem* P, const upr_dims&
     j -= d.nu;
     if (j < d.nu) return P->u_ub[j] - U[j];
     j -= d.nu;
-    int ci = j / 5, r = j % 5;
-    double e[3];
-    upr_friction_row_jac(P, ci, r, e);
-    const double* f = U + d.nq + 3 * ci;
-    return e[0] * f[0] + e[1] * f[1] + e[2] * f[2];
+    if (j < d.np) {
+        int ci = j / 5, r = j % 5;
+        double e[3];
+        upr_friction_row_jac(P, ci, r, e);
+        const double* f = U + d.nq + 3 * ci;
+        return e[0] * f[0] + e[1] * f[1] + e[2] * f[2];
+    }
+    j -= d.np;
+    double v = ob[j];
+    for (int i = 0; i < d.nq; ++i) v += ob[d.no + j * d.nq + i] * dxq[i];
+    return v;
 }
 // G_j . (sx, su)
-static inline UPR_HD double upr_ineq_dir(const upr_problem* P, const upr_dims& d, int j, const double* sx, const double* su) {
+static inline UPR_HD double upr_ineq_dir(const upr_problem* P, const upr_dims& d, int j, const double* sx, const double* su, const double* ob) {
     if (j < d.nx) return sx[j];
     j -= d.nx;
     if (j < d.nx) return -sx[j];
@@ -192,11 +202,17 @@ static inline UPR_HD double upr_ineq_dir(const upr_problem* P, const upr_dims& d
     j -= d.nu;
     if (j < d.nu) return -su[j];
     j -= d.nu;
-    int ci = j / 5, r = j % 5;
-    double e[3];
-    upr_friction_row_jac(P, ci, r, e);
-    const double* f = su + d.nq + 3 * ci;
-    return e[0] * f[0] + e[1] * f[1] + e[2] * f[2];
+    if (j < d.np) {
+        int ci = j / 5, r = j % 5;
+        double e[3];
+        upr_friction_row_jac(P, ci, r, e);
+        const double* f = su + d.nq + 3 * ci;
+        return e[0] * f[0] + e[1] * f[1] + e[2] * f[2];
+    }
+    j -= d.np;
+    double v = 0.0;
+    for (int i = 0; i < d.nq; ++i) v += ob[d.no + j * d.nq + i] * sx[i];
+    return v;
 }
 
 struct upr_qp_state {
@@ -235,6 +251,7 @@ static inline UPR_HD void upr_qp_load_stage(upr_qp_state& S, int k) {
         UPR_FOR(i, d.ne * d.nx) L[o.Cm + i] = rec[d.lin_gx + i];
         UPR_FOR(i, d.ne) L[o.ee + i] = rec[d.lin_g + i];
     }
+    if (d.no > 0 && k >= 1 && k < d.N) UPR_FOR(i, d.no * (1 + d.nq)) L[o.ob + i] = rec[d.lin_obs + i];
     UPR_FOR(i, d.nq) L[o.grad + i] = rec[d.lin_grad + i];
     {
         int nh = (k < d.N) ? d.nq * (d.nq + 1) / 2 : 3 * d.nq;
@@ -258,7 +275,7 @@ static inline UPR_HD void upr_qp_assemble(upr_qp_state& S, int k) {
         double s = 0.0, w = 0.0;
         if (upr_ineq_active(d, k, j)) {
             double t = L[o.tk + j], lam = L[o.lk + j];
-            double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk);
+            double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
             double rp = c - t;
             w = lam / t;
             if (S.mode == 0) s = w * rp;                       // predictor: rc = lam t
@@ -266,7 +283,7 @@ static inline UPR_HD void upr_qp_assemble(upr_qp_state& S, int k) {
             else {
                 double rc;
                 if (S.mode == 1) {                             // corrector: build and keep the target
-                    double dta = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk) + rp;
+                    double dta = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob) + rp;
                     double dla = -lam - w * dta;
                     rc = lam * t + dta * dla - S.sigma_mu;
                     rcg[j] = rc;
@@ -289,8 +306,23 @@ static inline UPR_HD void upr_qp_assemble(upr_qp_state& S, int k) {
             }
             g *= h;
         }
+        if (d.no > 0 && i < d.nq && k >= 1 && k < d.N) {
+            const int oc = 2 * d.nx + 2 * d.nu + d.np;
+            for (int r = 0; r < d.no; ++r) g += L[o.ob + d.no + r * d.nq + i] * L[o.sv + oc + r];
+        }
         L[o.gxs + i] = g + L[o.sv + ox + i] - L[o.sv + ox + d.nx + i];
         L[o.Wx + i] = L[o.wq + ox + i] + L[o.wq + ox + d.nx + i];
+    }
+    if (d.no > 0) UPR_FOR(e, d.nq * (d.nq + 1) / 2) {   // barrier Hessian of the collision rows: sum_r w_r J_r J_r'
+        double v = 0.0;
+        if (k >= 1 && k < d.N) {
+            int i = 0, rem = e;
+            while (rem >= d.nq - i) { rem -= d.nq - i; ++i; }
+            const int j = i + rem;   // upr_tri(nq, i, j) == e for i <= j
+            const int oc = 2 * d.nx + 2 * d.nu + d.np;
+            for (int r = 0; r < d.no; ++r) v += L[o.wq + oc + r] * L[o.ob + d.no + r * d.nq + i] * L[o.ob + d.no + r * d.nq + j];
+        }
+        L[o.hob + e] = v;
     }
     if (k < d.N) {
         UPR_FOR(i, d.nu) {
@@ -419,7 +451,7 @@ static inline UPR_HD void upr_qp_backward(upr_qp_state& S, bool mat) {
                 int i = e / nx, j = e % nx;
                 double v = 0.0;
                 if (i == j) v += h * P->Qdiag[i] + L[o.Wx + i];
-                if (i < nq && j < nq) v += h * L[o.hess + upr_tri(nq, i, j)];
+                if (i < nq && j < nq) { v += h * L[o.hess + upr_tri(nq, i, j)]; if (d.no > 0) v += L[o.hob + upr_tri(nq, i, j)]; }
                 L[o.Pm + e] += v;
             }
             UPR_SYNC();
@@ -688,7 +720,7 @@ static inline UPR_HD void upr_qp_costates(upr_qp_state& S, const double* nu_new,
         UPR_SYNC();
         UPR_FOR(i, nx) {
             double v = L[o.hx + i] + L[o.gxs + i] + (h * P->Qdiag[i] + L[o.Wx + i]) * L[o.sxk + i];
-            if (i < nq) for (int j = 0; j < nq; ++j) v += h * L[o.hess + upr_tri(nq, i, j)] * L[o.sxk + j];
+            if (i < nq) for (int j = 0; j < nq; ++j) v += (h * L[o.hess + upr_tri(nq, i, j)] + (d.no > 0 ? L[o.hob + upr_tri(nq, i, j)] : 0.0)) * L[o.sxk + j];
             for (int r = 0; r < ne; ++r) v += L[o.Cm + r * nx + i] * L[o.snu + r];
             L[o.wv + i] = v;
         }
@@ -713,6 +745,11 @@ static inline UPR_HD double upr_qp_ineq_sweep(upr_qp_state& S, int what, double 
     for (int k = 0; k <= d.N; ++k) {
         UPR_FOR(i, d.nx) { L[o.Xk + i] = S.xs[k * d.nx + i] + dx[k * d.nx + i]; L[o.sxk + i] = sx[k * d.nx + i]; }
         if (k < d.N) UPR_FOR(i, d.nu) { L[o.Uk + i] = S.us[k * d.nu + i] + du[k * d.nu + i]; L[o.suk + i] = su[k * d.nu + i]; }
+        if (d.no > 0 && k >= 1 && k < d.N) {
+            const double* rec = S.lin + (size_t)k * d.lin_stride;
+            UPR_FOR(i, d.no * (1 + d.nq)) L[o.ob + i] = rec[d.lin_obs + i];
+            UPR_FOR(i, d.nq) L[o.dxk + i] = dx[k * d.nx + i];
+        }
         UPR_SYNC();
         double* t = S.ws + d.ws_t + (size_t)k * d.ni_stage;
         double* lam = S.ws + d.ws_lam + (size_t)k * d.ni_stage;
@@ -720,10 +757,10 @@ static inline UPR_HD double upr_qp_ineq_sweep(upr_qp_state& S, int what, double 
         UPR_FOR(j, d.ni_stage) {
             if (!upr_ineq_active(d, k, j)) continue;
             double tj = t[j], lj = lam[j];
-            double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk);
+            double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
             double rp = c - tj;
             if (what == 3) { double a = fabs(rp); if (a > acc) acc = a; *aux += lj * tj; continue; }
-            double dt = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk) + rp;
+            double dt = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob) + rp;
             double rc = (S.mode == 0) ? lj * tj : rcg[j];
             double dl = -(rc + lj * dt) / tj;
             if (what == 0) {
@@ -823,11 +860,16 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
     for (int k = 0; k <= N; ++k) {
         UPR_FOR(i, nx) L[o.Xk + i] = S.xs[k * nx + i] + ws[d.ws_dx + k * nx + i];
         if (k < N) UPR_FOR(i, nu) L[o.Uk + i] = S.us[k * nu + i];
+        if (d.no > 0 && k >= 1 && k < N) {
+            const double* rec = S.lin + (size_t)k * d.lin_stride;
+            UPR_FOR(i, d.no * (1 + d.nq)) L[o.ob + i] = rec[d.lin_obs + i];
+            UPR_FOR(i, d.nq) L[o.dxk + i] = ws[d.ws_dx + k * nx + i];
+        }
         UPR_SYNC();
         UPR_FOR(j, d.ni_stage) {
             double t = 1.0, lam = 0.0;
             if (upr_ineq_active(d, k, j)) {
-                double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk);
+                double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
                 t = c > UPR_QP_THR ? c : UPR_QP_THR;
                 lam = UPR_QP_MU0 / t;
             }
@@ -835,7 +877,7 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
         }
         UPR_SYNC();
     }
-    const int ntot = N * (2 * nu + d.np) + N * 2 * nx;
+    const int ntot = N * (2 * nu + d.np) + N * 2 * nx + (N - 1) * d.no;
     double* pi_new = ws + d.ws_pin; double* nu_new = ws + d.ws_nun; double* dyN = ws + d.ws_dyN;
     double res[4] = {0, 0, 0, 0};
     int it = 0, status = 1;

@@ -117,6 +117,14 @@ class BatchMPC:
             ptr(out["grad"]), ptr(out["hess"]), ptr(out["ee"])))
         return out
 
+    def obstacle_rows(self, x, jac=True):
+        """Collision rows d (n, n_pairs) and d d / d q (n, n_pairs, nq) at n states (`obstacle_avoidance`)."""
+        x = cont(x).reshape(-1, self.nx)
+        n, npair, nq = x.shape[0], len(self.problem.pair_a), self.problem.nq
+        d = np.zeros((n, npair)); dq = np.zeros((n, npair, nq))
+        check(self._lib.upr_batch_obstacle_rows(self._h, n, ptr(x), ptr(d), ptr(dq) if jac else None))
+        return (d, dq) if jac else d
+
     def eq_input_jacobian(self, inst=0):
         gu = np.zeros((self.ne, self.nu))
         check(self._lib.upr_batch_eq_input_jacobian(self._h, int(inst), ptr(gu)))

@@ -47,6 +47,14 @@ class Problem:
     cost_tol: float = 1e-4
     terminal_constraint: bool = True
     use_feedback_policy: bool = False  # sqp.use_feedback_policy (controller.yaml:60)
+    # collision avoidance (controller_interface.cpp:172-228): spheres on chain frames (-1 world, i < nq link after
+    # joint i, nq tool frame) and the pairs kept obs_min_dist apart at knots 1..N-1
+    sph_frame: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    sph_off: np.ndarray = field(default_factory=lambda: np.zeros((0, 3)))
+    sph_r: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    pair_a: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    pair_b: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    obs_min_dist: float = 0.1  # controller.yaml:108
 
     @property
     def nq(self):

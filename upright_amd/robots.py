@@ -89,6 +89,7 @@ class Chain:
     tool_R: np.ndarray
     tool_p: np.ndarray
     name: str = ""
+    base_pose: tuple = None   # (x, y, yaw) of the locked base of the fixed-base arm
 
     @property
     def nq(self):
@@ -175,7 +176,7 @@ def ur10(base_pose=(-1.0, 1.0, 0.0), calibration=None):
     pb = np.array([base_pose[0], base_pose[1], 0.0])
     R0, p0 = _compose(Rb, pb, *_arm_mount(calibration))
     tR, tp = _tool(calibration)
-    return Chain(_ur10_joints(R0, p0), tR, tp, "ur10")
+    return Chain(_ur10_joints(R0, p0), tR, tp, "ur10", tuple(float(v) for v in base_pose))
 
 
 def from_config(robot_config):
@@ -192,3 +193,89 @@ def from_config(robot_config):
     if chain.nq != nq:
         raise ValueError(f"robot dims.q = {nq} does not match the {chain.name} chain ({chain.nq} joints)")
     return chain
+
+
+# ---- collision model ------------------------------------------------------------------------------------------------
+# Collision spheres of the Thing (upright_assets/thing/xacro/collision_links.urdf.xacro:32-181): name ->
+# (parent link, offset of the sphere centre in the parent link frame, radius).  Only translations matter for spheres.
+COLLISION_SPHERES = {
+    "balanced_object_collision_link": ("gripped_object", (0.0, 0.0, 0.07), 0.25),
+    "shoulder_collision_link": ("ur10_arm_upper_arm_link", (0.0, 0.0, 0.0), 0.15),
+    "wrist1_collision_link": ("ur10_arm_wrist_1_link", (0.0, 0.0, -0.05), 0.15),
+    "wrist3_collision_link": ("ur10_arm_wrist_3_link", (0.0, 0.0, 0.0), 0.15),
+    "base_collision_link": ("base_link", (0.0, 0.0, 0.0), 0.5),
+    "forearm_collision_sphere_link1": ("ur10_arm_forearm_link", (-0.2, 0.0, 0.06), 0.15),
+    "forearm_collision_sphere_link2": ("ur10_arm_forearm_link", (-0.4, 0.0, 0.06), 0.15),
+}
+# static obstacles of upright_assets/thing/xacro/obstacles/simple.urdf.xacro:41-100 (world frame)
+SIMPLE_OBSTACLES = {
+    f"sphere{i + 1}_{lvl}_link": ("world", (x, y, z), 0.25)
+    for i, (x, y) in enumerate(((0.0, 0.25), (1.5, 1.0), (-0.5, 2.0)))
+    for lvl, z in (("bottom", 0.25), ("middle", 0.5), ("top", 0.75))
+}
+# arm link -> index of the arm joint whose motion carries it (child link of that joint)
+_ARM_LINKS = {"ur10_arm_shoulder_link": 0, "ur10_arm_upper_arm_link": 1, "ur10_arm_forearm_link": 2,
+              "ur10_arm_wrist_1_link": 3, "ur10_arm_wrist_2_link": 4, "ur10_arm_wrist_3_link": 5}
+
+
+def link_frame(chain, link):
+    """Chain frame index of a URDF link: -1 = world (or a link that does not move with the chain, e.g. the base of
+    the fixed-base arm), i = link carried by joint i, nq = tool frame (`gripped_object`)."""
+    nq = chain.nq
+    base = nq - 6   # 3 planar base joints in front of the arm, or none
+    if link == "world":
+        return -1
+    if link == "gripped_object":
+        return nq
+    if link == "base_link":
+        return base - 1 if base > 0 else -1
+    if link in _ARM_LINKS:
+        return base + _ARM_LINKS[link]
+    raise ValueError(f"unknown link '{link}'")
+
+
+def collision_model(chain, pairs, spheres=None):
+    """Sphere table and pair index lists for the named collision pairs of `obstacles.collision_pairs`
+    (obstacles/simple.yaml:11-41; pinocchio appends `_0` to geometry names).  Returns a dict with the Problem fields
+    sph_frame, sph_off, sph_r, pair_a, pair_b."""
+    table = dict(COLLISION_SPHERES)
+    table.update(SIMPLE_OBSTACLES)
+    if spheres:
+        table.update(spheres)
+    names = []
+    for a, b in pairs:
+        for n in (a, b):
+            n = n[:-2] if n.endswith("_0") else n
+            if n not in table:
+                raise ValueError(f"unknown collision object '{n}'")
+            if n not in names:
+                names.append(n)
+    idx = {n: i for i, n in enumerate(names)}
+    strip = lambda n: n[:-2] if n.endswith("_0") else n
+    frames, offs = [], []
+    for n in names:
+        link, off, _ = table[n]
+        f = link_frame(chain, link)
+        off = np.asarray(off, dtype=np.float64)
+        if link == "base_link" and f == -1 and chain.base_pose is not None:
+            x, y, yaw = chain.base_pose
+            c, s = np.cos(yaw), np.sin(yaw)
+            off = np.array([x + c * off[0] - s * off[1], y + s * off[0] + c * off[1], off[2]])
+        frames.append(f); offs.append(off)
+    return dict(
+        sph_frame=np.array(frames, dtype=np.int32), sph_off=np.array(offs, dtype=np.float64).reshape(len(names), 3),
+        sph_r=np.array([table[n][2] for n in names], dtype=np.float64),
+        pair_a=np.array([idx[strip(a)] for a, _ in pairs], dtype=np.int32),
+        pair_b=np.array([idx[strip(b)] for _, b in pairs], dtype=np.int32),
+    )
+
+
+# obstacles/simple.yaml:11-41
+SIMPLE_COLLISION_PAIRS = (
+    [("wrist1_collision_link_0", f"sphere{i}_top_link_0") for i in (1, 2, 3)]
+    + [(f"forearm_collision_sphere_link{j}_0", f"sphere{i}_top_link_0") for i in (1, 2, 3) for j in (1, 2)]
+    + [("base_collision_link_0", f"sphere{i}_bottom_link_0") for i in (1, 2, 3)]
+    + [("balanced_object_collision_link_0", f"sphere{i}_top_link_0") for i in (1, 2, 3)]
+    + [("balanced_object_collision_link_0", f"sphere{i}_middle_link_0") for i in (1, 2, 3)]
+    + [("wrist1_collision_link_0", "shoulder_collision_link_0"), ("wrist1_collision_link_0", "base_collision_link_0")]
+)
