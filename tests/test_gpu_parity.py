@@ -667,3 +667,44 @@ def test_collision_avoidance(arrangements):
         p_end = O.ee_kinematics(xs[b, P.N])[:3]
         assert np.abs(p_end - way[b, 0]).max() < 1e-6               # the tray still reaches the target
     mpc.close(); free.close()
+
+
+def test_config3_shape_three_objects_and_static_obstacles(arrangements):
+    """BASELINE config 3: Thing + box_arch (3 bodies, 16 contact points: nx 27, nu 57, 18 equality + 80 friction rows
+    per knot) + the 20 named sphere pairs of obstacles/simple.yaml:11-41 (15 spheres), waypoint of _point3.yaml
+    ([0, -2, 0.25]).  Rows against the oracle; the SQP run: the first QPs are infeasible (the goal lies behind the
+    linearised obstacle half-spaces: both solvers stop at the iteration cap there, as HPIPM would) and the iteration
+    recovers to a converged, collision-free plan that reaches the target."""
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME
+
+    B = 2
+    P = thing_problem(arrangements["box_arch"], sqp_iters=10)
+    for k, v in robots.collision_model(P.chain, robots.SIMPLE_COLLISION_PAIRS).items():
+        setattr(P, k, v)
+    assert (P.nx, P.nu, P.nb, P.nc, len(P.pair_a), len(P.sph_r)) == (27, 57, 3, 16, 20, 15)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] = [0.3, 0.25]           # start clear of obstacle 3 (with this chain model the stock home pose is inside its margin)
+    way = waypoints_for(P, x0, offset=(0.0, -2.0, 0.25))
+    mpc = BatchMPC(P, B, way_p=way)
+    O = Oracle(P)
+    xr = x0[:1] + np.random.default_rng(5).uniform(-0.3, 0.3, (7, 27))
+    d, dq = mpc.obstacle_rows(xr)
+    for i in range(7):
+        do, dqo = O.obstacle_rows(xr[i])
+        assert np.abs(d[i] - do).max() < 1e-13 and np.abs(dq[i] - dqo).max() < 1e-12
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b in range(B):
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and st["qp_status_last"][b] == 0 and st["constraint_violation"][b] < 1e-3
+        rows = np.array([O.obstacle_rows(xs[b, k], jac=False) for k in range(1, P.N)])
+        assert rows.min() > -1e-6
+        assert np.abs(O.ee_kinematics(xs[b, P.N])[:3] - way[b, 0]).max() < 1e-5
+        # both reach the same local solution although the early (infeasible) QPs are not well defined
+        assert np.abs(xs[b] - xo).max() < 5e-3
+    mpc.close()
