@@ -678,20 +678,14 @@ struct upr_qp3 {
     }
 
     // ---- backward sweep, vector part, for the current right-hand side ----------------------------------------
-    // With w_k = p_{k+1} + P_{k+1} b_k the recursion is  p_k = c_k + A'w_k - K_k'(B'w_k),  c_k = gx_k + C_k'zt_k -
-    // K_k' gu_k[jerk]: one wave-local phase per knot (lane i < nx owns p_k[i] and column i of K_k, prefetched one
+    // With w_k = p_{k+1} + P_{k+1} b_k the recursion is  p_k = gx_k + C_k'zt_k + A'w_k - K_k'(gu_k[jerk] + B'w_k):
+    // one wave-local phase per knot (lane i < nx owns p_k[i] and column i of K_k, prefetched one
     // knot ahead).  w_k is kept (in the step array, which the forward sweep overwrites afterwards) for the
     // feed-forward  kff_k = Hjj_k^-1 (gu_k[jerk] + B'w_k)  of all knots at once.
     UPR_HDI double* Wk(int k) const { return L + O::S + (k + 1) * NX; }
     UPR_HDI void backward_vec() {
         const double irho = 1.0 / UPR_QP_RHO_N;
         terminal_residual();
-        UPR_FORT(e, (N - 1) * NX) {
-            const int k = 1 + e / NX, i = e % NX;
-            double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
-            for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * L[O::gus + k * NU + m];
-            L[O::cs + k * NX + i] = v;
-        }
         UPR_SYNC();
         toc(2);
         if (wave0()) {
@@ -714,9 +708,10 @@ struct upr_qp3 {
 #define UPR_LOADKC(dst, kk) do { if ((kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
 #define UPR_VECSTEP(kcx, kk) do { \
                     const double* w = Wk(kk); const int b_ = upr_opq(b); \
-                    double v = L[O::cs + (kk) * NX + i]; const double pbn = L[O::Pbs + ((kk) - 1) * NX + i]; \
+                    const double* gu = L + O::gus + (kk) * NU; \
+                    double v = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; const double pbn = L[O::Pbs + ((kk) - 1) * NX + i]; \
                     for (int a = 0; a <= b_; ++a) v += coefA(a, b_) * w[a * NQ + j]; \
-                    _Pragma("unroll") for (int m = 0; m < NQ; ++m) v -= kcx[m] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]); \
+                    _Pragma("unroll") for (int m = 0; m < NQ; ++m) v -= kcx[m] * (gu[m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]); \
                     Wk((kk) - 1)[i] = v + pbn; \
                     UPR_WSYNC(); } while (0)
                 UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
@@ -735,9 +730,9 @@ struct upr_qp3 {
                 const double* w = Wk(k);
                 UPR_FORT(i, NX) {
                     const int b = i / NQ, j = i % NQ;
-                    double v = L[O::cs + k * NX + i];
+                    double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
                     for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
-                    for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * (h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
+                    for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * (L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
                     Wk(k - 1)[i] = v + L[O::Pbs + (k - 1) * NX + i];
                 }
             }
@@ -900,12 +895,18 @@ struct upr_qp3 {
             pin[e] = v;
         }
         UPR_SYNC();
+        // pi_k = r_k + A' pi_{k+1}: all r_k of a joint are fetched first (independent loads), then the three running sums
+        // are carried in registers -- a load / store pair per knot through global memory would serialise 19 round trips
         UPR_FORT(j, NQ) {
+            double r[N][3];
+#pragma unroll
+            for (int k = 1; k < N; ++k) { r[k][0] = pin[k * NX + j]; r[k][1] = pin[k * NX + NQ + j]; r[k][2] = pin[k * NX + 2 * NQ + j]; }
             double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
+#pragma unroll
             for (int k = N - 1; k >= 1; --k) {
-                const double nq_ = pin[k * NX + j] + pq;
-                const double nv_ = pin[k * NX + NQ + j] + h * pq + pvv;
-                const double na_ = pin[k * NX + 2 * NQ + j] + h2 * pq + h * pvv + pa;
+                const double nq_ = r[k][0] + pq;
+                const double nv_ = r[k][1] + h * pq + pvv;
+                const double na_ = r[k][2] + h2 * pq + h * pvv + pa;
                 pq = nq_; pvv = nv_; pa = na_;
                 pin[k * NX + j] = pq; pin[k * NX + NQ + j] = pvv; pin[k * NX + 2 * NQ + j] = pa;
             }
