@@ -72,14 +72,16 @@ struct upr_qp3_lds {
                          xlb = ek + r2(C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
                          rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
                          // working set of the sweeps
-                         Pa = df + r2(C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX), vm = hux + r2(C::NQ * C::NX),
-                         hjj = vm + r2(C::NQ * C::NX), vc = hjj + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
-                         pv = ck + r2(C::NE * C::NX), wv = pv + r2(C::NX), hx = wv + r2(C::NX), huj = hx + r2(C::NX), yj = huj + r2(C::NQ),
-                         bk = yj + r2(C::NQ), yN = bk + r2(C::NX), dyN = yN + r2(C::NEN),
-                         eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + r2(C::NT),
-                         // LDS-resident Riccati store: feedback K = Hjj^-1 Hux, P+ b, feed-forward kff = Hjj^-1 huj, huj, Lj^-1 (packed lower)
-                         prf = misc + 16, lsik = prf + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX), hujs = kffs + r2(C::N * C::NQ),
-                         pv2 = hujs + r2(C::N * C::NQ), bks = pv2 + r2(C::NX), total = bks + r2(C::N * C::NX);
+                         Pa = df + r2(C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX),
+                         // V = Lj^-1 Hux and the packed factor Lj of the knot in work and of the previous one (double buffered:
+                         // K = Lj^-T V of the previous knot is formed by an idle wave while wave 0 factors the next)
+                         vm = hux + r2(C::NQ * C::NX), lk = vm + 2 * r2(C::NQ * C::NX),
+                         hjj = lk + 2 * r2(C::NH), vc = hjj + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
+                         yN = ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
+                         eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
+                         // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
+                         prf = misc + 16, lsik = prf + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         bks = kffs + r2(C::N * C::NQ), total = bks + r2(C::N * C::NX);
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -418,6 +420,22 @@ struct upr_qp3 {
     // preload the matrix-core accumulators with sym(A'P+A) + Q~ + Vc'Vc | barrier | P = acc - V'V | barrier.
     // The feedback K = Lj^-T V is not on this critical path: it is formed for all knots at once afterwards.
     // Knot 0 needs only the factor of Hjj_0 (the first state is fixed: no P_0, no K_0).
+    UPR_HDI static constexpr int vmb(int k) { return O::vm + (k & 1) * O::r2(NQ * NX); }
+    UPR_HDI static constexpr int lkb(int k) { return O::lk + (k & 1) * O::r2(C::NH); }
+    // column c of the feedback K_k = Lj_k^-T V_k by back substitution out of the LDS copies of V_k and Lj_k
+    UPR_HDI void feedback_column(int k, int c) {
+        const double* Lp = L + lkb(k); const double* V = L + vmb(k);
+        double kk[NQ];
+#pragma unroll
+        for (int i = NQ - 1; i >= 0; --i) {
+            double t = V[i * NX + c];
+#pragma unroll
+            for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
+            kk[i] = t * Lp[i * (i + 1) / 2 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + c] = kk[i];
+    }
     UPR_HDI void backward_mat() {
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
@@ -554,6 +572,10 @@ struct upr_qp3 {
                     acc[tile] = a4;
                 }
             }
+            // feedback of the PREVIOUS knot, K_{k+1} = Lj^-T V_{k+1}, on the last wave while wave 0 factors this one
+            if (k + 1 < N && wave == ((nwaves > 1) ? nwaves - 1 : 0)) { if (lane < NX) feedback_column(k + 1, lane); }
+#else
+            if (k + 1 < N) UPR_FORT(c, NX) feedback_column(k + 1, c);
 #endif
             // wave 0: Cholesky of the augmented matrix M = [Hjj | Hux] (nq x (nq + nx)), one lane per COLUMN, all
             // columns in lock step: at pivot p every lane scales its entry of row p (lane c < nq obtains L[c][p],
@@ -582,10 +604,10 @@ struct upr_qp3 {
                 toc(13);
                 if (c < NQ) {
 #pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2];
+                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) { G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2]; L[lkb(k) + c * (c + 1) / 2 + p2] = x[p2]; }
                 } else if (c < NQ + NX && (k > 0 || fbk)) {
 #pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + (c - NQ)] = x[p2]; G[F::Ks + k * NQ * NX + p2 * NX + (c - NQ)] = x[p2]; }
+                    for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + (c - NQ)] = x[p2];
                 }
 #else
                 if (tid() == 0) {
@@ -601,8 +623,8 @@ struct upr_qp3 {
                         for (int j = p2 + 1; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] -= y[c] * y[j];
                         for (int c = 0; c < NM; ++c) M[p2][c] = (c == p2) ? idg : y[c];
                     }
-                    for (int c = 0; c < NQ; ++c) for (int p2 = 0; p2 <= c; ++p2) G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = M[p2][c];
-                    if (k > 0 || fbk) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) { L[O::vm + p2 * NX + c] = M[p2][NQ + c]; G[F::Ks + k * NQ * NX + p2 * NX + c] = M[p2][NQ + c]; }
+                    for (int c = 0; c < NQ; ++c) for (int p2 = 0; p2 <= c; ++p2) { G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = M[p2][c]; L[lkb(k) + c * (c + 1) / 2 + p2] = M[p2][c]; }
+                    if (k > 0 || fbk) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + c] = M[p2][NQ + c];
                 }
 #endif
             }
@@ -622,7 +644,7 @@ struct upr_qp3 {
                     for (int s4 = 0; s4 < (NQ + 3) / 4; ++s4) {
                         const int r = 4 * s4 + kk;   // row of V
                         double a = 0.0, b = 0.0;
-                        if (r < NQ) { if (ci < NX) a = -L[O::vm + r * NX + ci]; if (cj < NX) b = L[O::vm + r * NX + cj]; }
+                        if (r < NQ) { if (ci < NX) a = -L[vmb(k) + r * NX + ci]; if (cj < NX) b = L[vmb(k) + r * NX + cj]; }
                         a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
                     }
 #pragma unroll
@@ -640,7 +662,7 @@ struct upr_qp3 {
                     if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
                     if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
                     for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
-                    for (int m = 0; m < NQ; ++m) v -= L[O::vm + m * NX + i] * L[O::vm + m * NX + j];
+                    for (int m = 0; m < NQ; ++m) v -= L[vmb(k) + m * NX + i] * L[vmb(k) + m * NX + j];
                     Pc[i * NX + j] = v; Pc[j * NX + i] = v;
                 }
             }
@@ -657,23 +679,8 @@ struct upr_qp3 {
             toc(15);
         }
         UPR_SYNC();
-        // feedback of knots 1 .. N-1, all at once: column e of K_k = Lj^-T V_k by back substitution, in place
-        UPR_FORT(e, N * NX) {
-            const int k = e / NX, c = e % NX;
-            if (k == 0 && !fbk) continue;
-            const double* Lp = G + F::Ljis + k * C::NH;
-            double* Kc = G + F::Ks + k * NQ * NX + c;
-            double kk[NQ];
-#pragma unroll
-            for (int i = NQ - 1; i >= 0; --i) {
-                double t = Kc[i * NX];
-#pragma unroll
-                for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
-                kk[i] = t * Lp[i * (i + 1) / 2 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) Kc[i * NX] = kk[i];
-        }
+        // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
+        if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
         UPR_SYNC();
     }
 
