@@ -81,7 +81,7 @@ struct upr_qp3_lds {
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
                          prf = misc + 16, lsik = prf + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
-                         bks = kffs + r2(C::N * C::NQ), total = bks + r2(C::N * C::NX);
+                         bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX), total = gee + r2(C::N * C::NQ);   // gee: end-effector part of the cost gradient
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -257,6 +257,9 @@ struct upr_qp3 {
     // level 0: reduced gradients + residuals only (KKT check); 1: + back-substitution vectors; 2: + factors
     UPR_HDI void prep(int level) {
         const bool factor = level >= 2;
+        // the corrector (level 1) follows the predictor (level 2) at the SAME iterate: what depends on the iterate alone
+        // (end-effector gradient, dynamics and equality residuals) is kept, only the barrier terms are rebuilt
+        const bool fresh = level != 1;
         const int tid_ = tid();
         // A: box rows (registers)
 #pragma unroll
@@ -272,8 +275,12 @@ struct upr_qp3 {
                 if (k < N) {
                     g = L[O::qd + i] * (X - L[O::xd + i]);
                     if (i < NQ) {
-                        double a = G[F::g0 + k * NQ + i];
-                        for (int j = 0; j < NQ; ++j) a += G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
+                        double a;
+                        if (fresh) {
+                            a = G[F::g0 + k * NQ + i];
+                            for (int j = 0; j < NQ; ++j) a += G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
+                            L[O::gee + k * NQ + i] = a;
+                        } else a = L[O::gee + k * NQ + i];
                         g += a;
                     }
                     g *= h;
@@ -296,7 +303,7 @@ struct upr_qp3 {
             }
         }
         // dynamics residual of every knot in absolute variables (multiple-shooting defect of the iterate)
-        UPR_FORT(e, N * NQ) {
+        if (fresh) UPR_FORT(e, N * NQ) {
             const int k = e / NQ, j = e % NQ;
             const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
             const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
@@ -348,11 +355,15 @@ struct upr_qp3 {
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
-            double v = G[F::e0 + e];
-            for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
-            double v2 = 0.0;
-            for (int i = 0; i < NFC; ++i) { v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i]; if (level > 0) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i]; }
-            L[O::ek + e] = v; L[O::ys + e] = v - v2;
+            double v, v2 = 0.0;
+            if (fresh) {
+                v = G[F::e0 + e];
+                for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
+                for (int i = 0; i < NFC; ++i) v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i];
+                L[O::ek + e] = v;
+            } else v = L[O::ek + e];
+            if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
+            L[O::ys + e] = v - v2;
         }
         if (factor) {
             UPR_FORT(e, N * NE * NE) {
