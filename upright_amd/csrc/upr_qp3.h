@@ -603,8 +603,8 @@ struct upr_qp3 {
                 bool ok = true;
 #pragma unroll
                 for (int p2 = 0; p2 < NQ; ++p2) {
-                    double piv = upr_readlane(x[p2], p2);
-                    if (!(piv > 0.0)) { ok = false; piv = 1.0; }
+                    const double piv = upr_readlane(x[p2], p2);
+                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
                     const double idg = upr_rsqrt(piv);
                     const double y = x[p2] * idg;
                     x[p2] = (c == p2) ? idg : y;   // the diagonal keeps its reciprocal (what the solves need)
