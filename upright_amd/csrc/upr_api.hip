@@ -114,6 +114,8 @@ struct upr_fb_src {
 // Linear feedback gains of the last QP, ocs2 sign convention (u = bias + K x): fb[B][N][nu][nx].
 // Jerk rows: -Hjj^-1 Hux from the Riccati recursion; contact-force rows: -Hff^-1 Df' S^-1 C (the forces
 // follow the state through the object-dynamics equality).
+// NEM / NFM: compile-time bounds of ne / nfc (the per-thread scratch vectors stay in registers for the small shapes)
+template <int NEM, int NFM>
 __global__ void feedback_kernel(const upr_problem* P, upr_dims d, upr_fb_src src, const double* ws, const double* lin,
                                 const double* Df, double* fb) {
     const int b = blockIdx.x;
@@ -138,7 +140,7 @@ __global__ void feedback_kernel(const upr_problem* P, upr_dims d, upr_fb_src src
         const double* Ck = lin + ((size_t)b * (N + 1) + k) * d.lin_stride + d.lin_gx;
         const double* Lsi = w + src.lsi_base + (long)k * src.lsi_stride;
         const double* Lfi = w + src.lfi_base + (long)k * src.lfi_stride;
-        double t1[6 * UPR_MAX_BODIES], t2[6 * UPR_MAX_BODIES], t3[3 * UPR_MAX_CONTACTS];
+        double t1[NEM], t2[NEM], t3[NFM];
         for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = 0; m <= r; ++m) v += Lsi[r * ne + m] * Ck[m * nx + c]; t1[r] = v; }
         for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = r; m < ne; ++m) v += Lsi[m * ne + r] * t1[m]; t2[r] = v; }
         for (int i = 0; i < nfc; ++i) { double v = 0.0; for (int r = 0; r < ne; ++r) v += Dfb[r * nfc + i] * t2[r]; t3[i] = v; }
@@ -416,7 +418,8 @@ int advance_impl(upr_batch* h) {
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
     }
     if (h->fb) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
-        hipLaunchKernelGGL(feedback_kernel, dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
+        if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
+        else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
         UPR_HIP(hipGetLastError());
     }
     // remember the solution for the next warm start / policy evaluation
