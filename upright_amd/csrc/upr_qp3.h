@@ -725,13 +725,14 @@ struct upr_qp3 {
                 double kc0[NQ], kc1[NQ], kc2[NQ];
 #define UPR_LOADKC(dst, kk) do { if ((kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
 #define UPR_VECSTEP(kcx, kk) do { \
-                    const double* w = Wk(kk); const int b_ = upr_opq(b); \
-                    const double* gu = L + O::gus + (kk) * NU; \
+                    const double* w = Wk(kk); const double* gu = L + O::gus + (kk) * NU; \
                     double v = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; const double pbn = L[O::Pbs + ((kk) - 1) * NX + i]; \
-                    for (int a = 0; a <= b_; ++a) v += coefA(a, b_) * w[a * NQ + j]; \
+                    v += ca0 * w[j] + ca1 * w[NQ + j] + ca2 * w[2 * NQ + j]; \
                     _Pragma("unroll") for (int m = 0; m < NQ; ++m) v -= kcx[m] * (gu[m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]); \
                     Wk((kk) - 1)[i] = v + pbn; \
                     UPR_WSYNC(); } while (0)
+                // column (b, j) of A' without branches: coefficients of w[(a, j)], zero for a > b
+                const double ca0 = coefA(0, b), ca1 = (b >= 1) ? coefA(1, b) : 0.0, ca2 = (b >= 2) ? 1.0 : 0.0;
                 UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
                 // fully unrolled: inside a loop the compiler's s_waitcnt bookkeeping collapses the three prefetch stages into one
 #pragma unroll
@@ -797,23 +798,27 @@ struct upr_qp3 {
             // prefetch); the three partial dot products of a joint are summed inside its quad by DPP
             static_assert(4 * NQ <= 64, "one quad per joint");
             {
-                const int l = lane(), j = l >> 2, b = l & 3;
-                const bool act = (b < 3) && (j < NQ);
-                const int i = act ? b * NQ + j : 0;
+                const int l = lane();
+                const bool act = ((l & 3) < 3) && ((l >> 2) < NQ);
+                const int j = act ? (l >> 2) : 0, b = act ? (l & 3) : 0;
+                const int i = b * NQ + j;
+                const bool first = act && b == 0;   // the lane of a quad that adds the feed-forward term
                 double kq0[NQ], kq1[NQ], kq2[NQ];
 #define UPR_LOADKQ(dst, kk) do { if (act && (kk) < N) { _Pragma("unroll") for (int c = 0; c < NQ; ++c) dst[c] = G[F::Ks + (kk) * NQ * NX + j * NX + b * NQ + c]; } } while (0)
 #define UPR_FWDSTEP(kqx, kk) do { \
-                    const double* sx = Sx(kk); const int b_ = upr_opq(b); \
-                    double d = 0.0, r = 0.0; \
-                    if (act) { \
-                        d = (b_ == 0) ? L[O::kffs + (kk) * NQ + j] : 0.0; \
-                        _Pragma("unroll") for (int c = 0; c < NQ; ++c) d += kqx[c] * sx[b_ * NQ + c]; \
-                        r = L[O::bks + (kk) * NX + i]; \
-                        for (int a = b_; a < 3; ++a) r += coefA(b_, a) * sx[a * NQ + j]; \
-                    } \
+                    const double* sx = Sx(kk); \
+                    const double kf = L[O::kffs + (kk) * NQ + j]; \
+                    double d = first ? kf : 0.0; \
+                    _Pragma("unroll") for (int c = 0; c < NQ; ++c) d += kqx[c] * sx[b * NQ + c]; \
+                    const double r = L[O::bks + (kk) * NX + i] + ra0 * sx[j] + ra1 * sx[NQ + j] + ra2 * sx[2 * NQ + j]; \
                     d += upr_dpp_quad<0xB1>(d); d += upr_dpp_quad<0x4E>(d); \
-                    if (act) { Sx((kk) + 1)[i] = r - coefB(b_) * d; if (b_ == 0) Su(kk)[j] = -d; } \
+                    if (act) { Sx((kk) + 1)[i] = r - cb * d; if (b == 0) Su(kk)[j] = -d; } \
                     UPR_WSYNC(); } while (0)
+                // row (b, j) of A and entry b of B without branches (idle lanes of a quad work on clamped indices)
+                const double ra0 = (b == 0) ? 1.0 : 0.0, ra1 = (b == 0) ? h : ((b == 1) ? 1.0 : 0.0), ra2 = (b == 0) ? h2 : ((b == 1) ? h : 1.0);
+                const double cb = coefB(b);
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) { kq0[c] = 0.0; kq1[c] = 0.0; kq2[c] = 0.0; }
                 UPR_LOADKQ(kq0, 1); UPR_LOADKQ(kq1, 2); UPR_LOADKQ(kq2, 3);
 #pragma unroll
                 for (int k = 1; k < N; k += 3) {
