@@ -529,7 +529,12 @@ struct upr_qp3 {
                         const int f = e - NQ * NQ, pr = f / NX, c = f % NX, r2 = NE - 1 - pr;
                         const double* Ls = L + O::lsik;
                         double v1 = 0.0, v2 = 0.0;
-                        for (int m = 0; m <= r2; ++m) { const double cm = L[O::ck + m * NX + c]; if (m <= pr) v1 += Ls[pr * NE + m] * cm; v2 += Ls[r2 * NE + m] * cm; }
+                        // full-length rows with the entries above the diagonal masked: no lane-dependent trip count
+#pragma unroll
+                        for (int m = 0; m < NE; ++m) {
+                            const double cm = L[O::ck + m * NX + c], l1 = Ls[pr * NE + m], l2 = Ls[r2 * NE + m];
+                            v1 += ((m <= pr) ? l1 : 0.0) * cm; v2 += ((m <= r2) ? l2 : 0.0) * cm;
+                        }
                         L[O::vc + pr * NX + c] = v1; L[O::vc + r2 * NX + c] = v2;
                     }
                 } else if (e >= PB0) {
