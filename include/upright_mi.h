@@ -92,6 +92,19 @@ typedef struct upr_problem {
     int n_pairs;
     int pair_a[UPR_MAX_PAIRS], pair_b[UPR_MAX_PAIRS];
     double obs_min_dist; /* controller.yaml:108 */
+    /* pair_b == -1: the ground half-space z >= 0 (controller_interface.cpp:93-101).
+     * n_dyn (0 or 1) dynamic obstacles (system_dynamics.h:29-39; obstacles/dynamic.yaml): the state handed to
+     * set_observation / returned by get_solution / evaluate is [robot x (3 nq), obstacle r, v, a (9)]; the obstacle is
+     * uncontrolled, so inside the solve it is the ballistic function of time of its observed state.  Spheres with
+     * sph_frame == -2 ride on it. */
+    int n_dyn;
+    /* projectile_path_constraint.h:12-167 ("projectile_constraint"): rows w s (|c_i - r_closest| - dist_i),
+     * w = proj_scale / dist_i, c_i the centre of sphere proj_sph[i], r_closest the closest future point of the
+     * obstacle's path, s the per-instance activation flag (upr_batch_set_projectile_flag) */
+    int n_proj;
+    int proj_sph[8];
+    double proj_dist[8];
+    double proj_scale;
 } upr_problem;
 
 const char* upr_last_error(void);
@@ -126,7 +139,8 @@ void upr_batch_destroy(upr_batch* h);
 int upr_batch_reset(upr_batch* h, const double* way_p);
 
 /* ControllerInterface.setObservation (pybindings.cpp:369-370): t[B] (or t[1] broadcast if
- * t_stride == 0), x[B][nx]. Host pointers. */
+ * t_stride == 0), x[B][nx_full], nx_full = 3 nq + 9 n_dyn. Host pointers.  Every x / xs argument of this interface has
+ * nx_full entries per state; the feedback gains have nx_full columns (zero for the obstacle part). */
 int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x);
 
 /* Overwrite the initial guess (operating points, controller_interface.cpp:376-383): xs[B][N+1][nx],
@@ -160,6 +174,10 @@ int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const
  * Riccati recursion, contact-force rows from the elimination of the object-dynamics equality
  * (f = f* - Hff^-1 Df' S^-1 C dx). */
 int upr_batch_get_feedback(upr_batch* h, double* K);
+
+/* activation flag of the projectile constraint per instance: the 8th entry of the target state
+ * (reference_trajectory.h; set by the target-flag protocol of mrt_node.cpp:243-265).  s[B]; default 0. */
+int upr_batch_set_projectile_flag(upr_batch* h, const double* s);
 
 /* ControllerInterface.getLastSolveTime (pybindings.cpp:366), milliseconds of the last advance */
 double upr_batch_last_solve_ms(const upr_batch* h);

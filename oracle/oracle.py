@@ -29,6 +29,8 @@ class OrcProblem(C.Structure):
         ("terminal_constraint", C.c_int),
         ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", d * 3 * MAXS), ("sph_r", d * MAXS),
         ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", d),
+        ("n_dyn", C.c_int), ("dyn_x0", d * 9), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", d * 8),
+        ("proj_scale", d), ("proj_s", d),
     ]
 
 
@@ -100,6 +102,11 @@ def to_orc(P):
         o.sph_frame[i] = int(P.sph_frame[i]); o.sph_r[i] = float(P.sph_r[i]); _fill(o.sph_off[i], P.sph_off[i])
     for i in range(npair):
         o.pair_a[i], o.pair_b[i] = int(P.pair_a[i]), int(P.pair_b[i])
+    o.n_dyn = int(getattr(P, "n_dyn", 0))
+    nproj = len(getattr(P, "proj_sph", ()))
+    o.n_proj, o.proj_scale, o.proj_s = nproj, float(getattr(P, "proj_scale", 1.0)), 0.0
+    for i in range(nproj):
+        o.proj_sph[i] = int(P.proj_sph[i]); o.proj_dist[i] = float(P.proj_dist[i])
     return o
 
 
@@ -180,10 +187,16 @@ class Oracle:
         self.L.orc_sphere_centers(C.byref(self.o), _p(_c(x)), _p(c))
         return c
 
-    def obstacle_rows(self, x, jac=True):
-        n = self.o.n_pairs
+    def set_dynamic_obstacle(self, x_obs, flag=1.0):
+        """Observed state [r, v, a] of the dynamic obstacle at the start of the horizon and the target's activation
+        flag of the projectile constraint."""
+        _fill(self.o.dyn_x0, x_obs)
+        self.o.proj_s = float(flag)
+
+    def obstacle_rows(self, x, jac=True, tau=0.0):
+        n = self.o.n_pairs + self.o.n_proj
         dd = np.zeros(n); dq = np.zeros((n, self.P.nq))
-        self.L.orc_obstacle_rows(C.byref(self.o), _p(_c(x)), _p(dd), _p(dq) if jac else None)
+        self.L.orc_obstacle_rows(C.byref(self.o), _p(_c(x)), d(tau), _p(dd), _p(dq) if jac else None)
         return (dd, dq) if jac else dd
 
     def qp_feedback(self, t0, x0, xs, us):

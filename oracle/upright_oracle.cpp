@@ -158,9 +158,11 @@ EEState<T> ee_kin(const orc_problem* P, const T* x) {
 
 // centres of the collision spheres: the same chain walk, positions only
 template <class T>
-void sphere_centers(const orc_problem* P, const T* x, std::vector<V3<T>>& c) {
+void sphere_centers(const orc_problem* P, const T* x, double tau, std::vector<V3<T>>& c) {
     const int nq = P->nq;
     c.assign(P->n_sph, V3<T>{{T(0.0), T(0.0), T(0.0)}});
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2)   // dynamic obstacle: ballistic, independent of the robot
+        for (int i = 0; i < 3; ++i) c[s][i] = T(P->dyn_x0[i] + tau * P->dyn_x0[3 + i] + 0.5 * tau * tau * P->dyn_x0[6 + i] + P->sph_off[s][i]);
     M3<T> R; for (int i = 0; i < 9; ++i) R.m[i] = T((i % 4 == 0) ? 1.0 : 0.0);
     V3<T> o{{T(0.0), T(0.0), T(0.0)}};
     auto place = [&](int frame) {
@@ -178,14 +180,44 @@ void sphere_centers(const orc_problem* P, const T* x, std::vector<V3<T>>& c) {
     R = mm(R, from_d<T>(P->tool_R));
     place(nq);
 }
+// projectile_path_constraint.h:12-45
+inline double cubic_newton(double a, double b, double c, double d, double x0, double tol) {
+    double x = x0;
+    for (int i = 0; i < 10; ++i) {
+        const double f = a * x * x * x + b * x * x + c * x + d, df = 3 * a * x * x + 2 * b * x + c;
+        const double upd = f / df;
+        x -= upd;
+        if (std::fabs(upd) < tol) return x;
+    }
+    return x;
+}
 template <class T>
-void obstacle_rows(const orc_problem* P, const T* x, T* d) {
+void obstacle_rows(const orc_problem* P, const T* x, double tau, T* d) {
     std::vector<V3<T>> c;
-    sphere_centers<T>(P, x, c);
+    sphere_centers<T>(P, x, tau, c);
     for (int r = 0; r < P->n_pairs; ++r) {
         const int a = P->pair_a[r], b = P->pair_b[r];
+        if (b < 0) { d[r] = c[a][2] - T(P->sph_r[a] + P->obs_min_dist); continue; }   // ground half-space
         V3<T> e = sub(c[a], c[b]);
         d[r] = sqrt(dot(e, e)) - T(P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+    }
+    // projectile path rows (the closest time is held fixed in the derivative, projectile_path_constraint.h:118-145)
+    double ro[3], vo[3], ao[3];
+    for (int i = 0; i < 3; ++i) { ao[i] = P->dyn_x0[6 + i]; vo[i] = P->dyn_x0[3 + i] + tau * ao[i]; ro[i] = P->dyn_x0[i] + tau * P->dyn_x0[3 + i] + 0.5 * tau * tau * ao[i]; }
+    for (int i = 0; i < P->n_proj; ++i) {
+        const V3<T>& cl = c[P->proj_sph[i]];
+        double dt = 0.0;
+        if (P->proj_s > 0.5) {
+            double dr[3] = {val(cl[0]) - ro[0], val(cl[1]) - ro[1], val(cl[2]) - ro[2]};
+            const double gg = ao[0] * ao[0] + ao[1] * ao[1] + ao[2] * ao[2], vg = vo[0] * ao[0] + vo[1] * ao[1] + vo[2] * ao[2];
+            const double vv = vo[0] * vo[0] + vo[1] * vo[1] + vo[2] * vo[2], dg = dr[0] * ao[0] + dr[1] * ao[1] + dr[2] * ao[2];
+            const double dv = dr[0] * vo[0] + dr[1] * vo[1] + dr[2] * vo[2];
+            dt = std::max(0.0, cubic_newton(gg, 3 * vg, 2 * (vv - dg), -2 * dv, 0.0, 1e-4));
+        }
+        V3<T> e;
+        for (int j = 0; j < 3; ++j) e[j] = cl[j] - T(ro[j] + dt * vo[j] + 0.5 * dt * dt * ao[j]);
+        const double w = P->proj_scale / P->proj_dist[i];
+        d[P->n_pairs + i] = T(w * P->proj_s) * (sqrt(dot(e, e)) - T(P->proj_dist[i]));
     }
 }
 
@@ -814,7 +846,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 // intermediate cost and its derivatives scaled by dt, defects b = f(x_k,u_k) - x_{k+1}).
 void build_qp(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us, QP& qp) {
     const int nx = orc_nx(P), nu = orc_nu(P), N = P->N, ne = 6 * P->nb, np = (P->nf == 3 ? 5 * P->nc : 0);
-    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq; qp.no = P->n_pairs;
+    qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq; qp.no = P->n_pairs + P->n_proj;
     Dyn dyn{P->nq, nx, nu, P->dt};
     dyn.dense(qp.A, qp.B);
     qp.st.assign(N, StageQP());
@@ -848,7 +880,7 @@ void build_qp(const orc_problem* P, double t0, const double* x0, const double* x
         if (qp.no > 0 && k >= 1) {   // collision rows: d(q) + dd/dq dq >= 0
             s.gd.assign(qp.no, 0.0); s.Gx.assign((size_t)qp.no * nx, 0.0);
             vec dq((size_t)qp.no * P->nq);
-            orc_obstacle_rows(P, x, s.gd.data(), dq.data());
+            orc_obstacle_rows(P, x, k * P->dt, s.gd.data(), dq.data());
             for (int r = 0; r < qp.no; ++r) for (int j = 0; j < P->nq; ++j) s.Gx[r * nx + j] = dq[r * P->nq + j];
         }
     }
@@ -868,26 +900,26 @@ void build_qp(const orc_problem* P, double t0, const double* x0, const double* x
 extern "C" {
 
 int orc_nx(const orc_problem* P) { return 3 * P->nq; }
+int orc_nu(const orc_problem* P) { return P->nq + P->nf * P->nc; }
 
 void orc_sphere_centers(const orc_problem* P, const double* x, double* c) {
     std::vector<V3<double>> cs;
-    sphere_centers<double>(P, x, cs);
+    sphere_centers<double>(P, x, 0.0, cs);
     for (int s = 0; s < P->n_sph; ++s) for (int i = 0; i < 3; ++i) c[3 * s + i] = cs[s][i];
 }
 
-void orc_obstacle_rows(const orc_problem* P, const double* x, double* d, double* dq) {
-    const int nq = P->nq, np = P->n_pairs;
+void orc_obstacle_rows(const orc_problem* P, const double* x, double tau, double* d, double* dq) {
+    const int nq = P->nq, np = P->n_pairs + P->n_proj;
     if (np == 0) return;
-    obstacle_rows<double>(P, x, d);
+    obstacle_rows<double>(P, x, tau, d);
     if (!dq) return;
     std::vector<Dual> xd(nq), dd(np);
     for (int j = 0; j < nq; ++j) {
         for (int i = 0; i < nq; ++i) xd[i] = Dual(x[i], i == j ? 1.0 : 0.0);
-        obstacle_rows<Dual>(P, xd.data(), dd.data());
+        obstacle_rows<Dual>(P, xd.data(), tau, dd.data());
         for (int r = 0; r < np; ++r) dq[r * nq + j] = dd[r].d;
     }
 }
-int orc_nu(const orc_problem* P) { return P->nq + P->nf * P->nc; }
 
 void orc_object_dynamics(const orc_problem* P, const double* forces, const double* C, const double* w,
                          const double* al, const double* a, double* out) {
@@ -1012,7 +1044,7 @@ void orc_performance(const orc_problem* P, double t0, const double* x0, const do
         if (np > 0) { orc_ineq_constraint(P, u, h.data()); for (int r = 0; r < np; ++r) { double v = std::min(0.0, h[r]); ineq_sse += P->dt * v * v; } }
         for (int i = 0; i < nu; ++i) { double v = std::min(0.0, std::min(u[i] - P->u_lb[i], P->u_ub[i] - u[i])); ineq_sse += P->dt * v * v; }
         if (k >= 1) for (int i = 0; i < nx; ++i) { double v = std::min(0.0, std::min(x[i] - P->x_lb[i], P->x_ub[i] - x[i])); ineq_sse += P->dt * v * v; }
-        if (k >= 1 && P->n_pairs > 0) { vec dd(P->n_pairs); orc_obstacle_rows(P, x, dd.data(), nullptr); for (double v : dd) { v = std::min(0.0, v); ineq_sse += P->dt * v * v; } }
+        if (k >= 1 && P->n_pairs + P->n_proj > 0) { vec dd(P->n_pairs + P->n_proj); orc_obstacle_rows(P, x, k * P->dt, dd.data(), nullptr); for (double v : dd) { v = std::min(0.0, v); ineq_sse += P->dt * v * v; } }
     }
     const double* xN = xs + (size_t)N * nx;
     for (int i = 0; i < nx; ++i) { double v = std::min(0.0, std::min(xN[i] - P->x_lb[i], P->x_ub[i] - xN[i])); ineq_sse += v * v; }

@@ -98,11 +98,25 @@ typedef struct {
     int n_pairs;
     int pair_a[ORC_MAX_PAIRS], pair_b[ORC_MAX_PAIRS];
     double obs_min_dist;
+    /* pair_b == -1: the ground half-space z >= 0 (controller_interface.cpp:93-101): d = c_a.z - r_a - obs_min_dist.
+     * sph_frame == -2: the dynamic obstacle (system_dynamics.h:29-39: [r, v, a] with rdot = v, vdot = a, adot = 0),
+     * whose OBSERVED state at the start of the horizon is dyn_x0; it is uncontrolled, so over the horizon it is the
+     * known ballistic function of time r(tau) = r0 + tau v0 + tau^2/2 a0. */
+    int n_dyn;          /* 0 or 1 */
+    double dyn_x0[9];
+    /* projectile_path_constraint.h:12-167: rows w s (|c - r_closest| - dist_i), w = proj_scale / dist_i, c the centre of
+     * sphere proj_sph[i], r_closest the closest FUTURE point of the obstacle's path (cubic by Newton, 10 steps, 1e-4) */
+    int n_proj;
+    int proj_sph[8];
+    double proj_dist[8];
+    double proj_scale;
+    double proj_s;      /* activation flag of the target (8th entry of the target state) */
 } orc_problem;
 
 int orc_nx(const orc_problem* P);
-/* obstacle rows at state x: d[n_pairs] and (if not NULL) dq[n_pairs][nq] = d d / d q */
-void orc_obstacle_rows(const orc_problem* P, const double* x, double* d, double* dq);
+/* state rows at state x, tau seconds after the observation: d[n_pairs + n_proj] (collision pairs, then projectile
+ * rows) and (if not NULL) dq[n_pairs + n_proj][nq] = d d / d q */
+void orc_obstacle_rows(const orc_problem* P, const double* x, double tau, double* d, double* dq);
 /* sphere centres c[n_sph][3] at configuration q = x[0:nq] */
 void orc_sphere_centers(const orc_problem* P, const double* x, double* c);
 int orc_nu(const orc_problem* P);

@@ -62,11 +62,16 @@ void emu_make_Df(const upr_problem* P, int B, const double* body_params, double*
     }
 }
 
+// optional dynamic-obstacle data (test hook): observed state per instance and projectile flags
+static const double* g_dyn = nullptr; static const double* g_pflag = nullptr;
+void emu_set_dynamic(const double* dyn, const double* pflag) { g_dyn = dyn; g_pflag = pflag; }
+
 void emu_linearize(const upr_problem* P, int B, const double* body_params, const double* way_p, const double* t0,
                    const double* xs, const double* us, double* lin) {
     upr_lin_args A;
     A.P = P; A.d = upr_make_dims(P); A.body_params = body_params; A.way_p = way_p; A.t0 = t0; A.xs = xs; A.us = us;
     A.inst = nullptr; A.lin = lin; A.ee_out = nullptr; A.npoints = B * (P->N + 1);
+    if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
     if (P->nq == 6) lin_all<6>(A); else lin_all<9>(A);
 }
 
@@ -118,6 +123,7 @@ void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const d
     upr_ls_args A;
     A.P = P; A.d = upr_make_dims(P); if (ws_stride > 0) A.d.ws_stride = (int)ws_stride; A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
     A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter;
+    if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
     std::vector<double> L(64);
     for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data()); else upr_ls_instance<9>(ctx, A, b, L.data()); }

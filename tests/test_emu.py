@@ -210,3 +210,64 @@ def test_collision_rows_kernel_source(arrangements):
         P.way_p = way[b]
         perf = Oracle(P).performance(0.0, x0[b], xs_bad[b], us[b])
         assert perf[3] > 1e-3 and abs(st0[b, 5] - np.sqrt(perf[1] + perf[2] + perf[3])) < 1e-10
+
+
+def _projectile_case(arrangements, B, **kw):
+    """Thing + bottle, a ball (dynamic obstacle, obstacles/dynamic.yaml:5-17) whose path crosses the straight tray
+    path 0.6 m from the start one second from now; rows: two self-collision pairs, wrist-vs-ground, tray-vs-ball and
+    one projectile-path row on the tray's collision link (ral23/experiments/projectile/_base.yaml:81-87)."""
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME
+
+    P = thing_problem(arrangements["pink_bottle"], **kw)
+    pairs = [("wrist1_collision_link_0", "shoulder_collision_link_0"), ("wrist3_collision_link_0", "ground"),
+             ("forearm_collision_sphere_link2_0", "projectile1")]
+    for k, v in robots.collision_model(P.chain, pairs, dynamic={"projectile1": 0.2}).items():
+        setattr(P, k, v)
+    P.n_dyn = 1
+    robots.add_projectile_rows(P, ["balanced_object_collision_link"], [0.35], 0.2)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    p, _ = P.chain.forward(THING_HOME)
+    way = np.tile(p + np.array([0.0, -1.2, 0.0]), (B, 1, 1))
+    T = 1.0
+    v0 = np.array([2.5, 0.0, 0.5 * 9.81 * T]); a0 = np.array([0.0, 0.0, -9.81])
+    dyn = np.zeros((B, 9))
+    for b in range(B):
+        cross = p + np.array([0.0, -0.6 - 0.05 * b, 0.25])
+        dyn[b] = np.concatenate([cross - v0 * T - 0.5 * a0 * T * T, v0, a0])
+    xs, us = stationary_guess(x0, P.N, P.nu)
+    return P, x0, way, np.ascontiguousarray(xs), np.ascontiguousarray(us), dyn
+
+
+def test_projectile_rows_kernel_source(arrangements):
+    """dynamic-obstacle sphere, ground half-space and projectile-path rows of the linearisation kernel
+    against the oracle (the obstacle is propagated ballistically to every knot; the projectile row's gradient holds
+    the closest time fixed as projectile_path_constraint.h:118-145 does), and the QP on the oracle's iterate path."""
+    B = 2
+    P, x0, way, xs, us, dyn = _projectile_case(arrangements, B, qp_tol=0.0, qp_iter_max=4)
+    assert list(P.sph_frame).count(-2) == 1 and list(P.pair_b).count(-1) == 1 and len(P.proj_sph) == 1
+    e = Emu(P, B)
+    flags = np.array([1.0, 1.0])
+    e.E.emu_set_dynamic(p(dyn), p(flags))
+    rng = np.random.default_rng(3)
+    xr = xs + rng.uniform(-0.2, 0.2, xs.shape)
+    lin = e.linearize(way, np.zeros(B), xr, us)
+    nrow = 4
+    assert e.lin_stride == 223 + nrow * 10
+    for b in range(B):
+        O = Oracle(P); O.set_dynamic_obstacle(dyn[b], 1.0)
+        for k in range(P.N):
+            d, dq = O.obstacle_rows(xr[b, k], tau=k * P.dt)
+            r = lin[b, k, 223:]
+            # collision rows to rounding; the projectile row goes through a Newton iteration with a 1e-4 stopping test
+            assert np.abs(r[:3] - d[:3]).max() < 1e-12 and np.abs(r[nrow:].reshape(nrow, 9)[:3] - dq[:3]).max() < 1e-11
+            assert abs(r[3] - d[3]) < 1e-9 and np.abs(r[nrow:].reshape(nrow, 9)[3] - dq[3]).max() < 1e-8
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        O = Oracle(P); O.set_dynamic_obstacle(dyn[b], 1.0)
+        dxo, duo, so, rc = O.qp_step(0.0, x0[b], xs[b], us[b])
+        # (this first QP is infeasible -- the goal lies behind the linearised rows -- so the iterates part quickly)
+        assert np.abs(dx[b] - dxo).max() < 1e-5 * max(1, np.abs(dxo).max())
+    e.E.emu_set_dynamic(None, None)

@@ -39,6 +39,7 @@ class UprProblem(C.Structure):
         ("use_feedback_policy", C.c_int),
         ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", (C.c_double * 3) * MAXS), ("sph_r", C.c_double * MAXS),
         ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", C.c_double),
+        ("n_dyn", C.c_int), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", C.c_double * 8), ("proj_scale", C.c_double),
     ]
 
 
@@ -86,6 +87,11 @@ def problem_to_c(P):
         o.sph_frame[i] = int(P.sph_frame[i]); o.sph_r[i] = float(P.sph_r[i]); _fill(o.sph_off[i], P.sph_off[i])
     for i in range(npair):
         o.pair_a[i], o.pair_b[i] = int(P.pair_a[i]), int(P.pair_b[i])
+    o.n_dyn, o.n_proj, o.proj_scale = int(P.n_dyn), len(P.proj_sph), float(P.proj_scale)
+    if o.n_proj > 8:
+        raise ValueError("at most 8 projectile-path rows")
+    for i in range(o.n_proj):
+        o.proj_sph[i] = int(P.proj_sph[i]); o.proj_dist[i] = float(P.proj_dist[i])
     return o
 
 
@@ -110,6 +116,7 @@ PROTOTYPES = [
     ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
     ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_linearize_points", C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    ("upr_batch_set_projectile_flag", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_obstacle_rows", C.c_int, [C.c_void_p, C.c_int, dp, dp, dp]),
     ("upr_batch_eq_input_jacobian", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("upr_batch_qp_step", C.c_int, [C.c_void_p, dp, dp]),

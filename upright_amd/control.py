@@ -158,11 +158,23 @@ class ControllerSettings(bindings.ControllerSettings):
             # obstacle geometry: the reference compiles obstacles.urdf from xacro includes; here the include names
             # select the sphere table (upright_amd/robots.py documents the numbers and their xacro provenance)
             self.obstacle_settings.obstacle_urdf_path = ";".join((obs.get("urdf") or {}).get("includes", []))
-            if obs.get("dynamic"):
-                self.dims.o = len(obs["dynamic"])
+            x0_obs = []
+            for oc in obs.get("dynamic") or []:   # wrappers.py:363-383
+                o = bindings.DynamicObstacle()
+                o.name, o.radius = oc["name"], oc["radius"]
+                for mc in oc["modes"]:
+                    m = bindings.DynamicObstacleMode()
+                    m.time = mc["time"]; m.position = np.array(mc["position"], dtype=np.float64)
+                    m.velocity = np.array(mc["velocity"], dtype=np.float64); m.acceleration = np.array(mc["acceleration"], dtype=np.float64)
+                    o.modes.push_back(m)
+                self.obstacle_settings.dynamic_obstacles.push_back(o)
+                x0_obs.append(np.concatenate([o.modes[0].position, np.zeros(6)]))   # static until the sensors update it
+            self.dims.o = len(x0_obs)
+            self._x0_obs = np.concatenate(x0_obs) if x0_obs else np.zeros(0)
         if x0 is None:
             x0 = pa(config["robot"]["x0"])
             assert x0.shape == (self.dims.robot.x,)
+            x0 = np.concatenate([x0, getattr(self, "_x0_obs", np.zeros(0))])
         self.initial_state = np.array(x0, dtype=np.float64)
         assert self.initial_state.shape == (self.dims.x(),)
         self.xd = np.array(config.get("desired_state", np.zeros_like(self.initial_state)), dtype=np.float64)

@@ -232,10 +232,8 @@ class VectorFunctionLinearApproximation:
 def problem_from_settings(s):
     """ControllerSettings -> Problem (what ControllerInterface's constructor assembles,
     controller_interface.cpp:103-393).  Raises RuntimeError for OCP terms outside the accelerated path."""
-    if s.obstacle_settings.enabled and len(s.obstacle_settings.dynamic_obstacles) > 0:
-        raise RuntimeError("dynamic obstacles are not supported by the MI355X engine yet (SURVEY.md 8f.2)")
-    if s.projectile_path_constraint_enabled:
-        raise RuntimeError("projectile path constraint is not supported by the MI355X engine yet (SURVEY.md 8f.2)")
+    if len(s.obstacle_settings.dynamic_obstacles) > 1:
+        raise RuntimeError("the MI355X engine supports one dynamic obstacle")
     if s.inertial_alignment_settings.cost_enabled or s.inertial_alignment_settings.constraint_enabled:
         raise RuntimeError("inertial alignment is outside the accelerated path (SURVEY.md section 2, row 12)")
     if s.end_effector_box_constraint_enabled:
@@ -247,8 +245,8 @@ def problem_from_settings(s):
     if s.sqp.hpipm.slacks.enabled:
         raise RuntimeError("HPIPM slack variables are not supported by the MI355X engine yet")
     d = s.dims
-    if d.o != 0:
-        raise RuntimeError("dynamic obstacles are not supported by the MI355X engine yet (SURVEY.md 8f.2)")
+    if d.o != len(s.obstacle_settings.dynamic_obstacles) or d.o > 1:
+        raise RuntimeError("dims.o must equal the number of dynamic obstacles (at most one)")
     base = robot_base_type_to_string(s.robot_base_type)
     chain = robots.from_config({"base_type": base, "dims": {"q": d.robot.q}, "base_pose": list(s.base_pose)})
     from .core_bindings import contact_tables
@@ -291,15 +289,22 @@ def problem_from_settings(s):
         sqp_iters=int(s.sqp.sqp_iteration), qp_iter_max=int(s.sqp.hpipm.iter_max), use_feedback_policy=bool(s.sqp.use_feedback_policy),
         delta_tol=float(s.sqp.delta_tol), cost_tol=float(s.sqp.cost_tol), **tables,
     )
-    if s.obstacle_settings.enabled:
-        # controller_interface.cpp:172-228,450-481: sphere pairs by name, hard state inequality "obstacle_avoidance"
-        try:
-            cm = robots.collision_model(chain, [tuple(p) for p in s.obstacle_settings.collision_link_pairs])
-        except ValueError as e:
-            raise RuntimeError(str(e))
-        for k, v in cm.items():
-            setattr(P, k, v)
-        P.obs_min_dist = float(s.obstacle_settings.minimum_distance)
+    P.n_dyn = d.o
+    try:
+        if s.obstacle_settings.enabled:
+            # controller_interface.cpp:172-228,450-481: sphere pairs by name, hard state inequality "obstacle_avoidance"
+            dyn = {o.name: o.radius for o in s.obstacle_settings.dynamic_obstacles}
+            cm = robots.collision_model(chain, [tuple(p) for p in s.obstacle_settings.collision_link_pairs], dynamic=dyn)
+            for k, v in cm.items():
+                setattr(P, k, v)
+            P.obs_min_dist = float(s.obstacle_settings.minimum_distance)
+        if s.projectile_path_constraint_enabled:
+            # controller_interface.cpp:272-294; the constraint reads the LAST 9 entries of the state
+            if d.o != 1:
+                raise RuntimeError("projectile_path_constraint needs one dynamic obstacle")
+            robots.add_projectile_rows(P, s.projectile_path_collision_links, s.projectile_path_distances, s.projectile_path_scale)
+    except ValueError as e:
+        raise RuntimeError(str(e))
     return P.validate()
 
 
@@ -326,6 +331,10 @@ class ControllerInterface:
             if self._mpc is not None:
                 self._mpc.close()
             self._mpc = BatchMPC(self.problem, 1)
+        if self.problem.n_dyn:
+            # 8th entry of the target state: activation of the projectile constraint (projectile_path_constraint.h:88-90)
+            x0t = np.asarray(target.xs[0], dtype=np.float64)
+            self._mpc.set_projectile_flag(float(x0t[7]) if x0t.size > 7 else 0.0)
         self._first = True
 
     def reset(self, targetTrajectories):
@@ -336,7 +345,7 @@ class ControllerInterface:
 
     def setObservation(self, t, x, u):
         x = np.asarray(x)
-        if x.dtype != np.float64 or x.shape != (self.problem.nx,):
+        if x.dtype != np.float64 or x.shape != (self.problem.nx_full,):
             raise TypeError("setObservation(): incompatible function arguments (x must be float64 of length nx)")
         self._t, self._x = float(t), x.copy()
 
@@ -367,7 +376,7 @@ class ControllerInterface:
         return self._mpc.last_solve_ms()
 
     def getStateDim(self):
-        return self.problem.nx
+        return self.problem.nx_full
 
     def getInputDim(self):
         return self.problem.nu
@@ -384,10 +393,12 @@ class ControllerInterface:
         return self._lin(t, x, u)["g"][0]
 
     def getStateInputInequalityConstraintValue(self, name, t, x, u):
-        if name == "obstacle_avoidance" and len(self.problem.pair_a) > 0:
+        if name in ("obstacle_avoidance", "projectile_constraint") and len(self.problem.pair_a) + len(self.problem.proj_sph) > 0:
             if self._mpc is None:
                 self._mpc = BatchMPC(self.problem, 1)
-            return self._mpc.obstacle_rows(np.asarray(x, dtype=np.float64), jac=False)[0]
+            rows = self._mpc.obstacle_rows(np.asarray(x, dtype=np.float64), jac=False)[0]
+            npair = len(self.problem.pair_a)
+            return rows[:npair] if name == "obstacle_avoidance" else rows[npair:]
         if name != "contact_forces" or self.problem.nf != 3:
             raise RuntimeError(f"no inequality constraint named '{name}'")
         from .engine import core_friction_rows

@@ -204,6 +204,11 @@ struct upr_batch {
     int *done = nullptr, *has_prev = nullptr;
     double* prof = nullptr;
     double *fb = nullptr, *xs_lin = nullptr;   // feedback gains of the last solve
+    // dynamic obstacle (n_dyn == 1): observed state per instance (device + host copies, and the one the stored
+    // solution belongs to), activation flag of the projectile rows
+    double *dyn0 = nullptr, *pflag = nullptr;
+    std::vector<double> hdyn0, hdyn_prev, htprev;
+    int nxf = 0;   // interface state dimension 3 nq + 9 n_dyn
     bool guess_set = false;
     double last_ms = 0.0;
     int qp_nt = 0;
@@ -231,9 +236,12 @@ int check_problem(const upr_problem* P) {
     if (P->Wee[3] != 0 || P->Wee[4] != 0 || P->Wee[5] != 0) return fail("end-effector orientation weights are not supported");
     if (P->n_sph < 0 || P->n_sph > UPR_MAX_SPHERES) return fail("n_sph out of range");
     if (P->n_pairs < 0 || P->n_pairs > UPR_MAX_PAIRS) return fail("n_pairs out of range");
-    for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -1 || P->sph_frame[i] > P->nq) return fail("sph_frame out of range");
+    if (P->n_dyn < 0 || P->n_dyn > 1) return fail("n_dyn must be 0 or 1");
+    if (P->n_proj < 0 || P->n_proj > 8 || (P->n_proj > 0 && P->n_dyn != 1)) return fail("projectile rows need one dynamic obstacle (n_proj <= 8)");
+    for (int i = 0; i < P->n_proj; ++i) if (P->proj_sph[i] < 0 || P->proj_sph[i] >= P->n_sph || !(P->proj_dist[i] > 0)) return fail("projectile row out of range");
+    for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -2 || P->sph_frame[i] > P->nq || (P->sph_frame[i] == -2 && P->n_dyn != 1)) return fail("sph_frame out of range");
     for (int i = 0; i < P->n_pairs; ++i)
-        if (P->pair_a[i] < 0 || P->pair_a[i] >= P->n_sph || P->pair_b[i] < 0 || P->pair_b[i] >= P->n_sph || P->pair_a[i] == P->pair_b[i]) return fail("collision pair out of range");
+        if (P->pair_a[i] < 0 || P->pair_a[i] >= P->n_sph || P->pair_b[i] < -1 || P->pair_b[i] >= P->n_sph || P->pair_a[i] == P->pair_b[i]) return fail("collision pair out of range");
     for (int i = 0; i < P->nc; ++i) {
         if (P->contact_body2[i] < 0 || P->contact_body2[i] >= P->nb) return fail("contact_body2 must index a balanced body");
         if (P->contact_body1[i] >= P->nb) return fail("contact_body1 out of range");
@@ -349,6 +357,7 @@ upr_lin_args traj_lin_args(upr_batch* h) {
     A.P = h->dP; A.d = h->d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = h->t0;
     A.xs = h->xs; A.us = h->us; A.inst = nullptr; A.lin = h->lin; A.ee_out = nullptr;
     A.npoints = h->B * (h->d.N + 1);
+    A.dyn = h->dyn0; A.pflag = h->pflag;
     return A;
 }
 upr_qp_args make_qp_args(upr_batch* h) {
@@ -414,7 +423,7 @@ int advance_impl(upr_batch* h) {
         { KernelTimer T(h, 1); if (launch_qp(h, make_qp_args(h))) return 1; T.stop(); }
         upr_ls_args L;
         L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
-        L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it;
+        L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
     }
     if (h->fb) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
@@ -422,6 +431,7 @@ int advance_impl(upr_batch* h) {
         else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
         UPR_HIP(hipGetLastError());
     }
+    h->hdyn_prev = h->hdyn0;
     // remember the solution for the next warm start / policy evaluation
     UPR_HIP(hipMemcpyAsync(h->xs_prev, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
     UPR_HIP(hipMemcpyAsync(h->us_prev, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
@@ -487,11 +497,13 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (need_device()) return nullptr;
     upr_batch* h = new upr_batch();
     h->P = *P; h->d = upr_make_dims(P); h->B = B;
+    h->nxf = h->d.nx + 9 * P->n_dyn;
+    h->hdyn0.assign((size_t)B * 9 * P->n_dyn, 0.0); h->hdyn_prev = h->hdyn0; h->htprev.assign(B, 0.0);
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
     // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
-    h->use_qp3 = qp3_has_shape(*P) && P->n_pairs == 0;
-    h->use_qp2 = qp2_has_shape(*P) && P->n_pairs == 0;
+    h->use_qp3 = qp3_has_shape(*P) && P->n_pairs + P->n_proj == 0;
+    h->use_qp2 = qp2_has_shape(*P) && P->n_pairs + P->n_proj == 0;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
     if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }
@@ -513,7 +525,8 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
         dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) ||
-        dev_alloc(&h->has_prev, B) || (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)))
+        dev_alloc(&h->has_prev, B) || (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
+        (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9) || dev_alloc(&h->pflag, B))))
         return bad();
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
     hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
@@ -541,6 +554,8 @@ void upr_batch_destroy(upr_batch* h) {
     if (!h) return;
     hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
     if (h->fb) hipFree(h->fb);
+    if (h->dyn0) hipFree(h->dyn0);
+    if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
     hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -557,7 +572,7 @@ int upr_batch_reset(upr_batch* h, const double* way_p) {
     return 0;
 }
 
-int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x) {
+static int set_observation_core(upr_batch* h, const double* t, int t_stride, const double* x) {
     if (!h) return fail("null batch");
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
@@ -567,7 +582,7 @@ int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const
     return 0;
 }
 
-int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us) {
+static int set_guess_core(upr_batch* h, const double* xs, const double* us) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
     UPR_HIP(hipMemcpyAsync(h->xs, xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyHostToDevice, h->stream));
@@ -597,7 +612,7 @@ int upr_batch_advance(upr_batch* h) {
     return 0;
 }
 
-int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
+static int get_solution_core(upr_batch* h, double* ts, double* xs, double* us) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
     UPR_HIP(hipStreamSynchronize(h->stream));
@@ -611,7 +626,7 @@ int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
     return 0;
 }
 
-int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
+static int evaluate_core(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
     double *dt_ = nullptr, *dx = nullptr, *du = nullptr;
@@ -628,7 +643,7 @@ int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_ou
     return 0;
 }
 
-int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
+static int evaluate_policy_core(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
     if (!h) return fail("null batch");
     if (!h->fb) return fail("upr_batch_evaluate_policy: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
@@ -647,7 +662,7 @@ int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const
     return 0;
 }
 
-int upr_batch_get_feedback(upr_batch* h, double* K) {
+static int get_feedback_core(upr_batch* h, double* K) {
     if (!h) return fail("null batch");
     if (!h->fb) return fail("upr_batch_get_feedback: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
@@ -667,7 +682,7 @@ int upr_batch_get_stats(upr_batch* h, double* stats) {
 
 // points mode of the linearisation kernel: records of n arbitrary (x, u) pairs back on the host
 static int linearize_points_impl(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
-                                 std::vector<double>& rec, double* ee) {
+                                 std::vector<double>& rec, double* ee, const double* dyn_pts = nullptr) {
     const upr_dims& d = h->d;
     for (int i = 0; i < n; ++i) if (inst[i] < 0 || inst[i] >= h->B) return fail("instance index out of range");
     int* dinst = nullptr; double *dt_, *dx, *du, *dlin, *dee;
@@ -680,12 +695,18 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     upr_lin_args A;
     A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
     A.lin = dlin; A.ee_out = dee; A.npoints = n;
+    double* ddyn = nullptr;
+    if (h->P.n_dyn) {   // points mode: the obstacle state of every point as given
+        if (dev_alloc(&ddyn, (size_t)n * 9)) return 1;
+        if (dyn_pts) UPR_HIP(hipMemcpy(ddyn, dyn_pts, sizeof(double) * n * 9, hipMemcpyHostToDevice));
+        A.dyn = ddyn; A.pflag = h->pflag;
+    }
     if (do_linearize(h, A)) return 1;
     UPR_HIP(hipStreamSynchronize(h->stream));
     rec.assign((size_t)n * d.lin_stride, 0.0);
     UPR_HIP(hipMemcpy(rec.data(), dlin, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
     if (ee) UPR_HIP(hipMemcpy(ee, dee, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
-    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee);
+    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee); if (ddyn) hipFree(ddyn);
     return 0;
 }
 
@@ -694,8 +715,16 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
     if (!h) return fail("null batch");
     if (n <= 0) return 0;
     const upr_dims& d = h->d;
-    std::vector<double> rec;
-    if (linearize_points_impl(h, n, inst, t, x, u, rec, ee)) return 1;
+    std::vector<double> rec, xr, dyn;
+    if (h->P.n_dyn) {   // interface states [robot x, obstacle]; Jacobian outputs keep the 3 nq robot columns
+        xr.resize((size_t)n * d.nx); dyn.resize((size_t)n * 9);
+        for (int i = 0; i < n; ++i) {
+            std::memcpy(xr.data() + (size_t)i * d.nx, x + (size_t)i * h->nxf, sizeof(double) * d.nx);
+            std::memcpy(dyn.data() + (size_t)i * 9, x + (size_t)i * h->nxf + d.nx, sizeof(double) * 9);
+        }
+        x = xr.data();
+    }
+    if (linearize_points_impl(h, n, inst, t, x, u, rec, ee, h->P.n_dyn ? dyn.data() : nullptr)) return 1;
     for (int i = 0; i < n; ++i) {
         const double* r = rec.data() + (size_t)i * d.lin_stride;
         if (g) std::memcpy(g + (size_t)i * d.ne, r + d.lin_g, sizeof(double) * d.ne);
@@ -710,11 +739,15 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
 int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* dd, double* dq) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
-    if (d.no == 0) return fail("upr_batch_obstacle_rows: the problem has no collision pairs");
+    if (d.no == 0) return fail("upr_batch_obstacle_rows: the problem has no collision pairs / projectile rows");
     if (n <= 0) return 0;
     std::vector<int> inst(n, 0);
-    std::vector<double> t(n, 0.0), u((size_t)n * d.nu, 0.0), rec;
-    if (linearize_points_impl(h, n, inst.data(), t.data(), x, u.data(), rec, nullptr)) return 1;
+    std::vector<double> t(n, 0.0), u((size_t)n * d.nu, 0.0), rec, xr((size_t)n * d.nx), dyn((size_t)n * 9 * h->P.n_dyn);
+    for (int i = 0; i < n; ++i) {   // interface states: [robot x, obstacle r v a]
+        std::memcpy(xr.data() + (size_t)i * d.nx, x + (size_t)i * h->nxf, sizeof(double) * d.nx);
+        if (h->P.n_dyn) std::memcpy(dyn.data() + (size_t)i * 9, x + (size_t)i * h->nxf + d.nx, sizeof(double) * 9);
+    }
+    if (linearize_points_impl(h, n, inst.data(), t.data(), xr.data(), u.data(), rec, nullptr, h->P.n_dyn ? dyn.data() : nullptr)) return 1;
     for (int i = 0; i < n; ++i) {
         const double* r = rec.data() + (size_t)i * d.lin_stride + d.lin_obs;
         std::memcpy(dd + (size_t)i * d.no, r, sizeof(double) * d.no);
@@ -734,7 +767,7 @@ int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu) {
     return 0;
 }
 
-int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus) {
+static int qp_step_core(upr_batch* h, double* dxs, double* dus) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
     if (do_linearize(h, traj_lin_args(h))) return 1;
@@ -817,4 +850,112 @@ int upr_batch_reset_async(upr_batch* h) {
     return 0;
 }
 
+
+// ---- interface states: [robot x (3 nq), dynamic obstacle r v a (9 n_dyn)] ------------------------------------------------
+// The kernels work on the robot state; the obstacle is uncontrolled (system_dynamics.h:29-39), so its part of every
+// trajectory is the ballistic continuation of its observed state.  With n_dyn == 0 these wrappers are pass-throughs.
+static void narrow_states(const upr_batch* h, const double* xf, size_t n, std::vector<double>& xr) {
+    xr.resize(n * h->d.nx);
+    for (size_t i = 0; i < n; ++i) std::memcpy(xr.data() + i * h->d.nx, xf + i * h->nxf, sizeof(double) * h->d.nx);
+}
+static void obstacle_after(const double* xo, double tau, double* out) {
+    for (int i = 0; i < 3; ++i) { out[6 + i] = xo[6 + i]; out[3 + i] = xo[3 + i] + tau * xo[6 + i]; out[i] = xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * xo[6 + i]; }
+}
+
+int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn) return set_observation_core(h, t, t_stride, x);
+    std::vector<double> xr;
+    narrow_states(h, x, h->B, xr);
+    for (int b = 0; b < h->B; ++b) std::memcpy(h->hdyn0.data() + (size_t)b * 9, x + (size_t)b * h->nxf + h->d.nx, sizeof(double) * 9);
+    UPR_HIP(hipMemcpy(h->dyn0, h->hdyn0.data(), sizeof(double) * h->B * 9, hipMemcpyHostToDevice));
+    return set_observation_core(h, t, t_stride, xr.data());
+}
+
+int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn) return set_guess_core(h, xs, us);
+    std::vector<double> xr;
+    narrow_states(h, xs, (size_t)h->B * (h->d.N + 1), xr);
+    return set_guess_core(h, xr.data(), us);
+}
+
+int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn || !xs) return get_solution_core(h, ts, xs, us);
+    const upr_dims& d = h->d;
+    std::vector<double> xr((size_t)h->B * (d.N + 1) * d.nx);
+    if (get_solution_core(h, ts, xr.data(), us)) return 1;
+    for (int b = 0; b < h->B; ++b) for (int k = 0; k <= d.N; ++k) {
+        double* o = xs + ((size_t)b * (d.N + 1) + k) * h->nxf;
+        std::memcpy(o, xr.data() + ((size_t)b * (d.N + 1) + k) * d.nx, sizeof(double) * d.nx);
+        obstacle_after(h->hdyn0.data() + (size_t)b * 9, k * h->P.dt, o + d.nx);
+    }
+    return 0;
+}
+
+static void widen_eval(upr_batch* h, const double* t, int t_stride, const double* xr, double* x_out) {
+    std::vector<double> tp(h->B);
+    (void)hipMemcpy(tp.data(), h->tprev, sizeof(double) * h->B, hipMemcpyDeviceToHost);
+    for (int b = 0; b < h->B; ++b) {
+        double* o = x_out + (size_t)b * h->nxf;
+        std::memcpy(o, xr + (size_t)b * h->d.nx, sizeof(double) * h->d.nx);
+        double tau = t[(size_t)b * (t_stride ? 1 : 0)] - tp[b];
+        obstacle_after(h->hdyn_prev.data() + (size_t)b * 9, tau > 0.0 ? tau : 0.0, o + h->d.nx);
+    }
+}
+
+int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn) return evaluate_core(h, t, t_stride, x_out, u_out);
+    std::vector<double> xr((size_t)h->B * h->d.nx);
+    if (evaluate_core(h, t, t_stride, xr.data(), u_out)) return 1;
+    widen_eval(h, t, t_stride, xr.data(), x_out);
+    return 0;
+}
+
+int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn) return evaluate_policy_core(h, t, t_stride, x_obs, x_out, u_out);
+    std::vector<double> xo, xr((size_t)h->B * h->d.nx);
+    narrow_states(h, x_obs, h->B, xo);
+    if (evaluate_policy_core(h, t, t_stride, xo.data(), xr.data(), u_out)) return 1;
+    widen_eval(h, t, t_stride, xr.data(), x_out);
+    return 0;
+}
+
+int upr_batch_get_feedback(upr_batch* h, double* K) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn) return get_feedback_core(h, K);
+    const upr_dims& d = h->d;
+    std::vector<double> Kr((size_t)h->B * d.N * d.nu * d.nx);
+    if (get_feedback_core(h, Kr.data())) return 1;
+    const size_t rows = (size_t)h->B * d.N * d.nu;
+    for (size_t r = 0; r < rows; ++r) {   // the obstacle is not fed back: zero columns
+        std::memcpy(K + r * h->nxf, Kr.data() + r * d.nx, sizeof(double) * d.nx);
+        for (int c = d.nx; c < h->nxf; ++c) K[r * h->nxf + c] = 0.0;
+    }
+    return 0;
+}
+
+int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus) {
+    if (!h) return fail("null batch");
+    if (!h->P.n_dyn || !dxs) return qp_step_core(h, dxs, dus);
+    const upr_dims& d = h->d;
+    std::vector<double> xr((size_t)h->B * (d.N + 1) * d.nx);
+    if (qp_step_core(h, xr.data(), dus)) return 1;
+    const size_t n = (size_t)h->B * (d.N + 1);
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(dxs + i * h->nxf, xr.data() + i * d.nx, sizeof(double) * d.nx);
+        for (int c = d.nx; c < h->nxf; ++c) dxs[i * h->nxf + c] = 0.0;
+    }
+    return 0;
+}
+
+int upr_batch_set_projectile_flag(upr_batch* h, const double* sflag) {
+    if (!h) return fail("null batch");
+    if (!h->pflag) return fail("upr_batch_set_projectile_flag: the problem has no dynamic obstacle");
+    UPR_HIP(hipMemcpy(h->pflag, sflag, sizeof(double) * h->B, hipMemcpyHostToDevice));
+    return 0;
+}
 }  // extern "C"

@@ -91,7 +91,7 @@ static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
     d.ne = 6 * P->nb; d.np = (P->nf == 3) ? 5 * P->nc : 0;
     d.neN = P->terminal_constraint ? 3 + 2 * P->nq : 0;
     d.lin_g = 0; d.lin_gx = d.ne; d.lin_cost = d.lin_gx + d.ne * d.nx; d.lin_grad = d.lin_cost + 1;
-    d.no = P->n_pairs;
+    d.no = P->n_pairs + P->n_proj;
     d.lin_hess = d.lin_grad + d.nq; d.lin_obs = d.lin_hess + d.nq * (d.nq + 1) / 2; d.lin_stride = d.lin_obs + d.no * (1 + d.nq);
     d.ni_stage = 2 * d.nx + 2 * d.nu + d.np + d.no;
     d.ss_kx = 0; d.ss_hjj = d.ss_kx + d.nq * d.nx; d.ss_hff = d.ss_hjj + d.nq * d.nq;

@@ -180,15 +180,63 @@ static inline UPR_HD void upr_sphere_walk(const upr_problem* P, const double* x,
     upr_rmul_const(R, P->tool_R);
     place(NQ);
 }
-// values of the collision rows at a configuration (line search): d[n_pairs]
-template <int NQ>
-static inline UPR_HD void upr_obstacle_values(const upr_problem* P, const double* x, double* d) {
-    double c[UPR_MAX_SPHERES][3];
-    upr_sphere_walk<double, NQ>(P, x, -1, [&](int s, const double* cs) { c[s][0] = cs[0]; c[s][1] = cs[1]; c[s][2] = cs[2]; });
-    for (int r = 0; r < P->n_pairs; ++r) {
+// closest FUTURE time of a ballistic path r0 + t v0 + t^2/2 g to the point c (projectile_path_constraint.h:12-45:
+// stationary point of the squared distance by Newton on the cubic, 10 steps from t = 0, tolerance 1e-4)
+static inline UPR_HD double upr_projectile_closest_time(const double* c, const double* r0, const double* v0, const double* g) {
+    const double dr[3] = {c[0] - r0[0], c[1] - r0[1], c[2] - r0[2]};
+    const double a = g[0] * g[0] + g[1] * g[1] + g[2] * g[2], b = 3.0 * (v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2]);
+    const double cc = 2.0 * (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] - (dr[0] * g[0] + dr[1] * g[1] + dr[2] * g[2]));
+    const double dd = -2.0 * (dr[0] * v0[0] + dr[1] * v0[1] + dr[2] * v0[2]);
+    double x = 0.0;
+    for (int i = 0; i < 10; ++i) {
+        const double f = ((a * x + b) * x + cc) * x + dd, df = (3.0 * a * x + 2.0 * b) * x + cc;
+        const double upd = f / df;
+        x -= upd;
+        if (fabs(upd) < 1e-4) break;
+    }
+    return x > 0.0 ? x : 0.0;
+}
+// obstacle state tau seconds after its observation xo = [r, v, a]
+static inline UPR_HD void upr_obstacle_at(const double* xo, double tau, double* r, double* v, double* a) {
+    for (int i = 0; i < 3; ++i) { a[i] = xo[6 + i]; v[i] = xo[3 + i] + tau * a[i]; r[i] = xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * a[i]; }
+}
+// one state row from the sphere centres: collision pair / ground row r < n_pairs, projectile row otherwise.
+// cen(s, i) returns coordinate i of the centre of sphere s; returns the value and the unit direction n (the row's
+// gradient is wgt * n . d c_a/dq - wgt * n . d c_b/dq, b < 0: no second sphere)
+template <class CEN>
+static inline UPR_HD double upr_state_row(const upr_problem* P, int r, CEN cen, const double* ro, const double* vo, const double* ao, double flag,
+                                          int* sa, int* sb, double* n, double* wgt) {
+    if (r < P->n_pairs) {
         const int a = P->pair_a[r], b = P->pair_b[r];
-        const double e0 = c[a][0] - c[b][0], e1 = c[a][1] - c[b][1], e2 = c[a][2] - c[b][2];
-        d[r] = sqrt(e0 * e0 + e1 * e1 + e2 * e2) - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+        *sa = a; *sb = b; *wgt = 1.0;
+        if (b < 0) { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; return cen(a, 2) - (P->sph_r[a] + P->obs_min_dist); }
+        double e[3] = {cen(a, 0) - cen(b, 0), cen(a, 1) - cen(b, 1), cen(a, 2) - cen(b, 2)};
+        const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        for (int i = 0; i < 3; ++i) n[i] = e[i] / dist;
+        return dist - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+    }
+    const int i = r - P->n_pairs, a = P->proj_sph[i];
+    *sa = a; *sb = -1;
+    const double c[3] = {cen(a, 0), cen(a, 1), cen(a, 2)};
+    const double dt = (flag > 0.5) ? upr_projectile_closest_time(c, ro, vo, ao) : 0.0;
+    double e[3];
+    for (int j = 0; j < 3; ++j) e[j] = c[j] - (ro[j] + dt * vo[j] + 0.5 * dt * dt * ao[j]);
+    const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int j = 0; j < 3; ++j) n[j] = e[j] / dist;
+    *wgt = flag * P->proj_scale / P->proj_dist[i];
+    return *wgt * (dist - P->proj_dist[i]);
+}
+// values of the state rows at a configuration (line search): d[n_pairs + n_proj]; xo: obstacle state at this knot
+template <int NQ>
+static inline UPR_HD void upr_obstacle_values(const upr_problem* P, const double* x, const double* xo, double flag, double* d) {
+    double c[UPR_MAX_SPHERES][3];
+    double ro[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
+    if (xo) upr_obstacle_at(xo, 0.0, ro, vo, ao);
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2) for (int i = 0; i < 3; ++i) c[s][i] = ro[i] + P->sph_off[s][i];
+    upr_sphere_walk<double, NQ>(P, x, -1, [&](int s, const double* cs) { c[s][0] = cs[0]; c[s][1] = cs[1]; c[s][2] = cs[2]; });
+    for (int r = 0; r < P->n_pairs + P->n_proj; ++r) {
+        int sa, sb; double n[3], w;
+        d[r] = upr_state_row(P, r, [&](int s, int i) { return c[s][i]; }, ro, vo, ao, flag, &sa, &sb, n, &w);
     }
 }
 

@@ -35,6 +35,10 @@ struct upr_lin_args {
     double* lin;                // [npoints][lin_stride]
     double* ee_out;             // optional [npoints][3] end-effector position
     int npoints;
+    // dynamic obstacle: observed state [r, v, a] per instance (trajectory mode: propagated to the knot) or per point
+    // (points mode, taken as is); activation flag of the projectile rows per instance.  NULL when n_dyn == 0.
+    const double* dyn = nullptr;
+    const double* pflag = nullptr;
 };
 
 struct upr_lin_point {
@@ -117,11 +121,22 @@ static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_po
 // collision rows (only when the problem has pairs), two sub-phases around a barrier:
 //   a: lane l < nq walks the chain with the tangent along q_l and leaves every sphere centre's tangent in LDS
 //      (lane 0 also the values);  b: lane r owns pair r: distance and its gradient n . (dc_a/dq - dc_b/dq)
+// obstacle state at this point (trajectory mode: k dt after the observation)
+static inline UPR_HD void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point& q, double* ro, double* vo, double* ao) {
+    for (int i = 0; i < 3; ++i) { ro[i] = 0.0; vo[i] = 0.0; ao[i] = 0.0; }
+    if (!A.dyn) return;
+    if (A.inst) upr_obstacle_at(A.dyn + (size_t)q.p * 9, 0.0, ro, vo, ao);
+    else upr_obstacle_at(A.dyn + (size_t)q.b * 9, q.k * A.P->dt, ro, vo, ao);
+}
 template <int NQ>
 static inline UPR_HD void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_problem* P = A.P;
     double* sc = sh + upr_lin_lds_base(A.d);
     if (q.terminal || lane >= NQ) return;
+    double ro[3], vo[3], ao[3];
+    upr_lin_obstacle(A, q, ro, vo, ao);
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2)   // rides on the obstacle: no dependence on q
+        for (int i = 0; i < 3; ++i) { sc[(s * 3 + i) * (1 + NQ) + 1 + lane] = 0.0; if (lane == 0) sc[(s * 3 + i) * (1 + NQ)] = ro[i] + P->sph_off[s][i]; }
     upr_sphere_walk<upr_dd, NQ>(P, sh, lane, [&](int s, const upr_dd* c) {
         for (int i = 0; i < 3; ++i) {
             sc[(s * 3 + i) * (1 + NQ) + 1 + lane] = c[i].d;
@@ -134,16 +149,16 @@ static inline UPR_HD void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_l
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const double* sc = sh + upr_lin_lds_base(d);
     if (q.terminal) return;
+    double ro[3], vo[3], ao[3];
+    upr_lin_obstacle(A, q, ro, vo, ao);
+    const double flag = A.pflag ? A.pflag[q.b] : 0.0;
     for (int r = lane; r < d.no; r += UPR_LPK) {
-        const int a = P->pair_a[r], b = P->pair_b[r];
-        double e[3];
-        for (int i = 0; i < 3; ++i) e[i] = sc[(a * 3 + i) * (1 + NQ)] - sc[(b * 3 + i) * (1 + NQ)];
-        const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-        q.out[d.lin_obs + r] = dist - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
+        int sa, sb; double n[3], w;
+        q.out[d.lin_obs + r] = upr_state_row(P, r, [&](int s, int i) { return sc[(s * 3 + i) * (1 + NQ)]; }, ro, vo, ao, flag, &sa, &sb, n, &w);
         for (int j = 0; j < NQ; ++j) {
             double v = 0.0;
-            for (int i = 0; i < 3; ++i) v += e[i] * (sc[(a * 3 + i) * (1 + NQ) + 1 + j] - sc[(b * 3 + i) * (1 + NQ) + 1 + j]);
-            q.out[d.lin_obs + d.no + r * NQ + j] = v / dist;
+            for (int i = 0; i < 3; ++i) v += n[i] * (sc[(sa * 3 + i) * (1 + NQ) + 1 + j] - (sb >= 0 ? sc[(sb * 3 + i) * (1 + NQ) + 1 + j] : 0.0));
+            q.out[d.lin_obs + d.no + r * NQ + j] = w * v;
         }
     }
 }

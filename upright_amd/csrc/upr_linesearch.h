@@ -24,6 +24,8 @@ struct upr_ls_args {
     double* stats;         // [B][UPR_NSTATS]
     int* done;             // [B] convergence flag
     int iter;              // SQP iteration index (0-based)
+    const double* dyn = nullptr;    // [B][9] observed dynamic-obstacle state (NULL: none)
+    const double* pflag = nullptr;  // [B] projectile activation flag
 };
 
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
@@ -45,8 +47,9 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
         iq += wt * v * v;
     }
     if (d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1)
-        double dd[UPR_MAX_PAIRS];
-        upr_obstacle_values<NQ>(P, X, dd);
+        double dd[UPR_MAX_PAIRS + 8], xo[9];
+        if (A.dyn) { upr_obstacle_at(A.dyn + (size_t)b * 9, k * h, xo, xo + 3, xo + 6); }
+        upr_obstacle_values<NQ>(P, X, A.dyn ? xo : nullptr, A.pflag ? A.pflag[b] : 0.0, dd);
         for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, dd[r]); iq += h * v * v; }
     }
     upr_ee<double> E;

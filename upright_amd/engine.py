@@ -17,6 +17,7 @@ class BatchMPC:
         self.problem = problem.validate()
         self.B = int(B)
         self.nx, self.nu, self.N = problem.nx, problem.nu, problem.N
+        self.nxf = problem.nx_full   # interface state: robot state + 9 per dynamic obstacle
         self.ne = 6 * problem.nb
         if body_params is None:
             body_params = np.broadcast_to(problem.body_params, (self.B,) + problem.body_params.shape)
@@ -48,12 +49,12 @@ class BatchMPC:
         check(self._lib.upr_batch_reset(self._h, ptr(self.way_p) if way_p is not None else None))
 
     def set_observation(self, t, x):
-        x = cont(x).reshape(self.B, self.nx)
+        x = cont(x).reshape(self.B, self.nxf)
         t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
         check(self._lib.upr_batch_set_observation(self._h, ptr(t), 1, ptr(x)))
 
     def set_guess(self, xs, us):
-        xs = cont(xs).reshape(self.B, self.N + 1, self.nx)
+        xs = cont(xs).reshape(self.B, self.N + 1, self.nxf)
         us = cont(us).reshape(self.B, self.N, self.nu)
         check(self._lib.upr_batch_set_guess(self._h, ptr(xs), ptr(us)))
 
@@ -68,7 +69,7 @@ class BatchMPC:
 
     def solution(self):
         ts = np.zeros((self.B, self.N + 1))
-        xs = np.zeros((self.B, self.N + 1, self.nx))
+        xs = np.zeros((self.B, self.N + 1, self.nxf))
         us = np.zeros((self.B, self.N, self.nu))
         check(self._lib.upr_batch_get_solution(self._h, ptr(ts), ptr(xs), ptr(us)))
         return ts, xs, us
@@ -77,10 +78,10 @@ class BatchMPC:
         """Plan state and input at time t.  With x_obs (B, nx) and use_feedback_policy the input is the linear
         policy u*(t) + K(t) (x_obs - x*(t)) of the last solve (ocs2::LinearController), else the feed-forward input."""
         t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
-        x = np.zeros((self.B, self.nx))
+        x = np.zeros((self.B, self.nxf))
         u = np.zeros((self.B, self.nu))
         if x_obs is not None and self.problem.use_feedback_policy:
-            xo = cont(x_obs).reshape(self.B, self.nx)
+            xo = cont(x_obs).reshape(self.B, self.nxf)
             check(self._lib.upr_batch_evaluate_policy(self._h, ptr(t), 1, ptr(xo), ptr(x), ptr(u)))
         else:
             check(self._lib.upr_batch_evaluate(self._h, ptr(t), 1, ptr(x), ptr(u)))
@@ -88,7 +89,7 @@ class BatchMPC:
 
     def feedback_gains(self):
         """K[B][N][nu][nx] at the knots of the last solve (u = bias + K x, ocs2 sign)."""
-        K = np.zeros((self.B, self.N, self.nu, self.nx))
+        K = np.zeros((self.B, self.N, self.nu, self.nxf))
         check(self._lib.upr_batch_get_feedback(self._h, ptr(K)))
         return K
 
@@ -102,7 +103,7 @@ class BatchMPC:
 
     # -- term-level access ----------------------------------------------------------------------------
     def linearize_points(self, x, u, t=None, inst=None):
-        x = cont(x).reshape(-1, self.nx)
+        x = cont(x).reshape(-1, self.nxf)
         n = x.shape[0]
         u = cont(u).reshape(n, self.nu)
         t = cont(np.zeros(n) if t is None else np.broadcast_to(np.asarray(t, dtype=np.float64), (n,)))
@@ -119,11 +120,16 @@ class BatchMPC:
 
     def obstacle_rows(self, x, jac=True):
         """Collision rows d (n, n_pairs) and d d / d q (n, n_pairs, nq) at n states (`obstacle_avoidance`)."""
-        x = cont(x).reshape(-1, self.nx)
-        n, npair, nq = x.shape[0], len(self.problem.pair_a), self.problem.nq
+        x = cont(x).reshape(-1, self.nxf)
+        n, npair, nq = x.shape[0], len(self.problem.pair_a) + len(self.problem.proj_sph), self.problem.nq
         d = np.zeros((n, npair)); dq = np.zeros((n, npair, nq))
         check(self._lib.upr_batch_obstacle_rows(self._h, n, ptr(x), ptr(d), ptr(dq) if jac else None))
         return (d, dq) if jac else d
+
+    def set_projectile_flag(self, s):
+        """Activation flag of the projectile rows per instance (8th entry of the target state)."""
+        s = cont(np.broadcast_to(np.asarray(s, dtype=np.float64), (self.B,)))
+        check(self._lib.upr_batch_set_projectile_flag(self._h, ptr(s)))
 
     def eq_input_jacobian(self, inst=0):
         gu = np.zeros((self.ne, self.nu))
@@ -131,7 +137,7 @@ class BatchMPC:
         return gu
 
     def qp_step(self):
-        dxs = np.zeros((self.B, self.N + 1, self.nx))
+        dxs = np.zeros((self.B, self.N + 1, self.nxf))
         dus = np.zeros((self.B, self.N, self.nu))
         check(self._lib.upr_batch_qp_step(self._h, ptr(dxs), ptr(dus)))
         return dxs, dus

@@ -234,40 +234,73 @@ def link_frame(chain, link):
     raise ValueError(f"unknown link '{link}'")
 
 
-def collision_model(chain, pairs, spheres=None):
+def collision_model(chain, pairs, spheres=None, dynamic=None):
     """Sphere table and pair index lists for the named collision pairs of `obstacles.collision_pairs`
-    (obstacles/simple.yaml:11-41; pinocchio appends `_0` to geometry names).  Returns a dict with the Problem fields
-    sph_frame, sph_off, sph_r, pair_a, pair_b."""
+    (obstacles/simple.yaml:11-41, obstacles/dynamic.yaml:19-37; pinocchio appends `_0` to geometry names).
+    `dynamic`: {name: radius} of the dynamic obstacles (controller_interface.cpp:55-82: a sphere on a translating
+    joint); "ground" is the half-space z >= 0 (controller_interface.cpp:93-101).  Returns a dict with the Problem
+    fields sph_frame, sph_off, sph_r, pair_a, pair_b (pair_b = -1: ground)."""
     table = dict(COLLISION_SPHERES)
     table.update(SIMPLE_OBSTACLES)
     if spheres:
         table.update(spheres)
+    for n, r in (dynamic or {}).items():
+        table[n] = ("dynamic", (0.0, 0.0, 0.0), float(r))
+    strip = lambda n: n[:-2] if n.endswith("_0") else n
     names = []
     for a, b in pairs:
+        if strip(a) == "ground":
+            raise ValueError("'ground' must be the second object of a collision pair")
         for n in (a, b):
-            n = n[:-2] if n.endswith("_0") else n
+            n = strip(n)
+            if n == "ground":
+                continue
             if n not in table:
                 raise ValueError(f"unknown collision object '{n}'")
             if n not in names:
                 names.append(n)
     idx = {n: i for i, n in enumerate(names)}
-    strip = lambda n: n[:-2] if n.endswith("_0") else n
+    idx["ground"] = -1
     frames, offs = [], []
     for n in names:
         link, off, _ = table[n]
-        f = link_frame(chain, link)
         off = np.asarray(off, dtype=np.float64)
-        if link == "base_link" and f == -1 and chain.base_pose is not None:
-            x, y, yaw = chain.base_pose
-            c, s = np.cos(yaw), np.sin(yaw)
-            off = np.array([x + c * off[0] - s * off[1], y + s * off[0] + c * off[1], off[2]])
+        if link == "dynamic":
+            f = -2
+        else:
+            f = link_frame(chain, link)
+            if link == "base_link" and f == -1 and chain.base_pose is not None:
+                x, y, yaw = chain.base_pose
+                c, s = np.cos(yaw), np.sin(yaw)
+                off = np.array([x + c * off[0] - s * off[1], y + s * off[0] + c * off[1], off[2]])
         frames.append(f); offs.append(off)
     return dict(
         sph_frame=np.array(frames, dtype=np.int32), sph_off=np.array(offs, dtype=np.float64).reshape(len(names), 3),
         sph_r=np.array([table[n][2] for n in names], dtype=np.float64),
         pair_a=np.array([idx[strip(a)] for a, _ in pairs], dtype=np.int32),
         pair_b=np.array([idx[strip(b)] for _, b in pairs], dtype=np.int32),
+        sphere_names=names,
     )
+
+
+def add_projectile_rows(P, links, distances, scale):
+    """projectile_path_constraint (controller_interface.cpp:272-294): the checked link positions are the origins of
+    the named collision links; they become (or reuse) entries of the problem's sphere table."""
+    names = list(getattr(P, "sphere_names", []))
+    frames, offs, rads = list(P.sph_frame), [np.asarray(o) for o in P.sph_off], list(P.sph_r)
+    idxs = []
+    for n in links:
+        n = n[:-2] if n.endswith("_0") else n
+        if n not in names:
+            if n not in COLLISION_SPHERES:
+                raise ValueError(f"unknown collision object '{n}'")
+            link, off, r = COLLISION_SPHERES[n]
+            names.append(n); frames.append(link_frame(P.chain, link)); offs.append(np.asarray(off, dtype=np.float64)); rads.append(r)
+        idxs.append(names.index(n))
+    P.sphere_names = names
+    P.sph_frame = np.array(frames, dtype=np.int32); P.sph_off = np.array(offs, dtype=np.float64).reshape(len(names), 3); P.sph_r = np.array(rads, dtype=np.float64)
+    P.proj_sph = np.array(idxs, dtype=np.int32); P.proj_dist = np.asarray(distances, dtype=np.float64).copy(); P.proj_scale = float(scale)
+    return P
 
 
 # obstacles/simple.yaml:11-41
