@@ -708,3 +708,57 @@ def test_config3_shape_three_objects_and_static_obstacles(arrangements):
         # both reach the same local solution although the early (infeasible) QPs are not well defined
         assert np.abs(xs[b] - xo).max() < 5e-3
     mpc.close()
+
+
+def test_dynamic_obstacle_and_projectile_constraint(arrangements):
+    """SURVEY 8f.2 / BASELINE config 5: the state carries a dynamic obstacle [r, v, a] (system_dynamics.h:29-39,
+    nx 27 + 9), spheres ride on it, the ground is a half-space, and the projectile-path constraint
+    (projectile_path_constraint.h) keeps the tray's collision link 0.35 m away from the ball's FUTURE path while the
+    target's flag is set.  A ball crosses the straight tray path one second from now."""
+    from test_emu import _projectile_case
+
+    B = 3
+    P, x0r, way, xs0r, us0, dyn = _projectile_case(arrangements, B, sqp_iters=32)   # two of three converge in 25 iterations
+    assert P.nx_full == 36
+    x0 = np.concatenate([x0r, dyn], axis=1)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_projectile_flag(1.0)
+    # rows through the C-ABI (interface states: obstacle part taken as given), against the oracle
+    rng = np.random.default_rng(2)
+    xq = x0.copy(); xq[:, :27] += rng.uniform(-0.2, 0.2, (B, 27))
+    d, dq = mpc.obstacle_rows(xq)
+    for b in range(B):
+        O = Oracle(P); O.set_dynamic_obstacle(xq[b, 27:], 1.0)
+        do, dqo = O.obstacle_rows(xq[b, :27])
+        assert np.abs(d[b][:3] - do[:3]).max() < 1e-12 and np.abs(dq[b][:3] - dqo[:3]).max() < 1e-11
+        assert abs(d[b][3] - do[3]) < 1e-9 and np.abs(dq[b][3] - dqo[3]).max() < 1e-8
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    ts, xs, us = mpc.solution()
+    st = mpc.stats()
+    assert xs.shape == (B, P.N + 1, 36)
+    free = BatchMPC(P, B, way_p=way)          # same problem, flag off: the projectile rows vanish
+    free.set_projectile_flag(0.0)
+    free.set_observation(0.0, x0)
+    free.advance()
+    _, xf, _ = free.solution()
+    for b in range(B):
+        # obstacle part of the trajectory: ballistic continuation of the observation (exact discretisation)
+        for k in (0, 7, P.N):
+            tau = k * P.dt
+            exp = np.concatenate([dyn[b, :3] + tau * dyn[b, 3:6] + 0.5 * tau ** 2 * dyn[b, 6:], dyn[b, 3:6] + tau * dyn[b, 6:], dyn[b, 6:]])
+            assert np.abs(xs[b, k, 27:] - exp).max() < 1e-12
+        P.way_p = way[b]
+        O = Oracle(P); O.set_dynamic_obstacle(dyn[b], 1.0)
+        xo, uo, so, rc = O.solve(0.0, x0r[b], xs0r[b], us0[b])
+        assert rc == 0 and st["qp_status_last"][b] == 0 and st["constraint_violation"][b] < 1e-3
+        assert np.abs(xs[b, :, :27] - xo).max() < 5e-3
+        rows = np.array([O.obstacle_rows(xs[b, k, :27], jac=False, tau=k * P.dt) for k in range(1, P.N)])
+        rows_free = np.array([O.obstacle_rows(xf[b, k, :27], jac=False, tau=k * P.dt) for k in range(1, P.N)])
+        assert rows.min() > -1e-4 and rows[:, 3].min() < 1e-4          # the projectile row is active, nothing violated (SQP tolerance)
+        assert rows_free[:, 3].min() < -0.05                            # flag off: the tray cuts through the ball's path
+        assert np.abs(O.ee_kinematics(xs[b, P.N, :27])[:3] - way[b, 0]).max() < 1e-3   # delta_tol of the SQP
+    # policy / plan evaluation returns interface states too
+    xe, ue = mpc.evaluate(0.05)
+    assert xe.shape == (B, 36) and np.abs(xe[:, 27:30] - (dyn[:, :3] + 0.05 * dyn[:, 3:6] + 0.5 * 0.05 ** 2 * dyn[:, 6:])).max() < 1e-12
+    mpc.close(); free.close()

@@ -910,8 +910,11 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
         upr_qp_forward(S, nu_new, dyN);
         S.mode = 3;
         upr_qp_costates(S, nu_new, dyN, pi_new);
-        double a = 0.995 * upr_reduce(ctx, L + o.red, upr_qp_ineq_sweep(S, 0, 0.0, nullptr), 2);
+        // step length: the largest feasible one, capped at 1, then shortened by 0.995 (HPIPM's update_var rule:
+        // never a full step, so slacks and multipliers stay strictly positive)
+        double a = upr_reduce(ctx, L + o.red, upr_qp_ineq_sweep(S, 0, 0.0, nullptr), 2);
         if (a > 1.0) a = 1.0;
+        a *= 0.995;
         upr_qp_ineq_sweep(S, 2, a, nullptr);
         UPR_FOR(i, (N + 1) * nx) {
             ws[d.ws_dx + i] += a * ws[d.ws_sx + i];

@@ -769,8 +769,9 @@ struct upr_qp2 {
             forward(); toc(6);
             mode = 3;
             costates(); toc(9);
-            double a = 0.995 * upr_reduce(ctx, L + o.red, ineq_sweep(0, 0.0, nullptr), 2);
+            double a = upr_reduce(ctx, L + o.red, ineq_sweep(0, 0.0, nullptr), 2);
             if (a > 1.0) a = 1.0;
+            a *= 0.995;   // see upr_qp.h
             ineq_sweep(2, a, nullptr);
             UPR_FOR(e, n1 * NX) {
                 const double s = L[o.S + e];

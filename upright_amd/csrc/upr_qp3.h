@@ -1185,8 +1185,9 @@ struct upr_qp3 {
             forward(); toc(6);
             mode = 3;
             costates(); toc(9);
-            double a = 0.995 * reduce(ineq_sweep(0, 0.0, nullptr), 2);
+            double a = reduce(ineq_sweep(0, 0.0, nullptr), 2);
             if (a > 1.0) a = 1.0;
+            a *= 0.995;   // see upr_qp.h
             ineq_sweep(2, a, nullptr);
             UPR_SYNC();
             UPR_FORT(e, N1 * NX) {
