@@ -84,10 +84,6 @@ def test_problem_from_settings_and_unsupported_terms(arrangements):
     with pytest.raises(RuntimeError, match="unknown collision object"):
         control_bindings.problem_from_settings(s)
     s.obstacle_settings.collision_link_pairs.pop()
-    s.obstacle_settings.dynamic_obstacles.append(object())
-    with pytest.raises(RuntimeError, match="dynamic obstacles"):
-        control_bindings.problem_from_settings(s)
-    s.obstacle_settings.dynamic_obstacles.pop()
     s.obstacle_settings.enabled = False
     s.balancing_settings.enabled = False
     with pytest.raises(RuntimeError):
@@ -161,6 +157,40 @@ def test_arrangement_parser_errors_and_geometry():
     ov = A.overlap_polygon(sq, sq + 0.5)
     assert ov.shape == (4, 2) and np.allclose(sorted(map(tuple, ov)), [(0.5, 0.5), (0.5, 1), (1, 0.5), (1, 1)])
     assert A.overlap_polygon(sq, sq + 2.0) is None
+
+
+def test_dynamic_obstacle_and_projectile_settings(arrangements):
+    """BASELINE config 5 (ral23/experiments/projectile/_base.yaml:26-100 + obstacles/dynamic.yaml:1-36): one dynamic
+    obstacle appends 9 entries to the state, named pairs may involve it and the ground, the projectile-path rows
+    check the listed collision links."""
+    import copy
+
+    g = copy.deepcopy(json.load(open(GOLD / "configs.json"))["full_bottle_point1"]["controller"])
+    g["obstacles"] = {
+        "enabled": True, "minimum_distance": 0.1,
+        "dynamic": [{"name": "projectile1", "radius": 0.2,
+                     "modes": [{"time": 0, "position": [0, -10, 0], "velocity": [0, 0, 0], "acceleration": [0, 0, -9.81]}]}],
+        "collision_pairs": [["wrist1_collision_link_0", "shoulder_collision_link_0"], ["wrist3_collision_link_0", "ground"],
+                            ["balanced_object_collision_link_0", "projectile1"]],
+    }
+    g["projectile_path_constraint"] = {"enabled": True, "distances": [0.35], "scale": 0.2, "collision_links": ["balanced_object_collision_link"]}
+    bodies, contacts = control.objects_from_fixture(arrangements["pink_bottle"])
+    s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
+    assert s.dims.o == 1 and s.dims.x() == 36 and s.initial_state.shape == (36,)
+    assert np.array_equal(s.initial_state[27:], [0, -10, 0, 0, 0, 0, 0, 0, 0])       # static until observed (wrappers.py:378-383)
+    P = control_bindings.problem_from_settings(s)
+    assert (P.nx, P.nx_full, P.n_dyn) == (27, 36, 1)
+    assert list(P.sph_frame) == [6, 4, 8, 9, -2] and list(P.pair_b) == [1, -1, 4] and list(P.pair_a) == [0, 2, 3]
+    assert list(P.proj_sph) == [3] and np.allclose(P.proj_dist, [0.35]) and P.proj_scale == 0.2 and P.sph_r[4] == 0.2
+    g["obstacles"]["collision_pairs"].append(["ground", "wrist1_collision_link_0"])
+    s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
+    with pytest.raises(RuntimeError, match="second object"):
+        control_bindings.problem_from_settings(s)
+    g["obstacles"]["collision_pairs"].pop()
+    g["obstacles"]["dynamic"].append(dict(g["obstacles"]["dynamic"][0], name="projectile2"))
+    s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
+    with pytest.raises(RuntimeError, match="one dynamic obstacle"):
+        control_bindings.problem_from_settings(s)
 
 
 def test_target_trajectories_and_dimensions():

@@ -275,9 +275,9 @@ def problem_from_settings(s):
     # controller_interface.cpp:330-357
     f_lb = np.full(nf * nc, 0.0 if frictionless else -1e2)
     f_ub = np.full(nf * nc, 1e2)
-    xd = np.asarray(s.xd, dtype=np.float64)
+    xd = np.asarray(s.xd, dtype=np.float64)[: d.robot.x]   # the cost acts on the robot block (controller_interface.cpp:400-420)
     if xd.size == 0:
-        xd = np.zeros(d.x())
+        xd = np.zeros(d.robot.x)
     P = Problem(
         chain=chain, nf=nf, N=N, dt=dt, gravity=np.asarray(s.gravity, dtype=np.float64),
         Qdiag=np.diag(np.asarray(s.state_weight)).copy(),
