@@ -161,7 +161,7 @@ def main():
         qp_tflops = qp_flops / (kt["qp_ms"] * 1e-3) / 1e12 if kt["qp_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic() if B == 1024 else ({}, None)
         out = {
-            "metric": "batched MPC solves/sec (Thing + 1 object, horizon 20)",
+            "metric": "batched MPC solves/sec + ms/SQP-iter, Thing 1-obj horizon=20, 1/2/4/8 GPU",   # BASELINE.json:metric verbatim; value = solves/s
             "value": value,
             "unit": "solves/s",
             "n_gpus": world,
