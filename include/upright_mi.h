@@ -105,6 +105,12 @@ typedef struct upr_problem {
     int proj_sph[8];
     double proj_dist[8];
     double proj_scale;
+    /* soft constraints: ocs2 hpipm_interface SlackSettings (upright_control/src/pybindings.cpp:160-181; values
+     * upright_control/src/upright_control/wrappers.py:121-143).  A softened row c(z) >= 0 becomes c(z) + sigma >= 0,
+     * sigma >= 0, with cost 1/2 Z sigma^2 + z sigma (Z: L2, z: L1 penalty; "lower" for lower bounds and polytopic
+     * rows, "upper" for upper bounds).  Soft problems run the generic QP kernel. */
+    int soft_state_box, soft_input_box, soft_poly;
+    double soft_L2_lower, soft_L2_upper, soft_L1_lower, soft_L1_upper;
 } upr_problem;
 
 const char* upr_last_error(void);

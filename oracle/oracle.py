@@ -31,6 +31,8 @@ class OrcProblem(C.Structure):
         ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", d),
         ("n_dyn", C.c_int), ("dyn_x0", d * 9), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", d * 8),
         ("proj_scale", d), ("proj_s", d),
+        ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
+        ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
     ]
 
 
@@ -107,6 +109,10 @@ def to_orc(P):
     o.n_proj, o.proj_scale, o.proj_s = nproj, float(getattr(P, "proj_scale", 1.0)), 0.0
     for i in range(nproj):
         o.proj_sph[i] = int(P.proj_sph[i]); o.proj_dist[i] = float(P.proj_dist[i])
+    sl = getattr(P, "slacks", None) or {}
+    o.soft_state_box, o.soft_input_box, o.soft_poly = int(bool(sl.get("state_box"))), int(bool(sl.get("input_box"))), int(bool(sl.get("poly_ineq")))
+    o.soft_L2_lower, o.soft_L2_upper = float(sl.get("lower_L2_penalty", 100.0)), float(sl.get("upper_L2_penalty", 100.0))
+    o.soft_L1_lower, o.soft_L1_upper = float(sl.get("lower_L1_penalty", 0.0)), float(sl.get("upper_L1_penalty", 0.0))
     return o
 
 

@@ -407,6 +407,10 @@ struct StageQP {
 };
 struct QP {
     int N, nx, nu, ne, np, neN, nfc, no = 0;
+    // soft constraints (ocs2 hpipm_interface SlackSettings, upright_control/src/pybindings.cpp:160-181; defaults of
+    // wrappers.py:121-143): which row classes get a slack sigma >= 0 with cost 1/2 Z sigma^2 + z sigma
+    bool soft_x = false, soft_u = false, soft_poly = false;
+    double ZL = 100, ZU = 100, zL = 0, zU = 0;
     vec A, B;
     std::vector<StageQP> st;  // N stages
     vec QN, qN, CN, eN, xlN, xuN;
@@ -597,6 +601,16 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     auto has_obs = [&](int k) { return no > 0 && k >= 1 && k < N; };
     const int oo = 2 * nx + 2 * nu + np;
     auto nik = [&](int k) { return (k >= 1 ? 2 * nx : 0) + (k < N ? 2 * nu + np : 0) + (has_obs(k) ? no : 0); };
+    // row class of slot i of stage k: 0 x lower, 1 x upper, 2 u lower, 3 u upper, 4 polytopic (friction / collision / projectile)
+    auto row_class = [&](int k, int i) {
+        if (k >= 1) { if (i < nx) return 0; if (i < 2 * nx) return 1; i -= 2 * nx; }
+        if (k < N) { if (i < nu) return 2; if (i < 2 * nu) return 3; }
+        return 4;
+    };
+    auto is_soft = [&](int k, int i) { const int c = row_class(k, i); return c < 2 ? qp.soft_x : (c < 4 ? qp.soft_u : qp.soft_poly); };
+    auto pen_Z = [&](int k, int i) { const int c = row_class(k, i); return (c == 1 || c == 3) ? qp.ZU : qp.ZL; };
+    auto pen_z = [&](int k, int i) { const int c = row_class(k, i); return (c == 1 || c == 3) ? qp.zU : qp.zL; };
+    const bool any_soft = qp.soft_x || qp.soft_u || qp.soft_poly;
     std::vector<vec> t(N + 1), lam(N + 1), dt_(N + 1), dlam(N + 1), dt_aff(N + 1), dlam_aff(N + 1), cval(N + 1);
     std::vector<vec> dx(N + 1, vec(nx, 0.0)), du(N, vec(nu, 0.0)), pi(N + 1, vec(nx, 0.0)), nu_(N, vec(ne, 0.0));
     std::vector<vec> ddx(N + 1, vec(nx, 0.0)), ddu(N, vec(nu, 0.0)), pi_new(N + 1, vec(nx, 0.0)), nu_new(N, vec(ne, 0.0));
@@ -604,6 +618,16 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     dx[0] = qp.dx0;
     int ntot = 0;
     for (int k = 0; k <= N; ++k) { int n = nik(k); t[k].assign(n, 0); lam[k].assign(n, 0); dt_[k].assign(n, 0); dlam[k].assign(n, 0); dt_aff[k] = dt_[k]; dlam_aff[k] = dt_[k]; cval[k] = dt_[k]; ntot += n; }
+    // slack part of the softened rows: sigma >= 0 (tau its own slack, gam its multiplier)
+    std::vector<vec> sig(N + 1), tau(N + 1), gam(N + 1), dsig(N + 1), dtau(N + 1), dgam(N + 1), dtau_aff(N + 1), dgam_aff(N + 1), rcs(N + 1), rps(N + 1);
+    std::vector<vec> weff(N + 1), geff(N + 1);
+    int nsoft = 0;
+    for (int k = 0; k <= N; ++k) {
+        const size_t n = t[k].size();
+        for (auto* v : {&sig[k], &tau[k], &gam[k], &dsig[k], &dtau[k], &dgam[k], &dtau_aff[k], &dgam_aff[k], &rcs[k], &rps[k], &weff[k], &geff[k]}) v->assign(n, 0.0);
+        for (size_t i = 0; i < n; ++i) if (is_soft(k, (int)i)) ++nsoft;
+    }
+    ntot += nsoft;
 
     // c(z) for each inequality
     auto eval_c = [&](const std::vector<vec>& X, const std::vector<vec>& U, std::vector<vec>& c) {
@@ -635,6 +659,8 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     if (getenv("ORC_MU0")) mu0 = atof(getenv("ORC_MU0"));
     for (int k = 0; k <= N; ++k)
         for (size_t i = 0; i < t[k].size(); ++i) { t[k][i] = std::max(cval[k][i], thr); lam[k][i] = mu0 / t[k][i]; }
+    if (any_soft) for (int k = 0; k <= N; ++k)
+        for (size_t i = 0; i < t[k].size(); ++i) if (is_soft(k, (int)i)) { sig[k][i] = 0.0; tau[k][i] = thr; gam[k][i] = mu0 / thr; }
 
     // forces are the tail of u: the force block spans the equality rows iff nu - nq >= ne
     const double rho_prox = (qp.nfc < ne) ? 1e-6 : 0.0;
@@ -652,7 +678,8 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
         eval_c(dx, du, cval);
         double mu = 0, r_ineq = 0;
         for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
-            rp[k][i] = cval[k][i] - t[k][i]; r_ineq = std::max(r_ineq, std::fabs(rp[k][i])); mu += lam[k][i] * t[k][i];
+            rp[k][i] = cval[k][i] + sig[k][i] - t[k][i]; r_ineq = std::max(r_ineq, std::fabs(rp[k][i])); mu += lam[k][i] * t[k][i];
+            if (any_soft && is_soft(k, (int)i)) { rps[k][i] = sig[k][i] - tau[k][i]; r_ineq = std::max(r_ineq, std::fabs(rps[k][i])); mu += gam[k][i] * tau[k][i]; }
         }
         mu /= std::max(1, ntot);
         double r_eq = 0, r_stat = 0;
@@ -703,22 +730,31 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                 r_stat = std::max(r_stat, std::fabs(v));
             }
         }
-        sol.res[0] = r_stat; sol.res[1] = r_eq; sol.res[2] = r_ineq; sol.res[3] = mu;
+        if (any_soft) for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) if (is_soft(k, (int)i))
+            r_stat = std::max(r_stat, std::fabs(pen_Z(k, (int)i) * sig[k][i] + pen_z(k, (int)i) - lam[k][i] - gam[k][i]));
+                sol.res[0] = r_stat; sol.res[1] = r_eq; sol.res[2] = r_ineq; sol.res[3] = mu;
         if (getenv("ORC_DEBUG")) printf("orc it %d res %.3e %.3e %.3e %.3e\n", it, r_stat, r_eq, r_ineq, mu);
         if (it > 0 && r_stat < tol && r_eq < tol && r_ineq < tol && mu < tol) { sol.status = 0; break; }
         if (it == iter_max) break;
 
+        // effective barrier weight of every row: lam / t, and for a softened row the same after the elimination of its
+        // slack, w (Z + w_s) / (Z + w + w_s) with w_s = gam / tau
+        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
+            const double w = lam[k][i] / t[k][i];
+            weff[k][i] = w;
+            if (any_soft && is_soft(k, (int)i)) { const double Z = pen_Z(k, (int)i), ws = gam[k][i] / tau[k][i]; weff[k][i] = w * (Z + ws) / (Z + w + ws); }
+        }
         // ---------------- factorisation with W = lam / t
         for (int k = 0; k <= N; ++k) {
             int o = 0;
             std::fill(Hxx_add[k].begin(), Hxx_add[k].end(), 0.0);
-            if (k >= 1) { for (int i = 0; i < nx; ++i) Hxx_add[k][i] = lam[k][i] / t[k][i] + lam[k][nx + i] / t[k][nx + i]; o += 2 * nx; }
+            if (k >= 1) { for (int i = 0; i < nx; ++i) Hxx_add[k][i] = weff[k][i] + weff[k][nx + i]; o += 2 * nx; }
             if (k < N) {
                 const StageQP& s = qp.st[k];
                 std::fill(Huu_add[k].begin(), Huu_add[k].end(), 0.0);
-                for (int i = 0; i < nu; ++i) Huu_add[k][i * nu + i] = lam[k][o + i] / t[k][o + i] + lam[k][o + nu + i] / t[k][o + nu + i];
+                for (int i = 0; i < nu; ++i) Huu_add[k][i * nu + i] = weff[k][o + i] + weff[k][o + nu + i];
                 for (int r = 0; r < np; ++r) {
-                    double w = lam[k][o + 2 * nu + r] / t[k][o + 2 * nu + r];
+                    double w = weff[k][o + 2 * nu + r];
                     for (int i = 0; i < nu; ++i) { double gi = s.Gu[r * nu + i]; if (gi == 0.0) continue;
                         for (int j = 0; j < nu; ++j) Huu_add[k][i * nu + j] += w * gi * s.Gu[r * nu + j]; }
                 }
@@ -730,7 +766,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
             Hxx_dense[k].assign((size_t)nx * nx, 0.0);
             const StageQP& s = qp.st[k];
             for (int r = 0; r < no; ++r) {
-                const double w = lam[k][oo + r] / t[k][oo + r];
+                const double w = weff[k][oo + r];
                 for (int i = 0; i < nx; ++i) { const double gi = s.Gx[r * nx + i]; if (gi == 0.0) continue;
                     for (int j = 0; j < nx; ++j) Hxx_dense[k][i * nx + j] += w * gi * s.Gx[r * nx + j]; }
             }
@@ -739,31 +775,42 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 
         // solve the Newton system for a given complementarity target rc (per inequality):
         //   lam*dt + t*dlam = -rc ;  dt = G dz + rp ;  =>  dlam = -(rc + lam*(G dz + rp)) / t
-        auto newton = [&](std::vector<vec>& dT, std::vector<vec>& dL) {
+        auto newton = [&](std::vector<vec>& dT, std::vector<vec>& dL, std::vector<vec>& dTau, std::vector<vec>& dGam) {
             std::vector<vec> hx = gx, hu = gu;
+            // gradient multiplier of every row, (rc + lam rp) / t; a softened row also carries what the elimination of its
+            // slack leaves behind: - w a / D, a = r_sigma + (rc + lam rp) / t + (rc_s + gam rp_s) / tau, D = Z + w + w_s
+            for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
+                const double g0 = (rc[k][i] + lam[k][i] * rp[k][i]) / t[k][i];
+                geff[k][i] = g0;
+                if (any_soft && is_soft(k, (int)i)) {
+                    const double Z = pen_Z(k, (int)i), w = lam[k][i] / t[k][i], ws = gam[k][i] / tau[k][i];
+                    const double a = (Z * sig[k][i] + pen_z(k, (int)i) - lam[k][i] - gam[k][i]) + g0 + (rcs[k][i] + gam[k][i] * rps[k][i]) / tau[k][i];
+                    geff[k][i] = g0 - w * a / (Z + w + ws);
+                }
+            }
             for (int k = 0; k <= N; ++k) {
                 int o = 0;
                 // gradient of the reduced system: g - G' * ( -(rc + lam*rp)/t )  = g + G'(rc + lam rp)/t
                 if (k >= 1) {
                     for (int i = 0; i < nx; ++i) {
-                        hx[k][i] += (rc[k][i] + lam[k][i] * rp[k][i]) / t[k][i];
-                        hx[k][i] -= (rc[k][nx + i] + lam[k][nx + i] * rp[k][nx + i]) / t[k][nx + i];
+                        hx[k][i] += geff[k][i];
+                        hx[k][i] -= geff[k][nx + i];
                     }
                     o += 2 * nx;
                 }
                 if (k < N) {
                     const StageQP& s = qp.st[k];
                     for (int i = 0; i < nu; ++i) {
-                        hu[k][i] += (rc[k][o + i] + lam[k][o + i] * rp[k][o + i]) / t[k][o + i];
-                        hu[k][i] -= (rc[k][o + nu + i] + lam[k][o + nu + i] * rp[k][o + nu + i]) / t[k][o + nu + i];
+                        hu[k][i] += geff[k][o + i];
+                        hu[k][i] -= geff[k][o + nu + i];
                     }
                     for (int r = 0; r < np; ++r) {
-                        int ii = o + 2 * nu + r; double w = (rc[k][ii] + lam[k][ii] * rp[k][ii]) / t[k][ii];
+                        int ii = o + 2 * nu + r; double w = geff[k][ii];
                         for (int j = 0; j < nu; ++j) hu[k][j] += s.Gu[r * nu + j] * w;
                     }
                 }
                 if (has_obs(k)) for (int r = 0; r < no; ++r) {
-                    const int ii = oo + r; const double w = (rc[k][ii] + lam[k][ii] * rp[k][ii]) / t[k][ii];
+                    const int ii = oo + r; const double w = geff[k][ii];
                     for (int j = 0; j < nx; ++j) hx[k][j] += qp.st[k].Gx[r * nx + j] * w;
                 }
             }
@@ -788,38 +835,60 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                     for (int r = 0; r < np; ++r) { double v = rp[k][o + 2 * nu + r]; for (int j = 0; j < nu; ++j) v += s.Gu[r * nu + j] * ddu[k][j]; dT[k][o + 2 * nu + r] = v; }
                 }
                 if (has_obs(k)) for (int r = 0; r < no; ++r) { double v = rp[k][oo + r]; for (int j = 0; j < nx; ++j) v += qp.st[k].Gx[r * nx + j] * ddx[k][j]; dT[k][oo + r] = v; }
+                if (any_soft) for (size_t i = 0; i < t[k].size(); ++i) if (is_soft(k, (int)i)) {
+                    // dT so far is G dz + rp; the slack step follows from the eliminated row of the Newton system
+                    const double Z = pen_Z(k, (int)i), w = lam[k][i] / t[k][i], ws = gam[k][i] / tau[k][i];
+                    const double gdz = dT[k][i] - rp[k][i];
+                    const double a = (Z * sig[k][i] + pen_z(k, (int)i) - lam[k][i] - gam[k][i]) + (rc[k][i] + lam[k][i] * rp[k][i]) / t[k][i]
+                                     + (rcs[k][i] + gam[k][i] * rps[k][i]) / tau[k][i];
+                    dsig[k][i] = -(a + w * gdz) / (Z + w + ws);
+                    dT[k][i] += dsig[k][i];
+                    dTau[k][i] = dsig[k][i] + rps[k][i];
+                    dGam[k][i] = -(rcs[k][i] + gam[k][i] * dTau[k][i]) / tau[k][i];
+                }
                 for (size_t i = 0; i < t[k].size(); ++i) dL[k][i] = -(rc[k][i] + lam[k][i] * dT[k][i]) / t[k][i];
             }
         };
-        auto max_step = [&](const std::vector<vec>& dT, const std::vector<vec>& dL) {
+        auto max_step = [&](const std::vector<vec>& dT, const std::vector<vec>& dL, const std::vector<vec>& dTau, const std::vector<vec>& dGam) {
             double a = 1.0;
             for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
                 if (dT[k][i] < 0) a = std::min(a, -t[k][i] / dT[k][i]);
                 if (dL[k][i] < 0) a = std::min(a, -lam[k][i] / dL[k][i]);
+                if (any_soft && is_soft(k, (int)i)) {
+                    if (dTau[k][i] < 0) a = std::min(a, -tau[k][i] / dTau[k][i]);
+                    if (dGam[k][i] < 0) a = std::min(a, -gam[k][i] / dGam[k][i]);
+                }
             }
             return a;
         };
         // predictor
-        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) rc[k][i] = lam[k][i] * t[k][i];
-        newton(dt_aff, dlam_aff);
-        double a_aff = max_step(dt_aff, dlam_aff);
+        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) { rc[k][i] = lam[k][i] * t[k][i]; rcs[k][i] = gam[k][i] * tau[k][i]; }
+        newton(dt_aff, dlam_aff, dtau_aff, dgam_aff);
+        double a_aff = max_step(dt_aff, dlam_aff, dtau_aff, dgam_aff);
         double mu_aff = 0;
-        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) mu_aff += (lam[k][i] + a_aff * dlam_aff[k][i]) * (t[k][i] + a_aff * dt_aff[k][i]);
+        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
+            mu_aff += (lam[k][i] + a_aff * dlam_aff[k][i]) * (t[k][i] + a_aff * dt_aff[k][i]);
+            if (any_soft && is_soft(k, (int)i)) mu_aff += (gam[k][i] + a_aff * dgam_aff[k][i]) * (tau[k][i] + a_aff * dtau_aff[k][i]);
+        }
         mu_aff /= std::max(1, ntot);
         double sigma = std::pow(mu_aff / mu, 3.0);
         // keep the complementarity target from collapsing far below the tolerance while the other
         // residuals are still converging (weights lam/t would overflow the factorisation otherwise)
         if (sigma * mu < 1e-2 * tol) sigma = 1e-2 * tol / mu;
         // corrector
-        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) rc[k][i] = lam[k][i] * t[k][i] + dt_aff[k][i] * dlam_aff[k][i] - sigma * mu;
-        newton(dt_, dlam);
-        double alpha = std::min(1.0, 0.995 * max_step(dt_, dlam));
+        for (int k = 0; k <= N; ++k) for (size_t i = 0; i < t[k].size(); ++i) {
+            rc[k][i] = lam[k][i] * t[k][i] + dt_aff[k][i] * dlam_aff[k][i] - sigma * mu;
+            rcs[k][i] = gam[k][i] * tau[k][i] + dtau_aff[k][i] * dgam_aff[k][i] - sigma * mu;
+        }
+        newton(dt_, dlam, dtau, dgam);
+        double alpha = std::min(1.0, 0.995 * max_step(dt_, dlam, dtau, dgam));
         for (int k = 0; k <= N; ++k) {
             if (k >= 1) for (int i = 0; i < nx; ++i) dx[k][i] += alpha * ddx[k][i];
             if (k < N) for (int i = 0; i < nu; ++i) du[k][i] += alpha * ddu[k][i];
             for (int i = 0; i < nx; ++i) pi[k][i] += alpha * (pi_new[k][i] - pi[k][i]);
             if (k < N) for (int r = 0; r < ne; ++r) nu_[k][r] += alpha * (nu_new[k][r] - nu_[k][r]);
             for (size_t i = 0; i < t[k].size(); ++i) { t[k][i] += alpha * dt_[k][i]; lam[k][i] += alpha * dlam[k][i]; }
+            if (any_soft) for (size_t i = 0; i < t[k].size(); ++i) if (is_soft(k, (int)i)) { sig[k][i] += alpha * dsig[k][i]; tau[k][i] += alpha * dtau[k][i]; gam[k][i] += alpha * dgam[k][i]; }
         }
         for (int r = 0; r < neN; ++r) yN[r] += alpha * dyN[r];
     }
@@ -847,6 +916,8 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 void build_qp(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us, QP& qp) {
     const int nx = orc_nx(P), nu = orc_nu(P), N = P->N, ne = 6 * P->nb, np = (P->nf == 3 ? 5 * P->nc : 0);
     qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq; qp.no = P->n_pairs + P->n_proj;
+    qp.soft_x = P->soft_state_box != 0; qp.soft_u = P->soft_input_box != 0; qp.soft_poly = P->soft_poly != 0;
+    qp.ZL = P->soft_L2_lower; qp.ZU = P->soft_L2_upper; qp.zL = P->soft_L1_lower; qp.zU = P->soft_L1_upper;
     Dyn dyn{P->nq, nx, nu, P->dt};
     dyn.dense(qp.A, qp.B);
     qp.st.assign(N, StageQP());

@@ -111,6 +111,10 @@ typedef struct {
     double proj_dist[8];
     double proj_scale;
     double proj_s;      /* activation flag of the target (8th entry of the target state) */
+    /* soft constraints: ocs2 hpipm_interface SlackSettings (upright_control/src/pybindings.cpp:160-181; defaults of
+     * upright_control/src/upright_control/wrappers.py:121-143: L2 100, L1 0, slack lower bound 0) */
+    int soft_state_box, soft_input_box, soft_poly;
+    double soft_L2_lower, soft_L2_upper, soft_L1_lower, soft_L1_upper;
 } orc_problem;
 
 int orc_nx(const orc_problem* P);

@@ -82,6 +82,8 @@ struct upr_dims {
     int ss_kx, ss_hjj, ss_hff, ss_sinv, ss_ku0, ss_uf0, ss_snu, ss_pb, ss_stride;
     // per-instance workspace (doubles)
     int ws_dx, ws_du, ws_sx, ws_su, ws_pi, ws_nu, ws_yN, ws_pin, ws_nun, ws_dyN, ws_t, ws_lam, ws_rc, ws_store, ws_stride;
+    int soft;                               // any soft row class (slack arrays below are empty otherwise)
+    int ws_sig, ws_tau, ws_gam, ws_rcs;     // per slot: slack sigma, its own slack tau and multiplier gam, its complementarity target
 };
 
 static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
@@ -103,7 +105,10 @@ static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
     d.ws_pi = d.ws_su + d.N * d.nu; d.ws_nu = d.ws_pi + n1 * d.nx; d.ws_yN = d.ws_nu + d.N * d.ne;
     d.ws_pin = d.ws_yN + d.neN; d.ws_nun = d.ws_pin + n1 * d.nx; d.ws_dyN = d.ws_nun + d.N * d.ne;
     d.ws_t = d.ws_dyN + d.neN; d.ws_lam = d.ws_t + n1 * d.ni_stage; d.ws_rc = d.ws_lam + n1 * d.ni_stage;
-    d.ws_store = d.ws_rc + n1 * d.ni_stage;
+    d.soft = (P->soft_state_box || P->soft_input_box || P->soft_poly) ? 1 : 0;
+    const int nsl = d.soft ? n1 * d.ni_stage : 0;
+    d.ws_sig = d.ws_rc + n1 * d.ni_stage; d.ws_tau = d.ws_sig + nsl; d.ws_gam = d.ws_tau + nsl; d.ws_rcs = d.ws_gam + nsl;
+    d.ws_store = d.ws_rcs + nsl;
     d.ws_stride = d.ws_store + d.N * d.ss_stride;
     d.ws_stride = (d.ws_stride + 15) & ~15;
     return d;

@@ -54,7 +54,7 @@ struct upr_qp_args {
 struct upr_qp_lds {
     int Pm, Tm, Kx, Hjj, Lji, Cm, SC, Df, Yf, Sm, Lsi, Hff;
     int pv, wv, hx, bk, Xk, Xn, Uk, dxk, duk, sxk, suk, huj, huf, ku0, uf0, ee, snu, nuv, gxs, gus, Wx, Wu;
-    int tk, lk, sv, wq, gjr, gjc, grad, hess, ob, hob, red, misc, total;   // ob: collision rows [d no][J no*nq]; hob: their barrier Hessian (packed)
+    int tk, lk, sv, wq, gjr, gjc, grad, hess, ob, hob, sgk, tak, gak, red, misc, total;   // sgk/tak/gak: slack part of the stage's soft rows   // ob: collision rows [d no][J no*nq]; hob: their barrier Hessian (packed)
 };
 static inline UPR_HD upr_qp_lds upr_qp_lds_layout(const upr_dims& d, int nt) {
     upr_qp_lds L; int o = 0;
@@ -71,6 +71,7 @@ static inline UPR_HD upr_qp_lds upr_qp_lds_layout(const upr_dims& d, int nt) {
     int gm = d.nq > d.ne ? d.nq : d.ne;
     L.gjr = take(gm); L.gjc = take(gm); L.grad = take(d.nq); L.hess = take(d.nq * (d.nq + 1) / 2 > 3 * d.nq ? d.nq * (d.nq + 1) / 2 : 3 * d.nq);
     L.ob = take(d.no * (1 + d.nq)); L.hob = take(d.no > 0 ? d.nq * (d.nq + 1) / 2 : 0);
+    L.sgk = take(d.soft ? d.ni_stage : 0); L.tak = take(d.soft ? d.ni_stage : 0); L.gak = take(d.soft ? d.ni_stage : 0);
     L.red = take(nt); L.misc = take(16);
     L.total = o;
     return L;
@@ -168,6 +169,32 @@ static inline UPR_HD bool upr_ineq_active(const upr_dims& d, int k, int j) {
     if (j >= 2 * d.nx + 2 * d.nu + d.np) return k >= 1 && k < d.N;   // collision rows: knots 1..N-1
     return k < d.N;
 }
+// soft rows (hpipm_interface SlackSettings): is slot j softened, and its L2 / L1 penalties
+static inline UPR_HD bool upr_slot_soft(const upr_problem* P, const upr_dims& d, int j) {
+    if (j < 2 * d.nx) return P->soft_state_box != 0;
+    if (j < 2 * d.nx + 2 * d.nu) return P->soft_input_box != 0;
+    return P->soft_poly != 0;
+}
+static inline UPR_HD bool upr_slot_upper(const upr_dims& d, int j) {
+    return (j >= d.nx && j < 2 * d.nx) || (j >= 2 * d.nx + d.nu && j < 2 * d.nx + 2 * d.nu);
+}
+// One softened row c + sigma - t = 0 (lam), sigma - tau = 0 (gam), cost 1/2 Z sigma^2 + z sigma.  The slack step is
+// eliminated from the Newton system: d sigma = -(a + w G dz) / D,  D = Z + w + w_s,
+// a = (Z sigma + z - lam - gam) + (rc + lam rp) / t + (rc_s + gam rp_s) / tau.  What remains for the reduced system is
+// the effective weight w (Z + w_s) / D and the gradient multiplier (rc + lam rp) / t - w a / D.
+struct upr_soft_row {
+    double Z, z, w, ws, D, a, rps;
+};
+static inline UPR_HD upr_soft_row upr_soft_terms(const upr_problem* P, const upr_dims& d, int j, double t, double lam, double sig, double tau, double gam,
+                                                 double rp, double rc, double rcs) {
+    upr_soft_row r;
+    const bool up = upr_slot_upper(d, j);
+    r.Z = up ? P->soft_L2_upper : P->soft_L2_lower; r.z = up ? P->soft_L1_upper : P->soft_L1_lower;
+    r.w = lam / t; r.ws = gam / tau; r.D = r.Z + r.w + r.ws; r.rps = sig - tau;
+    r.a = (r.Z * sig + r.z - lam - gam) + (rc + lam * rp) / t + (rcs + gam * r.rps) / tau;
+    return r;
+}
+
 // value c_j at absolute (X, U); collision rows are linear in the step from the linearisation point:
 // ob = [d no][J no*nq] of this knot, dxq = dx_k[0:nq]
 static inline UPR_HD double upr_ineq_value(const upr_problem* P, const upr_dims& d, int j, const double* X, const double* U,

@@ -62,6 +62,9 @@ class Problem:
     proj_sph: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
     proj_dist: np.ndarray = field(default_factory=lambda: np.zeros(0))
     proj_scale: float = 1.0
+    # HPIPM soft constraints (hpipm_interface SlackSettings, wrappers.py:121-143): None / {} = hard constraints; keys
+    # state_box, input_box, poly_ineq (bool), lower/upper_L2_penalty (100), lower/upper_L1_penalty (0)
+    slacks: dict = None
 
     @property
     def nq(self):
