@@ -271,3 +271,45 @@ def test_projectile_rows_kernel_source(arrangements):
         # (this first QP is infeasible -- the goal lies behind the linearised rows -- so the iterates part quickly)
         assert np.abs(dx[b] - dxo).max() < 1e-5 * max(1, np.abs(dxo).max())
     e.E.emu_set_dynamic(None, None)
+
+
+def test_soft_rows_kernel_source(arrangements):
+    """HPIPM slack variables (hpipm_interface SlackSettings, wrappers.py:121-143): the generic QP kernel with
+    softened state-box / input-box / polytopic rows follows the oracle's iterate path, on a feasible instance and on
+    one whose first knot is infeasible (base acceleration beyond what the friction cone balances) where the hard QP
+    ends at its iteration cap."""
+    B = 2
+    soft = dict(state_box=True, input_box=True, poly_ineq=True, lower_L2_penalty=100.0, upper_L2_penalty=50.0, lower_L1_penalty=0.0, upper_L1_penalty=0.5)
+    P, x0, way, xs, us = _case(arrangements, B, 11, qp_tol=0.0, qp_iter_max=6)
+    x0[1, 18] = 5.0
+    xs[1, :, 18] = 5.0
+    P.slacks = soft
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert stats[b, 1] == 6 == so.qp_iters_last
+        assert np.abs(dx[b] - dxo).max() < 1e-7 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 1e-7 * max(1, np.abs(duo).max())
+        assert np.allclose(stats[b, 6:10], list(so.qp_res), rtol=5e-2, atol=1e-9)
+    # (the violated instance stalls near 1e-8 in r_stat / r_eq -- weights span 16 decades -- so converge to 1e-7)
+    P.qp_tol, P.qp_iter_max = 1e-7, 40
+    e = Emu(P, B)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert rc == 0 and stats[b, 2] == 0 and abs(stats[b, 1] - so.qp_iters_last) <= 1
+        assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max())
+    # only the polytopic rows softened: boxes stay hard (instance 1 then violates its acceleration box: not compared)
+    P.slacks = dict(poly_ineq=True)
+    e = Emu(P, B)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    for b in range(1):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert stats[b, 2] == 0 and rc == 0
+        assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())

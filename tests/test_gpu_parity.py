@@ -379,6 +379,42 @@ def test_infeasible_instance_is_flagged_not_propagated(arrangements):
     mpc.close()
 
 
+def test_soft_constraints_absorb_an_infeasible_first_knot(arrangements):
+    """HPIPM slack variables (hpipm_interface SlackSettings through pybindings.cpp:160-181; wrappers.py:121-143): with
+    every inequality class softened the instance of the test above -- friction cone violated at the fixed first knot --
+    gets a usable plan that matches the oracle's soft solve, and the feasible neighbours keep (to the penalty's
+    accuracy) their hard-constrained plans.  Soft problems run the generic QP kernel."""
+    B = 4
+    P, x0, way = _setup(arrangements, B, seed=61)
+    x0[2, 18] = 5.0
+    hard = BatchMPC(P, B, way_p=way)
+    hard.set_observation(0.0, x0); hard.advance()
+    _, xh, uh = hard.solution()
+    hard.close()
+    P.slacks = dict(state_box=True, input_box=True, poly_ineq=True, lower_L2_penalty=100.0, upper_L2_penalty=100.0)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    st = mpc.stats()
+    _, xs, us = mpc.solution()
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b in range(B):
+        P.way_p = way[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        if b == 2:
+            # weights span 16 decades on this instance: the last IPM iterations stall near 1e-7 on both sides
+            assert st["qp_res_ineq"][b] < 1e-6 and st["qp_res_eq"][b] < 1e-6
+            assert np.abs(xs[b] - xo).max() < 1e-3 and st["step_alpha_last"][b] > 0
+            # the plan brakes the base: the violating acceleration is gone within a few knots
+            assert abs(xs[b, 5, 18]) < 1.0
+        else:
+            assert st["qp_status_last"][b] == 0 and so.qp_status_last == 0
+            assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+            assert np.abs(xs[b] - xh[b]).max() < 1e-3
+    mpc.close()
+
+
 def _manager_from_golden(name, arrangements, arr="pink_bottle", x0=None, **override):
     import copy
     import json
@@ -413,8 +449,9 @@ def _level_tool(chain, q_home):
 
 @pytest.mark.parametrize("name,override,level", [
     ("ur10_demo", {}, True),                                       # BASELINE configs[0]: fixed-base UR10, frictionless (nx 18, nu 10)
-    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, True),    # configs 2': Thing, frictionless (nx 27, nu 13); HPIPM slacks are not in the engine
-    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, False),   # as configured (tray 1 degree off level): infeasible first knot
+    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, True),    # configs 2': Thing, frictionless (nx 27, nu 13), hard rows
+    ("thing_demo", {}, True),                                      # as configured: HPIPM slacks on every inequality class (thing_demo.yaml)
+    ("thing_demo", {}, False),                                     # ... and the tray 1 degree off level: infeasible first knot (an EQUALITY: slacks do not help)
     ("full_bottle_point1", {}, False),                             # headline H through the manager
 ])
 def test_reference_call_sequence_other_configs(arrangements, name, override, level):
@@ -433,11 +470,12 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
     ts, xs, us = m.get_mpc_trajectory()
     assert xs.shape == (P.N + 1, P.nx) and us.shape == (P.N + 1, P.nu) and np.allclose(ts, P.dt * np.arange(P.N + 1))
     xs0, us0 = stationary_guess(x0[None], P.N, P.nu)
+    assert (P.slacks is not None) == (name == "thing_demo" and not override)
     xo, uo, so, rc = Oracle(P).solve(0.0, x0, xs0[0], us0[0])
     st = m.mpc._mpc.stats()
     if P.nf == 1 and not level:
-        # hard constraints, no slacks: both solvers stop at the iteration cap (as HPIPM does in the reference), the
-        # plans agree to the accuracy an unconverged QP allows and stay usable
+        # the violated rows are equalities, which HPIPM's slacks do not soften: both solvers stop at the iteration cap
+        # (as HPIPM does in the reference), the plans agree to the accuracy an unconverged QP allows and stay usable
         assert so.qp_status_last == 1 and st["qp_status_last"][0] == 1
         assert np.abs(xs - xo).max() < 1e-3 and np.all(np.isfinite(us))
     else:

@@ -40,6 +40,8 @@ class UprProblem(C.Structure):
         ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", (C.c_double * 3) * MAXS), ("sph_r", C.c_double * MAXS),
         ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", C.c_double),
         ("n_dyn", C.c_int), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", C.c_double * 8), ("proj_scale", C.c_double),
+        ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
+        ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
     ]
 
 
@@ -92,6 +94,10 @@ def problem_to_c(P):
         raise ValueError("at most 8 projectile-path rows")
     for i in range(o.n_proj):
         o.proj_sph[i] = int(P.proj_sph[i]); o.proj_dist[i] = float(P.proj_dist[i])
+    sl = P.slacks or {}
+    o.soft_state_box, o.soft_input_box, o.soft_poly = int(bool(sl.get("state_box"))), int(bool(sl.get("input_box"))), int(bool(sl.get("poly_ineq")))
+    o.soft_L2_lower, o.soft_L2_upper = float(sl.get("lower_L2_penalty", 100.0)), float(sl.get("upper_L2_penalty", 100.0))
+    o.soft_L1_lower, o.soft_L1_upper = float(sl.get("lower_L1_penalty", 0.0)), float(sl.get("upper_L1_penalty", 0.0))
     return o
 
 

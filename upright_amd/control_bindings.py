@@ -242,8 +242,9 @@ def problem_from_settings(s):
         raise RuntimeError("operating points are not supported by the MI355X engine yet")
     if not s.balancing_settings.enabled:
         raise RuntimeError("Balancing constraints disabled: the MI355X engine accelerates the balancing OCP only")
-    if s.sqp.hpipm.slacks.enabled:
-        raise RuntimeError("HPIPM slack variables are not supported by the MI355X engine yet")
+    sl = s.sqp.hpipm.slacks
+    if sl.enabled and (sl.upper_low_bound != 0 or sl.lower_low_bound != 0):
+        raise RuntimeError("slack lower bounds other than 0 are not supported by the MI355X engine")
     d = s.dims
     if d.o != len(s.obstacle_settings.dynamic_obstacles) or d.o > 1:
         raise RuntimeError("dims.o must equal the number of dynamic obstacles (at most one)")
@@ -290,6 +291,11 @@ def problem_from_settings(s):
         delta_tol=float(s.sqp.delta_tol), cost_tol=float(s.sqp.cost_tol), **tables,
     )
     P.n_dyn = d.o
+    if sl.enabled:
+        # hpipm_interface SlackSettings (pybindings.cpp:160-181): which row classes get a slack and its penalties
+        P.slacks = dict(state_box=bool(sl.state_box), input_box=bool(sl.input_box), poly_ineq=bool(sl.poly_ineq),
+                        lower_L2_penalty=float(sl.lower_L2_penalty), upper_L2_penalty=float(sl.upper_L2_penalty),
+                        lower_L1_penalty=float(sl.lower_L1_penalty), upper_L1_penalty=float(sl.upper_L1_penalty))
     try:
         if s.obstacle_settings.enabled:
             # controller_interface.cpp:172-228,450-481: sphere pairs by name, hard state inequality "obstacle_avoidance"

@@ -238,6 +238,10 @@ int check_problem(const upr_problem* P) {
     if (P->n_pairs < 0 || P->n_pairs > UPR_MAX_PAIRS) return fail("n_pairs out of range");
     if (P->n_dyn < 0 || P->n_dyn > 1) return fail("n_dyn must be 0 or 1");
     if (P->n_proj < 0 || P->n_proj > 8 || (P->n_proj > 0 && P->n_dyn != 1)) return fail("projectile rows need one dynamic obstacle (n_proj <= 8)");
+    if (P->soft_state_box || P->soft_input_box || P->soft_poly) {
+        if (!(P->soft_L2_lower >= 0) || !(P->soft_L2_upper >= 0) || !(P->soft_L1_lower >= 0) || !(P->soft_L1_upper >= 0)) return fail("slack penalties must be non-negative");
+        if (!(P->soft_L2_lower + P->soft_L1_lower > 0) || !(P->soft_L2_upper + P->soft_L1_upper > 0)) return fail("softened rows need a positive L1 or L2 penalty");
+    }
     for (int i = 0; i < P->n_proj; ++i) if (P->proj_sph[i] < 0 || P->proj_sph[i] >= P->n_sph || !(P->proj_dist[i] > 0)) return fail("projectile row out of range");
     for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -2 || P->sph_frame[i] > P->nq || (P->sph_frame[i] == -2 && P->n_dyn != 1)) return fail("sph_frame out of range");
     for (int i = 0; i < P->n_pairs; ++i)
@@ -502,8 +506,9 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
     // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
-    h->use_qp3 = qp3_has_shape(*P) && P->n_pairs + P->n_proj == 0;
-    h->use_qp2 = qp2_has_shape(*P) && P->n_pairs + P->n_proj == 0;
+    const bool plain = P->n_pairs + P->n_proj == 0 && !(P->soft_state_box || P->soft_input_box || P->soft_poly);   // rows only the generic kernel has
+    h->use_qp3 = qp3_has_shape(*P) && plain;
+    h->use_qp2 = qp2_has_shape(*P) && plain;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
     if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }

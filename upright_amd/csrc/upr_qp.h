@@ -287,6 +287,12 @@ static inline UPR_HD void upr_qp_load_stage(upr_qp_state& S, int k) {
     const double* t = S.ws + d.ws_t + (size_t)k * d.ni_stage;
     const double* lam = S.ws + d.ws_lam + (size_t)k * d.ni_stage;
     UPR_FOR(j, d.ni_stage) { L[o.tk + j] = t[j]; L[o.lk + j] = lam[j]; }
+    if (d.soft) {
+        const double* sg = S.ws + d.ws_sig + (size_t)k * d.ni_stage;
+        const double* ta = S.ws + d.ws_tau + (size_t)k * d.ni_stage;
+        const double* ga = S.ws + d.ws_gam + (size_t)k * d.ni_stage;
+        UPR_FOR(j, d.ni_stage) { L[o.sgk + j] = sg[j]; L[o.tak + j] = ta[j]; L[o.gak + j] = ga[j]; }
+    }
     UPR_SYNC();
 }
 
@@ -305,7 +311,29 @@ static inline UPR_HD void upr_qp_assemble(upr_qp_state& S, int k) {
             double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
             double rp = c - t;
             w = lam / t;
-            if (S.mode == 0) s = w * rp;                       // predictor: rc = lam t
+            if (d.soft && upr_slot_soft(P, d, j)) {
+                // softened row: the slack is eliminated, leaving an effective weight and gradient multiplier
+                const double sig = L[o.sgk + j], tau = L[o.tak + j], gam = L[o.gak + j];
+                rp += sig;
+                if (S.mode == 2) s = -lam;
+                else {
+                    double* rcsg = S.ws + d.ws_rcs + (size_t)k * d.ni_stage;
+                    double rc = lam * t, rcs = gam * tau;
+                    if (S.mode == 1) {
+                        const upr_soft_row a0 = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
+                        const double gdz = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob);
+                        const double dsa = -(a0.a + a0.w * gdz) / a0.D;
+                        const double dta = gdz + rp + dsa, dtaua = dsa + a0.rps;
+                        const double dla = -lam - a0.w * dta, dga = -gam - a0.ws * dtaua;
+                        rc = lam * t + dta * dla - S.sigma_mu; rcs = gam * tau + dtaua * dga - S.sigma_mu;
+                        rcg[j] = rc; rcsg[j] = rcs;
+                    } else if (S.mode == 3) { rc = rcg[j]; rcs = rcsg[j]; }
+                    const upr_soft_row r = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
+                    s = (rc + lam * rp) / t - r.w * r.a / r.D - lam;
+                    w = r.w * (r.Z + r.ws) / r.D;
+                }
+            }
+            else if (S.mode == 0) s = w * rp;                  // predictor: rc = lam t
             else if (S.mode == 2) s = -lam;                    // plain Lagrangian gradient
             else {
                 double rc;
@@ -762,7 +790,8 @@ static inline UPR_HD void upr_qp_costates(upr_qp_state& S, const double* nu_new,
 //   what = 0: largest feasible step (per-thread partial of alpha_max)
 //   what = 1: partial sum of (lam + a dlam)(t + a dt) for a = alpha
 //   what = 2: apply t += a dt, lam += a dlam
-//   what = 3: partial max of |c - t| (r_ineq); *aux accumulates the partial sum of lam*t
+//   what = 3: partial max of |c - t| (r_ineq); aux[0] accumulates the partial sum of lam*t (+ gam*tau of softened rows),
+//             aux[1] the partial max of the slack stationarity |Z sigma + z - lam - gam|
 static inline UPR_HD double upr_qp_ineq_sweep(upr_qp_state& S, int what, double alpha, double* aux) {
     const upr_ctx& ctx = S.ctx; const upr_dims& d = S.d; double* L = S.L; const upr_qp_lds& o = S.o;
     const upr_problem* P = S.P;
@@ -786,6 +815,36 @@ static inline UPR_HD double upr_qp_ineq_sweep(upr_qp_state& S, int what, double 
             double tj = t[j], lj = lam[j];
             double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
             double rp = c - tj;
+            if (d.soft && upr_slot_soft(P, d, j)) {
+                double* sg = S.ws + d.ws_sig + (size_t)k * d.ni_stage; double* ta = S.ws + d.ws_tau + (size_t)k * d.ni_stage;
+                double* ga = S.ws + d.ws_gam + (size_t)k * d.ni_stage; const double* rcsg = S.ws + d.ws_rcs + (size_t)k * d.ni_stage;
+                const double sig = sg[j], tau = ta[j], gam = ga[j];
+                rp += sig;
+                const double rc = (S.mode == 0) ? lj * tj : rcg[j], rcs = (S.mode == 0) ? gam * tau : rcsg[j];
+                const upr_soft_row r = upr_soft_terms(P, d, j, tj, lj, sig, tau, gam, rp, rc, rcs);
+                if (what == 3) {
+                    double a = fmax(fabs(rp), fabs(r.rps)); if (a > acc) acc = a;
+                    aux[0] += lj * tj + gam * tau;
+                    aux[1] = fmax(aux[1], fabs(r.Z * sig + r.z - lj - gam));
+                    continue;
+                }
+                const double gdz = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob);
+                const double ds = -(r.a + r.w * gdz) / r.D;
+                const double dt = gdz + rp + ds, dtau = ds + r.rps;
+                const double dl = -(rc + lj * dt) / tj, dg = -(rcs + gam * dtau) / tau;
+                if (what == 0) {
+                    if (dt < 0.0) { double a = -tj / dt; if (a < acc) acc = a; }
+                    if (dl < 0.0) { double a = -lj / dl; if (a < acc) acc = a; }
+                    if (dtau < 0.0) { double a = -tau / dtau; if (a < acc) acc = a; }
+                    if (dg < 0.0) { double a = -gam / dg; if (a < acc) acc = a; }
+                } else if (what == 1) {
+                    acc += (lj + alpha * dl) * (tj + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
+                } else {
+                    t[j] = tj + alpha * dt; lam[j] = lj + alpha * dl;
+                    sg[j] = sig + alpha * ds; ta[j] = tau + alpha * dtau; ga[j] = gam + alpha * dg;
+                }
+                continue;
+            }
             if (what == 3) { double a = fabs(rp); if (a > acc) acc = a; *aux += lj * tj; continue; }
             double dt = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob) + rp;
             double rc = (S.mode == 0) ? lj * tj : rcg[j];
@@ -858,12 +917,13 @@ static inline UPR_HD void upr_qp_residuals(upr_qp_state& S, int ntot, double* re
         UPR_SYNC();
     }
     S.mode = save_mode;
-    double lt = 0.0;
-    double r_in = upr_qp_ineq_sweep(S, 3, 0.0, &lt);
+    double lt[2] = {0.0, 0.0};
+    double r_in = upr_qp_ineq_sweep(S, 3, 0.0, lt);
+    r_stat = fmax(r_stat, lt[1]);
     res[0] = upr_reduce(ctx, L + o.red, r_stat, 1);
     res[1] = upr_reduce(ctx, L + o.red, r_eq, 1);
     res[2] = upr_reduce(ctx, L + o.red, r_in, 1);
-    res[3] = upr_reduce(ctx, L + o.red, lt, 0) / (ntot > 0 ? ntot : 1);
+    res[3] = upr_reduce(ctx, L + o.red, lt[0], 0) / (ntot > 0 ? ntot : 1);
 }
 
 // The whole QP for instance b.  L: workgroup scratch of upr_qp_lds_layout(...).total doubles.
@@ -901,10 +961,17 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
                 lam = UPR_QP_MU0 / t;
             }
             ws[d.ws_t + k * d.ni_stage + j] = t; ws[d.ws_lam + k * d.ni_stage + j] = lam;
+            if (d.soft) {                                      // slack 0, its own barrier pair at (thr, mu0 / thr)
+                const bool sf = upr_ineq_active(d, k, j) && upr_slot_soft(P, d, j);
+                ws[d.ws_tau + k * d.ni_stage + j] = sf ? UPR_QP_THR : 1.0; ws[d.ws_gam + k * d.ni_stage + j] = sf ? UPR_QP_MU0 / UPR_QP_THR : 0.0;
+            }
         }
         UPR_SYNC();
     }
-    const int ntot = N * (2 * nu + d.np) + N * 2 * nx + (N - 1) * d.no;
+    int ntot = N * (2 * nu + d.np) + N * 2 * nx + (N - 1) * d.no;
+    if (P->soft_state_box) ntot += N * 2 * nx;               // each softened row adds the pair (tau, gam)
+    if (P->soft_input_box) ntot += N * 2 * nu;
+    if (P->soft_poly) ntot += N * d.np + (N - 1) * d.no;
     double* pi_new = ws + d.ws_pin; double* nu_new = ws + d.ws_nun; double* dyN = ws + d.ws_dyN;
     double res[4] = {0, 0, 0, 0};
     int it = 0, status = 1;
