@@ -117,11 +117,17 @@ struct upr_fb_src {
 // NEM / NFM: compile-time bounds of ne / nfc (the per-thread scratch vectors stay in registers for the small shapes)
 template <int NEM, int NFM>
 __global__ void feedback_kernel(const upr_problem* P, upr_dims d, upr_fb_src src, const double* ws, const double* lin,
-                                const double* Df, double* fb) {
+                                const double* Df, const double* stats, double* fb) {
     const int b = blockIdx.x;
     const int N = d.N, nq = d.nq, nx = d.nx, nu = d.nu, ne = d.ne, nfc = d.nfc, nf = d.nf;
     const double* w = ws + (size_t)b * d.ws_stride;
     double* out = fb + (size_t)b * N * nu * nx;
+    if (stats[(size_t)b * UPR_NSTATS + 2] == 2.0) {
+        // the last QP's factorisation broke down (status 2, no step taken): its factors are not a policy; the instance
+        // keeps its plan as a feed-forward input until the next successful solve
+        for (int e = threadIdx.x; e < N * nu * nx; e += blockDim.x) out[e] = 0.0;
+        return;
+    }
     for (int e = threadIdx.x; e < N * nq * nx; e += blockDim.x) {
         const int k = e / (nq * nx), j = (e % (nq * nx)) / nx, c = e % nx;
         double v;
@@ -431,8 +437,8 @@ int advance_impl(upr_batch* h) {
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
     }
     if (h->fb) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
-        if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
-        else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->fb);
+        if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
+        else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
         UPR_HIP(hipGetLastError());
     }
     h->hdyn_prev = h->hdyn0;
