@@ -71,6 +71,18 @@ static inline UPR_HD double upr_rsqrt(double x) {
 #endif
 }
 
+// 1/x the same way: hardware estimate + one second-order step y (1 + e + e^2), e = 1 - x y (the IEEE division
+// sequence costs ~100 dependent cycles; the flat phases of the QP kernel are bound by two or three of them per row)
+static inline UPR_HD double upr_rcp(double x) {
+#ifdef UPR_HOST_EMU
+    return 1.0 / x;
+#else
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, fma(e, e, e), y);
+#endif
+}
+
 // derived dimensions
 struct upr_dims {
     int nq, nb, nc, nf, N, nx, nu, nfc, ne, np, neN, no;   // no: collision pairs (state rows at knots 1..N-1)

@@ -244,12 +244,13 @@ struct upr_qp3 {
     // one inequality row: slack residual, weight and reduced-gradient multiplier for the current mode
     UPR_HDI void row(double c, double ds, double t, double lam, double& cterm, double& s, double& w) const {
         const double rp = c - t;
-        w = lam / t;
+        const double rt = upr_rcp(t);
+        w = lam * rt;
         if (mode == 0) s = w * rp;
         else if (mode == 2) s = -lam;
         else {
             if (mode == 1) { const double dta = ds + rp; const double dla = -lam - w * dta; cterm = dta * dla - sigma_mu; }
-            s = (lam * t + cterm + lam * rp) / t - lam;
+            s = (lam * t + cterm + lam * rp) * rt - lam;
         }
     }
 
@@ -311,7 +312,7 @@ struct upr_qp3 {
             L[O::bks + k * NX + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
             L[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
         }
-        UPR_SYNC();
+        UPR_SYNC(); toc(1);
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
@@ -335,7 +336,18 @@ struct upr_qp3 {
                     for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
                     if (level == 0) continue;
                     double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
-                    if (factor) { if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0; for (int a = 0; a < 9; ++a) Bk[a] = Hc[a]; }
+                    if (factor) {
+                        if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
+                        for (int a = 0; a < 9; ++a) Bk[a] = Hc[a];
+                        // Z = Lf^-1 Df' of this contact (S = Z'Z + rho I is assembled in phase C); staged where the sweeps keep P
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) {
+                            const double* dr = L + O::df + r * NFC + 3 * ci;
+                            const double d0 = dr[0], d1 = dr[1], d2 = dr[2];
+                            double* zr = L + O::Pa + (k * NE + r) * NFC + 3 * ci;
+                            zr[0] = Hc[0] * d0; zr[1] = Hc[3] * d0 + Hc[4] * d1; zr[2] = Hc[6] * d0 + Hc[7] * d1 + Hc[8] * d2;
+                        }
+                    }
                     double yv[3], hv[3];
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * guf[b2]; yv[a] = v; }
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * yv[b2]; hv[a] = v; }
@@ -343,14 +355,18 @@ struct upr_qp3 {
                 } else {
                     if (level == 0) continue;
                     const int uo = k * NU + NQ + ci;
-                    if (factor) G[F::lfi + k * C::NLF + ci] = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
+                    if (factor) {
+                        const double lf0 = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
+                        G[F::lfi + k * C::NLF + ci] = lf0;
+                        for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
+                    }
                     const double lf = G[F::lfi + k * C::NLF + ci];
                     const double yv = lf * L[O::gus + uo];
                     G[F::yf + k * NFC + ci] = yv; L[O::hf + k * NFC + ci] = lf * yv;
                 }
             }
         }
-        UPR_SYNC();
+        UPR_SYNC(); toc(11);
         // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
@@ -365,54 +381,74 @@ struct upr_qp3 {
             if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
             L[O::ys + e] = v - v2;
         }
+        toc(2);
         if (factor) {
             UPR_FORT(e, N * NE * NE) {
                 const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
                 if (c > r) continue;
                 double acc = (r == c) ? UPR_QP_RHO_S : 0.0;
-                for (int i = 0; i < NFC; ++i) {
-                    double zr, zc;
-                    if (NF == 3) {
-                        const int ci = i / 3, a = i % 3;
-                        const double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
-                        zr = 0.0; zc = 0.0;
-                        for (int b2 = 0; b2 <= a; ++b2) { zr += Bk[3 * a + b2] * L[O::df + r * NFC + 3 * ci + b2]; zc += Bk[3 * a + b2] * L[O::df + c * NFC + 3 * ci + b2]; }
-                    } else { const double lf = G[F::lfi + k * C::NLF + i]; zr = lf * L[O::df + r * NFC + i]; zc = lf * L[O::df + c * NFC + i]; }
-                    acc += zr * zc;
-                }
-                G[F::lsi + k * NE * NE + r * NE + c] = acc;
+                const double* zr = L + O::Pa + (k * NE + r) * NFC; const double* zc = L + O::Pa + (k * NE + c) * NFC;
+#pragma unroll
+                for (int i = 0; i < NFC; ++i) acc += zr[i] * zc[i];
+                L[O::hux + k * NE * NE + r * NE + c] = acc;
             }
         }
-        UPR_SYNC();
+        UPR_SYNC(); toc(5);
         if (level == 0) return;
-        // D: one lane per knot: Schur factor (in place), ys = Lsi ee, zt = Lsi' ys
+        // (phase E's rows of C come out of global memory: fetched here, consumed behind phase D)
+        constexpr int QE = (N * NX + NT - 1) / NT;
+        double ckp[QE][NE];
+#pragma unroll
+        for (int q = 0; q < QE; ++q) {
+            const int e = tid_ + q * NT;
+            if (e < N * NX) {
+                const double* Ck = rec(e / NX) + lin_gx + e % NX;
+#pragma unroll
+                for (int r = 0; r < NE; ++r) ckp[q][r] = Ck[r * NX];
+            }
+        }
+        // D: one lane per knot: Schur factor (LDS staging -> global), ys = Lsi ee, zt = Lsi' ys
         UPR_FORT(k, N) {
             double* Ls = G + F::lsi + k * NE * NE;
-            if (factor) { if (!upr_chol_inv_serial<NE>(Ls, Ls)) L[O::misc] = 1.0; }
+            double Lr[NE * NE];                                   // the inverse factor stays in registers for the two products
+            if (factor) {
+                if (!upr_chol_inv_serial<NE>(L + O::hux + k * NE * NE, Lr)) L[O::misc] = 1.0;
+#pragma unroll
+                for (int e = 0; e < NE * NE; ++e) Ls[e] = Lr[e];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NE; ++r)
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) Lr[r * NE + m] = Ls[r * NE + m];
+            }
             double ee[NE], yv[NE];
 #pragma unroll
             for (int r = 0; r < NE; ++r) ee[r] = L[O::ys + k * NE + r];
 #pragma unroll
             for (int r = 0; r < NE; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * ee[m];
+                for (int m = 0; m <= r; ++m) v += Lr[r * NE + m] * ee[m];
                 yv[r] = v; }
 #pragma unroll
             for (int r = 0; r < NE; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * yv[m];
+                for (int m = r; m < NE; ++m) v += Lr[m * NE + r] * yv[m];
                 L[O::ys + k * NE + r] = yv[r]; L[O::zt + k * NE + r] = v; }
         }
-        UPR_SYNC();
+        UPR_SYNC(); toc(8);
         // E: cs = C' zt
-        UPR_FORT(e, N * NX) {
-            const int k = e / NX, i = e % NX;
-            const double* Ck = rec(k) + lin_gx;
-            double v = 0.0;
-            for (int r = 0; r < NE; ++r) v += Ck[r * NX + i] * L[O::zt + k * NE + r];
-            L[O::cs + e] = v;
+#pragma unroll
+        for (int q = 0; q < QE; ++q) {
+            const int e = tid_ + q * NT;
+            if (e < N * NX) {
+                const int k = e / NX;
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NE; ++r) v += ckp[q][r] * L[O::zt + k * NE + r];
+                L[O::cs + e] = v;
+            }
         }
-        UPR_SYNC();
+        UPR_SYNC(); toc(0);
     }
 
     // terminal residual [p_d - p - Jp dq ; v ; a] at the current iterate -> L[eN]
@@ -492,6 +528,7 @@ struct upr_qp3 {
             // a wave with anything else)
             constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NPAIR;
             static_assert(PB0 >= NQ * NQ + NPAIR, "P+ b jobs overlap the others");
+            static_assert(N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux, "prep stages Z and S in the sweeps' working set");
             UPR_FORT(e, PB0 + NX) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
@@ -949,15 +986,16 @@ struct upr_qp3 {
         if (what == 3) { const double a = fabs(rp); if (a > acc) acc = a; *aux += lam * t; return; }
         const double dt = ds + rp;
         const double rc = (mode == 0) ? lam * t : lam * t + cterm;
-        const double dl = -(rc + lam * dt) / t;
+        const double rt = upr_rcp(t);
+        const double dl = -(rc + lam * dt) * rt;
         if (what == 0) {
-            if (dt < 0.0) { const double a = -t / dt; if (a < acc) acc = a; }
-            if (dl < 0.0) { const double a = -lam / dl; if (a < acc) acc = a; }
+            // acc carries 1 / alpha_max: the row's limits are t / -dt and lam / -dlam (no division, no branch)
+            acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
         else { t += alpha * dt; lam += alpha * dl; }
     }
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux) {
-        double acc = (what == 0) ? 1e30 : 0.0;
+        double acc = 0.0;
         const int tid_ = tid();
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -993,6 +1031,7 @@ struct upr_qp3 {
                 }
             }
         }
+        if (what == 0) acc = acc > 1e-30 ? 1.0 / acc : 1e30;
         return acc;
     }
 
