@@ -49,7 +49,9 @@ struct upr_qp3_far {
                          ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE), cv = zt, nun = zt + r2(C::N * C::NE), lfi = nun + r2(C::N * C::NE),
                          Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * C::NH), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
                          hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NE * C::NE),
-                         total = Ks + r2(C::N * C::NQ * C::NX);
+                         // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
+                         // set-up and its step: 20 registers less to carry through the sweeps)
+                         cxr = Ks + r2(C::N * C::NQ * C::NX), total = cxr + r2((2 * C::QX + 2 * C::QU) * C::NT);
 };
 
 // global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
@@ -184,9 +186,29 @@ struct upr_qp3 {
     int mode;
     bool fbk;   // the feedback gain of the first knot is wanted (use_feedback_policy)
     // lane-owned box rows: [item][0 = lower, 1 = upper]
-    double tx[C::QX][2], lx[C::QX][2], cx[C::QX][2];
-    double tu[C::QU][2], lu[C::QU][2], cu[C::QU][2];
+    double tx[C::QX][2], lx[C::QX][2];
+    double tu[C::QU][2], lu[C::QU][2];
+    static constexpr int NCT = 2 * C::QX + 2 * C::QU;   // corrector targets per lane (F::cxr)
+    struct zero_targets_t { double v[NCT]; };
+    UPR_HDI static const double (&zero_targets())[NCT] { static constexpr zero_targets_t z = {}; return z.v; }
+    UPR_HDI void load_targets(double (&ctm)[NCT]) const {
+        const int tid_ = tid();
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) ctm[i] = G[F::cxr + i * NT + tid_];
+    }
 
+    // The box rows are the values the register allocator parks in scratch around the sweeps.  One use of all of them
+    // at the top of every flat phase makes the reloads one batch (issued back to back, one wait) instead of one exposed
+    // scratch round trip per row at its first use.
+    UPR_HDI void touch_rows() const {
+#ifndef UPR_HOST_EMU
+        if constexpr (C::QX == 3 && C::QU == 2)   // the 256-thread layout (the one that runs two workgroups per CU)
+            asm volatile("" :: "v"(tx[0][0]), "v"(tx[0][1]), "v"(tx[1][0]), "v"(tx[1][1]), "v"(tx[2][0]), "v"(tx[2][1]),
+                               "v"(lx[0][0]), "v"(lx[0][1]), "v"(lx[1][0]), "v"(lx[1][1]), "v"(lx[2][0]), "v"(lx[2][1]),
+                               "v"(tu[0][0]), "v"(tu[0][1]), "v"(tu[1][0]), "v"(tu[1][1]),
+                               "v"(lu[0][0]), "v"(lu[0][1]), "v"(lu[1][0]), "v"(lu[1][1]));
+#endif
+    }
     UPR_HDI const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
     UPR_HDI double* Zx(int k) const { return L + O::Z + k * NX; }
     UPR_HDI double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
@@ -262,6 +284,7 @@ struct upr_qp3 {
         // (end-effector gradient, dynamics and equality residuals) is kept, only the barrier terms are rebuilt
         const bool fresh = level != 1;
         const int tid_ = tid();
+        touch_rows();
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -270,8 +293,10 @@ struct upr_qp3 {
                 const int zo = NX + ix, k = 1 + ix / NX, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
                 double s0, s1, w0, w1;
-                row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], cx[q][0], s0, w0);
-                row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], cx[q][1], s1, w1);
+                double c0 = 0.0, c1 = 0.0;
+                row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], c0, s0, w0);
+                row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], c1, s1, w1);
+                if (mode == 1) { G[F::cxr + (2 * q) * NT + tid_] = c0; G[F::cxr + (2 * q + 1) * NT + tid_] = c1; }
                 double g = 0.0;
                 if (k < N) {
                     g = L[O::qd + i] * (X - L[O::xd + i]);
@@ -297,8 +322,10 @@ struct upr_qp3 {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
                 double s0, s1, w0, w1;
-                row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], cu[q][0], s0, w0);
-                row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], cu[q][1], s1, w1);
+                double c0 = 0.0, c1 = 0.0;
+                row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], c0, s0, w0);
+                row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], c1, s1, w1);
+                if (mode == 1) { G[F::cxr + (2 * C::QX + 2 * q) * NT + tid_] = c0; G[F::cxr + (2 * C::QX + 2 * q + 1) * NT + tid_] = c1; }
                 L[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
                 L[O::wu + iu] = w0 + w1;
             }
@@ -825,6 +852,15 @@ struct upr_qp3 {
     // forward sweep, closed-loop form  sx+ = A sx + b - B (K sx + kff): one wave-local phase per knot, lane
     // (block b, joint j) owns sx+[b nq + j] and row j of K_k (prefetched one knot ahead)
     UPR_HDI void forward() {
+#ifndef UPR_HOST_EMU
+        // The flat tail's global data (rows of C, the Schur factors, the contact factors and yf) are constants of this
+        // call: the waves that idle during the serial sweep fetch them into registers meanwhile, and the tail runs on
+        // those waves (lane index tl) out of registers and LDS.
+        constexpr int NTL = NT - 64, CH = (NX + 3) / 4, QV = (N * NE * 4 + NTL - 1) / NTL, QCT = (C::NCI + NTL - 1) / NTL;
+        static_assert(N <= NTL && NTL % 4 == 0, "tail lanes");
+        const int tl = tid() - 64;
+        double ckq[QV][CH], lsr[NE * NE], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
+#endif
         if (wave0()) {
             // knot 0: sx_0 = 0
             UPR_FORT(i, NX) {
@@ -888,9 +924,109 @@ struct upr_qp3 {
             }
 #endif
         }
+#ifndef UPR_HOST_EMU
+        else {
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                const int e4 = tl + q * NTL;
+                if (e4 < N * NE * 4) {
+                    const int e = e4 >> 2, part = e4 & 3;
+                    const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) ckq[q][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                }
+            }
+            if (tl < N) {
+#pragma unroll
+                for (int r = 0; r < NE; ++r)
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) lsr[r * NE + m] = G[F::lsi + tl * NE * NE + r * NE + m];
+            }
+#pragma unroll
+            for (int q = 0; q < QCT; ++q) {
+                const int ic = tl + q * NTL;
+                if (ic < C::NCI) {
+                    const int k = ic / NC, ci = ic % NC;
+                    if (NF == 3) {
+#pragma unroll
+                        for (int a = 0; a < 9; ++a) bkq[q][a] = G[F::lfi + k * C::NLF + 9 * ci + a];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) yfq[q][a] = G[F::yf + k * NFC + 3 * ci + a];
+                    } else { bkq[q][0] = G[F::lfi + k * C::NLF + ci]; yfq[q][0] = G[F::yf + k * NFC + ci]; }
+                }
+            }
+        }
+#endif
         UPR_SYNC();
         toc(4);
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
+#ifndef UPR_HOST_EMU
+        // cv: a quad per row of C (four column chunks), summed by DPP
+#pragma unroll
+        for (int q = 0; q < QV; ++q) {
+            const int e4 = tl + q * NTL;
+            const bool act = tl >= 0 && e4 < N * NE * 4;
+            const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+            double v = 0.0;
+            if (act) {
+                const double* sx = Sx(e / NE) + part * CH;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckq[q][c] * sx[c];
+            }
+            v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+            if (act && part == 0) L[O::cv + e] = v;
+        }
+        UPR_SYNC_LDS();
+        // nu+ of a knot by its lane: in place over cv (LDS, what the contact step and the costates read) and to global
+        if (tl >= 0 && tl < N) {
+            const int k = tl;
+            double cvr[NE], t1[NE];
+#pragma unroll
+            for (int r = 0; r < NE; ++r) cvr[r] = L[O::cv + k * NE + r];
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = L[O::ys + k * NE + r];
+#pragma unroll
+                for (int m = 0; m <= r; ++m) v += lsr[r * NE + m] * cvr[m];
+                t1[r] = v; }
+#pragma unroll
+            for (int r = 0; r < NE; ++r) { double v = 0.0;
+#pragma unroll
+                for (int m = r; m < NE; ++m) v += lsr[m * NE + r] * t1[m];
+                L[O::cv + k * NE + r] = v; G[F::nun + k * NE + r] = v; }
+        }
+        UPR_SYNC_LDS();
+#pragma unroll
+        for (int q = 0; q < QCT; ++q) {
+            const int ic = tl + q * NTL;
+            if (tl >= 0 && ic < C::NCI) {
+                const int k = ic / NC, ci = ic % NC;
+                if (NF == 3) {
+                    double dfn[3], tf[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { double v = 0.0;
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * L[O::cv + k * NE + r];
+                        dfn[a] = v; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { double v = yfq[q][a];
+#pragma unroll
+                        for (int b2 = 0; b2 <= a; ++b2) v += bkq[q][3 * a + b2] * dfn[b2];
+                        tf[a] = v; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { double v = 0.0;
+#pragma unroll
+                        for (int b2 = a; b2 < 3; ++b2) v += bkq[q][3 * b2 + a] * tf[b2];
+                        Su(k)[NQ + 3 * ci + a] = -v; }
+                } else {
+                    double dfn = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) dfn += L[O::df + r * NFC + ci] * L[O::cv + k * NE + r];
+                    const double lf = bkq[q][0];
+                    Su(k)[NQ + ci] = -lf * (yfq[q][0] + lf * dfn);
+                }
+            }
+        }
+#else
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX; const double* sx = Sx(k);
@@ -911,7 +1047,7 @@ struct upr_qp3 {
             for (int r = 0; r < NE; ++r) { double v = 0.0;
 #pragma unroll
                 for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * t1[m];
-                G[F::nun + k * NE + r] = v; }
+                L[O::cv + k * NE + r] = v; G[F::nun + k * NE + r] = v; }
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
@@ -932,6 +1068,7 @@ struct upr_qp3 {
                 }
             }
         }
+#endif
         if (neN > 0) UPR_FORT(q, C::NEN) {
             double v;
             if (q < 3) { v = L[O::eN + q]; for (int j = 0; j < NQ; ++j) v -= L[O::jN + q * NQ + j] * Sx(N)[j]; }
@@ -952,7 +1089,7 @@ struct upr_qp3 {
                 v += h * L[O::qd + i] * sx[i];
                 if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
                 const double* Ck = rec(k) + lin_gx;
-                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * G[F::nun + k * NE + q];
+                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * L[O::cv + k * NE + q];
             } else if (neN > 0) {
                 if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
                 else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
@@ -994,17 +1131,18 @@ struct upr_qp3 {
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
         else { t += alpha * dt; lam += alpha * dl; }
     }
-    UPR_HDI double ineq_sweep(int what, double alpha, double* aux) {
+    UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
         double acc = 0.0;
         const int tid_ = tid();
+        touch_rows();
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
-                sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], cx[q][0], acc, aux);
-                sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], cx[q][1], acc, aux);
+                sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], acc, aux);
+                sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], acc, aux);
             }
         }
 #pragma unroll
@@ -1013,8 +1151,8 @@ struct upr_qp3 {
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
-                sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], cu[q][0], acc, aux);
-                sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], cu[q][1], acc, aux);
+                sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q], acc, aux);
+                sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1], acc, aux);
             }
         }
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
@@ -1040,7 +1178,7 @@ struct upr_qp3 {
     UPR_HDI void residuals(int ntot, double* res, bool full) {
         if (!full) {
             double lt0 = 0.0;
-            const double r_in0 = ineq_sweep(3, 0.0, &lt0);
+            const double r_in0 = ineq_sweep(3, 0.0, &lt0, zero_targets());
             res[0] = 0.0; res[1] = 0.0; res[2] = r_in0; res[3] = lt0;
             reduce4(res);
             res[0] = 1e300; res[1] = 1e300;
@@ -1087,7 +1225,7 @@ struct upr_qp3 {
         UPR_SYNC();
         if (neN > 0) UPR_FORT(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
         double lt = 0.0;
-        const double r_in = ineq_sweep(3, 0.0, &lt);
+        const double r_in = ineq_sweep(3, 0.0, &lt, zero_targets());
         res[0] = r_stat; res[1] = r_eq; res[2] = r_in; res[3] = lt;
         reduce4(res);
         res[3] /= (ntot > 0 ? ntot : 1);
@@ -1152,7 +1290,7 @@ struct upr_qp3 {
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid() + q * NT;
-            tx[q][0] = tx[q][1] = 1.0; lx[q][0] = lx[q][1] = 0.0; cx[q][0] = cx[q][1] = 0.0;
+            tx[q][0] = tx[q][1] = 1.0; lx[q][0] = lx[q][1] = 0.0;
             if (ix < C::NXI) {
                 const int i = ix % NX; const double X = L[O::Z + NX + ix];
                 const double c0 = X - L[O::xlb + i], c1 = L[O::xub + i] - X;
@@ -1163,7 +1301,7 @@ struct upr_qp3 {
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid() + q * NT;
-            tu[q][0] = tu[q][1] = 1.0; lu[q][0] = lu[q][1] = 0.0; cu[q][0] = cu[q][1] = 0.0;
+            tu[q][0] = tu[q][1] = 1.0; lu[q][0] = lu[q][1] = 0.0;
             if (iu < C::NUI) {
                 const int i = iu % NU; const double U = L[O::Z + N1 * NX + iu];
                 const double c0 = U - L[O::ulb + i], c1 = L[O::uub + i] - U;
@@ -1211,9 +1349,9 @@ struct upr_qp3 {
             backward_vec(); toc(8);
             if (L[O::misc] != 0.0) { status = 2; break; }
             forward(); toc(6);
-            double a_aff = reduce(ineq_sweep(0, 0.0, nullptr), 2);
+            double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
             if (a_aff > 1.0) a_aff = 1.0;
-            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr), 0) / ntot;
+            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets()), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
@@ -1223,11 +1361,13 @@ struct upr_qp3 {
             backward_vec(); toc(8);
             forward(); toc(6);
             mode = 3;
+            double ctm[NCT];
+            load_targets(ctm);   // (in flight during the costates)
             costates(); toc(9);
-            double a = reduce(ineq_sweep(0, 0.0, nullptr), 2);
+            double a = reduce(ineq_sweep(0, 0.0, nullptr, ctm), 2);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
-            ineq_sweep(2, a, nullptr);
+            ineq_sweep(2, a, nullptr, ctm);
             UPR_SYNC();
             UPR_FORT(e, N1 * NX) {
                 if (e >= NX) L[O::Z + e] += a * L[O::S + e];
