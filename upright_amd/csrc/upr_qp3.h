@@ -851,7 +851,10 @@ struct upr_qp3 {
 
     // forward sweep, closed-loop form  sx+ = A sx + b - B (K sx + kff): one wave-local phase per knot, lane
     // (block b, joint j) owns sx+[b nq + j] and row j of K_k (prefetched one knot ahead)
-    UPR_HDI void forward() {
+    // COST: the corrector's pass -- the costates of the full step follow the tail (their rows of C and of the end-effector
+    // Hessian are fetched by the idle waves as well)
+    template <bool COST>
+    UPR_HDI void forward(double (&ctm)[NCT]) {   // ctm: the corrector targets for the step sweeps that follow (COST only)
 #ifndef UPR_HOST_EMU
         // The flat tail's global data (rows of C, the Schur factors, the contact factors and yf) are constants of this
         // call: the waves that idle during the serial sweep fetch them into registers meanwhile, and the tail runs on
@@ -860,6 +863,9 @@ struct upr_qp3 {
         static_assert(N <= NTL && NTL % 4 == 0, "tail lanes");
         const int tl = tid() - 64;
         double ckq[QV][CH], lsr[NE * NE], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
+        constexpr int QCS = (N * NX + NTL - 1) / NTL;
+        constexpr int QH = (N * NQ + NTL - 1) / NTL;
+        double heeq[QH][NQ], ckc[QCS][NE];
 #endif
         if (wave0()) {
             // knot 0: sx_0 = 0
@@ -942,6 +948,26 @@ struct upr_qp3 {
 #pragma unroll
                     for (int m = 0; m <= r; ++m) lsr[r * NE + m] = G[F::lsi + tl * NE * NE + r * NE + m];
             }
+            if (COST) {
+#pragma unroll
+                for (int q = 0; q < QH; ++q) {
+                    const int e = tl + q * NTL;
+                    if (e < N * NQ) {
+                        const int k = e / NQ, i = e % NQ;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) heeq[q][j] = G[F::hee + k * C::NH + upr_tri(NQ, i, j)];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QCS; ++q) {
+                    const int e = tl + q * NTL;
+                    if (e < N * NX) {
+                        const double* Ck = rec(e / NX) + lin_gx + e % NX;
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) ckc[q][r] = Ck[r * NX];
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < QCT; ++q) {
                 const int ic = tl + q * NTL;
@@ -975,6 +1001,19 @@ struct upr_qp3 {
             }
             v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
             if (act && part == 0) L[O::cv + e] = v;
+        }
+        if (COST) {   // end-effector Hessian part of the costates (the gee slot is free after the corrector's prep)
+#pragma unroll
+            for (int q = 0; q < QH; ++q) {
+                const int e = tl + q * NTL;
+                if (tl >= 0 && e < N * NQ) {
+                    const double* sx = Sx(e / NQ);
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) v += heeq[q][j] * sx[j];
+                    L[O::gee + e] = h * v;
+                }
+            }
         }
         UPR_SYNC_LDS();
         // nu+ of a knot by its lane: in place over cv (LDS, what the contact step and the costates read) and to global
@@ -1075,12 +1114,62 @@ struct upr_qp3 {
             else v = L[O::eN + q] + Sx(N)[NQ + (q - 3)];
             L[O::dyN + q] = v / UPR_QP_RHO_N;
         }
+#ifndef UPR_HOST_EMU
+        UPR_SYNC_LDS();
+        if (COST) {
+            // costates of the full step, staged where the sweeps keep P (LDS; the update reads them there)
+            double* pin = L + O::Pa;
+#pragma unroll
+            for (int q = 0; q < QCS; ++q) {
+                const int e = tl + q * NTL;
+                if (tl >= 0 && e < N * NX) {
+                    const int k = e / NX, i = e % NX;
+                    const double sxi = Sx(k)[i];
+                    double v = L[O::gxs + e] + L[O::wx + e] * sxi + h * L[O::qd + i] * sxi;
+                    if (i < NQ) v += L[O::gee + k * NQ + i];
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) v += ckc[q][r] * L[O::cv + k * NE + r];
+                    pin[e] = v;
+                }
+            }
+            if (tl < 0 && tl + 64 < NX) {
+                const int i = tl + 64, e = N * NX + i;
+                double v = L[O::gxs + e] + L[O::wx + e] * Sx(N)[i];
+                if (neN > 0) {
+                    if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
+                    else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
+                }
+                pin[e] = v;
+            }
+            UPR_SYNC_LDS();
+            costate_sums();
+        }
+#else
         UPR_SYNC();
+        if (COST) costates();
+#endif
     }
 
-    // costates of the full step (into global pin)
+    // pi_k = r_k + A' pi_{k+1}: three running sums per joint, in place (LDS)
+    UPR_HDI void costate_sums() {
+        double* pin = L + O::Pa;
+        UPR_FORT(j, NQ) {
+            double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
+#pragma unroll
+            for (int k = N - 1; k >= 1; --k) {
+                const double nq_ = pin[k * NX + j] + pq;
+                const double nv_ = pin[k * NX + NQ + j] + h * pq + pvv;
+                const double na_ = pin[k * NX + 2 * NQ + j] + h2 * pq + h * pvv + pa;
+                pq = nq_; pvv = nv_; pa = na_;
+                pin[k * NX + j] = pq; pin[k * NX + NQ + j] = pvv; pin[k * NX + 2 * NQ + j] = pa;
+            }
+        }
+        UPR_SYNC_LDS();
+    }
+
+    // costates of the full step (host emulation: the same sums out of global memory)
     UPR_HDI void costates() {
-        double* pin = ws + W::pin;
+        double* pin = L + O::Pa;
         UPR_FORT(e, N1 * NX) {
             const int k = e / NX, i = e % NX;
             const double* sx = Sx(k);
@@ -1097,23 +1186,7 @@ struct upr_qp3 {
             pin[e] = v;
         }
         UPR_SYNC();
-        // pi_k = r_k + A' pi_{k+1}: all r_k of a joint are fetched first (independent loads), then the three running sums
-        // are carried in registers -- a load / store pair per knot through global memory would serialise 19 round trips
-        UPR_FORT(j, NQ) {
-            double r[N][3];
-#pragma unroll
-            for (int k = 1; k < N; ++k) { r[k][0] = pin[k * NX + j]; r[k][1] = pin[k * NX + NQ + j]; r[k][2] = pin[k * NX + 2 * NQ + j]; }
-            double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
-#pragma unroll
-            for (int k = N - 1; k >= 1; --k) {
-                const double nq_ = r[k][0] + pq;
-                const double nv_ = r[k][1] + h * pq + pvv;
-                const double na_ = r[k][2] + h2 * pq + h * pvv + pa;
-                pq = nq_; pvv = nv_; pa = na_;
-                pin[k * NX + j] = pq; pin[k * NX + NQ + j] = pvv; pin[k * NX + 2 * NQ + j] = pa;
-            }
-        }
-        UPR_SYNC();
+        costate_sums();
     }
 
     // ---- sweeps over the lane-owned rows with the current step ------------------------------------------------
@@ -1348,7 +1421,7 @@ struct upr_qp3 {
             backward_mat(); toc(5);
             backward_vec(); toc(8);
             if (L[O::misc] != 0.0) { status = 2; break; }
-            forward(); toc(6);
+            { double unused[NCT]; forward<false>(unused); } toc(6);
             double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
             if (a_aff > 1.0) a_aff = 1.0;
             const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets()), 0) / ntot;
@@ -1359,11 +1432,10 @@ struct upr_qp3 {
             mode = 1;
             prep(1); toc(1);
             backward_vec(); toc(8);
-            forward(); toc(6);
             mode = 3;
             double ctm[NCT];
-            load_targets(ctm);   // (in flight during the costates)
-            costates(); toc(9);
+            forward<true>(ctm); toc(6);
+            load_targets(ctm);
             double a = reduce(ineq_sweep(0, 0.0, nullptr, ctm), 2);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
@@ -1371,7 +1443,7 @@ struct upr_qp3 {
             UPR_SYNC();
             UPR_FORT(e, N1 * NX) {
                 if (e >= NX) L[O::Z + e] += a * L[O::S + e];
-                ws[W::pi + e] += a * (ws[W::pin + e] - ws[W::pi + e]);
+                ws[W::pi + e] += a * (L[O::Pa + e] - ws[W::pi + e]);
             }
             UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
             UPR_FORT(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
