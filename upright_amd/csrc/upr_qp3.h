@@ -51,7 +51,8 @@ struct upr_qp3_far {
                          hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NE * C::NE),
                          // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
                          // set-up and its step: 20 registers less to carry through the sweeps)
-                         cxr = Ks + r2(C::N * C::NQ * C::NX), total = cxr + r2((2 * C::QX + 2 * C::QU) * C::NT);
+                         cxr = Ks + r2(C::N * C::NQ * C::NX), rows = cxr + r2((2 * C::QX + 2 * C::QU) * C::NT),   // rows: parked (t, lam) of the box rows
+                         total = rows + r2((4 * C::QX + 4 * C::QU) * C::NT);
 };
 
 // global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
@@ -197,17 +198,25 @@ struct upr_qp3 {
         for (int i = 0; i < NCT; ++i) ctm[i] = G[F::cxr + i * NT + tid_];
     }
 
-    // The box rows are the values the register allocator parks in scratch around the sweeps.  One use of all of them
-    // at the top of every flat phase makes the reloads one batch (issued back to back, one wait) instead of one exposed
-    // scratch round trip per row at its first use.
-    UPR_HDI void touch_rows() const {
-#ifndef UPR_HOST_EMU
-        if constexpr (C::QX == 3 && C::QU == 2)   // the 256-thread layout (the one that runs two workgroups per CU)
-            asm volatile("" :: "v"(tx[0][0]), "v"(tx[0][1]), "v"(tx[1][0]), "v"(tx[1][1]), "v"(tx[2][0]), "v"(tx[2][1]),
-                               "v"(lx[0][0]), "v"(lx[0][1]), "v"(lx[1][0]), "v"(lx[1][1]), "v"(lx[2][0]), "v"(lx[2][1]),
-                               "v"(tu[0][0]), "v"(tu[0][1]), "v"(tu[1][0]), "v"(tu[1][1]),
-                               "v"(lu[0][0]), "v"(lu[0][1]), "v"(lu[1][0]), "v"(lu[1][1]));
-#endif
+    // The box rows live in registers through the flat phases only.  Around the sweeps (which need every register) they
+    // are parked in global memory [slot][lane]: written once per iteration after the step, read back behind the two
+    // forward sweeps (by the idle waves during the sweep, by wave 0 right after it).
+    static constexpr int NROWV = 4 * C::QX + 4 * C::QU;
+    UPR_HDI void store_rows() const {
+        const int tid_ = tid();
+        double* R = G + F::rows + tid_;
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) { R[(4 * q) * NT] = tx[q][0]; R[(4 * q + 1) * NT] = tx[q][1]; R[(4 * q + 2) * NT] = lx[q][0]; R[(4 * q + 3) * NT] = lx[q][1]; }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) { R[(4 * C::QX + 4 * q) * NT] = tu[q][0]; R[(4 * C::QX + 4 * q + 1) * NT] = tu[q][1]; R[(4 * C::QX + 4 * q + 2) * NT] = lu[q][0]; R[(4 * C::QX + 4 * q + 3) * NT] = lu[q][1]; }
+    }
+    UPR_HDI void load_rows() {
+        const int tid_ = tid();
+        const double* R = G + F::rows + tid_;
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) { tx[q][0] = R[(4 * q) * NT]; tx[q][1] = R[(4 * q + 1) * NT]; lx[q][0] = R[(4 * q + 2) * NT]; lx[q][1] = R[(4 * q + 3) * NT]; }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) { tu[q][0] = R[(4 * C::QX + 4 * q) * NT]; tu[q][1] = R[(4 * C::QX + 4 * q + 1) * NT]; lu[q][0] = R[(4 * C::QX + 4 * q + 2) * NT]; lu[q][1] = R[(4 * C::QX + 4 * q + 3) * NT]; }
     }
     UPR_HDI const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
     UPR_HDI double* Zx(int k) const { return L + O::Z + k * NX; }
@@ -284,7 +293,6 @@ struct upr_qp3 {
         // (end-effector gradient, dynamics and equality residuals) is kept, only the barrier terms are rebuilt
         const bool fresh = level != 1;
         const int tid_ = tid();
-        touch_rows();
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -929,9 +937,13 @@ struct upr_qp3 {
                 }
             }
 #endif
+#ifndef UPR_HOST_EMU
+            load_rows();   // (wave 0: in flight while the other waves run the tail)
+#endif
         }
 #ifndef UPR_HOST_EMU
         else {
+            load_rows();
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
                 const int e4 = tl + q * NTL;
@@ -1207,7 +1219,6 @@ struct upr_qp3 {
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
         double acc = 0.0;
         const int tid_ = tid();
-        touch_rows();
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
@@ -1382,6 +1393,7 @@ struct upr_qp3 {
                 lu[q][0] = UPR_QP_MU0 / tu[q][0]; lu[q][1] = UPR_QP_MU0 / tu[q][1];
             }
         }
+        store_rows();
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
             if (ic < C::NCI) {
@@ -1440,6 +1452,7 @@ struct upr_qp3 {
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
             ineq_sweep(2, a, nullptr, ctm);
+            store_rows();
             UPR_SYNC();
             UPR_FORT(e, N1 * NX) {
                 if (e >= NX) L[O::Z + e] += a * L[O::S + e];
