@@ -293,6 +293,50 @@ struct upr_qp3 {
         // (end-effector gradient, dynamics and equality residuals) is kept, only the barrier terms are rebuilt
         const bool fresh = level != 1;
         const int tid_ = tid();
+        // global operands of the later phases, requested here and consumed behind phase A: the end-effector gradient /
+        // Hessian rows (g0, hee), the friction rows' (t, lam) and -- on the device, a quad per row -- the rows of C
+        constexpr int QG = (N * NQ + NT - 1) / NT;
+        double heeP[QG][NQ + 1];
+        if (fresh) {
+#pragma unroll
+            for (int q = 0; q < QG; ++q) {
+                const int e = tid_ + q * NT;
+                if (e >= NQ && e < N * NQ) {
+                    const int k = e / NQ, i = e % NQ;
+                    heeP[q][NQ] = G[F::g0 + e];
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) heeP[q][j] = G[F::hee + k * C::NH + upr_tri(NQ, i, j)];
+                }
+            }
+        }
+        double ctP[C::QC][5], clP[C::QC][5];
+        if (NF == 3) {
+#pragma unroll
+            for (int q = 0; q < C::QC; ++q) {
+                const int ic = tid_ + q * NT;
+                if (ic < C::NCI) {
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) { ctP[q][r] = G[F::ct + 5 * ic + r]; clP[q][r] = G[F::cl + 5 * ic + r]; }
+                }
+            }
+        }
+#ifndef UPR_HOST_EMU
+        constexpr int CH = (NX + 3) / 4, QR = (N * NE * 4 + NT - 1) / NT;
+        double ckr[QR][CH], e0r[QR];
+        if (fresh) {
+#pragma unroll
+            for (int q = 0; q < QR; ++q) {
+                const int e4 = tid_ + q * NT;
+                if (e4 < N * NE * 4) {
+                    const int e = e4 >> 2, part = e4 & 3;
+                    const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) ckr[q][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                    e0r[q] = G[F::e0 + e];
+                }
+            }
+        }
+#endif
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -305,20 +349,7 @@ struct upr_qp3 {
                 row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], c0, s0, w0);
                 row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], c1, s1, w1);
                 if (mode == 1) { G[F::cxr + (2 * q) * NT + tid_] = c0; G[F::cxr + (2 * q + 1) * NT + tid_] = c1; }
-                double g = 0.0;
-                if (k < N) {
-                    g = L[O::qd + i] * (X - L[O::xd + i]);
-                    if (i < NQ) {
-                        double a;
-                        if (fresh) {
-                            a = G[F::g0 + k * NQ + i];
-                            for (int j = 0; j < NQ; ++j) a += G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * L[O::Z + k * NX + j];
-                            L[O::gee + k * NQ + i] = a;
-                        } else a = L[O::gee + k * NQ + i];
-                        g += a;
-                    }
-                    g *= h;
-                }
+                const double g = (k < N) ? h * L[O::qd + i] * (X - L[O::xd + i]) : 0.0;   // (the end-effector part is added behind the barrier)
                 L[O::gxs + zo] = g + s0 - s1;
                 L[O::wx + zo] = w0 + w1;
             }
@@ -348,6 +379,22 @@ struct upr_qp3 {
             L[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
         }
         UPR_SYNC(); toc(1);
+        // end-effector part of the state gradient (knots 1 .. N-1), kept in gee for the corrector's pass
+#pragma unroll
+        for (int q = 0; q < QG; ++q) {
+            const int e = tid_ + q * NT;
+            if (e >= NQ && e < N * NQ) {
+                const int k = e / NQ, i = e % NQ;
+                double a;
+                if (fresh) {
+                    a = heeP[q][NQ];
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) a += heeP[q][j] * L[O::Z + k * NX + j];
+                    L[O::gee + e] = a;
+                } else a = L[O::gee + e];
+                L[O::gxs + k * NX + i] += h * a;
+            }
+        }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
@@ -363,8 +410,8 @@ struct upr_qp3 {
                         const double* e3 = L + O::erow + 3 * (5 * ci + r);
                         const double c = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
                         const double ds = e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2];
-                        double s, wgt, ct_ = G[F::cc + 5 * ic + r];
-                        row(c, ds, G[F::ct + 5 * ic + r], G[F::cl + 5 * ic + r], ct_, s, wgt);
+                        double s, wgt, ct_ = 0.0;
+                        row(c, ds, ctP[q][r], clP[q][r], ct_, s, wgt);
                         if (mode == 1) G[F::cc + 5 * ic + r] = ct_;
                         for (int a = 0; a < 3; ++a) { guf[a] += e3[a] * s; for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2]; }
                     }
@@ -403,6 +450,36 @@ struct upr_qp3 {
         }
         UPR_SYNC(); toc(11);
         // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
+#ifndef UPR_HOST_EMU
+        if (fresh) {
+            // C Zx by quads (four column chunks of a row, summed by DPP)
+#pragma unroll
+            for (int q = 0; q < QR; ++q) {
+                const int e4 = tid_ + q * NT;
+                const bool act = e4 < N * NE * 4;
+                const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+                double v = 0.0;
+                if (act) {
+                    const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q][c] * zx[c];
+                }
+                v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+                if (act && part == 0) L[O::ek + e] = v + e0r[q];
+            }
+            UPR_SYNC_LDS();
+        }
+        UPR_FORT(e, N * NE) {
+            const int k = e / NE, r = e % NE;
+            double v = L[O::ek + e], v2 = 0.0;
+            if (fresh) {
+                for (int i = 0; i < NFC; ++i) v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i];
+                L[O::ek + e] = v;
+            }
+            if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
+            L[O::ys + e] = v - v2;
+        }
+#else
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
@@ -416,6 +493,7 @@ struct upr_qp3 {
             if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
             L[O::ys + e] = v - v2;
         }
+#endif
         toc(2);
         if (factor) {
             UPR_FORT(e, N * NE * NE) {
