@@ -8,7 +8,7 @@ arr=json.load(open('tests/golden/arrangements.json'))
 P=thing_problem(arr['pink_bottle'])
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
 x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
-names=["residuals","prep","vec:c_k flat","vec:sweep","fwd:sweep","bwd_mat(K flat)","fwd:flat tail","aff sweeps","vec:kff flat","costates","update","init","mat:ph0+1","mat:chol(lane0)","mat:subst","mat:ph5"]
+names=["residuals","prep A: box rows","prep B: contacts","prep C: eq residual, S","prep D: Schur factor","prep E: C' zt","mat: phase 1","mat: aug. Cholesky","mat: V, K store","mat: P update","vec: sweep","vec/mat: flat parts","fwd: sweep","fwd: tail + costates","aff sweeps","update + init"]
 for nt in sys.argv[2:] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
     mpc=BatchMPC(P,B,way_p=way); mpc.set_observation(0.0,x0)

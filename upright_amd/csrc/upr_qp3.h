@@ -448,7 +448,7 @@ struct upr_qp3 {
                 }
             }
         }
-        UPR_SYNC(); toc(11);
+        UPR_SYNC(); toc(2);
         // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
 #ifndef UPR_HOST_EMU
         if (fresh) {
@@ -494,7 +494,6 @@ struct upr_qp3 {
             L[O::ys + e] = v - v2;
         }
 #endif
-        toc(2);
         if (factor) {
             UPR_FORT(e, N * NE * NE) {
                 const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
@@ -506,7 +505,7 @@ struct upr_qp3 {
                 L[O::hux + k * NE * NE + r * NE + c] = acc;
             }
         }
-        UPR_SYNC(); toc(5);
+        UPR_SYNC(); toc(3);
         if (level == 0) return;
         // (phase E's rows of C come out of global memory: fetched here, consumed behind phase D)
         constexpr int QE = (N * NX + NT - 1) / NT;
@@ -548,7 +547,7 @@ struct upr_qp3 {
                 for (int m = r; m < NE; ++m) v += Lr[m * NE + r] * yv[m];
                 L[O::ys + k * NE + r] = yv[r]; L[O::zt + k * NE + r] = v; }
         }
-        UPR_SYNC(); toc(8);
+        UPR_SYNC(); toc(4);
         // E: cs = C' zt
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
@@ -561,7 +560,7 @@ struct upr_qp3 {
                 L[O::cs + e] = v;
             }
         }
-        UPR_SYNC(); toc(0);
+        UPR_SYNC(); toc(5);
     }
 
     // terminal residual [p_d - p - Jp dq ; v ; a] at the current iterate -> L[eN]
@@ -700,7 +699,7 @@ struct upr_qp3 {
                 }
             }
             UPR_SYNC_LDS();
-            toc(12);
+            toc(6);
 #ifndef UPR_HOST_EMU
             // Matrix-core path.  The 32 x 32 padded result is three 16 x 16 tiles ((0,0), (0,1), (1,1); the lower
             // triangle is mirrored) of v_mfma_f64_16x16x4_f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and
@@ -767,7 +766,7 @@ struct upr_qp3 {
                     for (int j = p2 + 1; j < NQ; ++j) x[j] -= y * upr_readlane(y, j);
                 }
                 if (!ok && c == 0) L[O::misc] = 1.0;
-                toc(13);
+                toc(7);
                 if (c < NQ) {
 #pragma unroll
                     for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) { G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2]; L[lkb(k) + c * (c + 1) / 2 + p2] = x[p2]; }
@@ -796,7 +795,7 @@ struct upr_qp3 {
             }
             if (k == 0) break;
             UPR_SYNC_LDS();
-            toc(14);
+            toc(8);
             // P = sym(A'P+A) + Q~ + Vc'Vc - V'V (upper triangle, mirrored)
 #ifndef UPR_HOST_EMU
             if (MFMA) {
@@ -842,7 +841,7 @@ struct upr_qp3 {
                 }
             }
             UPR_SYNC_LDS();
-            toc(15);
+            toc(9);
         }
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
@@ -860,7 +859,7 @@ struct upr_qp3 {
         const double irho = 1.0 / UPR_QP_RHO_N;
         terminal_residual();
         UPR_SYNC();
-        toc(2);
+        toc(11);
         if (wave0()) {
             UPR_FORT(i, NX) {
                 double v = L[O::gxs + N * NX + i];
@@ -913,7 +912,7 @@ struct upr_qp3 {
 #endif
         }
         UPR_SYNC();
-        toc(3);
+        toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
         UPR_FORT(k, N) {
             const double* Lp = G + F::Ljis + k * C::NH;
@@ -1074,7 +1073,7 @@ struct upr_qp3 {
         }
 #endif
         UPR_SYNC();
-        toc(4);
+        toc(12);
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
 #ifndef UPR_HOST_EMU
         // cv: a quad per row of C (four column chunks), summed by DPP
@@ -1490,7 +1489,7 @@ struct upr_qp3 {
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
-        toc(11);
+        toc(15);
         for (;; ++it) {
             // the KKT test can only pass once the complementarity average and the inequality residual are below the
             // tolerance: until then the stationarity / equality residuals are not evaluated
@@ -1507,24 +1506,24 @@ struct upr_qp3 {
             if (it >= P->qp_iter_max) break;
             const double mu = res[3];
             mode = 0;
-            prep(2); toc(1);
-            backward_mat(); toc(5);
-            backward_vec(); toc(8);
+            prep(2);
+            backward_mat(); toc(11);
+            backward_vec(); toc(11);
             if (L[O::misc] != 0.0) { status = 2; break; }
-            { double unused[NCT]; forward<false>(unused); } toc(6);
+            { double unused[NCT]; forward<false>(unused); } toc(13);
             double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
             if (a_aff > 1.0) a_aff = 1.0;
             const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets()), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
-            toc(7);
+            toc(14);
             mode = 1;
-            prep(1); toc(1);
-            backward_vec(); toc(8);
+            prep(1);
+            backward_vec(); toc(11);
             mode = 3;
             double ctm[NCT];
-            forward<true>(ctm); toc(6);
+            forward<true>(ctm); toc(13);
             load_targets(ctm);
             double a = reduce(ineq_sweep(0, 0.0, nullptr, ctm), 2);
             if (a > 1.0) a = 1.0;
@@ -1540,7 +1539,7 @@ struct upr_qp3 {
             UPR_FORT(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
             UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
-            toc(10);
+            toc(15);
         }
         // ---- result: step from the linearisation point
         UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
