@@ -871,31 +871,54 @@ struct upr_qp3 {
             }
             UPR_WSYNC();
 #ifndef UPR_HOST_EMU
-            static_assert(NX <= 64, "one lane per state component");
-            const int i = tid();
-            if (i < NX) {
-                const int b = i / NQ, j = i % NQ;
-                // column i of K_k, K_{k-1}, K_{k-2}: three knots of register prefetch cover the L2 / fabric latency
+            // Lane 4 j + b (b < 3) owns component (b, j) of the costate vector and carries it in a REGISTER from knot to
+            // knot: the recursion never waits on LDS.  Per knot: B'w + gu of a joint is a sum inside its quad (DPP), the
+            // nine of them reach every lane through scalar registers (v_readlane), A'w is quad-local (DPP broadcasts);
+            // w is written to LDS for the later phases without being read back here.  Column i of K_k, K_{k-1}, K_{k-2}:
+            // three knots of register prefetch cover the L2 / fabric latency.
+            static_assert(4 * NQ <= 64, "one quad per joint");
+            {
+                const int l = lane();
+                const bool act = ((l & 3) < 3) && ((l >> 2) < NQ);
+                const int j = act ? (l >> 2) : 0, b = act ? (l & 3) : 0;
+                const int i = b * NQ + j;
                 double kc0[NQ], kc1[NQ], kc2[NQ];
-#define UPR_LOADKC(dst, kk) do { if ((kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
-#define UPR_VECSTEP(kcx, kk) do { \
-                    const double* w = Wk(kk); const double* gu = L + O::gus + (kk) * NU; \
-                    double v = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; const double pbn = L[O::Pbs + ((kk) - 1) * NX + i]; \
-                    v += ca0 * w[j] + ca1 * w[NQ + j] + ca2 * w[2 * NQ + j]; \
-                    _Pragma("unroll") for (int m = 0; m < NQ; ++m) v -= kcx[m] * (gu[m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]); \
-                    Wk((kk) - 1)[i] = v + pbn; \
-                    UPR_WSYNC(); } while (0)
+#define UPR_LOADKC(dst, kk) do { if (act && (kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
+                // operands of a step that do not depend on the recursion (fetched one step ahead)
+#define UPR_LOADST(gk, pk, uk, kk) do { if ((kk) >= 1) { gk = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; pk = L[O::Pbs + ((kk) - 1) * NX + i]; uk = L[O::gus + (kk) * NU + j]; } } while (0)
+#define UPR_VECSTEP(kcx, gk, pk, uk, kk) do { \
+                    double rq = cbq * wv; \
+                    rq += upr_dpp_quad<0xB1>(rq); rq += upr_dpp_quad<0x4E>(rq); \
+                    rq += uk; \
+                    const double w0 = upr_dpp_quad<0x00>(wv), w1 = upr_dpp_quad<0x55>(wv), w2 = upr_dpp_quad<0xAA>(wv); \
+                    double v0 = gk + ca0 * w0, v1 = ca1 * w1, v2 = ca2 * w2; \
+                    _Pragma("unroll") for (int m = 0; m < NQ; m += 3) { \
+                        v0 -= kcx[m] * upr_readlane(rq, 4 * m); \
+                        if (m + 1 < NQ) v1 -= kcx[m + 1] * upr_readlane(rq, 4 * (m + 1)); \
+                        if (m + 2 < NQ) v2 -= kcx[m + 2] * upr_readlane(rq, 4 * (m + 2)); } \
+                    wv = ((v0 + v1) + v2) + pk; \
+                    if (act) Wk((kk) - 1)[i] = wv; } while (0)
                 // column (b, j) of A' without branches: coefficients of w[(a, j)], zero for a > b
                 const double ca0 = coefA(0, b), ca1 = (b >= 1) ? coefA(1, b) : 0.0, ca2 = (b >= 2) ? 1.0 : 0.0;
+                const double cbq = act ? coefB(b) : 0.0;
+#pragma unroll
+                for (int m = 0; m < NQ; ++m) { kc0[m] = 0.0; kc1[m] = 0.0; kc2[m] = 0.0; }
                 UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
+                double wv = Wk(N - 1)[i];
+                double ga = 0.0, pa = 0.0, ua = 0.0, gb = 0.0, pb = 0.0, ub = 0.0;
+                UPR_LOADST(ga, pa, ua, N - 1);
                 // fully unrolled: inside a loop the compiler's s_waitcnt bookkeeping collapses the three prefetch stages into one
 #pragma unroll
-                for (int k = N - 1; k >= 1; k -= 3) {
-                    UPR_VECSTEP(kc0, k); UPR_LOADKC(kc0, k - 3);
-                    if (k - 1 >= 1) { UPR_VECSTEP(kc1, k - 1); UPR_LOADKC(kc1, k - 4); }
-                    if (k - 2 >= 1) { UPR_VECSTEP(kc2, k - 2); UPR_LOADKC(kc2, k - 5); }
+                for (int k = N - 1; k >= 1; k -= 6) {
+                    UPR_LOADST(gb, pb, ub, k - 1); UPR_VECSTEP(kc0, ga, pa, ua, k); UPR_LOADKC(kc0, k - 3);
+                    if (k - 1 >= 1) { UPR_LOADST(ga, pa, ua, k - 2); UPR_VECSTEP(kc1, gb, pb, ub, k - 1); UPR_LOADKC(kc1, k - 4); }
+                    if (k - 2 >= 1) { UPR_LOADST(gb, pb, ub, k - 3); UPR_VECSTEP(kc2, ga, pa, ua, k - 2); UPR_LOADKC(kc2, k - 5); }
+                    if (k - 3 >= 1) { UPR_LOADST(ga, pa, ua, k - 4); UPR_VECSTEP(kc0, gb, pb, ub, k - 3); UPR_LOADKC(kc0, k - 6); }
+                    if (k - 4 >= 1) { UPR_LOADST(gb, pb, ub, k - 5); UPR_VECSTEP(kc1, ga, pa, ua, k - 4); UPR_LOADKC(kc1, k - 7); }
+                    if (k - 5 >= 1) { UPR_LOADST(ga, pa, ua, k - 6); UPR_VECSTEP(kc2, gb, pb, ub, k - 5); UPR_LOADKC(kc2, k - 8); }
                 }
 #undef UPR_LOADKC
+#undef UPR_LOADST
 #undef UPR_VECSTEP
             }
 #else
