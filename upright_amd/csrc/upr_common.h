@@ -55,6 +55,11 @@ static __device__ __forceinline__ double upr_readlane(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+// value of the lane whose BYTE address (4 * lane) is `addr4`, per lane (ds_bpermute_b32 twice)
+static __device__ __forceinline__ double upr_bpermute(double v, int addr4) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 #endif
 #define UPR_FOR(i, n) for (int i = upr_opq(ctx.tid); i < (n); i += ctx.nt)
 

@@ -134,6 +134,11 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
     for (int i = 0; i < n; ++i) Li[i * n + j] = c[i];
 }
 
+// knots of register prefetch for the rows / columns of K in the vector and forward sweeps (a step takes 0.7 - 1.1 k
+// cycles, an L2 miss 2 - 3.5 k under load)
+#ifndef UPR_QP3_KSTAGES
+#define UPR_QP3_KSTAGES 6
+#endif
 template <class C>
 #define UPR_FORT(i, n) for (int i = tid(); i < (n); i += stride())
 
@@ -882,7 +887,7 @@ struct upr_qp3 {
                 const bool act = ((l & 3) < 3) && ((l >> 2) < NQ);
                 const int j = act ? (l >> 2) : 0, b = act ? (l & 3) : 0;
                 const int i = b * NQ + j;
-                double kc0[NQ], kc1[NQ], kc2[NQ];
+                double kc[UPR_QP3_KSTAGES][NQ];   // column i of K_k, ..., K_{k-S+1}: S knots of register prefetch cover the L2 / fabric latency
 #define UPR_LOADKC(dst, kk) do { if (act && (kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
                 // operands of a step that do not depend on the recursion (fetched one step ahead)
 #define UPR_LOADST(gk, pk, uk, kk) do { if ((kk) >= 1) { gk = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; pk = L[O::Pbs + ((kk) - 1) * NX + i]; uk = L[O::gus + (kk) * NU + j]; } } while (0)
@@ -902,20 +907,21 @@ struct upr_qp3 {
                 const double ca0 = coefA(0, b), ca1 = (b >= 1) ? coefA(1, b) : 0.0, ca2 = (b >= 2) ? 1.0 : 0.0;
                 const double cbq = act ? coefB(b) : 0.0;
 #pragma unroll
-                for (int m = 0; m < NQ; ++m) { kc0[m] = 0.0; kc1[m] = 0.0; kc2[m] = 0.0; }
-                UPR_LOADKC(kc0, N - 1); UPR_LOADKC(kc1, N - 2); UPR_LOADKC(kc2, N - 3);
-                double wv = Wk(N - 1)[i];
-                double ga = 0.0, pa = 0.0, ua = 0.0, gb = 0.0, pb = 0.0, ub = 0.0;
-                UPR_LOADST(ga, pa, ua, N - 1);
-                // fully unrolled: inside a loop the compiler's s_waitcnt bookkeeping collapses the three prefetch stages into one
+                for (int st = 0; st < UPR_QP3_KSTAGES; ++st) {
 #pragma unroll
-                for (int k = N - 1; k >= 1; k -= 6) {
-                    UPR_LOADST(gb, pb, ub, k - 1); UPR_VECSTEP(kc0, ga, pa, ua, k); UPR_LOADKC(kc0, k - 3);
-                    if (k - 1 >= 1) { UPR_LOADST(ga, pa, ua, k - 2); UPR_VECSTEP(kc1, gb, pb, ub, k - 1); UPR_LOADKC(kc1, k - 4); }
-                    if (k - 2 >= 1) { UPR_LOADST(gb, pb, ub, k - 3); UPR_VECSTEP(kc2, ga, pa, ua, k - 2); UPR_LOADKC(kc2, k - 5); }
-                    if (k - 3 >= 1) { UPR_LOADST(ga, pa, ua, k - 4); UPR_VECSTEP(kc0, gb, pb, ub, k - 3); UPR_LOADKC(kc0, k - 6); }
-                    if (k - 4 >= 1) { UPR_LOADST(gb, pb, ub, k - 5); UPR_VECSTEP(kc1, ga, pa, ua, k - 4); UPR_LOADKC(kc1, k - 7); }
-                    if (k - 5 >= 1) { UPR_LOADST(ga, pa, ua, k - 6); UPR_VECSTEP(kc2, gb, pb, ub, k - 5); UPR_LOADKC(kc2, k - 8); }
+                    for (int m = 0; m < NQ; ++m) kc[st][m] = 0.0;
+                    UPR_LOADKC(kc[st], N - 1 - st);
+                }
+                double wv = Wk(N - 1)[i];
+                double gs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0}, us2[2] = {0.0, 0.0};
+                UPR_LOADST(gs[(N - 1) & 1], ps[(N - 1) & 1], us2[(N - 1) & 1], N - 1);
+                // fully unrolled (static register indices; inside a loop the compiler's s_waitcnt bookkeeping would also
+                // collapse the prefetch stages into one)
+#pragma unroll
+                for (int k = N - 1; k >= 1; --k) {
+                    UPR_LOADST(gs[(k - 1) & 1], ps[(k - 1) & 1], us2[(k - 1) & 1], k - 1);
+                    UPR_VECSTEP(kc[(N - 1 - k) % UPR_QP3_KSTAGES], gs[k & 1], ps[k & 1], us2[k & 1], k);
+                    UPR_LOADKC(kc[(N - 1 - k) % UPR_QP3_KSTAGES], k - UPR_QP3_KSTAGES);
                 }
 #undef UPR_LOADKC
 #undef UPR_LOADST
@@ -986,39 +992,56 @@ struct upr_qp3 {
             }
             UPR_WSYNC();
 #ifndef UPR_HOST_EMU
-            // lane 4 j + b (b < 3) owns sx+[b nq + j] and the nq entries K_k[j][b nq ..] (three knots of register
-            // prefetch); the three partial dot products of a joint are summed inside its quad by DPP
+            // lane 4 j + b (b < 3) owns x[(b, j)] and carries it in a REGISTER from knot to knot, together with the nq
+            // entries K_k[j][b nq ..] (three knots of register prefetch).  Per knot the lane fetches the nq entries of its
+            // block from the lanes that own them (ds_bpermute: the LDS crossbar without the memory -- broadcasting all
+            // 27 entries through v_readlane was measured slower than the LDS round trip it replaces),
+            // the three partial dot products of a joint are summed inside its quad by DPP, and the row of
+            // A is quad-local (DPP broadcasts).  x is written to LDS for the later phases, never read back here.
             static_assert(4 * NQ <= 64, "one quad per joint");
             {
                 const int l = lane();
                 const bool act = ((l & 3) < 3) && ((l >> 2) < NQ);
-                const int j = act ? (l >> 2) : 0, b = act ? (l & 3) : 0;
-                const int i = b * NQ + j;
-                const bool first = act && b == 0;   // the lane of a quad that adds the feed-forward term
-                double kq0[NQ], kq1[NQ], kq2[NQ];
+                const int j = act ? (l >> 2) : 0, b = act ? (l & 3) : 3;
+                const int i = (act ? b : 0) * NQ + j;
+                double kq[UPR_QP3_KSTAGES][NQ];
 #define UPR_LOADKQ(dst, kk) do { if (act && (kk) < N) { _Pragma("unroll") for (int c = 0; c < NQ; ++c) dst[c] = G[F::Ks + (kk) * NQ * NX + j * NX + b * NQ + c]; } } while (0)
-#define UPR_FWDSTEP(kqx, kk) do { \
-                    const double* sx = Sx(kk); \
-                    const double kf = L[O::kffs + (kk) * NQ + j]; \
-                    double d = first ? kf : 0.0; \
-                    _Pragma("unroll") for (int c = 0; c < NQ; ++c) d += kqx[c] * sx[b * NQ + c]; \
-                    const double r = L[O::bks + (kk) * NX + i] + ra0 * sx[j] + ra1 * sx[NQ + j] + ra2 * sx[2 * NQ + j]; \
+#define UPR_LOADST(bk, fk, kk) do { if ((kk) < N) { bk = L[O::bks + (kk) * NX + i]; fk = L[O::kffs + (kk) * NQ + j]; } } while (0)
+#define UPR_FWDSTEP(kqx, bk, fk, kk) do { \
+                    double xs[NQ]; \
+                    _Pragma("unroll") for (int c = 0; c < NQ; ++c) xs[c] = upr_bpermute(xv, src + 16 * c); \
+                    __builtin_amdgcn_sched_barrier(0);   /* all permutes in flight before the first product */ \
+                    double d0 = (b == 0) ? fk : 0.0, d1 = 0.0, d2 = 0.0; \
+                    _Pragma("unroll") for (int c = 0; c < NQ; c += 3) { \
+                        d0 += kqx[c] * xs[c]; \
+                        if (c + 1 < NQ) d1 += kqx[c + 1] * xs[c + 1]; \
+                        if (c + 2 < NQ) d2 += kqx[c + 2] * xs[c + 2]; } \
+                    double d = act ? (d0 + d1) + d2 : 0.0; \
                     d += upr_dpp_quad<0xB1>(d); d += upr_dpp_quad<0x4E>(d); \
-                    if (act) { Sx((kk) + 1)[i] = r - cb * d; if (b == 0) Su(kk)[j] = -d; } \
-                    UPR_WSYNC(); } while (0)
-                // row (b, j) of A and entry b of B without branches (idle lanes of a quad work on clamped indices)
-                const double ra0 = (b == 0) ? 1.0 : 0.0, ra1 = (b == 0) ? h : ((b == 1) ? 1.0 : 0.0), ra2 = (b == 0) ? h2 : ((b == 1) ? h : 1.0);
-                const double cb = coefB(b);
+                    const double x0 = upr_dpp_quad<0x00>(xv), x1 = upr_dpp_quad<0x55>(xv), x2 = upr_dpp_quad<0xAA>(xv); \
+                    xv = ((bk + ra0 * x0) + (ra1 * x1 + ra2 * x2)) - cb * d; \
+                    if (act) { Sx((kk) + 1)[i] = xv; if (b == 0) Su(kk)[j] = -d; } } while (0)
+                // row (b, j) of A and entry b of B without branches
+                const double ra0 = (b == 0) ? 1.0 : 0.0, ra1 = (b == 0) ? h : ((b == 1) ? 1.0 : 0.0), ra2 = (b == 0) ? h2 : ((b == 1) ? h : ((b == 2) ? 1.0 : 0.0));
+                const double cb = act ? coefB(b) : 0.0;
+                const int src = 4 * (l & 3);   // byte address of lane (b, 0) for ds_bpermute: lane (b, c) is 16 c further
 #pragma unroll
-                for (int c = 0; c < NQ; ++c) { kq0[c] = 0.0; kq1[c] = 0.0; kq2[c] = 0.0; }
-                UPR_LOADKQ(kq0, 1); UPR_LOADKQ(kq1, 2); UPR_LOADKQ(kq2, 3);
+                for (int st = 0; st < UPR_QP3_KSTAGES; ++st) {
 #pragma unroll
-                for (int k = 1; k < N; k += 3) {
-                    UPR_FWDSTEP(kq0, k); UPR_LOADKQ(kq0, k + 3);
-                    if (k + 1 < N) { UPR_FWDSTEP(kq1, k + 1); UPR_LOADKQ(kq1, k + 4); }
-                    if (k + 2 < N) { UPR_FWDSTEP(kq2, k + 2); UPR_LOADKQ(kq2, k + 5); }
+                    for (int c = 0; c < NQ; ++c) kq[st][c] = 0.0;
+                    UPR_LOADKQ(kq[st], 1 + st);
+                }
+                double xv = Sx(1)[i];
+                double bs[2] = {0.0, 0.0}, fs[2] = {0.0, 0.0};
+                UPR_LOADST(bs[1], fs[1], 1);
+#pragma unroll
+                for (int k = 1; k < N; ++k) {
+                    UPR_LOADST(bs[(k + 1) & 1], fs[(k + 1) & 1], k + 1);
+                    UPR_FWDSTEP(kq[(k - 1) % UPR_QP3_KSTAGES], bs[k & 1], fs[k & 1], k);
+                    UPR_LOADKQ(kq[(k - 1) % UPR_QP3_KSTAGES], k + UPR_QP3_KSTAGES);
                 }
 #undef UPR_LOADKQ
+#undef UPR_LOADST
 #undef UPR_FWDSTEP
             }
 #else
