@@ -1016,7 +1016,7 @@ struct upr_qp3 {
                         d0 += kqx[c] * xs[c]; \
                         if (c + 1 < NQ) d1 += kqx[c + 1] * xs[c + 1]; \
                         if (c + 2 < NQ) d2 += kqx[c + 2] * xs[c + 2]; } \
-                    double d = act ? (d0 + d1) + d2 : 0.0; \
+                    double d = (d0 + d1) + d2;   /* (idle lanes: K = 0 and a finite x, exactly 0) */ \
                     d += upr_dpp_quad<0xB1>(d); d += upr_dpp_quad<0x4E>(d); \
                     const double x0 = upr_dpp_quad<0x00>(xv), x1 = upr_dpp_quad<0x55>(xv), x2 = upr_dpp_quad<0xAA>(xv); \
                     xv = ((bk + ra0 * x0) + (ra1 * x1 + ra2 * x2)) - cb * d; \
