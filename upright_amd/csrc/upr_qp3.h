@@ -743,7 +743,12 @@ struct upr_qp3 {
                 }
             }
             // feedback of the PREVIOUS knot, K_{k+1} = Lj^-T V_{k+1}, on the last wave while wave 0 factors this one
-            if (k + 1 < N && wave == ((nwaves > 1) ? nwaves - 1 : 0)) { if (lane < NX) feedback_column(k + 1, lane); }
+            // (the same wave copies the packed factor of that knot to global memory for the feed-forward phase: one coalesced
+            // store off the critical path instead of nine predicated ones by the factoring lanes)
+            if (k + 1 < N && wave == ((nwaves > 1) ? nwaves - 1 : 0)) {
+                if (lane < NX) feedback_column(k + 1, lane);
+                if (lane < C::NH) G[F::Ljis + (k + 1) * C::NH + lane] = L[lkb(k + 1) + lane];
+            }
 #else
             if (k + 1 < N) UPR_FORT(c, NX) feedback_column(k + 1, c);
 #endif
@@ -774,7 +779,7 @@ struct upr_qp3 {
                 toc(7);
                 if (c < NQ) {
 #pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) { G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = x[p2]; L[lkb(k) + c * (c + 1) / 2 + p2] = x[p2]; }
+                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) L[lkb(k) + c * (c + 1) / 2 + p2] = x[p2];
                 } else if (c < NQ + NX && (k > 0 || fbk)) {
 #pragma unroll
                     for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + (c - NQ)] = x[p2];
@@ -851,6 +856,9 @@ struct upr_qp3 {
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
         if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
+#ifndef UPR_HOST_EMU
+        UPR_FORT(e, C::NH) G[F::Ljis + e] = L[lkb(0) + e];
+#endif
         UPR_SYNC();
     }
 
