@@ -752,37 +752,51 @@ struct upr_qp3 {
 #else
             if (k + 1 < N) UPR_FORT(c, NX) feedback_column(k + 1, c);
 #endif
-            // wave 0: Cholesky of the augmented matrix M = [Hjj | Hux] (nq x (nq + nx)), one lane per COLUMN, all
-            // columns in lock step: at pivot p every lane scales its entry of row p (lane c < nq obtains L[c][p],
-            // lane nq + c' obtains V[p][c'] = (Lj^-1 Hux)[p][c']) and eliminates it from the rows below with the
-            // multipliers L[j][p] read from lanes j through scalar registers -- the factorisation and the forward
-            // substitution are one pass of nq dependent pivots, without LDS traffic in between.
+            // wave 0: EVERY lane factors Hjj for itself in registers (right-looking, 9 dependent pivots) and carries its own
+            // column of Hux through the same eliminations: V = Lj^-1 Hux comes out with the factor and nothing is
+            // exchanged between lanes.  (The one-column-per-lane form of the same elimination broadcast each multiplier
+            // through a v_readlane pair: 94 of them per knot at ~20 cycles of latency each, 4.4 k cycles per knot.)
             if (wave0()) {
 #ifndef UPR_HOST_EMU
-                static_assert(NQ + NX <= 64, "one lane per column of [Hjj | Hux]");
+                static_assert(NX <= 64, "one lane per column of Hux");
                 const int c = tid();
-                double x[NQ];
+                const int cc = (c < NX) ? c : 0;
+                const bool hasv = (k > 0 || fbk);
+                double a[NQ][NQ], hx[NQ];
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) x[j] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((c < NQ + NX && (k > 0 || fbk)) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::hjj + i * NQ + j];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) hx[j] = hasv ? L[O::hux + j * NX + cc] : 0.0;
                 bool ok = true;
 #pragma unroll
                 for (int p2 = 0; p2 < NQ; ++p2) {
-                    const double piv = upr_readlane(x[p2], p2);
+                    const double piv = a[p2][p2];
                     ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
                     const double idg = upr_rsqrt(piv);
-                    const double y = x[p2] * idg;
-                    x[p2] = (c == p2) ? idg : y;   // the diagonal keeps its reciprocal (what the solves need)
 #pragma unroll
-                    for (int j = p2 + 1; j < NQ; ++j) x[j] -= y * upr_readlane(y, j);
+                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
+                    hx[p2] *= idg;
+#pragma unroll
+                    for (int j = p2 + 1; j < NQ; ++j) {
+#pragma unroll
+                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
+                        hx[j] -= a[j][p2] * hx[p2];
+                    }
+                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal (what the solves need)
                 }
                 if (!ok && c == 0) L[O::misc] = 1.0;
                 toc(7);
-                if (c < NQ) {
+                if (c == NX) {   // one lane outside the V columns stores the packed factor
 #pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) if (p2 <= c) L[lkb(k) + c * (c + 1) / 2 + p2] = x[p2];
-                } else if (c < NQ + NX && (k > 0 || fbk)) {
+                    for (int i = 0; i < NQ; ++i)
 #pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + (c - NQ)] = x[p2];
+                        for (int j = 0; j <= i; ++j) L[lkb(k) + i * (i + 1) / 2 + j] = a[i][j];
+                }
+                if (c < NX && hasv) {
+#pragma unroll
+                    for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + c] = hx[p2];
                 }
 #else
                 if (tid() == 0) {
