@@ -196,6 +196,10 @@ def test_collision_rows_kernel_source(arrangements):
         assert stats[b, 1] == 6 == so.qp_iters_last
         assert np.abs(dx[b] - dxo).max() < 1e-6 * max(1, np.abs(dxo).max())
         assert np.abs(du[b] - duo).max() < 1e-6 * max(1, np.abs(duo).max())
+    # the production kernel (rows folded into the end-effector Hessian slot of its matrix sweep) follows the same path
+    dx3, du3, stats3, _ = e.qp(3, xs, us, x0, lin)
+    assert np.all(stats3[:, 1] == 6)
+    assert np.abs(dx3 - dx).max() < 1e-7 * max(1, np.abs(dx).max()) and np.abs(du3 - du).max() < 1e-7 * max(1, np.abs(du).max())
     # ... and they matter: without them the base drives into the obstacle's margin
     P2, _, _, _, _ = _case(arrangements, B, 4, qp_tol=0.0, qp_iter_max=6)
     e2 = Emu(P2, B)
@@ -270,6 +274,8 @@ def test_projectile_rows_kernel_source(arrangements):
         dxo, duo, so, rc = O.qp_step(0.0, x0[b], xs[b], us[b])
         # (this first QP is infeasible -- the goal lies behind the linearised rows -- so the iterates part quickly)
         assert np.abs(dx[b] - dxo).max() < 1e-5 * max(1, np.abs(dxo).max())
+    dx3, du3, stats3, _ = e.qp(3, xs, us, x0, lin)
+    assert np.all(stats3[:, 1] == stats[:, 1]) and np.abs(dx3 - dx).max() < 1e-5 * max(1, np.abs(dx).max())
     e.E.emu_set_dynamic(None, None)
 
 

@@ -70,3 +70,21 @@ run("config 4: robust 8-corner (per-instance params)", P, x0, waypoints_for(P, x
 P = thing_problem(arr["pink_bottle"], nf=1)
 level(P.chain, THING_HOME)
 run("config 2': Thing + pink_bottle frictionless", P, x0, waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0)))
+# config 5: Thing + bottle, thrown ball (dynamic obstacle) + self-collision / ground pairs + projectile-path row
+sys.path.insert(0, str(ROOT / "tests"))
+from test_emu import _projectile_case  # noqa: E402
+
+P, x0r, way, _, _, dyn = _projectile_case(arr, B, use_feedback_policy=True)
+mpc = BatchMPC(P, B, way_p=way)
+mpc.set_projectile_flag(1.0)
+x0f = np.concatenate([x0r, dyn], axis=1)
+mpc.set_observation(0.0, x0f); mpc.advance(); mpc.sync()
+t = time.perf_counter()
+for _ in range(5):
+    mpc.reset_async(); mpc.set_observation(0.0, x0f); mpc.advance_async()
+mpc.sync()
+ms = 1e3 * (time.perf_counter() - t) / 5
+st = mpc.stats()
+print(f"{'config 5: thrown ball (3 pairs + projectile row)':44s} B={B:5d} nx={P.nx}+9 nu={P.nu} eq=6 pairs={len(P.pair_a):2d}  {ms:8.2f} ms/solve-batch  "
+      f"{B / ms * 1e3:9.0f} solves/s  qp iters {st['qp_iters_last'].mean():.1f}  converged {np.mean(st['qp_status_last'] == 0):.2f}")
+mpc.close()

@@ -513,7 +513,8 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
     // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
     const bool plain = P->n_pairs + P->n_proj == 0 && !(P->soft_state_box || P->soft_input_box || P->soft_poly);   // rows only the generic kernel has
-    h->use_qp3 = qp3_has_shape(*P) && plain;
+    const bool soft = P->soft_state_box || P->soft_input_box || P->soft_poly;
+    h->use_qp3 = qp3_has_shape(*P) && !soft && P->n_pairs + P->n_proj <= UPR_QP3_NOMAX;   // (the production kernel takes up to UPR_QP3_NOMAX state rows per knot)
     h->use_qp2 = qp2_has_shape(*P) && plain;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }

@@ -42,6 +42,9 @@ struct upr_qp3_cfg {
 // "far" arrays: per-instance data that only the flat (stage-parallel) phases touch, plus the Riccati feedback
 // store that the back-substitutions stream with a one-knot register prefetch.  They live in global memory
 // (L2-resident) so that two workgroups fit the 160 KB of LDS of a CU.
+#ifndef UPR_QP3_NOMAX
+#define UPR_QP3_NOMAX 16   // state-polytopic rows per knot this kernel takes (more: the generic kernel)
+#endif
 template <class C>
 struct upr_qp3_far {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
@@ -52,7 +55,12 @@ struct upr_qp3_far {
                          // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
                          // set-up and its step: 20 registers less to carry through the sweeps)
                          cxr = Ks + r2(C::N * C::NQ * C::NX), rows = cxr + r2((2 * C::QX + 2 * C::QU) * C::NT),   // rows: parked (t, lam) of the box rows
-                         total = rows + r2((4 * C::QX + 4 * C::QU) * C::NT);
+                         // state-polytopic (collision / projectile) rows of knots 1 .. N-1, at most UPR_QP3_NOMAX per knot: slack,
+                         // multiplier, corrector target, affine part d - G xs_q; heew = hee + (1/h) sum_r w_r G_r G_r' (what the
+                         // matrix sweep and the costates use in place of hee when such rows exist)
+                         ot = rows + r2((4 * C::QX + 4 * C::QU) * C::NT), ol = ot + (C::N - 1) * UPR_QP3_NOMAX, oc = ol + (C::N - 1) * UPR_QP3_NOMAX,
+                         od0 = oc + (C::N - 1) * UPR_QP3_NOMAX, heew = od0 + (C::N - 1) * UPR_QP3_NOMAX,
+                         total = heew + r2(C::N * C::NH);
 };
 
 // global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
@@ -188,6 +196,8 @@ struct upr_qp3 {
     const double* xs; const double* us; const double* x0; const double* lin; const double* Dfg;
     double* ws;
     int lin_stride, lin_g, lin_gx, lin_grad, lin_hess, neN;
+    int no, lin_obs, hee_w;   // state-polytopic rows per knot (knots 1 .. N-1), their record offset, and F::hee or F::heew
+    UPR_HDI const double* orow(int k, int r) const { return lin + (size_t)k * lin_stride + lin_obs + no + r * NQ; }
     double h, h2, h3, sigma_mu;
     int mode;
     bool fbk;   // the feedback gain of the first knot is wanted (use_feedback_policy)
@@ -342,6 +352,18 @@ struct upr_qp3 {
             }
         }
 #endif
+        // state-polytopic rows d + G (q - q_lin) >= 0 of knots 1 .. N-1 (collision pairs, projectile path): multiplier s and
+        // weight w of every row, staged in the LDS the sweeps use for Hux / V until the gradient and Hessian passes below
+        if (no > 0) UPR_FORT(e, (N - 1) * no) {
+            const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+            const double* g = orow(k, r);
+            double c = G[F::od0 + ei], ds = 0.0;
+            for (int i = 0; i < NQ; ++i) { c += g[i] * L[O::Z + k * NX + i]; ds += g[i] * L[O::S + k * NX + i]; }
+            double sr, wr, ct_ = 0.0;
+            row(c, ds, G[F::ot + ei], G[F::ol + ei], ct_, sr, wr);
+            if (mode == 1) G[F::oc + ei] = ct_;
+            L[O::hux + ei] = sr; L[O::hux + (N - 1) * UPR_QP3_NOMAX + ei] = wr;
+        }
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -397,8 +419,19 @@ struct upr_qp3 {
                     for (int j = 0; j < NQ; ++j) a += heeP[q][j] * L[O::Z + k * NX + j];
                     L[O::gee + e] = a;
                 } else a = L[O::gee + e];
-                L[O::gxs + k * NX + i] += h * a;
+                double go = 0.0;   // G' s of the state-polytopic rows
+                for (int r = 0; r < no; ++r) go += orow(k, r)[i] * L[O::hux + (k - 1) * UPR_QP3_NOMAX + r];
+                L[O::gxs + k * NX + i] += h * a + go;
             }
+        }
+        if (no > 0 && factor) UPR_FORT(e, (N - 1) * C::NH) {   // barrier Hessian of those rows next to the end-effector Hessian
+            const int k = 1 + e / C::NH, t = e % C::NH;
+            int i = 0, rem = t;
+            while (rem >= NQ - i) { rem -= NQ - i; ++i; }
+            const int j = i + rem;   // upr_tri(NQ, i, j) == t for i <= j
+            double v = 0.0;
+            for (int r = 0; r < no; ++r) { const double* g = orow(k, r); v += L[O::hux + (N - 1) * UPR_QP3_NOMAX + (k - 1) * UPR_QP3_NOMAX + r] * g[i] * g[j]; }
+            G[F::heew + k * C::NH + t] = G[F::hee + k * C::NH + t] + v / h;
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         for (int q = 0; q < C::QC; ++q) {
@@ -607,7 +640,7 @@ struct upr_qp3 {
             const double* Ck = rec(N - 1) + lin_gx;
             UPR_FORT(e, NE * NX) L[O::ck + e] = Ck[e];
             UPR_FORT(e, NE * NE) L[O::lsik + e] = G[F::lsi + (N - 1) * NE * NE + e];
-            UPR_FORT(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[F::hee + (N - 1) * C::NH + e];
+            UPR_FORT(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[hee_w + (N - 1) * C::NH + e];
         }
         UPR_FORT(e, NX * NX) {
             const int i = e / NX, j = e % NX;
@@ -633,7 +666,7 @@ struct upr_qp3 {
                 if (k > 0) {
                     if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
                     else if (f < NE * NX + NE * NE) v = G[F::lsi + (k - 1) * NE * NE + (f - NE * NX)];
-                    else if (f < NPF) v = G[F::hee + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
+                    else if (f < NPF) v = G[hee_w + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
                 }
                 ckn[q] = v;
             }
@@ -646,6 +679,7 @@ struct upr_qp3 {
             constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NPAIR;
             static_assert(PB0 >= NQ * NQ + NPAIR, "P+ b jobs overlap the others");
             static_assert(N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux, "prep stages Z and S in the sweeps' working set");
+            static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
             UPR_FORT(e, PB0 + NX) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
@@ -1112,7 +1146,7 @@ struct upr_qp3 {
                     if (e < N * NQ) {
                         const int k = e / NQ, i = e % NQ;
 #pragma unroll
-                        for (int j = 0; j < NQ; ++j) heeq[q][j] = G[F::hee + k * C::NH + upr_tri(NQ, i, j)];
+                        for (int j = 0; j < NQ; ++j) heeq[q][j] = G[hee_w + k * C::NH + upr_tri(NQ, i, j)];
                     }
                 }
 #pragma unroll
@@ -1333,7 +1367,7 @@ struct upr_qp3 {
             double v = L[O::gxs + e] + L[O::wx + e] * sx[i];
             if (k < N) {
                 v += h * L[O::qd + i] * sx[i];
-                if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * G[F::hee + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
+                if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * G[hee_w + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
                 const double* Ck = rec(k) + lin_gx;
                 for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * L[O::cv + k * NE + q];
             } else if (neN > 0) {
@@ -1397,6 +1431,15 @@ struct upr_qp3 {
                     if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
                 }
             }
+        }
+        if (no > 0) UPR_FORT(e, (N - 1) * no) {
+            const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+            const double* g = orow(k, r);
+            double c = G[F::od0 + ei], ds = 0.0;
+            for (int i = 0; i < NQ; ++i) { c += g[i] * L[O::Z + k * NX + i]; ds += g[i] * L[O::S + k * NX + i]; }
+            double t = G[F::ot + ei], lam = G[F::ol + ei];
+            sweep_row(what, alpha, c, ds, t, lam, G[F::oc + ei], acc, aux);
+            if (what == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
         }
         if (what == 0) acc = acc > 1e-30 ? 1.0 / acc : 1e30;
         return acc;
@@ -1482,6 +1525,7 @@ struct upr_qp3 {
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
         lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
+        no = A.d.no; lin_obs = A.d.lin_obs; hee_w = (no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
         prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
         if (prof) UPR_FORT(i, 16) L[O::prf + i] = 0.0;
@@ -1514,6 +1558,18 @@ struct upr_qp3 {
             for (int j = 0; j < NX; ++j) v -= Ck[j] * xs[k * NX + j];
             for (int i = 0; i < NFC; ++i) v -= L[O::df + r * NFC + i] * us[k * NU + NQ + i];
             G[F::e0 + e] = v;
+        }
+        if (no > 0) {
+            UPR_FORT(e, (N - 1) * no) {
+                const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                const double* g = orow(k, r);
+                const double d0 = rec(k)[lin_obs + r];   // value at the linearisation point = at the initial iterate (knots >= 1)
+                double v = d0;
+                for (int i = 0; i < NQ; ++i) v -= g[i] * xs[k * NX + i];
+                const double t = d0 > UPR_QP_THR ? d0 : UPR_QP_THR;
+                G[F::od0 + ei] = v; G[F::ot + ei] = t; G[F::ol + ei] = UPR_QP_MU0 / t; G[F::oc + ei] = 0.0;
+            }
+            UPR_FORT(e, C::NH) G[F::heew + e] = G[F::hee + e];   // knot 0 carries no such rows
         }
         // ---- initial slacks / multipliers
 #pragma unroll
@@ -1553,7 +1609,7 @@ struct upr_qp3 {
             }
         }
         UPR_SYNC();
-        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX;
+        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no;
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
