@@ -804,7 +804,15 @@ def test_closed_loop_thrown_ball(arrangements):
     """BASELINE config 5 in closed loop: re-solve every 10 ms (one SQP iteration per tick, warm started, linear
     feedback policy evaluated at the observed state), the plant is the exact triple integrator, the ball flies
     ballistically and is observed every tick.  With the target's flag set the tray gives way to the ball's path; with
-    the flag off the same run carries the tray through it."""
+    the flag off the same run carries the tray through it.
+
+    The flagged run is NOT a clean one, and the test pins that down instead of hiding it: while the ball passes
+    (ticks ~79-93) the forearm collision sphere sits up to 7 mm inside the ball's margin at the first free knot, a hard
+    row that one jerk-limited step cannot restore, so the QP is infeasible there -- for the CPU oracle on the same
+    states as well (status 2 / iteration cap; tools/dbg_ball.py dumps the first such tick).  3-6 ticks per instance
+    end with qp_status 1 (iteration cap) or 2 (factorisation broke down, no step taken).  The engine must report
+    them, keep the plan and the inputs finite, hand out ZERO feedback gains for a status-2 instance (its factors are
+    not a policy: upr_api.hip feedback_kernel), and solve cleanly again once the ball is gone."""
     from test_emu import _projectile_case
 
     B = 4
@@ -817,11 +825,18 @@ def test_closed_loop_thrown_ball(arrangements):
         x = np.concatenate([x0r, dyn], axis=1)
         t, dt = 0.0, 0.01
         mind = np.full(B, np.inf)
+        failed = np.zeros((150, B), dtype=bool)
+        zero_gain_checked = 0
         for tick in range(150):
             mpc.set_observation(t, x)
             mpc.advance()
+            status = mpc.stats()["qp_status_last"]
+            failed[tick] = status != 0
             _, u = mpc.evaluate(t, x_obs=x)
             assert np.all(np.isfinite(u))
+            for b in np.nonzero(status == 2)[0]:
+                assert not np.any(mpc.feedback_gains()[b]) and np.all(np.isfinite(mpc.solution()[1][b]))
+                zero_gain_checked += 1
             j = u[:, :9]
             q, v, a = x[:, :9], x[:, 9:18], x[:, 18:27]
             ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
@@ -833,5 +848,13 @@ def test_closed_loop_thrown_ball(arrangements):
                 mind[b] = min(mind[b], np.linalg.norm(tray - x[b, 27:30]))
         closest[flag] = mind
         mpc.close()
+        if flag == 1.0:
+            # measured [4, 3, 6, 3] failing ticks of 150 (generic and production QP kernel alike); a change here is a change
+            # of behaviour under infeasibility and should be looked at, not absorbed
+            assert failed.sum(axis=0).max() <= 8 and failed.sum() >= 4, failed.sum(axis=0)
+            assert not failed[:70].any() and not failed[110:].any(), np.nonzero(failed.any(axis=1))[0]
+            assert zero_gain_checked >= 1   # the status-2 path is exercised by this scenario
+        else:
+            assert not failed.any()
     # the constraint keeps the link 0.35 m from the PATH; one real-time iteration per tick holds the ball itself at >= 0.3 m
     assert closest[1.0].min() > 0.30 and closest[0.0].max() < 0.25
