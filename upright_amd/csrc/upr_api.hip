@@ -326,14 +326,19 @@ size_t qp2_ws_doubles(const upr_problem& P, const upr_dims& d) {
 }
 
 // third-structure kernel: instantiated for the headline shape (nq 9, nb 1, nc 4, nf 3, N 20)
-template <int NT>
-int launch_qp3(upr_batch* h, const upr_qp_args& A) {
-    typedef upr_qp3_cfg<9, 1, 4, 3, 20, NT> C;
+template <int NT, bool ROWS>
+int launch_qp3_rows(upr_batch* h, const upr_qp_args& A) {
+    typedef upr_qp3_cfg<9, 1, 4, 3, 20, NT, ROWS> C;
     const size_t lds = (size_t)upr_qp3_lds<C>::total * sizeof(double);
     if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((upr_qp3_kernel<C>), dim3(h->B), dim3(NT), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
+}
+// problems without state-polytopic rows run the instantiation that has none compiled in (upr_qp3.h, upr_qp3_cfg)
+template <int NT>
+int launch_qp3(upr_batch* h, const upr_qp_args& A) {
+    return (h->d.no > 0) ? launch_qp3_rows<NT, true>(h, A) : launch_qp3_rows<NT, false>(h, A);
 }
 bool qp3_has_shape(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 
