@@ -232,7 +232,7 @@ int upr_batch_enable_timing(upr_batch* h, int on);
 int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst);
 
 /* debug / test accessors: per-phase cycle counters of the production QP kernel (first call arms it,
- * later calls read and clear prof[B][16]); per-knot linearisation records lin[B][N+1][*stride] */
+ * later calls read and clear prof[B][4][16]: 16 phases as seen by lane 0 of each of the first four waves); per-knot linearisation records lin[B][N+1][*stride] */
 int upr_batch_qp_profile(upr_batch* h, double* out);
 int upr_batch_get_lin(upr_batch* h, double* lin, int* stride);
 

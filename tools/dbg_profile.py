@@ -9,7 +9,10 @@ P=thing_problem(arr['pink_bottle'])
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
 x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
 names=["residuals","prep A: box rows","prep B: contacts","prep C: eq residual, S","prep D: Schur factor","prep E: C' zt","mat: phase 1","mat: aug. Cholesky","mat: V, K store","mat: P update","vec: sweep","vec/mat: flat parts","fwd: sweep","fwd: tail + costates","aff sweeps","update + init"]
-for nt in sys.argv[2:] or ["256"]:
+MAT = "mat" in sys.argv[2:]
+if MAT:
+    names=["ph1 work","ph1 wait","ph2 work (chol | mfma preload, feedback)","ph2 wait","ph3 work (P update)","ph3 wait","-","wave 0: up to end of pivots","-","-","-","-","-","-","-","outside the matrix sweep"]
+for nt in [a for a in sys.argv[2:] if a != "mat"] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
     mpc=BatchMPC(P,B,way_p=way); mpc.set_observation(0.0,x0)
     mpc.advance()
@@ -17,8 +20,13 @@ for nt in sys.argv[2:] or ["256"]:
     mpc.reset(); mpc.advance()
     prof=mpc.qp_profile(); st=mpc.stats()
     its=st["qp_iters_last"]
-    per=prof[:, :16]/its[:,None]
+    per=prof/its[:,None,None]            # [B][wave][phase], cycles per IPM iteration as seen by lane 0 of each wave
+    m=per.mean(0)
     print("NT",nt,"solve ms",mpc.last_solve_ms(),"mean iters",its.mean())
-    for i,n in enumerate(names): print("   %-14s %10.0f cycles/iter  (%.1f%%)"%(n,per[:,i].mean(),100*per[:,i].mean()/per.sum(1).mean()))
-    print("   total cycles/iter",per.sum(1).mean())
+    print("   (a phase ends at a barrier: the wave with the LARGEST share arrived last; every counter read costs ~290 cycles)")
+    print("   %-26s %10s %10s %10s %10s"%("cycles / IPM iteration","wave 0","wave 1","wave 2","wave 3"))
+    for i,n in enumerate(names):
+        if n != "-": print("   %-42s %10.0f %10.0f %10.0f %10.0f"%(n,m[0,i],m[1,i],m[2,i],m[3,i]))
+    if MAT: print("   per knot (19 knots): divide by 19; wait ~ 0 marks the wave the barrier waits for")
+    print("   %-26s %10.0f %10.0f %10.0f %10.0f"%("total",*m.sum(1)))
     mpc.close()

@@ -6,12 +6,15 @@ upright_amd/csrc/*.hip by `__graft_entry__.build()`; if it is missing, importing
 loudly -- there is no Python or CPU fallback.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libupright_mi.so"
+# UPR_LIB selects another build of the same library for debugging (tools/build_prof.sh: libupright_mi_prof.so); the
+# default, and what the tests, smoke() and bench.py load, is the production build
+LIB_PATH = HERE / os.environ.get("UPR_LIB", "libupright_mi.so")
 
 MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU, MAXS, MAXP = 12, 32, 8, 8, 36, 108, 16, 32
 NSTATS = 12

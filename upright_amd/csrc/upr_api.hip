@@ -807,13 +807,13 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
     return 0;
 }
 
-/* debug: per-phase cycle counters of the production QP kernel, prof[B][16]; allocate on first use */
+/* debug: per-phase cycle counters of the production QP kernel, prof[B][4 waves][16]; allocate on first use */
 int upr_batch_qp_profile(upr_batch* h, double* out) {
     if (!h) return fail("null batch");
-    if (!h->prof) { if (dev_alloc(&h->prof, (size_t)h->B * 16)) return 1; return 0; }
+    if (!h->prof) { if (dev_alloc(&h->prof, (size_t)h->B * 64)) return 1; return 0; }
     UPR_HIP(hipStreamSynchronize(h->stream));
-    if (out) UPR_HIP(hipMemcpy(out, h->prof, sizeof(double) * h->B * 16, hipMemcpyDeviceToHost));
-    UPR_HIP(hipMemset(h->prof, 0, sizeof(double) * h->B * 16));
+    if (out) UPR_HIP(hipMemcpy(out, h->prof, sizeof(double) * h->B * 64, hipMemcpyDeviceToHost));
+    UPR_HIP(hipMemset(h->prof, 0, sizeof(double) * h->B * 64));
     return 0;
 }
 

@@ -95,7 +95,7 @@ struct upr_qp3_lds {
                          yN = ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
-                         prf = misc + 16, lsik = prf + 16, heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX), total = gee + r2(C::N * C::NQ);   // gee: end-effector part of the cost gradient
 };
 
@@ -741,6 +741,7 @@ struct upr_qp3 {
                     L[O::Pbs + k * NX + i] = (p0 + p1) + p2;
                 }
             }
+            mtoc(0);
             UPR_SYNC_LDS();
             toc(6);
 #ifndef UPR_HOST_EMU
@@ -856,6 +857,7 @@ struct upr_qp3 {
 #endif
             }
             if (k == 0) break;
+            mtoc(2);
             UPR_SYNC_LDS();
             toc(8);
             // P = sym(A'P+A) + Q~ + Vc'Vc - V'V (upper triangle, mirrored)
@@ -902,6 +904,7 @@ struct upr_qp3 {
                     else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
                 }
             }
+            mtoc(4);
             UPR_SYNC_LDS();
             toc(9);
         }
@@ -1510,12 +1513,34 @@ struct upr_qp3 {
     double* prof; long long tlast;
     UPR_HDI void tic() {
 #ifndef UPR_HOST_EMU
-        if (prof && tid() == 0) tlast = (long long)__builtin_readcyclecounter();
+        if (prof && lane() == 0) tlast = (long long)__builtin_readcyclecounter();
+#endif
+    }
+    // -DUPR_QP3_PROF_MAT (tools/build_prof.sh, never the production library): the matrix sweep in detail.  Every wave also
+    // reads the counter when it ARRIVES at each of the sweep's three barriers, so work and wait separate:
+    //   slot 0 / 1: phase 1 work / wait, 2 / 3: factorisation + matrix-core preload + feedback work / wait, 4 / 5: P update
+    //   work / wait, 7: wave 0 up to the end of its pivots; everything outside the sweep goes to slot 15.
+    UPR_HDI void mtoc(int id) {
+#ifdef UPR_QP3_PROF_MAT
+        toc(100 + id);
+#else
+        (void)id;
 #endif
     }
     UPR_HDI void toc(int id) {
 #ifndef UPR_HOST_EMU
-        if (prof && tid() == 0) { long long t = (long long)__builtin_readcyclecounter(); L[O::prf + id] += (double)(t - tlast); tlast = t; }
+#ifdef UPR_QP3_PROF_MAT
+        id = (id >= 100) ? id - 100 : ((id == 6) ? 1 : ((id == 8) ? 3 : ((id == 9) ? 5 : ((id == 7) ? 7 : 15))));
+#endif
+        // lane 0 of each of the first four waves keeps its own set: a barrier is passed when the LAST wave arrives, and only
+        // the per-wave view shows which one that is.  A read costs ~290 cycles; s_memtime is not ordered against VALU work,
+        // hence the scheduling fences.
+        if (prof && lane() == 0 && wb < 256) {
+            __builtin_amdgcn_sched_barrier(0);
+            long long t = (long long)__builtin_readcyclecounter();
+            L[O::prf + 16 * (wb >> 6) + id] += (double)(t - tlast); tlast = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #endif
     }
 
@@ -1531,8 +1556,8 @@ struct upr_qp3 {
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
-        prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
-        if (prof) UPR_FORT(i, 16) L[O::prf + i] = 0.0;
+        prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
+        if (prof) UPR_FORT(i, 64) L[O::prf + i] = 0.0;
         tic();
         // ---- constants and linearisation-point data into LDS
         UPR_FORT(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
@@ -1672,7 +1697,7 @@ struct upr_qp3 {
         // ---- result: step from the linearisation point
         UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
         UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
-        if (prof) UPR_FORT(i, 16) prof[i] += L[O::prf + i];
+        if (prof) UPR_FORT(i, 64) prof[i] += L[O::prf + i];
         if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;
             st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];

@@ -154,8 +154,8 @@ class BatchMPC:
         check(self._lib.upr_batch_reset_async(self._h))
 
     def qp_profile(self):
-        """Debug: arm (first call) / read-and-clear the per-phase cycle counters of the QP kernel."""
-        out = np.zeros((self.B, 16))
+        """Debug: arm (first call) / read-and-clear the per-phase cycle counters of the QP kernel, [B][wave 0..3][16]."""
+        out = np.zeros((self.B, 4, 16))
         check(self._lib.upr_batch_qp_profile(self._h, ptr(out)))
         return out
 
