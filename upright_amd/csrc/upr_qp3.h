@@ -715,7 +715,8 @@ struct upr_qp3 {
 #pragma unroll
                     for (int a = 0; a < 3; ++a) v += coefB(a) * (h3 * p[a][0] + h2 * p[a][1] + h * p[a][2]);
                     if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
-                    L[O::hjj + e] = v;
+                    // lower triangle, packed: the factoring wave reads it with paired 128-bit loads (it is the wave phase 2 waits for)
+                    if (jj <= ii) L[O::hjj + ii * (ii + 1) / 2 + jj] = v;
                 } else if (e < NQ * NQ + NPAIR) {
                     if (k > 0) {
                         const int f = e - NQ * NQ, pr = f / NX, c = f % NX, r2 = NE - 1 - pr;
@@ -805,7 +806,7 @@ struct upr_qp3 {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
 #pragma unroll
-                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::hjj + i * NQ + j];
+                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::hjj + i * (i + 1) / 2 + j];
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) hx[j] = hasv ? L[O::hux + j * NX + cc] : 0.0;
                 bool ok = true;
@@ -841,7 +842,7 @@ struct upr_qp3 {
                 if (tid() == 0) {
                     constexpr int NM = NQ + NX;
                     double M[NQ][NM];
-                    for (int j = 0; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] = (c < NQ) ? L[O::hjj + j * NQ + c] : ((k > 0 || fbk) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
+                    for (int j = 0; j < NQ; ++j) for (int c = 0; c < NM; ++c) M[j][c] = (c < NQ) ? L[O::hjj + (j >= c ? j * (j + 1) / 2 + c : c * (c + 1) / 2 + j)] : ((k > 0 || fbk) ? L[O::hux + j * NX + (c - NQ)] : 0.0);
                     for (int p2 = 0; p2 < NQ; ++p2) {
                         double piv = M[p2][p2];
                         if (!(piv > 0.0)) { L[O::misc] = 1.0; piv = 1.0; }
