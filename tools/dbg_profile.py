@@ -11,7 +11,7 @@ x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
 names=["residuals","prep A: box rows","prep B: contacts","prep C: eq residual, S","prep D: Schur factor","prep E: C' zt","mat: phase 1","mat: aug. Cholesky","mat: V, K store","mat: P update","vec: sweep","vec/mat: flat parts","fwd: sweep","fwd: tail + costates","aff sweeps","update + init"]
 MAT = "mat" in sys.argv[2:]
 if MAT:
-    names=["ph1 work","ph1 wait","ph2 work (chol | mfma preload, feedback)","ph2 wait","ph3 work (P update)","ph3 wait","-","wave 0: up to end of pivots","-","-","-","-","-","-","-","outside the matrix sweep"]
+    names=["ph1 work","ph1 wait","ph2: after last pivot -> arrival (stores | mfma preload, feedback)","ph2 wait","ph3 work (P update)","ph3 wait","wave 0: operand loads (hjj, hux)","wave 0: pivots 7, 8","wave 0: pivot 0","wave 0: pivot 1","wave 0: pivot 2","wave 0: pivot 3","wave 0: pivot 4","wave 0: pivot 5","wave 0: pivot 6","outside the matrix sweep"]
 for nt in [a for a in sys.argv[2:] if a != "mat"] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
     mpc=BatchMPC(P,B,way_p=way); mpc.set_observation(0.0,x0)
@@ -26,7 +26,7 @@ for nt in [a for a in sys.argv[2:] if a != "mat"] or ["256"]:
     print("   (a phase ends at a barrier: the wave with the LARGEST share arrived last; every counter read costs ~290 cycles)")
     print("   %-26s %10s %10s %10s %10s"%("cycles / IPM iteration","wave 0","wave 1","wave 2","wave 3"))
     for i,n in enumerate(names):
-        if n != "-": print("   %-42s %10.0f %10.0f %10.0f %10.0f"%(n,m[0,i],m[1,i],m[2,i],m[3,i]))
+        if n != "-": print("   %-68s %10.0f %10.0f %10.0f %10.0f"%(n,m[0,i],m[1,i],m[2,i],m[3,i]))
     if MAT: print("   per knot (19 knots): divide by 19; wait ~ 0 marks the wave the barrier waits for")
     print("   %-26s %10.0f %10.0f %10.0f %10.0f"%("total",*m.sum(1)))
     mpc.close()

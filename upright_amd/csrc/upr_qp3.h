@@ -810,8 +810,10 @@ struct upr_qp3 {
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) hx[j] = hasv ? L[O::hux + j * NX + cc] : 0.0;
                 bool ok = true;
+                mtoc(6);    // (instrumented build: operand loads of the factoring wave)
 #pragma unroll
                 for (int p2 = 0; p2 < NQ; ++p2) {
+                    if (p2 >= 1 && p2 <= 7) mtoc(7 + p2);   // pivots 0 .. 6 -> slots 8 .. 14; pivots 7, 8 end in slot 7 (toc(7) below)
                     const double piv = a[p2][p2];
                     ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
                     const double idg = upr_rsqrt(piv);
