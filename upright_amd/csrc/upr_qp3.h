@@ -656,7 +656,12 @@ struct upr_qp3 {
             Pc[e] = v;
         }
         UPR_SYNC();
-        constexpr int NPAIR = (NE / 2) * NX;   // Vc = Lsi C by row pairs (r, NE-1-r): equal work per job
+        // Vc = Lsi C by jobs of three rows (rows 0-2 or 3-5 of a column): 2 nx jobs, which fit ONE wave.  A wave that holds two
+        // job kinds runs them one after the other; with row pairs (3 nx jobs) the Vc jobs spilled onto the wave that also
+        // carries the overflow of the A'P+A jobs, and phase 1 waited for that wave (profiles/r01h_mat_waves.txt).
+        static_assert(NE % 3 == 0, "three rows per Vc job");
+        constexpr int NVC = (NE / 3) * NX;
+        constexpr int VC0 = (NT >= 256) ? 128 : NQ * NQ;   // first lane of the Vc jobs: a wave of their own where there is one
         for (int k = N - 1; k >= 0; --k) {
             // next knot's C, Lsi, Hee: global -> registers now, -> LDS after the barrier (their readers are in phase 1 /
             // in the accumulator preload of the NEXT knot)
@@ -676,12 +681,12 @@ struct upr_qp3 {
             }
             // phase 1.  Jobs [0, NQ*NQ): lane (ii, jj) loads the 9 block entries P+[(a,ii)][(c,jj)] once and emits the
             // entries of A'P+A it owns (upper triangle of the result), 3 of Hux = B'P+A and 1 of Hjj = B'P+B + R + W;
-            // then NPAIR jobs of Vc = Lsi C and NX jobs of P+ b.
+            // then NVC jobs of Vc = Lsi C and NX jobs of P+ b.
             // job -> lane map: A'P+A blocks from lane 0, Vc row pairs behind them, P+ b on the LAST wave of the workgroup
             // (a wave that holds two job kinds runs them one after the other: the 27-term dot products must not share
             // a wave with anything else)
-            constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NPAIR;
-            static_assert(PB0 >= NQ * NQ + NPAIR, "P+ b jobs overlap the others");
+            constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NVC;
+            static_assert(VC0 >= NQ * NQ && PB0 >= VC0 + NVC, "jobs overlap");
             static_assert(N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux, "prep stages Z and S in the sweeps' working set");
             static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
             UPR_FORT(e, PB0 + NX) {
@@ -717,18 +722,19 @@ struct upr_qp3 {
                     if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
                     // lower triangle, packed: the factoring wave reads it with paired 128-bit loads (it is the wave phase 2 waits for)
                     if (jj <= ii) L[O::hjj + ii * (ii + 1) / 2 + jj] = v;
-                } else if (e < NQ * NQ + NPAIR) {
+                } else if (e >= VC0 && e < VC0 + NVC) {
                     if (k > 0) {
-                        const int f = e - NQ * NQ, pr = f / NX, c = f % NX, r2 = NE - 1 - pr;
+                        const int f = e - VC0, g = f / NX, c = f % NX, r0 = 3 * g;
                         const double* Ls = L + O::lsik;
-                        double v1 = 0.0, v2 = 0.0;
+                        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
                         // full-length rows with the entries above the diagonal masked: no lane-dependent trip count
 #pragma unroll
                         for (int m = 0; m < NE; ++m) {
-                            const double cm = L[O::ck + m * NX + c], l1 = Ls[pr * NE + m], l2 = Ls[r2 * NE + m];
-                            v1 += ((m <= pr) ? l1 : 0.0) * cm; v2 += ((m <= r2) ? l2 : 0.0) * cm;
+                            const double cm = L[O::ck + m * NX + c];
+                            const double l0 = Ls[r0 * NE + m], l1 = Ls[(r0 + 1) * NE + m], l2 = Ls[(r0 + 2) * NE + m];
+                            v0 += ((m <= r0) ? l0 : 0.0) * cm; v1 += ((m <= r0 + 1) ? l1 : 0.0) * cm; v2 += ((m <= r0 + 2) ? l2 : 0.0) * cm;
                         }
-                        L[O::vc + pr * NX + c] = v1; L[O::vc + r2 * NX + c] = v2;
+                        L[O::vc + r0 * NX + c] = v0; L[O::vc + (r0 + 1) * NX + c] = v1; L[O::vc + (r0 + 2) * NX + c] = v2;
                     }
                 } else if (e >= PB0) {
                     const int i = e - PB0;
