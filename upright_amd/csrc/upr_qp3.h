@@ -685,11 +685,16 @@ struct upr_qp3 {
             // job -> lane map: A'P+A blocks from lane 0, Vc row pairs behind them, P+ b on the LAST wave of the workgroup
             // (a wave that holds two job kinds runs them one after the other: the 27-term dot products must not share
             // a wave with anything else)
-            constexpr int PB0 = (NT >= 256) ? NT - 64 : NQ * NQ + NVC;
-            static_assert(VC0 >= NQ * NQ && PB0 >= VC0 + NVC, "jobs overlap");
+            constexpr int PB0 = (NT >= 256) ? NT - 64 : ((NQ * NQ + NVC + 1) & ~1);
+            static_assert(VC0 >= NQ * NQ && PB0 >= VC0 + NVC && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
+#ifndef UPR_HOST_EMU
+            constexpr int NPB = 2 * NX;   // P+ b: a lane pair per row (two halves of the 27 terms, summed by DPP): it was the late wave of phase 1
+#else
+            constexpr int NPB = NX;
+#endif
             static_assert(N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux, "prep stages Z and S in the sweeps' working set");
             static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
-            UPR_FORT(e, PB0 + NX) {
+            UPR_FORT(e, PB0 + NPB) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
                     double p[3][3];
@@ -737,6 +742,20 @@ struct upr_qp3 {
                         L[O::vc + r0 * NX + c] = v0; L[O::vc + (r0 + 1) * NX + c] = v1; L[O::vc + (r0 + 2) * NX + c] = v2;
                     }
                 } else if (e >= PB0) {
+#ifndef UPR_HOST_EMU
+                    const int i = (e - PB0) >> 1, hf = (e - PB0) & 1;
+                    constexpr int HL = (NX + 1) / 2;   // 14 terms for the first half, 13 for the second
+                    const int c0 = hf * HL;
+                    double q0 = 0.0, q1 = 0.0;         // two independent chains
+#pragma unroll
+                    for (int j = 0; j < HL; j += 2) {
+                        q0 += ((c0 + j < NX) ? Pc[i * NX + c0 + j] : 0.0) * L[O::bks + k * NX + ((c0 + j < NX) ? c0 + j : 0)];
+                        if (j + 1 < HL) q1 += ((c0 + j + 1 < NX) ? Pc[i * NX + c0 + j + 1] : 0.0) * L[O::bks + k * NX + ((c0 + j + 1 < NX) ? c0 + j + 1 : 0)];
+                    }
+                    double pb = q0 + q1;
+                    pb += upr_dpp_quad<0xB1>(pb);      // the partner lane of the pair (both are active)
+                    if (hf == 0) L[O::Pbs + k * NX + i] = pb;
+#else
                     const int i = e - PB0;
                     double p0 = 0.0, p1 = 0.0, p2 = 0.0;   // three independent chains
 #pragma unroll
@@ -746,6 +765,7 @@ struct upr_qp3 {
                         p2 += Pc[i * NX + 2 * NQ + j] * L[O::bks + k * NX + 2 * NQ + j];
                     }
                     L[O::Pbs + k * NX + i] = (p0 + p1) + p2;
+#endif
                 }
             }
             mtoc(0);
