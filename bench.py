@@ -9,11 +9,17 @@ timed region; the timed region contains only device work (+ the RCCL all-gather 
 when --gpus > 1).  One JSON line is printed by rank 0 (contract in the task description).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                       # launches 8 ranks itself (torch.distributed.run, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+The other BASELINE configurations that fit one GPU are timed as `extra_workloads` of the same line (N = 1 only),
+each with its own roofline object: configs[2] (Thing + 3 stacked objects + static obstacles, batch 4096) and
+configs[3] (upright_robust 8-corner arrangement with per-instance inertial parameters, 1024 per GPU).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -23,34 +29,41 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# algorithmic HBM bytes of the linearisation per knot and algorithmic flops of one
-# IPM iteration of the QP per instance at the headline configuration H.
+METRIC = "batched MPC solves/sec + ms/SQP-iter, Thing 1-obj horizon=20, 1/2/4/8 GPU"   # BASELINE.json:metric verbatim; value = solves/s
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_FP64_TFLOPS = 78.6    # public MI355X fp64 vector = matrix peak (not in the local guide)
 
 
+# ---- algorithmic bytes / flops ------------------------------------------------------------
 def bytes_per_knot(P):
+    """Non-constant HBM bytes of one shooting knot of the linearisation: (x, u) in, g and dg/dx out, end-effector
+    cost / gradient / packed Gauss-Newton Hessian out, + collision rows with their d/dq."""
     nx, nu, nq, ne = P.nx, P.nu, P.nq, 6 * P.nb
-    return 8 * ((nx + nu) + ne * (1 + nx) + (nq + nq * (nq + 1) // 2 + 1))
+    no = len(P.pair_a) + len(P.proj_sph)
+    return 8 * ((nx + nu) + ne * (1 + nx) + (nq + nq * (nq + 1) // 2 + 1) + no * (1 + nq))
 
 
 def qp_flops_per_iter(P):
+    """Classical dense Riccati count of one IPM iteration + barrier-Hessian update of the polytopic rows."""
     nx, nu, N = P.nx, P.nu, P.N
-    n_ineq = 5 * P.nc if P.nf == 3 else 0
+    n_ineq = (5 * P.nc if P.nf == 3 else 0) + len(P.pair_a) + len(P.proj_sph)
     ric = N * ((7.0 / 3.0) * nx ** 3 + 4 * nx * nx * nu + 2 * nx * nu * nu + nu ** 3 / 3.0)
     bar = 2.0 * N * n_ineq * (nx + nu) ** 2
     return ric + bar
 
 
+def _latest_profile(pattern):
+    files = sorted((ROOT / "profiles").glob(pattern))
+    return files[-1] if files else None
+
+
 def pmc_traffic():
-    """Per-launch HBM bytes of the two kernels from the committed rocprofv3 PMC passes (profiles/):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  They are measured at
-    the default workload (B = 1024); None when no profile is committed."""
+    """Per-launch HBM bytes of the headline kernels from the newest committed rocprofv3 PMC passes (profiles/):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  Measured at the default
+    workload (B = 1024); {} when no profile is committed."""
     import csv
 
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*_pmc_hbm.csv")):
-        best = f
+    best = _latest_profile("r*_pmc_hbm.csv")
     if best is None:
         return {}, None
     vals = {}
@@ -66,21 +79,298 @@ def pmc_traffic():
     return out, best.name
 
 
+def pmc_issued_flops():
+    """fp64 flops the QP kernel ISSUED per launch according to the newest committed instruction-mix pass
+    (profiles/r*_pmc_mfma.csv; wave instructions x 64 lanes: FMA 2 flops, MUL / ADD 1, one v_mfma_f64_16x16x4 = 2048)."""
+    import csv
+
+    best = _latest_profile("r*_pmc_mfma.csv")
+    if best is None:
+        return None, None
+    c = {}
+    for row in csv.reader(l for l in open(best) if not l.startswith("#")):
+        if len(row) == 4 and "upr_qp" in row[0]:
+            c[row[1]] = float(row[3])
+    if "SQ_INSTS_VALU_FMA_F64" not in c:
+        return None, best.name
+    flops = 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)) \
+        + 2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+    return flops, best.name
+
+
+# ---- workloads ----------------------------------------------------------------------------------------------------
+def _arrangements():
+    return json.load(open(ROOT / "tests" / "golden" / "arrangements.json"))
+
+
+def headline_workload(B, rank=0, world=1):
+    """configs[1]: nx 27, nu 21, 6 equality + 20 friction rows per knot, N = 20; sqp.use_feedback_policy as in
+    controller.yaml:60.  Rank r owns instances [r B, (r+1) B) of the global sample (weak scaling)."""
+    from upright_amd.distributed import shard_range
+    from upright_amd.problem import thing_problem
+    from upright_amd.sampling import level_tray_states, waypoints_for
+
+    P = thing_problem(_arrangements()["pink_bottle"], use_feedback_policy=True)
+    lo, hi = shard_range(B * world, rank, world)
+    x0 = level_tray_states(B * world, seed=0)[lo:hi]
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0), body_params=None,
+                name="configs[1]: Thing + pink_bottle (nx 27, nu 21, 6 eq + 20 friction rows/knot), N=20, dt=0.1, "
+                     f"batch={B} level-tray random start states per GPU, cold start, sqp_iteration=1, qp iter_max=30")
+
+
+def config3_workload(B):
+    """configs[2]: box_arch (3 bodies, 16 contact points, arrangements.yaml:8-51) + the 20 sphere pairs of
+    obstacles/simple.yaml:11-41, waypoint _point3 [0, -2, 0.25], seed 1."""
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME, thing_problem
+    from upright_amd.sampling import waypoints_for
+
+    P = thing_problem(_arrangements()["box_arch"])
+    for k, v in robots.collision_model(P.chain, robots.SIMPLE_COLLISION_PAIRS).items():
+        setattr(P, k, v)
+    rng = np.random.default_rng(1)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] = 0.3 + rng.uniform(-0.05, 0.05, B)
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(0.0, -2.0, 0.25)), body_params=None,
+                name=f"configs[2]: Thing + box_arch (3 bodies, 16 contacts: nx 27, nu 57, 18 eq + 80 friction + 20 collision rows/knot), "
+                     f"N=20, batch={B}, cold start, sqp_iteration=1")
+
+
+def config4_workload(B):
+    """configs[3]: the upright_robust 8-corner arrangement (planning_sim_loop.py:454-534), frictionless, per-instance
+    inertial parameters (CoM uniform in the CoM box, inertia scaled by {1, 0.5, 0.1}, :559), HPIPM slacks on the state
+    boxes and the general constraints, init_sqp_iteration 3 (upright_robust/config/demos/_base.yaml:62-75), waypoint
+    [-2, 1, 0], seed 2."""
+    from upright_amd.problem import THING_HOME, thing_problem
+    from upright_amd.sampling import waypoints_for
+
+    P = thing_problem(_arrangements()["robust_8corner"], nf=1, force_weight=0.0, sqp_iters=3)
+    P.slacks = dict(state_box=True, input_box=False, poly_ineq=True)
+    rng = np.random.default_rng(2)
+    bp = np.zeros((B, 8, 10))
+    for b in range(B):
+        sc = (1.0, 0.5, 0.1)[b % 3]
+        for i in range(8):
+            com = rng.uniform([-0.06, -0.06, -0.15], [0.06, 0.06, 0.15])
+            bp[b, i] = [1.0, *com, sc * 0.009375, 0, 0, sc * 0.009375, 0, sc * 0.00375]
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, :2] += rng.uniform(-0.25, 0.25, (B, 2))
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0)), body_params=bp,
+                name=f"configs[3]: upright_robust 8-corner arrangement (8 bodies, 32 frictionless contacts: nx 27, nu 41, 48 soft eq rows/knot), "
+                     f"per-instance inertial parameters, N=20, batch={B} per GPU, cold start, init_sqp_iteration=3")
+
+
+def make_engine(w):
+    from upright_amd.engine import BatchMPC
+
+    mpc = BatchMPC(w["P"], len(w["x0"]), way_p=w["way"], body_params=w["body_params"])
+    mpc.set_observation(0.0, w["x0"])
+    return mpc
+
+
+# ---- the timed loop of one rank -----------------------------------------------------------------------------------
+def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None):
+    """W untimed + K timed steps on this rank.  `mpc` is the engine (or a stand-in with the same methods: the gloo test
+    drives this function with fake solutions); `dist` a torch.distributed module with an initialised group or None.
+    Returns (max-over-ranks seconds of the timed region, gathered trajectories of the last step or None)."""
+    import torch
+
+    from upright_amd.distributed import all_gather_solutions
+
+    world = dist.get_world_size() if dist is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    B, n1 = mpc.B, P.N + 1
+    loc_x = loc_u = None
+    counts = [B] * world
+    if world > 1:
+        loc_x = torch.empty((B, n1, P.nx), dtype=torch.float64, device=device)
+        loc_u = torch.empty((B, P.N, P.nu), dtype=torch.float64, device=device)
+    gathered = [None]
+
+    def step():
+        mpc.reset_async()      # cold start: DefaultInitializer guess
+        mpc.advance_async()
+        if world > 1:          # exchange step: all-gather of the solved trajectories (SURVEY.md 8e)
+            mpc.copy_solution_device(loc_x.data_ptr(), loc_u.data_ptr())
+            mpc.sync()
+            gx, gu, _ = all_gather_solutions(loc_x, loc_u, counts=counts)
+            gathered[0] = (gx, gu)
+
+    def fence():
+        mpc.sync()
+        if sync_device is not None:
+            sync_device()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    mpc.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, gathered[0]
+
+
+def roofline_objects(P, B, kt, st, sqp_iters, headline):
+    """`roofline` (QP kernel: the dominant one) and `roofline_linearize` objects of one workload."""
+    knots = B * (P.N + 1)                                  # one linearise launch covers every knot of the batch once
+    lin_bytes = bytes_per_knot(P) * knots
+    lin_gbs = lin_bytes / (kt["linearize_ms"] * 1e-3) / 1e9 if kt["linearize_ms"] > 0 else 0.0
+    # IPM iterations of the LAST QP launch of the step, per instance (the launches of a step run similar counts)
+    qp_flops = qp_flops_per_iter(P) * float(np.sum(st["qp_iters_last"]))
+    qp_tflops = qp_flops / (kt["qp_ms"] * 1e-3) / 1e12 if kt["qp_ms"] > 0 else 0.0
+    traffic, traffic_src = pmc_traffic() if (headline and B == 1024) else ({}, None)
+    issued, issued_src = pmc_issued_flops() if (headline and B == 1024) else (None, None)
+    roof = {
+        "kernel": kt.get("qp_kernel", "upr_qp3_kernel"),
+        # fp64 FMA / matrix-core bound; `achieved` prices the SURVEY.md 8(d) classical dense Riccati count x the IPM
+        # iterations of the launch against its HIP-event duration -- an algorithmic-model rate, not executed flops
+        "bound": "mfma",
+        "achieved": qp_tflops,
+        "peak": PEAK_FP64_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": qp_tflops / PEAK_FP64_TFLOPS,
+        "traffic": traffic.get("qp"),
+        "traffic_source": traffic_src,
+        "avg_launch_ms": kt["qp_ms"],
+        "algorithmic_flops_per_launch": qp_flops,
+    }
+    if issued is not None and kt["qp_ms"] > 0:
+        # flops the kernel actually issued (committed instruction-mix counters of the same workload): the block
+        # structure removes about half of the classical count
+        roof["issued_flops_per_launch"] = issued
+        roof["achieved_issued"] = issued / (kt["qp_ms"] * 1e-3) / 1e12
+        roof["frac_issued"] = roof["achieved_issued"] / PEAK_FP64_TFLOPS
+        roof["issued_source"] = issued_src
+    lin = {
+        "kernel": "upr_linearize_kernel",
+        "bound": "hbm",
+        "achieved": lin_gbs,
+        "peak": PEAK_HBM_GBS,
+        "unit": "GB/s",
+        "frac": lin_gbs / PEAK_HBM_GBS,
+        "traffic": traffic.get("linearize"),
+        "algorithmic_bytes": lin_bytes,
+        "avg_launch_ms": kt["linearize_ms"],
+        "bytes_per_knot": bytes_per_knot(P),
+    }
+    return roof, lin
+
+
+def time_extra(w, steps, warmup):
+    """One more BASELINE configuration on this GPU: solves/s + its own roofline objects."""
+    args = argparse.Namespace(gpus=1, steps=steps, warmup=warmup)
+    mpc = make_engine(w)
+    import torch
+
+    elapsed, _ = rank_main(args, mpc, w["P"], sync_device=torch.cuda.synchronize)
+    kt, st = mpc.kernel_times(), mpc.stats()
+    B = mpc.B
+    roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False)
+    out = {
+        "workload": w["name"], "value": B * steps / elapsed, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / steps,
+        "ms_per_sqp_iter": 1e3 * elapsed / steps / max(1, kt["launches"][1] // steps), "steps": steps, "warmup": warmup,
+        "qp_converged_fraction": float(np.mean(st["qp_status_last"] == 0)), "qp_iters_mean": float(np.mean(st["qp_iters_last"])),
+        "roofline": roof, "roofline_linearize": lin,
+        "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
+    }
+    mpc.close()
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, n_sample):
+    """The oracle (oracle/upright_oracle.cpp, -O2 -fopenmp) on the first instances of the same batch, same cold start:
+    one thread, then OpenMP over instances on every host thread with at least 8 solves per thread."""
+    from oracle.oracle import Oracle
+    from upright_amd.sampling import stationary_guess
+
+    P, x0, way = w["P"], w["x0"], w["way"]
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    O = Oracle(P)
+    threads = os.cpu_count() or 1
+    n1 = min(len(x0), 64)
+    tc = time.perf_counter()
+    O.solve_batch(0.0, x0[:n1], xs0[:n1], us0[:n1], way_p=way[:n1], nthreads=1)
+    dt1 = time.perf_counter() - tc
+    n = min(len(x0), max(n_sample, 8 * threads))
+    reps = max(1, -(-8 * threads // n))          # fewer instances than 8 per thread: solve the sample several times
+    idx = np.tile(np.arange(n), reps)
+    O.solve_batch(0.0, x0[idx[:threads]], xs0[idx[:threads]], us0[idx[:threads]], way_p=way[idx[:threads]], nthreads=threads)   # spin the pool up
+    tc = time.perf_counter()
+    _, _, _, used = O.solve_batch(0.0, x0[idx], xs0[idx], us0[idx], way_p=way[idx], nthreads=threads)
+    dtn = time.perf_counter() - tc
+    return {
+        "value": len(idx) / dtn,
+        "unit": "solves/s",
+        "cores": used,
+        "kind": "port",
+        "sample": f"{len(idx)} solves ({len(idx) / used:.1f} per thread) of the first {n} instances of the same batch, same cold start; "
+                  f"oracle/upright_oracle.cpp (dense-stage Riccati IPM, -O2 -fopenmp), OpenMP over instances on {used} threads of "
+                  f"{cpu_model()}; the reference solver (OCS2 fork + HPIPM) is not available, see BASELINE.md",
+        "single_thread_value": n1 / dt1,
+        "single_thread_ms_per_solve": 1e3 * dt1 / n1,
+        "single_thread_sample": f"first {n1} instances, one thread",
+        "cpu_model": cpu_model(),
+        "host_threads": threads,
+    }
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N ranks (one per GPU) as a child process tree BEFORE this process touches the
+    GPU, relay the JSON line, exit with the children's code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="instances timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="instances of the CPU-baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3])")
+    ap.add_argument("--extra-steps", type=int, default=3)
     args = ap.parse_args()
 
-    import torch
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -89,80 +379,29 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
 
     import __graft_entry__ as g
 
     if not g.LIB.exists():
         g.build()
-    from upright_amd.engine import BatchMPC
-    from upright_amd.problem import thing_problem
-    from upright_amd.sampling import level_tray_states, stationary_guess, waypoints_for
 
-    arr = json.load(open(ROOT / "tests" / "golden" / "arrangements.json"))["pink_bottle"]
-    # nx 27, nu 21, 6 equality + 20 friction rows per knot, N = 20; sqp.use_feedback_policy as in controller.yaml:60
-    P = thing_problem(arr, use_feedback_policy=True)
-    B = args.batch
-    # shard: rank r owns instances [r*B, (r+1)*B) of the global sample (weak scaling: B per GPU)
-    x0_all = level_tray_states(B * world, seed=0)
-    x0 = x0_all[rank * B:(rank + 1) * B]
-    way = waypoints_for(P, x0)
-    mpc = BatchMPC(P, B, way_p=way)
-    mpc.set_observation(0.0, x0)
-
-    n1 = P.N + 1
-    gather_x = gather_u = loc_x = loc_u = None
-    if world > 1:
-        loc_x = torch.empty(B * n1 * P.nx, dtype=torch.float64, device="cuda")
-        loc_u = torch.empty(B * P.N * P.nu, dtype=torch.float64, device="cuda")
-        gather_x = torch.empty(world * B * n1 * P.nx, dtype=torch.float64, device="cuda")
-        gather_u = torch.empty(world * B * P.N * P.nu, dtype=torch.float64, device="cuda")
-
-    def step():
-        mpc.reset_async()      # cold start: DefaultInitializer guess
-        mpc.advance_async()
-        if world > 1:          # exchange step: all-gather of the solved trajectories
-            mpc.copy_solution_device(loc_x.data_ptr(), loc_u.data_ptr())
-            mpc.sync()
-            dist.all_gather_into_tensor(gather_x, loc_x)
-            dist.all_gather_into_tensor(gather_u, loc_u)
-
-    for _ in range(args.warmup):
-        step()
-    mpc.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    mpc.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    mpc.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    w = headline_workload(args.batch, rank, world)
+    P, B = w["P"], args.batch
+    mpc = make_engine(w)
+    elapsed, gathered = rank_main(args, mpc, P, dist=dist, sync_device=torch.cuda.synchronize)
+    if gathered is not None:
+        assert gathered[0].shape[0] == world * B and bool(torch.isfinite(gathered[0]).all())
     kt = mpc.kernel_times()
     st = mpc.stats()
     mpc.enable_timing(False)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        total_instances = B * world
-        value = total_instances * args.steps / elapsed
-        iters = float(np.sum(st["qp_iters_last"]))
-        knots = B * n1 * P.sqp_iters
-        lin_bytes = bytes_per_knot(P) * knots
-        lin_gbs = lin_bytes / (kt["linearize_ms"] * 1e-3) / 1e9 if kt["linearize_ms"] > 0 else 0.0
-        qp_flops = qp_flops_per_iter(P) * iters
-        qp_tflops = qp_flops / (kt["qp_ms"] * 1e-3) / 1e12 if kt["qp_ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic() if B == 1024 else ({}, None)
+        roof, lin = roofline_objects(P, B, kt, st, P.sqp_iters, headline=True)
         out = {
-            "metric": "batched MPC solves/sec + ms/SQP-iter, Thing 1-obj horizon=20, 1/2/4/8 GPU",   # BASELINE.json:metric verbatim; value = solves/s
-            "value": value,
+            "metric": METRIC,
+            "value": B * world * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -175,85 +414,25 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: Thing + pink_bottle (nx 27, nu 21, 6 eq + 20 friction rows/knot), N=20, dt=0.1, "
-                            f"batch={B} level-tray random start states per GPU, cold start, sqp_iteration=1, qp iter_max=30",
+                "workload": w["name"],
                 "batch_per_gpu": B,
                 "parallelism": f"instances sharded over {world} rank(s); all-gather of solved trajectories" if world > 1 else "single GPU",
                 "qp_converged_fraction": float(np.mean(st["qp_status_last"] == 0)),
                 "qp_iters_mean": float(np.mean(st["qp_iters_last"])),
             },
-            # dominant kernel = the QP (IPM/Riccati) kernel: fp64 FMA bound; achieved = SURVEY.md 8(d)
-            # classical Riccati flop count x IPM iterations of the launch / its HIP-event duration
-            "roofline": {
-                "kernel": "upr_qp_kernel",
-                "bound": "mfma",
-                "achieved": qp_tflops,
-                "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": qp_tflops / PEAK_FP64_TFLOPS,
-                "traffic": traffic.get("qp"),
-                "traffic_source": traffic_src,
-                "avg_launch_ms": kt["qp_ms"],
-            },
-            # the constraint / linearisation kernel the north_star asks HBM GB/s for
-            "roofline_linearize": {
-                "kernel": "upr_linearize_kernel",
-                "bound": "hbm",
-                "achieved": lin_gbs,
-                "peak": PEAK_HBM_GBS,
-                "unit": "GB/s",
-                "frac": lin_gbs / PEAK_HBM_GBS,
-                "traffic": traffic.get("linearize"),
-                "algorithmic_bytes": lin_bytes,
-                "avg_launch_ms": kt["linearize_ms"],
-                "bytes_per_knot": bytes_per_knot(P),
-            },
+            "roofline": roof,
+            "roofline_linearize": lin,
             "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
         }
-        if not args.no_cpu_baseline and world == 1:
-            import copy
-            from concurrent.futures import ThreadPoolExecutor
-
-            from oracle.oracle import Oracle
-
-            xs0, us0 = stationary_guess(x0, P.N, P.nu)
-
-            n = min(args.cpu_sample, B)
-            solvers = []
-            for b in range(n):   # one controller object per instance, built outside the timed region
-                Pb = copy.copy(P)
-                Pb.way_p = way[b]
-                solvers.append(Oracle(Pb))
-
-            def cpu_solve(b):
-                solvers[b].solve(0.0, x0[b], xs0[b], us0[b])   # ctypes call: the GIL is released while it runs
-
-            # (i) one thread
-            tc = time.perf_counter()
-            n1 = 0
-            while n1 < min(64, B) and time.perf_counter() - tc < 8.0:
-                cpu_solve(n1)
-                n1 += 1
-            dt1 = time.perf_counter() - tc
-            # (ii) every host core, instances in parallel (what the reference's sequential loop would become with
-            # one controller per core, planning_sim_loop.py:613-655)
-            cores = os.cpu_count() or 1
-            tc = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                list(ex.map(cpu_solve, range(n)))
-            dt_cpu = time.perf_counter() - tc
-            out["cpu_baseline"] = {
-                "value": n / dt_cpu,
-                "unit": "solves/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": f"first {n} instances of the same batch, same cold start, oracle/upright_oracle.cpp (dense-stage Riccati IPM, -O2), "
-                          f"one instance per thread on {cores} threads; reference solver (OCS2 fork + HPIPM) is not available, see BASELINE.md",
-                "single_thread_value": n1 / dt1,
-                "single_thread_ms_per_solve": 1e3 * dt1 / n1,
-            }
+        if world == 1 and not args.no_extra:
+            mpc.close()
+            out["extra_workloads"] = [time_extra(config3_workload(4096), args.extra_steps, 1),
+                                      time_extra(config4_workload(1024), args.extra_steps, 1)]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

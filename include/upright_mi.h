@@ -108,9 +108,18 @@ typedef struct upr_problem {
     /* soft constraints: ocs2 hpipm_interface SlackSettings (upright_control/src/pybindings.cpp:160-181; values
      * upright_control/src/upright_control/wrappers.py:121-143).  A softened row c(z) >= 0 becomes c(z) + sigma >= 0,
      * sigma >= 0, with cost 1/2 Z sigma^2 + z sigma (Z: L2, z: L1 penalty; "lower" for lower bounds and polytopic
-     * rows, "upper" for upper bounds).  Soft problems run the generic QP kernel. */
+     * rows, "upper" for upper bounds). */
     int soft_state_box, soft_input_box, soft_poly;
     double soft_L2_lower, soft_L2_upper, soft_L1_lower, soft_L1_upper;
+    /* soft_eq: the object-dynamics equality is softened as well.  ocs2's HPIPM interface hands state-input equalities to
+     * HPIPM as general (polytopic) constraints with lg = ug, so `slacks.poly_ineq` puts a slack pair on every such row:
+     * lg - sl <= C dx + D du + e <= ug + su.  With equal L2 penalties Z and no L1 penalty (the reference's defaults,
+     * wrappers.py:121-143) eliminating the pair leaves the quadratic penalty Z/2 |C dx + D du + e|^2, i.e. the
+     * regularised equality C dx + D du + e = nu / Z -- the Schur complement S = Df Hff^-1 Df' + I / Z.  This is what
+     * makes the frictionless multi-body problems of upright_robust (config/demos/_base.yaml:62-75) solvable at all:
+     * with hard rows they admit no motion ("config 4").  Requires soft_L2_lower == soft_L2_upper > 0 and zero
+     * L1 penalties. */
+    int soft_eq;
 } upr_problem;
 
 const char* upr_last_error(void);
@@ -156,6 +165,12 @@ int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us);
 /* ControllerInterface.advanceMpc (pybindings.cpp:375): one MPC solve = `sqp_iters` SQP iterations
  * (linearise -> QP -> filter line search) for every instance, all on the GPU. */
 int upr_batch_advance(upr_batch* h);
+
+/* SQP iterations of the NEXT advance only (afterwards `sqp_iters` of the problem again): ocs2's solver runs
+ * sqp.init_sqp_iteration iterations while it has no previous solution -- the first solve after construction or reset, and
+ * every solve with mpc.cold_start (upright_control/src/pybindings.cpp:148,194-195; controller.yaml:15,56-57;
+ * upright_robust/config/demos/_base.yaml:64-65 sets 3).  n = 0 cancels. */
+int upr_batch_set_sqp_iterations(upr_batch* h, int n);
 
 /* Same, but inputs stay in HBM and no host synchronisation is done (used by bench.py so that the
  * timed region contains only device work); upr_batch_sync waits for completion. */
@@ -217,6 +232,13 @@ int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu);
  * search: dxs[B][N+1][nx], dus[B][N][nu].  For QP-level parity tests. */
 int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus);
 
+/* The same QP with the multipliers it ended with, for an independent check of the optimality conditions
+ * (tests/kkt_check.py assembles the QP in numpy from upr_batch_get_lin and the problem constants): pi[B][N+1][nx]
+ * costates of the dynamics (pi_0 unused), nu[B][N][ne] multipliers of the object-dynamics rows, yN[B][3 + 2 nq] of the
+ * terminal equality, lam[B][N+1][ni] of the inequality rows with ni = 2 nx + 2 nu + np + no in the slot order
+ * [x lower][x upper][u lower][u upper][friction rows][collision / projectile rows]; *ni_out = ni.  Pointers may be NULL. */
+int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double* nu, double* yN, double* lam, int* ni_out);
+
 /* raw device pointers for zero-copy consumers (torch / RCCL all-gather of solved trajectories):
  * xs (B*(N+1)*nx doubles) and us (B*N*nu doubles) */
 int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us);
@@ -225,6 +247,8 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us);
  * engine's stream: out[0] = linearise, out[1] = QP, out[2] = line search; launches[3] = #launches */
 int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches);
 int upr_batch_enable_timing(upr_batch* h, int on);
+/* name of the QP kernel instantiation this handle launches (as rocprofv3 prints it): bench.py's roofline.kernel */
+const char* upr_batch_qp_kernel_name(const upr_batch* h);
 
 /* copy the current solution into caller-owned DEVICE buffers (torch tensors handed to the RCCL
  * all-gather of solved trajectories): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the

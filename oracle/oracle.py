@@ -33,6 +33,7 @@ class OrcProblem(C.Structure):
         ("proj_scale", d), ("proj_s", d),
         ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
         ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
+        ("soft_eq", C.c_int),
     ]
 
 
@@ -113,6 +114,7 @@ def to_orc(P):
     o.soft_state_box, o.soft_input_box, o.soft_poly = int(bool(sl.get("state_box"))), int(bool(sl.get("input_box"))), int(bool(sl.get("poly_ineq")))
     o.soft_L2_lower, o.soft_L2_upper = float(sl.get("lower_L2_penalty", 100.0)), float(sl.get("upper_L2_penalty", 100.0))
     o.soft_L1_lower, o.soft_L1_upper = float(sl.get("lower_L1_penalty", 0.0)), float(sl.get("upper_L1_penalty", 0.0))
+    o.soft_eq = int(bool(sl.get("equality", sl.get("poly_ineq"))))
     return o
 
 
@@ -210,6 +212,19 @@ class Oracle:
         dxs = np.zeros((P.N + 1, self.nx)); dus = np.zeros((P.N, self.nu)); K = np.zeros((P.N, self.nu, self.nx)); st = OrcStats()
         rc = self.L.orc_qp_feedback(C.byref(self.o), d(t0), _p(_c(x0)), _p(_c(xs)), _p(_c(us)), _p(dxs), _p(dus), _p(K), C.byref(st))
         return dxs, dus, K, st, rc
+
+    def solve_batch(self, t0, x0, xs, us, way_p=None, body_params=None, nthreads=0):
+        """n independent solves, OpenMP over instances inside the library.  Returns (xs, us, stats list, threads used)."""
+        x0 = _c(x0); n = x0.shape[0]
+        xs = _c(xs).copy(); us = _c(us).copy()
+        t0 = _c(np.broadcast_to(np.asarray(t0, dtype=np.float64), (n,)))
+        st = (OrcStats * n)()
+        wp = _c(way_p) if way_p is not None else None
+        bp = _c(body_params) if body_params is not None else None
+        self.L.orc_solve_batch.restype = C.c_int
+        used = self.L.orc_solve_batch(C.byref(self.o), C.c_int(n), _p(wp) if wp is not None else None, _p(bp) if bp is not None else None,
+                                      _p(t0), _p(x0), _p(xs), _p(us), st, C.c_int(int(nthreads)))
+        return xs, us, list(st), used
 
     def solve(self, t0, x0, xs, us):
         xs = _c(xs).copy(); us = _c(us).copy(); st = OrcStats()

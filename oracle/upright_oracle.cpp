@@ -13,6 +13,9 @@
 //   SQP / QP / FK        [UPSTREAM, absent] ocs2_sqp MultipleShootingSolver, HPIPM, Pinocchio:
 //                        restated from their published algorithms ("parity unpinned").
 #include "upright_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -409,7 +412,7 @@ struct QP {
     int N, nx, nu, ne, np, neN, nfc, no = 0;
     // soft constraints (ocs2 hpipm_interface SlackSettings, upright_control/src/pybindings.cpp:160-181; defaults of
     // wrappers.py:121-143): which row classes get a slack sigma >= 0 with cost 1/2 Z sigma^2 + z sigma
-    bool soft_x = false, soft_u = false, soft_poly = false;
+    bool soft_x = false, soft_u = false, soft_poly = false, soft_eq = false;
     double ZL = 100, ZU = 100, zL = 0, zU = 0;
     vec A, B;
     std::vector<StageQP> st;  // N stages
@@ -663,8 +666,11 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
         for (size_t i = 0; i < t[k].size(); ++i) if (is_soft(k, (int)i)) { sig[k][i] = 0.0; tau[k][i] = thr; gam[k][i] = mu0 / thr; }
 
     // forces are the tail of u: the force block spans the equality rows iff nu - nq >= ne
-    const double rho_prox = (qp.nfc < ne) ? 1e-6 : 0.0;
-    Riccati ric; ric.qp = &qp; ric.rho_s = (qp.nfc < ne) ? 1e-6 : 1e-12; ric.rhoN = 1e-6;
+    // softened stage equality (soft_eq): the row's slack pair with equal L2 penalties Z and no L1 term eliminates to the
+    // penalty Z/2 |C dz + e|^2 = the regularised equality C dz + e = nu / Z: rho_s = 1 / Z, no proximal carry-over
+    const double rho_soft = qp.soft_eq ? 1.0 / qp.ZL : 0.0;
+    const double rho_prox = qp.soft_eq ? 0.0 : ((qp.nfc < ne) ? 1e-6 : 0.0);
+    Riccati ric; ric.qp = &qp; ric.rho_s = qp.soft_eq ? rho_soft : ((qp.nfc < ne) ? 1e-6 : 1e-12); ric.rhoN = 1e-6;
     std::vector<vec> Hxx_add(N + 1, vec(nx, 0.0)), Huu_add(N, vec((size_t)nu * nu, 0.0)), Hxx_dense(no > 0 ? N + 1 : 0);
     std::vector<vec> gx(N + 1, vec(nx)), gu(N, vec(nu)), bres(N, vec(nx)), eres(N, vec(ne));
     std::vector<vec> rp(N + 1), rc(N + 1);
@@ -695,7 +701,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
                 double v = s.e[r];
                 for (int j = 0; j < nx; ++j) v += s.Ce[r * nx + j] * dx[k][j];
                 for (int j = 0; j < nu; ++j) v += s.De[r * nu + j] * du[k][j];
-                eres[k][r] = v; r_eq = std::max(r_eq, std::fabs(v));
+                eres[k][r] = v; r_eq = std::max(r_eq, std::fabs(v - rho_soft * nu_[k][r]));
             }
         }
         for (int r = 0; r < neN; ++r) {
@@ -916,7 +922,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
 void build_qp(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us, QP& qp) {
     const int nx = orc_nx(P), nu = orc_nu(P), N = P->N, ne = 6 * P->nb, np = (P->nf == 3 ? 5 * P->nc : 0);
     qp.N = N; qp.nx = nx; qp.nu = nu; qp.ne = ne; qp.np = np; qp.nfc = nu - P->nq; qp.no = P->n_pairs + P->n_proj;
-    qp.soft_x = P->soft_state_box != 0; qp.soft_u = P->soft_input_box != 0; qp.soft_poly = P->soft_poly != 0;
+    qp.soft_x = P->soft_state_box != 0; qp.soft_u = P->soft_input_box != 0; qp.soft_poly = P->soft_poly != 0; qp.soft_eq = P->soft_eq != 0;
     qp.ZL = P->soft_L2_lower; qp.ZU = P->soft_L2_upper; qp.zL = P->soft_L1_lower; qp.zU = P->soft_L1_upper;
     Dyn dyn{P->nq, nx, nu, P->dt};
     dyn.dense(qp.A, qp.B);
@@ -1199,6 +1205,34 @@ int orc_solve(const orc_problem* P, double t0, const double* x0, double* xs, dou
     }
     if (stats) *stats = st;
     return st.qp_status_last;
+}
+
+// n independent solves of one problem family, OpenMP over instances (the all-core CPU baseline --
+// what the reference's sequential sweep, planning_sim_loop.py:613-655, becomes with one controller per core).
+// Per instance: way_p[n][n_way][3] targets and body_params[n][nb][10] (either may be NULL = the family's), t0[n],
+// x0[n][nx]; xs[n][(N+1) nx] / us[n][N nu] hold the guesses on entry and the solutions on exit.  Every thread works on
+// its own copy of the problem; nthreads <= 0 = all the OpenMP runtime offers.  Returns the number of threads used.
+int orc_solve_batch(const orc_problem* P, int n, const double* way_p, const double* body_params, const double* t0,
+                    const double* x0, double* xs, double* us, orc_stats* stats, int nthreads) {
+    const int nx = orc_nx(P), nu = orc_nu(P), N = P->N;
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    used = nthreads;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        orc_problem Q = *P;   // thread-private family
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < n; ++b) {
+            if (way_p) std::memcpy(Q.way_p, way_p + (size_t)b * P->n_way * 3, sizeof(double) * P->n_way * 3);
+            if (body_params) std::memcpy(Q.body_params, body_params + (size_t)b * P->nb * 10, sizeof(double) * P->nb * 10);
+            orc_solve(&Q, t0[b], x0 + (size_t)b * nx, xs + (size_t)b * (N + 1) * nx, us + (size_t)b * N * nu, stats ? stats + b : nullptr);
+        }
+    }
+    return used;
 }
 
 }  // extern "C"

@@ -115,6 +115,11 @@ typedef struct {
      * upright_control/src/upright_control/wrappers.py:121-143: L2 100, L1 0, slack lower bound 0) */
     int soft_state_box, soft_input_box, soft_poly;
     double soft_L2_lower, soft_L2_upper, soft_L1_lower, soft_L1_upper;
+    /* the object-dynamics equality softened too: ocs2's HPIPM interface enters state-input equalities as general
+     * constraints with lg = ug, which `slacks.poly_ineq` covers.  Equal L2 penalties Z, no L1 penalty (the reference's
+     * defaults): the slack pair of a row eliminates to the quadratic penalty Z/2 |C dx + D du + e|^2, solved here as
+     * the regularised equality C dx + D du + e = nu / Z. */
+    int soft_eq;
 } orc_problem;
 
 int orc_nx(const orc_problem* P);
@@ -168,6 +173,11 @@ typedef struct {
  * us[N*nu] hold the initial guess on entry and the solution on exit. */
 int orc_solve(const orc_problem* P, double t0, const double* x0, double* xs, double* us,
               orc_stats* stats);
+
+/* n independent solves of one family with OpenMP over the instances (the all-core CPU baseline of bench.py).  way_p
+ * [n][n_way][3] and body_params[n][nb][10] may be NULL (= the family's); nthreads <= 0: all.  Returns threads used. */
+int orc_solve_batch(const orc_problem* P, int n, const double* way_p, const double* body_params, const double* t0,
+                    const double* x0, double* xs, double* us, orc_stats* stats, int nthreads);
 
 /* Build the QP of one SQP iteration at (xs, us) and solve it; dxs/dus get the step.
  * Exposed for QP-level parity tests. */

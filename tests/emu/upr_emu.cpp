@@ -47,6 +47,12 @@ void emu_dims(const upr_problem* P, int* out) {
     out[13] = d.nfc;
 }
 
+// where the generic kernel leaves its multipliers in the instance workspace (tests/kkt_check.py)
+void emu_kkt_offsets(const upr_problem* P, int* out) {
+    upr_dims d = upr_make_dims(P);
+    out[0] = d.ws_pi; out[1] = d.ws_nu; out[2] = d.ws_yN; out[3] = d.ws_lam; out[4] = d.ni_stage; out[5] = d.neN; out[6] = d.lin_obs; out[7] = d.no;
+}
+
 void emu_make_Df(const upr_problem* P, int B, const double* body_params, double* Df) {
     upr_dims d = upr_make_dims(P);
     std::vector<double> unit(d.nfc), Fw(6 * d.nb);

@@ -262,9 +262,21 @@ def main():
         "thing_demo": "upright_cmd/config/demos/thing_demo.yaml",
         "full_bottle_point1": "upright_cmd/config/ral23/experiments/freespace/full/full_bottle_point1.yaml",
         "full_arch_point3": "upright_cmd/config/ral23/experiments/freespace/full/full_arch_point3.yaml",
+        # BASELINE config 3: three stacked objects + the static obstacles of obstacles/simple.yaml
+        "static_arch_point3": "upright_cmd/config/ral23/experiments/static_obstacles/full/full_arch_point3.yaml",
+        # BASELINE config 5: dynamic obstacle (obstacles/dynamic.yaml) + projectile-path constraint
+        "projectile_head_on": "upright_cmd/config/ral23/experiments/projectile/projectile_head_on.yaml",
+        # BASELINE config 4: the upright_robust planning demo (slacks, init_sqp_iteration 3, T = 10 s); its arrangement
+        # is assembled at run time by planning_sim_loop.py:454-534 (robust_8corner above carries the same values)
+        "robust_sim": "upright_robust/config/demos/sim.yaml",
     }.items():
         d = core.parsing.load_config((REF / rel).as_posix())
         c = d["controller"]
+        if key == "robust_sim":   # what planning_sim_loop.py:513-534 writes into the config before parsing it
+            c["objects"].update({n: rcfg["objects"][n] for n in names})
+            c["arrangements"]["robust"] = rcfg["arrangements"]["robust_8corner"]
+            c["balancing"]["arrangement"] = "robust"
+            c["waypoints"] = [{"time": 0, "position": [-2.0, 1.0, 0], "orientation": [0, 0, 0, 1]}]
         # keep what the ControllerSettings mirror reads; drop the (large) unrelated object tables
         keep = {
             k: c[k]

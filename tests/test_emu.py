@@ -285,7 +285,7 @@ def test_soft_rows_kernel_source(arrangements):
     one whose first knot is infeasible (base acceleration beyond what the friction cone balances) where the hard QP
     ends at its iteration cap."""
     B = 2
-    soft = dict(state_box=True, input_box=True, poly_ineq=True, lower_L2_penalty=100.0, upper_L2_penalty=50.0, lower_L1_penalty=0.0, upper_L1_penalty=0.5)
+    soft = dict(state_box=True, input_box=True, poly_ineq=True, equality=False, lower_L2_penalty=100.0, upper_L2_penalty=50.0, lower_L1_penalty=0.0, upper_L1_penalty=0.5)
     P, x0, way, xs, us = _case(arrangements, B, 11, qp_tol=0.0, qp_iter_max=6)
     x0[1, 18] = 5.0
     xs[1, :, 18] = 5.0
@@ -311,7 +311,7 @@ def test_soft_rows_kernel_source(arrangements):
         assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
         assert np.abs(du[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max())
     # only the polytopic rows softened: boxes stay hard (instance 1 then violates its acceleration box: not compared)
-    P.slacks = dict(poly_ineq=True)
+    P.slacks = dict(poly_ineq=True, equality=False)
     e = Emu(P, B)
     dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
     for b in range(1):
@@ -319,3 +319,59 @@ def test_soft_rows_kernel_source(arrangements):
         dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
         assert stats[b, 2] == 0 and rc == 0
         assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
+
+
+def _emu_kkt(e, ws, b):
+    """Multipliers the generic kernel left in the instance workspace, in the layout of BatchMPC.qp_kkt()."""
+    o = (C.c_int * 8)()
+    e.E.emu_kkt_offsets(C.byref(e.cp), o)
+    ws_pi, ws_nu, ws_yN, ws_lam, ni, neN = list(o)[:6]
+    n1, N = e.P.N + 1, e.P.N
+    w = ws[b]
+    lam = w[ws_lam:ws_lam + n1 * ni].reshape(n1, ni).copy()
+    lam[0, :2 * e.nx] = 0.0                       # slots that are not rows of the stage
+    lam[N, 2 * e.nx:] = 0.0
+    if ni > 2 * e.nx + 2 * e.nu + e.np_:
+        lam[0, 2 * e.nx + 2 * e.nu + e.np_:] = 0.0
+    return dict(pi=w[ws_pi:ws_pi + n1 * e.nx].reshape(n1, e.nx), nu=w[ws_nu:ws_nu + N * e.ne].reshape(N, e.ne),
+                yN=w[ws_yN:ws_yN + neN], lam=lam)
+
+
+def test_kkt_conditions_checked_in_numpy(arrangements):
+    """Optimality of the QP kernel's primal-dual point verified WITHOUT the oracle: tests/kkt_check.py assembles the
+    sub-problem in numpy from the linearisation records and the problem constants and evaluates stationarity,
+    feasibility and complementarity at what the kernel returned (N = 20, headline shape; then the softened 8-body
+    problem of BASELINE config 4).  The same check runs on the GPU kernels in tests/test_gpu_parity.py."""
+    from kkt_check import force_jacobian, kkt_residuals
+
+    B = 2
+    P, x0, way, xs, us = _case(arrangements, B, 5, qp_tol=1e-9, qp_iter_max=40)
+    e = Emu(P, B)
+    assert np.abs(force_jacobian(P, P.body_params) - e.Df[0]).max() < 1e-15
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    assert np.all(stats[:, 2] == 0)
+    for b in range(B):
+        sol = dict(dx=dx[b], du=du[b], **_emu_kkt(e, ws, b))
+        res = kkt_residuals(P, P.body_params, x0[b], xs[b], us[b], lin[b], sol)
+        assert res.max() < 1e-7, res
+        # the check has teeth: a perturbed primal point or multiplier is not a KKT point
+        bad = dict(sol); bad["du"] = du[b].copy(); bad["du"][3, 2] += 1e-3
+        assert kkt_residuals(P, P.body_params, x0[b], xs[b], us[b], lin[b], bad).max() > 1e-6
+        bad = dict(sol); bad["lam"] = sol["lam"].copy(); bad["lam"][5, 2 * P.nx + 1] += 1e-3
+        assert kkt_residuals(P, P.body_params, x0[b], xs[b], us[b], lin[b], bad).max() > 1e-6
+    # BASELINE config 4: eight bodies, frictionless, HPIPM slacks on the state boxes and the (equality) general rows
+    from upright_amd.problem import THING_HOME
+
+    P = thing_problem(arrangements["robust_8corner"], nf=1, force_weight=0.0, qp_tol=1e-9, qp_iter_max=40)
+    P.slacks = dict(state_box=True, input_box=False, poly_ineq=True)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (1, 1))
+    way = waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0))
+    xs, us = stationary_guess(x0, P.N, P.nu); xs = np.ascontiguousarray(xs); us = np.ascontiguousarray(us)
+    e = Emu(P, 1)
+    lin = e.linearize(way, np.zeros(1), xs, us)
+    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
+    assert stats[0, 2] == 0
+    sol = dict(dx=dx[0], du=du[0], **_emu_kkt(e, ws, 0))
+    res = kkt_residuals(P, P.body_params, x0[0], xs[0], us[0], lin[0], sol)
+    assert res.max() < 1e-7, res

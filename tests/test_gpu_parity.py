@@ -449,7 +449,8 @@ def _level_tool(chain, q_home):
     ("ur10_demo", {}, True),                                       # BASELINE configs[0]: fixed-base UR10, frictionless (nx 18, nu 10)
     ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, True),    # configs 2': Thing, frictionless (nx 27, nu 13), hard rows
     ("thing_demo", {}, True),                                      # as configured: HPIPM slacks on every inequality class (thing_demo.yaml)
-    ("thing_demo", {}, False),                                     # ... and the tray 1 degree off level: infeasible first knot (an EQUALITY: slacks do not help)
+    ("thing_demo", {}, False),                                     # ... and the tray 1 degree off level, as shipped: the general rows' slacks absorb the infeasible first knot
+    ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, False),   # hard rows, tray off level: infeasible first knot
     ("full_bottle_point1", {}, False),                             # headline H through the manager
 ])
 def test_reference_call_sequence_other_configs(arrangements, name, override, level):
@@ -469,11 +470,13 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
     assert xs.shape == (P.N + 1, P.nx) and us.shape == (P.N + 1, P.nu) and np.allclose(ts, P.dt * np.arange(P.N + 1))
     xs0, us0 = stationary_guess(x0[None], P.N, P.nu)
     assert (P.slacks is not None) == (name == "thing_demo" and not override)
+    if P.slacks is not None:
+        assert P.slacks["poly_ineq"]    # thing_demo.yaml: the general constraints (= the object-dynamics rows, nf = 1) carry slacks
     xo, uo, so, rc = Oracle(P).solve(0.0, x0, xs0[0], us0[0])
     st = m.mpc._mpc.stats()
-    if P.nf == 1 and not level:
-        # the violated rows are equalities, which HPIPM's slacks do not soften: both solvers stop at the iteration cap
-        # (as HPIPM does in the reference), the plans agree to the accuracy an unconverged QP allows and stay usable
+    if P.nf == 1 and not level and P.slacks is None:
+        # hard object-dynamics rows that the fixed first knot violates: both solvers stop at the iteration cap (as HPIPM
+        # does in the reference), the plans agree to the accuracy an unconverged QP allows and stay usable
         assert so.qp_status_last == 1 and st["qp_status_last"][0] == 1
         assert np.abs(xs - xo).max() < 1e-3 and np.all(np.isfinite(us))
     else:
@@ -858,3 +861,289 @@ def test_closed_loop_thrown_ball(arrangements):
             assert not failed.any()
     # the constraint keeps the link 0.35 m from the PATH; one real-time iteration per tick holds the ball itself at >= 0.3 m
     assert closest[1.0].min() > 0.30 and closest[0.0].max() < 0.25
+
+
+# ---- round 2 -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["3", "2", "1"])
+def test_kkt_conditions_of_gpu_solution_checked_in_numpy(arrangements, kernel, monkeypatch):
+    """the primal-dual point every QP kernel returns on the GPU satisfies the optimality conditions of
+    the sub-problem as assembled INDEPENDENTLY in numpy (tests/kkt_check.py: linearisation records + problem constants;
+    no oracle code, no kernel-side residuals) -- stationarity, feasibility, dual feasibility, complementarity <= 1e-7
+    at N = 20 for the headline shape."""
+    from kkt_check import kkt_residuals
+
+    monkeypatch.setenv("UPR_QP_KERNEL", kernel)
+    B = 6
+    P, x0, way = _setup(arrangements, B, seed=21, qp_tol=1e-9, qp_iter_max=40)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    sol = mpc.qp_kkt()
+    lin = mpc.lin_records()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] == 0)
+    for b in range(B):
+        res = kkt_residuals(P, P.body_params, x0[b], xs0[b], us0[b], lin[b], {k: v[b] for k, v in sol.items()})
+        assert res.max() < 1e-7, (b, res)
+    mpc.close()
+
+
+def test_kkt_conditions_config3_shape(arrangements):
+    """The same independent check on the BASELINE config 3 shape: box_arch (3 coupled bodies, 16 contacts, 80 friction
+    rows) with 20 collision rows per knot, at a feasible linearisation point."""
+    from kkt_check import kkt_residuals
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME
+
+    B = 2
+    P = thing_problem(arrangements["box_arch"], qp_tol=1e-9, qp_iter_max=60)
+    for k, v in robots.collision_model(P.chain, robots.SIMPLE_COLLISION_PAIRS).items():
+        setattr(P, k, v)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] = [0.3, 0.25]
+    way = waypoints_for(P, x0, offset=(-0.3, 0.3, 0.0))    # a target in front of the obstacle rows: the first QP is feasible
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    sol = mpc.qp_kkt()
+    lin = mpc.lin_records()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] == 0), st["qp_status_last"]
+    for b in range(B):
+        res = kkt_residuals(P, P.body_params, x0[b], xs0[b], us0[b], lin[b], {k: v[b] for k, v in sol.items()})
+        assert res.max() < 1e-7, (b, res)
+    mpc.close()
+
+
+def _robust_problem(arrangements, B, seed=2, **kw):
+    """BASELINE config 4 as the reference runs it (upright_robust/config/demos/_base.yaml:59-86; planning_sim_loop.py:
+    454-559): 8-corner arrangement, frictionless, force_weight 0, HPIPM slacks on the state boxes and the general
+    constraints (= the object-dynamics rows), init_sqp_iteration 3, waypoint [-2, 1, 0]; per-instance inertial
+    parameters: CoM uniform in the CoM box, inertia scaled by {1, 0.5, 0.1}."""
+    from upright_amd.problem import THING_HOME
+
+    P = thing_problem(arrangements["robust_8corner"], nf=1, force_weight=0.0, **kw)
+    P.slacks = dict(state_box=True, input_box=False, poly_ineq=True)
+    rng = np.random.default_rng(seed)
+    bp = np.zeros((B, P.nb, 10))
+    for b in range(B):
+        sc = (1.0, 0.5, 0.1)[b % 3]
+        for i in range(P.nb):
+            com = rng.uniform([-0.06, -0.06, -0.15], [0.06, 0.06, 0.15])
+            bp[b, i] = [1.0, *com, sc * 0.009375, 0, 0, sc * 0.009375, 0, sc * 0.00375]
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, :2] += rng.uniform(-0.25, 0.25, (B, 2))
+    return P, bp, x0, waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0))
+
+
+def test_config4_robust_mpc_solve_against_oracle(arrangements):
+    """BASELINE config 4 as a SOLVE: the first plan of the upright_robust controller (init_sqp_iteration = 3 SQP iterations
+    from the stationary guess, through upr_batch_set_sqp_iterations) for 8 instances with different inertial parameter
+    vectors, against the oracle run with each instance's parameters: trajectories to 1e-4 on state / input norms, every
+    QP converged.  With HARD object-dynamics rows the same problem admits no motion at all (eight CoMs, frictionless
+    contacts: omega = alpha = 0 and no horizontal acceleration): shown here by the oracle's status."""
+    import copy
+
+    B = 8
+    P, bp, x0, way = _robust_problem(arrangements, B)
+    mpc = BatchMPC(P, B, body_params=bp, way_p=way)
+    mpc.set_sqp_iterations(3)
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    assert np.all(st["sqp_iters_done"] == 3) and np.all(st["qp_status_last"] == 0)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b in range(B):
+        Pb = copy.copy(P); Pb.body_params = bp[b]; Pb.way_p = way[b]; Pb.sqp_iters = 3
+        xo, uo, so, rc = Oracle(Pb).solve(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and so.sqp_iters_done == 3
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4 and np.abs(xs[b] - xo).max() < 1e-4
+        gu = mpc.eq_input_jacobian(b)
+        # force_weight = 0: the split of a body's load between its four contact points is fixed by the barrier alone;
+        # what the problem determines is the jerk and the wrench on every body
+        assert np.abs(us[b][:, :9] - uo[:, :9]).max() < 1e-4 * max(1.0, np.abs(uo[:, :9]).max())
+        assert np.abs((us[b] - uo) @ gu.T).max() < 1e-4
+        assert abs(np.linalg.norm(us[b][:, :9]) - np.linalg.norm(uo[:, :9])) < 1e-4
+        p_end = Oracle(Pb).ee_kinematics(xs[b, P.N])[:3]
+        assert np.linalg.norm(p_end - way[b, 0]) < 0.5 * np.linalg.norm([2.0, 1.0])     # the plan moves towards the target
+    mpc.close()
+    # hard rows: no feasible motion -- the QP cannot close the equality (oracle: iteration cap, residual far from 0)
+    Ph = copy.copy(P); Ph.slacks = None; Ph.body_params = bp[0]; Ph.way_p = way[0]
+    _, _, sh, _ = Oracle(Ph).solve(0.0, x0[0], xs0[0], us0[0])
+    assert sh.qp_status_last == 1 and sh.qp_res[1] > 1e-3
+
+
+def test_config4_full_size_properties(arrangements):
+    """BASELINE config 4 at the per-GPU size (1024 scenarios): every QP converges, the accepted plans close the
+    multiple-shooting defects, respect the (hard) input boxes, and a second run is bit-identical."""
+    B = 1024
+    P, bp, x0, way = _robust_problem(arrangements, B)
+    runs = []
+    for _ in range(2):
+        mpc = BatchMPC(P, B, body_params=bp, way_p=way)
+        mpc.set_sqp_iterations(3)
+        mpc.set_observation(0.0, x0)
+        mpc.advance()
+        _, xs, us = mpc.solution()
+        st = mpc.stats()
+        runs.append((xs, us))
+        mpc.close()
+    assert np.all(st["qp_status_last"] == 0) and np.all(st["sqp_iters_done"] == 3)
+    for key in ("qp_res_stat", "qp_res_eq", "qp_res_ineq", "qp_res_comp"):
+        assert np.all(st[key] < P.qp_tol)
+    xs, us = runs[0]
+    h = P.dt
+    q, v, a, j = xs[:, :-1, :9], xs[:, :-1, 9:18], xs[:, :-1, 18:], us[:, :, :9]
+    pred = np.concatenate([q + h * v + 0.5 * h * h * a + h ** 3 / 6 * j, v + h * a + 0.5 * h * h * j, a + h * j], axis=2)
+    full = st["step_alpha_last"] == 1.0
+    assert full.mean() > 0.5 and np.abs(pred - xs[:, 1:])[full].max() < 1e-7
+    assert np.all(us >= P.u_lb - 1e-6) and np.all(us <= P.u_ub + 1e-6)       # input boxes are hard (slacks.input_box false)
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_two_waypoint_target_interpolation(arrangements):
+    """reference_trajectory.h:38-40 on the device: between two waypoints the target is alpha lhs + (1 - alpha) rhs with
+    alpha = (t_rhs - t) / (t_rhs - t_lhs).  The end-effector cost of the kernel at times inside, at and outside the
+    waypoint interval against the oracle, and a solve towards the moving target against the oracle."""
+    B = 2
+    P, x0, _ = _setup(arrangements, B, seed=4)
+    P.way_t = np.array([0.5, 1.5])
+    p0 = np.stack([P.chain.forward(x[:9])[0] for x in x0])
+    way = np.stack([p0 + [0.2, 0.0, 0.05], p0 + [-0.4, 0.5, 0.0]], axis=1)        # (B, 2, 3)
+    P.way_p = way[0]
+    mpc = BatchMPC(P, B, way_p=way)
+    ts = np.array([0.0, 0.5, 0.75, 1.0, 1.5, 1.9])
+    for b in range(B):
+        P.way_p = way[b]
+        O = Oracle(P)
+        out = mpc.linearize_points(np.tile(x0[b], (len(ts), 1)), np.zeros((len(ts), P.nu)), ts, inst=np.full(len(ts), b))
+        for i, t in enumerate(ts):
+            a = np.clip((1.5 - t) / 1.0, 0.0, 1.0)
+            target = a * way[b, 0] + (1 - a) * way[b, 1]
+            assert abs(out["cost"][i] - 0.5 * np.sum((out["ee"][i] - target) ** 2)) < 1e-12
+            c = O.stage_cost(t, x0[b], np.zeros(P.nu), derivs=False) - 0.5 * np.sum(P.Qdiag * (x0[b] - P.xd) ** 2)
+            assert abs(out["cost"][i] - c) < 1e-12
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
+        assert rc == 0 and np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+    mpc.close()
+
+
+def test_controller_interface_surface(arrangements):
+    """Every method pybindings.cpp:364-427 binds exists here: served from the engine (linear approximations, cost
+    models, the linear controller) or an explicit RuntimeError for solver internals; init_sqp_iteration and
+    mpc.cold_start are honoured."""
+    from upright_amd import control_bindings as bindings
+
+    m = _manager_from_golden("full_bottle_point1", arrangements, **{"sqp.init_sqp_iteration": 3})
+    P = m.mpc.problem
+    x0 = np.array(m.settings.initial_state)
+    m.warmstart()
+    st = m.mpc._mpc.stats()
+    assert st["sqp_iters_done"][0] == 3                       # first solve: init_sqp_iteration
+    m.step(0.02, x0)
+    assert m.mpc._mpc.stats()["sqp_iters_done"][0] == 1       # later solves: sqp_iteration
+    mpc = m.mpc
+    u = np.zeros(P.nu); u[9:] = 0.3
+    lin = mpc.stateInputEqualityConstraintLinearApproximation(0.0, x0, u)
+    g, gx, gu = Oracle(P).eq_constraint(x0, u)
+    assert np.abs(lin.f - g).max() < 1e-11 and np.abs(lin.dfdx - gx).max() < 1e-10 and np.abs(lin.dfdu - gu).max() < 1e-13
+    assert np.array_equal(mpc.flowMap(0.0, x0, u), np.concatenate([x0[9:], u[:9]]))
+    fl = mpc.flowMapLinearApproximation(0.0, x0, u)
+    assert np.allclose(fl.dfdx @ x0 + fl.dfdu @ u, fl.f)
+    qa = mpc.costQuadraticApproximation(0.0, x0, u)
+    c, gxo, guo, Hx, Ru = Oracle(P).stage_cost(0.0, x0, u)
+    assert abs(qa.f - c) < 1e-12 and np.abs(qa.dfdx - gxo).max() < 1e-11 and np.abs(qa.dfdu - guo).max() < 1e-14
+    assert np.abs(qa.dfdxx - Hx).max() < 1e-11 and abs(mpc.cost(0.0, x0, u) - c) < 1e-12
+    lc = mpc.getLinearController()
+    K = mpc.getLinearFeedbackGain(0.05)
+    assert len(lc.timeStamp) == P.N and K.shape == (P.nu, P.nx)
+    xo, uo = np.zeros(P.nx), np.zeros(P.nu)
+    mpc.evaluateMpcSolution(0.05, x0, xo, uo)
+    assert np.abs(mpc.getBias(0.05) + K @ x0 - uo).max() < 1e-9      # u = bias + K x at the observed state
+    for name, args in (("valueFunction", (0.0, x0)), ("valueFunctionStateDerivative", (0.0, x0)),
+                       ("stateInputEqualityConstraintLagrangian", (0.0, x0, u)), ("getStateInequalityConstraintValue", ("x", 0.0, x0)),
+                       ("visualizeTrajectory", ([], [], [], 1.0))):
+        with pytest.raises(RuntimeError):
+            getattr(mpc, name)(*args)
+    bound = ("getLastSolveTime getStateDim getInputDim setObservation setTargetTrajectories reset advanceMpc getMpcSolution "
+             "evaluateMpcSolution getLinearFeedbackGain getBias getLinearController flowMap flowMapLinearApproximation cost "
+             "costQuadraticApproximation valueFunction valueFunctionStateDerivative stateInputEqualityConstraint "
+             "stateInputEqualityConstraintLinearApproximation stateInputEqualityConstraintLagrangian "
+             "getStateInputEqualityConstraintValue getStateInputInequalityConstraintValue getStateInequalityConstraintValue "
+             "getCostValue visualizeTrajectory").split()
+    assert all(callable(getattr(bindings.ControllerInterface, n, None)) for n in bound)
+    # mpc.cold_start: every solve starts from the initializer's guess with init_sqp_iteration iterations
+    mc = _manager_from_golden("full_bottle_point1", arrangements, **{"sqp.init_sqp_iteration": 2, "mpc.cold_start": True})
+    mc.warmstart()
+    _, xs_a, _ = mc.get_mpc_trajectory()
+    mc.step(0.02, x0)
+    _, xs_b, _ = mc.get_mpc_trajectory()
+    assert mc.mpc._mpc.stats()["sqp_iters_done"][0] == 2 and np.array_equal(xs_a, xs_b)   # same observation, cold start: same plan
+
+
+def test_batch_controller_manager(arrangements):
+    """B controllers in lock step (BatchControllerManager) give, instance by instance, what B separate
+    ControllerManagers give: same cadence, same plans."""
+    import copy
+    import json
+    from pathlib import Path
+
+    from upright_amd import control
+
+    cfg = copy.deepcopy(json.load(open(Path(__file__).parent / "golden" / "configs.json"))["full_bottle_point1"]["controller"])
+    bodies, contacts = control.objects_from_fixture(arrangements["pink_bottle"])
+    x0s = level_tray_states(3, seed=8)
+    bm = control.BatchControllerManager.from_config(cfg, x0s, bodies=bodies, contacts=contacts)
+    bm.warmstart()
+    xb, ub = bm.step(0.012, x0s)
+    assert len(bm.schedule.times) == 1 and np.all(bm.qp_status() == 0)
+    _, xs_b, us_b = bm.get_mpc_trajectory()
+    for b in range(3):
+        m = control.ControllerManager.from_config(cfg, x0=x0s[b], bodies=bodies, contacts=contacts)
+        m.warmstart()
+        x1, u1 = m.step(0.012, x0s[b])
+        _, xs1, us1 = m.get_mpc_trajectory()
+        assert np.array_equal(xs1, xs_b[b]) and np.array_equal(us1[:-1], us_b[b])
+        assert np.array_equal(x1, xb[b]) and np.array_equal(u1, ub[b])
+
+
+def test_nccl_gather_of_real_solutions(arrangements):
+    """The RCCL branch of the exchange step on the hardware that is there (one GPU: world size 1): solved trajectories go
+    from the engine's HBM buffers through upr_batch_copy_solution_device into torch CUDA tensors and through
+    upright_amd.distributed.all_gather_solutions over the nccl backend -- the code path bench.py --gpus N runs."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from upright_amd.distributed import all_gather_solutions
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 16
+        P, x0, way = _setup(arrangements, B, seed=6)
+        mpc = BatchMPC(P, B, way_p=way)
+        mpc.set_observation(0.0, x0)
+        mpc.advance()
+        lx = torch.empty((B, P.N + 1, P.nx), dtype=torch.float64, device="cuda")
+        lu = torch.empty((B, P.N, P.nu), dtype=torch.float64, device="cuda")
+        mpc.copy_solution_device(lx.data_ptr(), lu.data_ptr())
+        mpc.sync()
+        gx, gu, counts = all_gather_solutions(lx, lu)
+        torch.cuda.synchronize()
+        _, xs, us = mpc.solution()
+        assert counts == [B] and np.array_equal(gx.cpu().numpy(), xs) and np.array_equal(gu.cpu().numpy(), us)
+        mpc.close()
+    finally:
+        dist.destroy_process_group()

@@ -45,6 +45,7 @@ class UprProblem(C.Structure):
         ("n_dyn", C.c_int), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", C.c_double * 8), ("proj_scale", C.c_double),
         ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
         ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
+        ("soft_eq", C.c_int),
     ]
 
 
@@ -101,6 +102,8 @@ def problem_to_c(P):
     o.soft_state_box, o.soft_input_box, o.soft_poly = int(bool(sl.get("state_box"))), int(bool(sl.get("input_box"))), int(bool(sl.get("poly_ineq")))
     o.soft_L2_lower, o.soft_L2_upper = float(sl.get("lower_L2_penalty", 100.0)), float(sl.get("upper_L2_penalty", 100.0))
     o.soft_L1_lower, o.soft_L1_upper = float(sl.get("lower_L1_penalty", 0.0)), float(sl.get("upper_L1_penalty", 0.0))
+    # the object-dynamics equality reaches HPIPM as a general constraint with lg = ug: `poly_ineq` softens it too
+    o.soft_eq = int(bool(sl.get("equality", sl.get("poly_ineq"))))
     return o
 
 
@@ -116,6 +119,7 @@ PROTOTYPES = [
     ("upr_batch_set_observation", C.c_int, [C.c_void_p, dp, C.c_int, dp]),
     ("upr_batch_set_guess", C.c_int, [C.c_void_p, dp, dp]),
     ("upr_batch_advance", C.c_int, [C.c_void_p]),
+    ("upr_batch_set_sqp_iterations", C.c_int, [C.c_void_p, C.c_int]),
     ("upr_batch_advance_async", C.c_int, [C.c_void_p]),
     ("upr_batch_sync", C.c_int, [C.c_void_p]),
     ("upr_batch_get_solution", C.c_int, [C.c_void_p, dp, dp, dp]),
@@ -129,9 +133,11 @@ PROTOTYPES = [
     ("upr_batch_obstacle_rows", C.c_int, [C.c_void_p, C.c_int, dp, dp, dp]),
     ("upr_batch_eq_input_jacobian", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("upr_batch_qp_step", C.c_int, [C.c_void_p, dp, dp]),
+    ("upr_batch_qp_kkt", C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, ip]),
     ("upr_batch_device_ptrs", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("upr_batch_kernel_times", C.c_int, [C.c_void_p, dp, ip]),
     ("upr_batch_enable_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("upr_batch_qp_kernel_name", C.c_char_p, [C.c_void_p]),
     ("upr_batch_copy_solution_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("upr_batch_reset_async", C.c_int, [C.c_void_p]),
     ("upr_batch_qp_profile", C.c_int, [C.c_void_p, dp]),

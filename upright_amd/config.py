@@ -1,97 +1,140 @@
-"""Configuration front-end: YAML with recursive `include:` and the number / array mini-DSL.
+"""Configuration front-end: YAML files layered through `include:` and the number / array mini-language.
 
-Own implementation of the semantics of `upright_core/src/upright_core/parsing.py:14-106` and
-docs/configuration.md:6-44 (includes are loaded first, in order; the including file overrides; `key`
-nests an include; maximum inclusion depth 5).  ROS package paths are resolved through an explicit
-{package: directory} map instead of rospkg.  Checked against the reference's own outputs in
-tests/golden/{configs,parse_dsl}.json.
+Semantics follow docs/configuration.md:6-44 of the reference and are pinned by its own outputs
+(tests/golden/{configs,parse_dsl}.json, produced by importing the reference's `load_config` / `parse_*`,
+`upright_core/src/upright_core/parsing.py:30-106`):
 
-Arrangement -> (bodies, contact points) parsing (`parsing.py:351-410`, `polyhedron.py`) is the next
-row of SURVEY.md section 8f and is not here yet: bodies / contacts are supplied by the caller or taken from
-tests/golden/arrangements.json (generated from the reference).
+* a file's `include` entries are resolved first, in list order, each to a complete layer of its own;
+  `key` nests a layer; later layers override earlier ones and the including file overrides them all;
+  mappings merge key by key, anything else is replaced; inclusion nests at most five levels deep;
+* a scalar may be written "<c>pi" (c times pi); an array is a list whose items are numbers, "<c>pi", or
+  "<v>rep<n>" (v repeated n times).
+
+ROS package names are resolved through an explicit {package: directory} registry (`register_package`)
+instead of rospkg.  The arrangement -> (bodies, contact points) step lives in `upright_amd/arrangement.py`.
 """
+import math
+import re
 from pathlib import Path
 
 import numpy as np
 import yaml
 
-PACKAGE_DIRS = {}
+MAX_INCLUDE_DEPTH = 5
+_PACKAGES = {}
+
+# "<c>pi" and "<v>rep<n>": the coefficient / value is any float literal, the count a non-negative integer
+_FLOAT = r"[+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?"
+_PI_TERM = re.compile(rf"^\s*({_FLOAT})pi\s*$")
+_REP_TERM = re.compile(rf"^\s*({_FLOAT})rep(\d+)\s*$")
 
 
 def register_package(name, directory):
-    PACKAGE_DIRS[name] = Path(directory)
+    """Tell the loader where the files of ROS package `name` live."""
+    _PACKAGES[name] = Path(directory)
 
 
-def recursive_dict_update(default, custom):
-    if not isinstance(default, dict) or not isinstance(custom, dict):
-        raise TypeError("Params of recursive_update should be dicts")
-    for key, val in custom.items():
-        if isinstance(val, dict) and isinstance(default.get(key), dict):
-            default[key] = recursive_dict_update(default[key], val)
-        else:
-            default[key] = val
-    return default
+def package_path(entry, as_string=True):
+    """{package, path} -> file path (the reference's `parse_ros_path`)."""
+    name = entry["package"]
+    if name not in _PACKAGES:
+        raise KeyError(f"package '{name}' is not registered (upright_amd.config.register_package)")
+    target = _PACKAGES[name] / entry["path"]
+    return target.as_posix() if as_string else target
 
 
-def parse_ros_path(d, as_string=True):
-    try:
-        base = PACKAGE_DIRS[d["package"]]
-    except KeyError:
-        raise KeyError(f"package '{d['package']}' is not registered (upright_amd.config.register_package)")
-    p = base / d["path"]
-    return p.as_posix() if as_string else p
+parse_ros_path = package_path   # the reference's name for it
 
 
-def load_config(path, depth=0, max_depth=5):
+def overlay(base, top):
+    """Merge mapping `top` onto mapping `base` in place and return `base`: nested mappings merge, every other
+    value of `top` replaces the one below."""
+    if not (isinstance(base, dict) and isinstance(top, dict)):
+        raise TypeError("overlay() merges two mappings")
+    pending = [(base, top)]
+    while pending:
+        lower, upper = pending.pop()
+        for key, value in upper.items():
+            below = lower.get(key)
+            if isinstance(value, dict) and isinstance(below, dict):
+                pending.append((below, value))
+            else:
+                lower[key] = value
+    return base
+
+
+recursive_dict_update = overlay   # the reference's name for it
+
+
+def _layers(path, depth, max_depth):
+    """The mappings that make up the file at `path`, lowest priority first."""
     if depth > max_depth:
         raise Exception(f"Maximum inclusion depth {max_depth} exceeded.")
-    with open(path) as f:
-        d = yaml.safe_load(f)
-    includes = d.pop("include", [])
+    with open(path) as stream:
+        own = yaml.safe_load(stream) or {}
+    stack = []
+    for entry in own.pop("include", None) or ():
+        layer = {}
+        for part in _layers(package_path(entry), depth + 1, max_depth):
+            overlay(layer, part)
+        stack.append({entry["key"]: layer} if "key" in entry else layer)
+    stack.append(own)
+    return stack
+
+
+def load_config(path, depth=0, max_depth=MAX_INCLUDE_DEPTH):
+    """Read a YAML file and fold in everything it includes."""
     merged = {}
-    for inc in includes:
-        sub = load_config(parse_ros_path(inc), depth=depth + 1, max_depth=max_depth)
-        if "key" in inc:
-            sub = {inc["key"]: sub}
-        merged = recursive_dict_update(merged, sub)
-    return recursive_dict_update(merged, d)
+    for layer in _layers(path, depth, max_depth):
+        overlay(merged, layer)
+    return merged
 
 
 def parse_number(x, dtype=float):
-    """'2pi' -> 2 * pi; anything else through dtype (parsing.py:63-71)."""
-    if type(x) == str and x.endswith("pi"):
-        return dtype(x[:-2]) * np.pi
+    """'2pi' -> 2 pi; everything else through `dtype`."""
+    if isinstance(x, str):
+        m = _PI_TERM.match(x)
+        if m:
+            return dtype(m.group(1)) * math.pi
     return dtype(x)
 
 
-def _parse_array_element(x):
+def _expand(item):
+    """One array item -> the list of floats it stands for."""
+    if not isinstance(item, str):
+        return [float(item)]
+    m = _REP_TERM.match(item)
+    if m:
+        return [float(m.group(1))] * int(m.group(2))
+    m = _PI_TERM.match(item)
+    if m:
+        return [float(m.group(1)) * math.pi]
     try:
-        return [float(x)]
+        return [float(item)]
     except ValueError:
-        if x.endswith("pi"):
-            return [float(x[:-2]) * np.pi]
-        if "rep" in x:
-            y, n = x.split("rep")
-            return float(y) * np.ones(int(n))
-        raise ValueError(f"Could not convert {x} to array element.")
+        raise ValueError(f"Could not convert {item} to array element.") from None
 
 
-def parse_array(a):
-    """['0rep3', '1', '2pi'] -> [0, 0, 0, 1, 6.283...] (parsing.py:74-91)."""
-    return np.concatenate([_parse_array_element(x) for x in a])
+def parse_array(items):
+    """['0rep3', '1', '2pi'] -> array([0, 0, 0, 1, 6.283...])."""
+    out = []
+    for item in items:
+        out.extend(_expand(item))
+    return np.array(out, dtype=np.float64)
 
 
-def parse_diag_matrix_dict(d):
-    return parse_number(d["scale"]) * np.diag(parse_array(d["diag"]))
+def parse_diag_matrix_dict(spec):
+    """{scale, diag} -> scale * diag(array)."""
+    return parse_number(spec["scale"]) * np.diag(parse_array(spec["diag"]))
 
 
-def parse_support_offset(d):
-    x = d.get("x", 0)
-    y = d.get("y", 0)
-    if "r" in d and "θ" in d:
-        r, th = d["r"], parse_number(d["θ"])
-        x += r * np.cos(th)
-        y += r * np.sin(th)
-    elif "r" in d or "θ" in d:
+def parse_support_offset(spec):
+    """Planar offset of an object on its support: Cartesian part (x, y) plus an optional polar part (r, θ)."""
+    has_r, has_angle = "r" in spec, "θ" in spec
+    if has_r != has_angle:
         raise ValueError("Radius and angle must *both* be specified in support offset.")
-    return np.array([x, y])
+    offset = np.array([spec.get("x", 0), spec.get("y", 0)], dtype=np.float64)
+    if has_r:
+        angle = parse_number(spec["θ"])
+        offset += spec["r"] * np.array([math.cos(angle), math.sin(angle)])
+    return offset

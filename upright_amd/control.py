@@ -61,8 +61,9 @@ class TargetTrajectories(bindings.TargetTrajectories):
 
 
 class ControllerSettings(bindings.ControllerSettings):
-    """wrappers.py:78-399: controller config dict -> settings struct.  `bodies` / `contacts` replace the
-    arrangement parser (`parsing.py:351-410`), which is not re-implemented yet."""
+    """wrappers.py:78-399: controller config dict -> settings struct.  `bodies` / `contacts` default to what
+    `upright_amd.arrangement.parse_control_objects` builds from the dict (the role of `parsing.py:351-410`); tests
+    pass the reference's own parser output (tests/golden/arrangements.json) instead."""
 
     def __init__(self, config, x0=None, bodies=None, contacts=None):
         super().__init__()
@@ -195,48 +196,84 @@ def objects_from_fixture(arr):
     return bodies, contacts
 
 
+class ReplanSchedule:
+    """When to re-solve: at most once per `period` of controller time, counted from the last solve
+    (`tracking.min_policy_update_time`, controller.yaml:33; the cadence of manager.py:158-168).  Also the log of
+    when each re-solve happened and how long it took in wall-clock seconds."""
+
+    def __init__(self, period):
+        self.period = float(period)
+        self.last = -np.inf
+        self.times = []
+        self.durations = []
+
+    def due(self, t):
+        return t >= self.last + self.period
+
+    def start_at(self, t):
+        """A solve at time t that is not logged (the warm start)."""
+        self.last = t
+
+    def timed(self, t, solve):
+        """Run `solve()`, log it as the re-solve of time t."""
+        tic = time.time()
+        solve()
+        self.durations.append(time.time() - tic)
+        self.times.append(t)
+        self.last = t
+
+
+class StateInputTrajectory:
+    """What `plan()` returns (upright_control trajectory.py): times, states and inputs of a rolled-out plan."""
+
+    def __init__(self, ts, xs, us):
+        self.ts, self.xs, self.us = np.array(ts), np.array(xs), np.array(us)
+
+
 class ControllerManager:
-    """manager.py:100-209."""
+    """One controller in closed loop (the role of manager.py:100-209): owns a `bindings.ControllerInterface`, feeds
+    it every observation, re-solves on the schedule above and hands back the policy's state / input for the tick.
+    Attribute and method names are the reference's, so mpc_sim.py-style loops run unchanged."""
 
     def __init__(self, settings, ref_trajectory, timestep):
         self.settings = settings
         self.ref = ref_trajectory
         self.timestep = timestep
+        self.schedule = ReplanSchedule(timestep)
         self.mpc = bindings.ControllerInterface(settings)
-        self.mpc.reset(self.ref)
-        self.last_planning_time = -np.inf
+        self.mpc.reset(ref_trajectory)
+        # caller-visible buffers, mutated in place by evaluateMpcSolution (manager.py:115-116,172)
         self.x_opt = np.zeros(settings.dims.x())
         self.u_opt = np.zeros(settings.dims.u())
-        self.replanning_times = []
-        self.replanning_durations = []
+
+    # the reference exposes these three as plain attributes
+    last_planning_time = property(lambda self: self.schedule.last)
+    replanning_times = property(lambda self: self.schedule.times)
+    replanning_durations = property(lambda self: self.schedule.durations)
 
     @classmethod
     def from_config(cls, config, x0=None, bodies=None, contacts=None):
+        """Controller dict -> manager whose target is the configured waypoints relative to the end-effector pose at
+        the initial state (wrappers.py:31-43)."""
         settings = ControllerSettings(config, x0=x0, bodies=bodies, contacts=contacts)
-        timestep = config["tracking"]["min_policy_update_time"]
-        chain = robots.from_config(config["robot"])
-        r_ew_w, C_we = chain.forward(settings.initial_state[: settings.dims.robot.q])
-        ref = TargetTrajectories.from_config(config, r_ew_w, rot_to_quat_xyzw(C_we), np.zeros(settings.dims.u()))
-        return cls(settings, ref, timestep)
+        q0 = settings.initial_state[: settings.dims.robot.q]
+        r_ew_w, C_we = robots.from_config(config["robot"]).forward(q0)
+        target = TargetTrajectories.from_config(config, r_ew_w, rot_to_quat_xyzw(C_we), np.zeros(settings.dims.u()))
+        return cls(settings, target, config["tracking"]["min_policy_update_time"])
 
     def update(self, ref):
         self.ref = ref
-        self.mpc.reset(self.ref)
+        self.mpc.reset(ref)
 
     def warmstart(self):
         self.mpc.setObservation(0, self.settings.initial_state, np.zeros(self.settings.dims.u()))
         self.mpc.advanceMpc()
-        self.last_planning_time = 0
+        self.schedule.start_at(0)
 
     def step(self, t, x):
         self.mpc.setObservation(t, x, self.u_opt)
-        if t >= self.last_planning_time + self.timestep:
-            t0 = time.time()
-            self.mpc.advanceMpc()
-            t1 = time.time()
-            self.last_planning_time = t
-            self.replanning_times.append(t)
-            self.replanning_durations.append(t1 - t0)
+        if self.schedule.due(t):
+            self.schedule.timed(t, self.mpc.advanceMpc)
         self.mpc.evaluateMpcSolution(t, x, self.x_opt, self.u_opt)
         return self.x_opt, self.u_opt
 
@@ -244,3 +281,81 @@ class ControllerManager:
         ts, xs, us = bindings.scalar_array(), bindings.vector_array(), bindings.vector_array()
         self.mpc.getMpcSolution(ts, xs, us)
         return np.array(ts), np.array(xs), np.array(us)
+
+    def plan(self, timestep, duration):
+        """Roll the closed loop forward on the plan itself: every `timestep` the policy's own state becomes the next
+        observation (manager.py:186-209)."""
+        ts, xs, us = [], [], []
+        t, x = 0.0, self.settings.initial_state
+        while t <= duration:
+            x, u = self.step(t, x)
+            ts.append(t); xs.append(x.copy()); us.append(u.copy())
+            t += timestep
+        return StateInputTrajectory(ts, xs, us)
+
+
+class BatchControllerManager:
+    """B controllers of one problem family in lock step on one GPU: what a sweep over start states, targets or
+    inertial-parameter samples runs (planning_sim_loop.py:613-655 does them one after the other).  Same cadence and
+    call order as `ControllerManager`, every call batched: observations x[B][nx], outputs x_opt[B][nx], u_opt[B][nu].
+
+    settings: a `ControllerSettings`; x0[B][nx] start states; targets[B][n_way][3] end-effector target positions
+    (default: every instance's own end-effector position at x0 plus the configured waypoint offsets);
+    body_params[B][nb][10] per-instance inertial parameters (default: the arrangement's)."""
+
+    def __init__(self, settings, config, x0, targets=None, body_params=None):
+        from .engine import BatchMPC
+
+        self.settings = settings
+        self.problem = bindings.problem_from_settings(settings)
+        x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+        self.B = x0.shape[0]
+        self.x0 = x0
+        way = config["waypoints"]
+        self.problem.way_t = np.array([w["time"] for w in way], dtype=np.float64)
+        if targets is None:
+            chain = self.problem.chain
+            offs = np.array([w["position"] for w in way], dtype=np.float64)
+            targets = np.stack([chain.forward(x[: self.problem.nq])[0] + offs for x in x0])
+        self.problem.way_p = np.asarray(targets[0], dtype=np.float64).reshape(len(way), 3)
+        self.mpc = BatchMPC(self.problem, self.B, body_params=body_params, way_p=np.asarray(targets, dtype=np.float64))
+        self.schedule = ReplanSchedule(config["tracking"]["min_policy_update_time"])
+        self.x_opt = np.zeros((self.B, self.problem.nx_full))
+        self.u_opt = np.zeros((self.B, self.problem.nu))
+        self._fresh = True   # no previous solution yet: the next solve runs init_sqp_iteration iterations
+
+    @classmethod
+    def from_config(cls, config, x0, targets=None, body_params=None, bodies=None, contacts=None):
+        x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+        settings = ControllerSettings(config, x0=x0[0], bodies=bodies, contacts=contacts)
+        return cls(settings, config, x0, targets=targets, body_params=body_params)
+
+    def _solve(self, t, x):
+        cold = bool(self.settings.mpc.cold_start)
+        if cold and not self._fresh:
+            self.mpc.reset()
+        if self._fresh or cold:
+            self.mpc.set_sqp_iterations(int(self.settings.sqp.init_sqp_iteration))
+        self.mpc.set_observation(t, x)
+        self.mpc.advance()
+        self._fresh = False
+
+    def warmstart(self):
+        self._solve(0.0, self.x0)
+        self.schedule.start_at(0)
+
+    def step(self, t, x):
+        x = np.asarray(x, dtype=np.float64).reshape(self.B, self.problem.nx_full)
+        if self.schedule.due(t):
+            self.schedule.timed(t, lambda: self._solve(t, x))
+        xo, uo = self.mpc.evaluate(t, x if self.problem.use_feedback_policy else None)
+        self.x_opt[:], self.u_opt[:] = xo, uo
+        return self.x_opt, self.u_opt
+
+    def qp_status(self):
+        """Status of the last solve's final QP per instance: 0 solved, 1 iteration limit, 2 numerical failure."""
+        return self.mpc.stats()["qp_status_last"].astype(int)
+
+    def get_mpc_trajectory(self):
+        ts, xs, us = self.mpc.solution()
+        return ts, xs, us

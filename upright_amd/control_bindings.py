@@ -1,12 +1,15 @@
 """Drop-in for the pybind11 module `upright_control.bindings` (upright_control/src/pybindings.cpp:43-428).
 
 Same class and attribute names; `ControllerInterface` drives one instance (B = 1) of the batched HIP
-engine through the C-ABI of libupright_mi.so.  What the engine does not cover yet raises RuntimeError at
-construction, the way the reference's constructor throws std::runtime_error -- never a silent fallback:
-obstacle avoidance, projectile constraint, inertial alignment, end-effector box, operating points,
-feedback gains.
+engine through the C-ABI of libupright_mi.so.  Covered: the balancing OCP (object-dynamics equality, friction
+rows), obstacle avoidance over sphere pairs, one dynamic obstacle with the projectile-path constraint, HPIPM
+slack settings, the linear feedback policy.  What the engine does not cover raises RuntimeError -- at
+construction for OCP terms (inertial alignment, end-effector box, operating points), at the call for the
+solver-internal getters (value function, Lagrangian, visualisation) -- the way the reference throws
+std::runtime_error; never a silent fallback.
 """
 import enum
+import warnings
 
 import numpy as np
 
@@ -229,6 +232,57 @@ class VectorFunctionLinearApproximation:
         self.f = np.zeros(0); self.dfdx = np.zeros((0, 0)); self.dfdu = np.zeros((0, 0))
 
 
+class VectorFunctionQuadraticApproximation(VectorFunctionLinearApproximation):
+    def __init__(self):
+        super().__init__()
+        self.dfdxx = matrix_array(); self.dfdux = matrix_array(); self.dfduu = matrix_array()
+
+
+class ScalarFunctionQuadraticApproximation:
+    """pybindings.cpp:326-338."""
+
+    def __init__(self):
+        self.f = 0.0
+        self.dfdx = np.zeros(0); self.dfdu = np.zeros(0)
+        self.dfdxx = np.zeros((0, 0)); self.dfdux = np.zeros((0, 0)); self.dfduu = np.zeros((0, 0))
+
+
+class LinearController:
+    """ocs2::LinearController as getLinearController returns it: u(t, x) = bias(t) + gain(t) x."""
+
+    def __init__(self):
+        self.timeStamp = scalar_array(); self.biasArray = vector_array(); self.gainArray = matrix_array()
+
+
+class SystemPinocchioMapping:
+    """pybindings.cpp:57-65; dynamics/system_pinocchio_mapping.h:81-142: state / input -> the generalised position,
+    velocity and acceleration of the Pinocchio model, in which the dynamic obstacles' coordinates come FIRST."""
+
+    def __init__(self, dims):
+        self.dims = dims
+
+    def _split(self, state):
+        x = np.asarray(state, dtype=np.float64)
+        d = self.dims
+        if x.shape != (d.x(),):
+            raise ValueError(f"state has shape {x.shape}, expected ({d.x()},)")
+        return x[: d.robot.x], [x[d.robot.x + 9 * i: d.robot.x + 9 * (i + 1)] for i in range(d.o)]
+
+    def get_pinocchio_joint_position(self, state):
+        xr, obs = self._split(state)
+        return np.concatenate([o[0:3] for o in obs] + [xr[: self.dims.robot.q]])
+
+    def get_pinocchio_joint_velocity(self, state, input):
+        xr, obs = self._split(state)
+        d = self.dims.robot
+        return np.concatenate([o[3:6] for o in obs] + [xr[d.q: d.q + d.v]])
+
+    def get_pinocchio_joint_acceleration(self, state, input):
+        xr, obs = self._split(state)
+        d = self.dims.robot
+        return np.concatenate([o[6:9] for o in obs] + [xr[d.q + d.v: d.q + 2 * d.v]])
+
+
 def problem_from_settings(s):
     """ControllerSettings -> Problem (what ControllerInterface's constructor assembles,
     controller_interface.cpp:103-393).  Raises RuntimeError for OCP terms outside the accelerated path."""
@@ -325,6 +379,7 @@ class ControllerInterface:
         self._t = 0.0
         self._x = np.array(settings.initial_state, dtype=np.float64)
         self._first = True
+        self.last_qp_status = 0   # hpipm status of the last solve's final QP: 0 solved, 1 iteration limit, 2 numerical failure
 
     def _set_target(self, target):
         self._target = target
@@ -358,10 +413,22 @@ class ControllerInterface:
     def advanceMpc(self):
         if self._mpc is None:
             raise RuntimeError("advanceMpc called before reset(targetTrajectories)")
-        # first solve uses init_sqp_iteration (controller.yaml:57), later ones sqp_iteration
+        # ocs2's SQP solver runs sqp.init_sqp_iteration iterations from the initializer's guess while it holds no
+        # previous solution (first solve after construction / reset), sqp.sqp_iteration warm-started ones afterwards;
+        # mpc.cold_start resets the solver before every solve (pybindings.cpp:148,194-195; controller.yaml:15,56-57)
+        cold = bool(self.settings.mpc.cold_start)
+        if cold and not self._first:
+            self._mpc.reset()
+        if self._first or cold:
+            self._mpc.set_sqp_iterations(int(self.settings.sqp.init_sqp_iteration))
         self._mpc.set_observation(self._t, self._x)
         self._mpc.advance()
         self._first = False
+        self.last_qp_status = int(self._mpc.stats()["qp_status_last"][0])
+        if self.last_qp_status != 0 and self.settings.sqp.print_solver_status:
+            # what ocs2 prints from hpipm's return code when print_solver_status is set
+            warnings.warn("QP of the last SQP iteration ended with status %d (%s)" % (
+                self.last_qp_status, "iteration limit" if self.last_qp_status == 1 else "numerical failure: step rejected"), RuntimeWarning)
 
     def evaluateMpcSolution(self, current_time, current_state, opt_state, opt_input):
         # controller_python_interface.h:46-55: the policy is evaluated at the CURRENT state (a LinearController when
@@ -422,6 +489,100 @@ class ControllerInterface:
 
     def stateInputEqualityConstraint(self, t, x, u):
         return self.getStateInputEqualityConstraintValue("object_dynamics", t, x, u)
+
+    def stateInputEqualityConstraintLinearApproximation(self, t, x, u):
+        """pybindings.cpp:405-408: {f, dfdx, dfdu} of the object-dynamics equality at (t, x, u)."""
+        out = self._lin(t, x, u)
+        P = self.problem
+        approx = VectorFunctionLinearApproximation()
+        approx.f = out["g"][0]
+        approx.dfdx = np.hstack([out["gx"][0], np.zeros((approx.f.size, P.nx_full - P.nx))])
+        approx.dfdu = self._mpc.eq_input_jacobian(0)
+        return approx
+
+    def flowMap(self, t, x, u):
+        """pybindings.cpp:388-389; system_dynamics.h:15-22,33-38: [v, a, jerk] for the robot, [v, a, 0] per obstacle."""
+        P = self.problem
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        nq = P.nq
+        parts = [x[nq:3 * nq], u[:nq]]
+        for i in range(P.n_dyn):
+            o = x[3 * nq + 9 * i: 3 * nq + 9 * (i + 1)]
+            parts += [o[3:9], np.zeros(3)]
+        return np.concatenate(parts)
+
+    def flowMapLinearApproximation(self, t, x, u):
+        """pybindings.cpp:390-392: the dynamics are linear time-invariant, so dfdx / dfdu are constant."""
+        P = self.problem
+        nq, nx, nu = P.nq, P.nx_full, P.nu
+        approx = VectorFunctionLinearApproximation()
+        approx.f = self.flowMap(t, x, u)
+        A = np.zeros((nx, nx)); B = np.zeros((nx, nu))
+        A[:2 * nq, nq:3 * nq] = np.eye(2 * nq)
+        B[2 * nq:3 * nq, :nq] = np.eye(nq)
+        for i in range(P.n_dyn):
+            o = 3 * nq + 9 * i
+            A[o:o + 6, o + 3:o + 9] = np.eye(6)
+        approx.dfdx, approx.dfdu = A, B
+        return approx
+
+    def cost(self, t, x, u):
+        """pybindings.cpp:393-394: intermediate cost = state_input_cost + end_effector_cost at (t, x, u)."""
+        return self.getCostValue("state_input_cost", t, x, u) + self.getCostValue("end_effector_cost", t, x, u)
+
+    def costQuadraticApproximation(self, t, x, u):
+        """pybindings.cpp:395-397: value, gradients and (Gauss-Newton) Hessians of the intermediate cost."""
+        P = self.problem
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        out = self._lin(t, x, u)
+        nq, nx, nxf = P.nq, P.nx, P.nx_full
+        q = ScalarFunctionQuadraticApproximation()
+        q.f = self.cost(t, x, u)
+        q.dfdx = np.zeros(nxf); q.dfdx[:nx] = P.Qdiag * (x[:nx] - P.xd); q.dfdx[:nq] += out["grad"][0]
+        q.dfdu = P.Rdiag * u
+        q.dfdxx = np.zeros((nxf, nxf)); q.dfdxx[:nx, :nx] = np.diag(P.Qdiag); q.dfdxx[:nq, :nq] += out["hess"][0]
+        q.dfduu = np.diag(P.Rdiag)
+        q.dfdux = np.zeros((P.nu, nxf))
+        return q
+
+    def getBias(self, t):
+        """pybindings.cpp:385: bias of the linear policy u = bias(t) + K(t) x (ocs2::LinearController), interpolated
+        between the knots like the gain."""
+        c = self.getLinearController()
+        ts = np.array(list(c.timeStamp))
+        return TargetTrajectories._interp(list(ts), list(c.biasArray), float(t))
+
+    def getLinearController(self):
+        """pybindings.cpp:386-387: the ocs2::LinearController of the last solve (knot times, biases, gains)."""
+        if not self.problem.use_feedback_policy:
+            raise RuntimeError("sqp.use_feedback_policy is false: the solution carries a feed-forward controller")
+        K = self._mpc.feedback_gains()[0]
+        ts, xs, us = self._mpc.solution()
+        c = LinearController()
+        for k in range(self.problem.N):
+            c.timeStamp.push_back(ts[0, k]); c.gainArray.push_back(K[k]); c.biasArray.push_back(us[0, k] - K[k] @ xs[0, k])
+        return c
+
+    # -- solver internals the accelerated path does not expose (pybindings.cpp:398-403,409-412,420-427) ------------
+    def _outside(self, name):
+        raise RuntimeError(f"ControllerInterface.{name} is outside the accelerated path of the MI355X engine")
+
+    def valueFunction(self, t, x):
+        self._outside("valueFunction")
+
+    def valueFunctionStateDerivative(self, t, x):
+        self._outside("valueFunctionStateDerivative")
+
+    def stateInputEqualityConstraintLagrangian(self, t, x, u):
+        self._outside("stateInputEqualityConstraintLagrangian")
+
+    def getStateInequalityConstraintValue(self, name, t, x):
+        # the reference looks `name` up among the STATE-ONLY constraints, of which the OCP has none
+        # (controller_python_interface.h:67-72; every inequality is registered as a state-input one)
+        raise RuntimeError(f"no state-only constraint named '{name}'")
+
+    def visualizeTrajectory(self, t, x, u, speed):
+        self._outside("visualizeTrajectory (ROS visualisation)")
 
     def getLinearFeedbackGain(self, t):
         """pybindings.cpp:382-384: gain of the linear policy at time t (linear interpolation between knots)."""

@@ -209,6 +209,7 @@ struct upr_batch {
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr, *has_prev = nullptr;
     double* prof = nullptr;
+    double* kkt = nullptr;   // multiplier export of the register-resident QP kernel (upr_batch_qp_kkt), allocated on first use
     double *fb = nullptr, *xs_lin = nullptr;   // feedback gains of the last solve
     // dynamic obstacle (n_dyn == 1): observed state per instance (device + host copies, and the one the stored
     // solution belongs to), activation flag of the projectile rows
@@ -216,6 +217,7 @@ struct upr_batch {
     std::vector<double> hdyn0, hdyn_prev, htprev;
     int nxf = 0;   // interface state dimension 3 nq + 9 n_dyn
     bool guess_set = false;
+    int sqp_iters_next = 0;   // > 0: SQP iterations of the next advance only (init_sqp_iteration of the first solve)
     double last_ms = 0.0;
     int qp_nt = 0;
     bool use_qp2 = false, use_qp3 = false;
@@ -224,6 +226,7 @@ struct upr_batch {
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
+    std::string qp_name;   // the QP kernel instantiation this handle launches
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_slot;
 };
@@ -248,6 +251,8 @@ int check_problem(const upr_problem* P) {
         if (!(P->soft_L2_lower >= 0) || !(P->soft_L2_upper >= 0) || !(P->soft_L1_lower >= 0) || !(P->soft_L1_upper >= 0)) return fail("slack penalties must be non-negative");
         if (!(P->soft_L2_lower + P->soft_L1_lower > 0) || !(P->soft_L2_upper + P->soft_L1_upper > 0)) return fail("softened rows need a positive L1 or L2 penalty");
     }
+    if (P->soft_eq && (!(P->soft_L2_lower > 0) || P->soft_L2_lower != P->soft_L2_upper || P->soft_L1_lower != 0 || P->soft_L1_upper != 0))
+        return fail("a softened object-dynamics equality needs equal positive L2 penalties and zero L1 penalties (the slack pair is eliminated to a quadratic penalty)");
     for (int i = 0; i < P->n_proj; ++i) if (P->proj_sph[i] < 0 || P->proj_sph[i] >= P->n_sph || !(P->proj_dist[i] > 0)) return fail("projectile row out of range");
     for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -2 || P->sph_frame[i] > P->nq || (P->sph_frame[i] == -2 && P->n_dyn != 1)) return fail("sph_frame out of range");
     for (int i = 0; i < P->n_pairs; ++i)
@@ -433,7 +438,9 @@ int advance_impl(upr_batch* h) {
         UPR_HIP(hipMemsetAsync(h->done, 0, sizeof(int) * h->B, h->stream));
         h->guess_set = false;
     }
-    for (int it = 0; it < h->P.sqp_iters; ++it) {
+    const int sqp_iters = h->sqp_iters_next > 0 ? h->sqp_iters_next : h->P.sqp_iters;
+    h->sqp_iters_next = 0;
+    for (int it = 0; it < sqp_iters; ++it) {
         { KernelTimer T(h, 0); if (do_linearize(h, traj_lin_args(h))) return 1; T.stop(); }
         { KernelTimer T(h, 1); if (launch_qp(h, make_qp_args(h))) return 1; T.stop(); }
         upr_ls_args L;
@@ -517,8 +524,8 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     const upr_dims& d = h->d;
     if (d.nx > UPR_LPK) { fail("nx exceeds the 32 tangent lanes of the linearisation kernel"); delete h; return nullptr; }
     // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
-    const bool plain = P->n_pairs + P->n_proj == 0 && !(P->soft_state_box || P->soft_input_box || P->soft_poly);   // rows only the generic kernel has
-    const bool soft = P->soft_state_box || P->soft_input_box || P->soft_poly;
+    const bool soft = P->soft_state_box || P->soft_input_box || P->soft_poly || P->soft_eq;
+    const bool plain = P->n_pairs + P->n_proj == 0 && !soft;   // rows only the generic kernel has
     h->use_qp3 = qp3_has_shape(*P) && !soft && P->n_pairs + P->n_proj <= UPR_QP3_NOMAX;   // (the production kernel takes up to UPR_QP3_NOMAX state rows per knot)
     h->use_qp2 = qp2_has_shape(*P) && plain;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
@@ -530,6 +537,13 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         size_t need = qp2_ws_doubles(*P, h->d);
         if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;
         if (qp3_has_shape(*P)) { need = upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
+    }
+    {
+        char buf[128];
+        if (h->use_qp3) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, %d, %s>>", P->nq, P->nb, P->nc, P->nf, P->N, h->qp_nt, h->d.no > 0 ? "true" : "false");
+        else if (h->use_qp2) snprintf(buf, sizeof(buf), "upr_qp2_kernel<upr_qp2_dims<%d, %d, %d, %d>, %d>", P->nq, P->nb, P->nc, P->nf, h->qp_nt == 512 ? 128 : h->qp_nt);
+        else snprintf(buf, sizeof(buf), "upr_qp_kernel<64>");
+        h->qp_name = buf;
     }
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
     auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };
@@ -574,7 +588,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof);
+    hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof); hipFree(h->kkt);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -606,6 +620,13 @@ static int set_guess_core(upr_batch* h, const double* xs, const double* us) {
     UPR_HIP(hipMemcpyAsync(h->us, us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyHostToDevice, h->stream));
     UPR_HIP(hipStreamSynchronize(h->stream));
     h->guess_set = true;
+    return 0;
+}
+
+int upr_batch_set_sqp_iterations(upr_batch* h, int n) {
+    if (!h) return fail("null batch");
+    if (n < 0 || n > 1000) return fail("upr_batch_set_sqp_iterations: n out of range");
+    h->sqp_iters_next = n;
     return 0;
 }
 
@@ -689,6 +710,8 @@ static int get_feedback_core(upr_batch* h, double* K) {
 }
 
 double upr_batch_last_solve_ms(const upr_batch* h) { return h ? h->last_ms : 0.0; }
+
+const char* upr_batch_qp_kernel_name(const upr_batch* h) { return h ? h->qp_name.c_str() : ""; }
 
 int upr_batch_get_stats(upr_batch* h, double* stats) {
     if (!h) return fail("null batch");
@@ -796,6 +819,52 @@ static int qp_step_core(upr_batch* h, double* dxs, double* dus) {
         const double* w = ws.data() + (size_t)b * d.ws_stride;
         if (dxs) std::memcpy(dxs + (size_t)b * (d.N + 1) * d.nx, w + d.ws_dx, sizeof(double) * (d.N + 1) * d.nx);
         if (dus) std::memcpy(dus + (size_t)b * d.N * d.nu, w + d.ws_du, sizeof(double) * d.N * d.nu);
+    }
+    return 0;
+}
+
+/* One QP at the current trajectory with everything an independent KKT check needs: the step and the multipliers the
+ * kernel ended with.  pi[B][N+1][nx] costates (pi_0 unused), nu[B][N][ne] stage-equality multipliers, yN[B][neN]
+ * terminal-equality multipliers, lam[B][N+1][ni] inequality multipliers, ni = 2 nx + 2 nu + np + no in the slot order
+ * [x lower][x upper][u lower][u upper][friction rows][collision / projectile rows]; *ni_out = ni.  Any pointer may be NULL. */
+int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double* nu, double* yN, double* lam, int* ni_out) {
+    if (!h) return fail("null batch");
+    if (h->P.n_dyn) return fail("upr_batch_qp_kkt: not available with a dynamic obstacle (interface states)");
+    const upr_dims& d = h->d;
+    if (ni_out) *ni_out = d.ni_stage;
+    const int kdoubles = upr_kkt_doubles(d);
+    if (h->use_qp3 && !h->kkt && dev_alloc(&h->kkt, (size_t)h->B * kdoubles)) return 1;
+    if (do_linearize(h, traj_lin_args(h))) return 1;
+    upr_qp_args A = make_qp_args(h);
+    if (h->use_qp3) { A.kkt = h->kkt; A.kkt_stride = kdoubles; }
+    if (launch_qp(h, A)) return 1;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> ws((size_t)h->B * d.ws_stride), kk;
+    UPR_HIP(hipMemcpy(ws.data(), h->ws, sizeof(double) * ws.size(), hipMemcpyDeviceToHost));
+    if (h->use_qp3) { kk.resize((size_t)h->B * kdoubles); UPR_HIP(hipMemcpy(kk.data(), h->kkt, sizeof(double) * kk.size(), hipMemcpyDeviceToHost)); }
+    const int n1 = d.N + 1;
+    int o_pi = d.ws_pi, o_nu = d.ws_nu, o_y = d.ws_yN, o_lam = d.ws_lam;
+    if (!h->use_qp3 && h->use_qp2) {
+#define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) { upr_qp2_ws<upr_qp2_dims<a, b, c, e>> w(d.N, d.neN); o_pi = w.pi; o_nu = w.nu; o_y = w.yN; o_lam = w.lam; }
+        UPR_QP2_SHAPES(X)
+#undef X
+    }
+    for (int b = 0; b < h->B; ++b) {
+        const double* w = ws.data() + (size_t)b * d.ws_stride;
+        if (dxs) std::memcpy(dxs + (size_t)b * n1 * d.nx, w + d.ws_dx, sizeof(double) * n1 * d.nx);
+        if (dus) std::memcpy(dus + (size_t)b * d.N * d.nu, w + d.ws_du, sizeof(double) * d.N * d.nu);
+        const double *spi, *snu, *sy, *sl;
+        if (h->use_qp3) { const double* k = kk.data() + (size_t)b * kdoubles; spi = k; snu = spi + n1 * d.nx; sy = snu + d.N * d.ne; sl = sy + d.neN; }
+        else { spi = w + o_pi; snu = w + o_nu; sy = w + o_y; sl = w + o_lam; }
+        if (pi) std::memcpy(pi + (size_t)b * n1 * d.nx, spi, sizeof(double) * n1 * d.nx);
+        if (nu) std::memcpy(nu + (size_t)b * d.N * d.ne, snu, sizeof(double) * d.N * d.ne);
+        if (yN && d.neN) std::memcpy(yN + (size_t)b * d.neN, sy, sizeof(double) * d.neN);
+        if (lam) {
+            // the generic kernels keep a multiplier value in slots that are not rows of the stage (x rows of knot 0, u rows of
+            // knot N, collision rows outside knots 1 .. N-1): report 0 there
+            for (int k = 0; k < n1; ++k) for (int j = 0; j < d.ni_stage; ++j)
+                lam[((size_t)b * n1 + k) * d.ni_stage + j] = upr_ineq_active(d, k, j) ? sl[(size_t)k * d.ni_stage + j] : 0.0;
+        }
     }
     return 0;
 }

@@ -35,6 +35,12 @@
 #define UPR_QP_RHO_S_PROX 1e-6
 static inline UPR_HD double upr_qp_rho_s(int ne, int nfc) { return (nfc < ne) ? UPR_QP_RHO_S_PROX : UPR_QP_RHO_S; }
 static inline UPR_HD double upr_qp_rho_prox(int ne, int nfc) { return (nfc < ne) ? UPR_QP_RHO_S_PROX : 0.0; }
+// Softened stage equality (upr_problem::soft_eq): the HPIPM slack pair of a row with equal L2 penalties Z and no L1 term
+// eliminates to the penalty Z/2 |C dz + e|^2, i.e. the regularised equality C dz + e = nu / Z.  In the Schur-complement
+// form that is rho_s = 1 / Z with no proximal carry-over, and the row's residual is C dz + e - nu / Z.
+static inline UPR_HD double upr_qp_rho_soft(const upr_problem* P) { return P->soft_eq ? 1.0 / P->soft_L2_lower : 0.0; }
+static inline UPR_HD double upr_qp_rho_s(const upr_problem* P, int ne, int nfc) { return P->soft_eq ? upr_qp_rho_soft(P) : upr_qp_rho_s(ne, nfc); }
+static inline UPR_HD double upr_qp_rho_prox(const upr_problem* P, int ne, int nfc) { return P->soft_eq ? 0.0 : upr_qp_rho_prox(ne, nfc); }
 #define UPR_QP_RHO_N 1e-6
 
 struct upr_qp_args {
@@ -48,7 +54,12 @@ struct upr_qp_args {
     double* ws;          // [B][ws_stride]
     double* stats;       // [B][UPR_NSTATS]
     double* prof;        // optional [B][16] per-phase cycle counters (debug), NULL = off
+    // optional export of the multipliers at exit (upr_batch_qp_kkt; kernels that keep them in registers / LDS write them
+    // here): per instance [pi (N+1) nx][nu N ne][yN neN][lam (N+1) ni_stage], lam in the slot layout of upr_ineq_active
+    double* kkt = nullptr;
+    int kkt_stride = 0;
 };
+static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + (d.N + 1) * d.ni_stage; }
 
 // LDS layout (doubles)
 struct upr_qp_lds {
@@ -558,7 +569,7 @@ static inline UPR_HD void upr_qp_backward(upr_qp_state& S, bool mat) {
             UPR_SYNC();
             UPR_FOR(e, ne * ne) {
                 int r = e / ne, c = e % ne;
-                double v = (r == c) ? upr_qp_rho_s(ne, nfc) : 0.0;
+                double v = (r == c) ? upr_qp_rho_s(P, ne, nfc) : 0.0;
                 for (int i = 0; i < nfc; ++i) v += L[o.Yf + i * ne + r] * L[o.Yf + i * ne + c];
                 L[o.Sm + e] = v;
             }
@@ -616,7 +627,7 @@ static inline UPR_HD void upr_qp_backward(upr_qp_state& S, bool mat) {
         UPR_FOR(i, nfc) L[o.huf + i] = upr_blk_up(d, L + o.Hff, L + o.uf0, i);
         UPR_SYNC();
         UPR_FOR(r, ne) {
-            double v = L[o.nuv + r] + upr_qp_rho_prox(ne, nfc) * S.ws[d.ws_nu + k * ne + r];
+            double v = L[o.nuv + r] + upr_qp_rho_prox(P, ne, nfc) * S.ws[d.ws_nu + k * ne + r];
             for (int i = 0; i < nfc; ++i) v -= L[o.Df + r * nfc + i] * L[o.huf + i];
             L[o.ee + r] = v;
         }
@@ -895,7 +906,7 @@ static inline UPR_HD void upr_qp_residuals(upr_qp_state& S, int ntot, double* re
                 r_stat = fmax(r_stat, fabs(v));
             }
             UPR_FOR(i, nx) r_eq = fmax(r_eq, fabs(L[o.bk + i]));
-            UPR_FOR(r, ne) r_eq = fmax(r_eq, fabs(L[o.nuv + r]));
+            UPR_FOR(r, ne) r_eq = fmax(r_eq, fabs(L[o.nuv + r] - upr_qp_rho_soft(P) * L[o.snu + r]));
         } else {
             if (d.neN > 0) {
                 UPR_FOR(r, d.neN) {

@@ -1727,6 +1727,27 @@ struct upr_qp3 {
         UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
         UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
         if (prof) UPR_FORT(i, 64) prof[i] += L[O::prf + i];
+        if (A.kkt) {   // multipliers for upr_batch_qp_kkt, in the generic kernel's slot layout
+            double* K = A.kkt + (size_t)b * A.kkt_stride;
+            const int ni = A.d.ni_stage, o_nu = N1 * NX, o_y = o_nu + N * NE, o_l = o_y + neN;
+            UPR_FORT(e, N1 * NX) K[e] = ws[W::pi + e];
+            UPR_FORT(e, N * NE) K[o_nu + e] = ws[W::nu + e];
+            UPR_FORT(q, neN) K[o_y + q] = L[O::yN + q];
+            UPR_FORT(e, N1 * ni) K[o_l + e] = 0.0;
+            UPR_SYNC();
+#pragma unroll
+            for (int q = 0; q < C::QX; ++q) {
+                const int ix = tid() + q * NT;
+                if (ix < C::NXI) { const int k = 1 + ix / NX, i = ix % NX; K[o_l + k * ni + i] = lx[q][0]; K[o_l + k * ni + NX + i] = lx[q][1]; }
+            }
+#pragma unroll
+            for (int q = 0; q < C::QU; ++q) {
+                const int iu = tid() + q * NT;
+                if (iu < C::NUI) { const int k = iu / NU, i = iu % NU; K[o_l + k * ni + 2 * NX + i] = lu[q][0]; K[o_l + k * ni + 2 * NX + NU + i] = lu[q][1]; }
+            }
+            if (NF == 3) UPR_FORT(e, 5 * C::NCI) { const int ic = e / 5, k = ic / NC, ci = ic % NC; K[o_l + k * ni + 2 * NX + 2 * NU + 5 * ci + e % 5] = G[F::cl + e]; }
+            if (no > 0) UPR_FORT(e, (N - 1) * no) { const int k = 1 + e / no, r = e % no; K[o_l + k * ni + 2 * NX + 2 * NU + C::NP + r] = G[F::ol + (k - 1) * UPR_QP3_NOMAX + r]; }
+        }
         if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;
             st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];

@@ -58,6 +58,10 @@ class BatchMPC:
         us = cont(us).reshape(self.B, self.N, self.nu)
         check(self._lib.upr_batch_set_guess(self._h, ptr(xs), ptr(us)))
 
+    def set_sqp_iterations(self, n):
+        """SQP iterations of the next advance only (sqp.init_sqp_iteration of a solve without a previous solution)."""
+        check(self._lib.upr_batch_set_sqp_iterations(self._h, int(n)))
+
     def advance(self):
         check(self._lib.upr_batch_advance(self._h))
 
@@ -142,6 +146,19 @@ class BatchMPC:
         check(self._lib.upr_batch_qp_step(self._h, ptr(dxs), ptr(dus)))
         return dxs, dus
 
+    def qp_kkt(self):
+        """One QP at the current trajectory: step and the multipliers the kernel ended with (see upr_batch_qp_kkt)."""
+        P = self.problem
+        ni = C.c_int(0)
+        nin = 2 * self.nx + 2 * self.nu + (5 * P.nc if P.nf == 3 else 0) + len(P.pair_a) + len(P.proj_sph)
+        out = dict(dx=np.zeros((self.B, self.N + 1, self.nx)), du=np.zeros((self.B, self.N, self.nu)),
+                   pi=np.zeros((self.B, self.N + 1, self.nx)), nu=np.zeros((self.B, self.N, self.ne)),
+                   yN=np.zeros((self.B, 3 + 2 * P.nq if P.terminal_constraint else 0)), lam=np.zeros((self.B, self.N + 1, nin)))
+        check(self._lib.upr_batch_qp_kkt(self._h, ptr(out["dx"]), ptr(out["du"]), ptr(out["pi"]), ptr(out["nu"]),
+                                         ptr(out["yN"]) if out["yN"].size else None, ptr(out["lam"]), C.byref(ni)))
+        assert ni.value == nin, (ni.value, nin)
+        return out
+
     def device_ptrs(self):
         xs, us = C.c_void_p(), C.c_void_p()
         check(self._lib.upr_batch_device_ptrs(self._h, C.byref(xs), C.byref(us)))
@@ -173,7 +190,8 @@ class BatchMPC:
         ms = np.zeros(3)
         n = np.zeros(3, dtype=np.int32)
         check(self._lib.upr_batch_kernel_times(self._h, ptr(ms), iptr(n)))
-        return dict(linearize_ms=ms[0], qp_ms=ms[1], linesearch_ms=ms[2], launches=n.tolist())
+        return dict(linearize_ms=ms[0], qp_ms=ms[1], linesearch_ms=ms[2], launches=n.tolist(),
+                    qp_kernel=self._lib.upr_batch_qp_kernel_name(self._h).decode())
 
 
 def core_object_dynamics(problem, body_params, forces, Cm, w, al, a):
