@@ -297,6 +297,19 @@ def cpu_model():
     return "unknown"
 
 
+def usable_threads():
+    """Host threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota (the GPU boxes
+    expose all 256 hardware threads of the host but grant a quota of a few CPUs: more threads than that only time-slice)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(w, n_sample):
     """The oracle (oracle/upright_oracle.cpp, -O2 -fopenmp) on the first instances of the same batch, same cold start:
     one thread, then OpenMP over instances on every host thread with at least 8 solves per thread."""
@@ -306,7 +319,7 @@ def cpu_baseline(w, n_sample):
     P, x0, way = w["P"], w["x0"], w["way"]
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
     O = Oracle(P)
-    threads = os.cpu_count() or 1
+    threads = usable_threads()
     n1 = min(len(x0), 64)
     tc = time.perf_counter()
     O.solve_batch(0.0, x0[:n1], xs0[:n1], us0[:n1], way_p=way[:n1], nthreads=1)
@@ -324,13 +337,14 @@ def cpu_baseline(w, n_sample):
         "cores": used,
         "kind": "port",
         "sample": f"{len(idx)} solves ({len(idx) / used:.1f} per thread) of the first {n} instances of the same batch, same cold start; "
-                  f"oracle/upright_oracle.cpp (dense-stage Riccati IPM, -O2 -fopenmp), OpenMP over instances on {used} threads of "
-                  f"{cpu_model()}; the reference solver (OCS2 fork + HPIPM) is not available, see BASELINE.md",
+                  f"oracle/upright_oracle.cpp (dense-stage Riccati IPM, -O2 -fopenmp), OpenMP over instances on {used} threads (what the "
+                  f"container's CPU quota grants of the {os.cpu_count()} hardware threads) of {cpu_model()}; the reference solver (OCS2 fork + HPIPM) is not available, see BASELINE.md",
         "single_thread_value": n1 / dt1,
         "single_thread_ms_per_solve": 1e3 * dt1 / n1,
         "single_thread_sample": f"first {n1} instances, one thread",
         "cpu_model": cpu_model(),
-        "host_threads": threads,
+        "host_threads": os.cpu_count(),
+        "usable_threads": threads,
     }
 
 

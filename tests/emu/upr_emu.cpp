@@ -86,7 +86,8 @@ void emu_qp(const upr_problem* P, int B, const double* xs, const double* us, con
     upr_qp_args A;
     A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
-    std::vector<double> L(upr_qp_lds_layout(A.d, 1).total + 16);
+    // LDS is not zero on the device: poison the scratch so that a read before the first write cannot pass unnoticed
+    std::vector<double> L(upr_qp_lds_layout(A.d, 1).total + 16, std::nan(""));
     for (int b = 0; b < B; ++b) upr_qp_solve(ctx, A, b, L.data());
 }
 

@@ -3,6 +3,7 @@ thread per workgroup, same headers as the GPU build) against the oracle.  They v
 and the mathematics of every kernel body before any GPU time is spent; the GPU execution itself is
 checked by tests/test_gpu_parity.py."""
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -13,7 +14,7 @@ from upright_amd import _capi
 from upright_amd.problem import thing_problem
 from upright_amd.sampling import level_tray_states, stationary_guess, waypoints_for
 
-EMU = Path(__file__).resolve().parent / "emu" / "libupr_emu.so"
+EMU = Path(os.environ.get("UPR_EMU_LIB", str(Path(__file__).resolve().parent / "emu" / "libupr_emu.so")))
 p = _capi.ptr
 
 
@@ -40,7 +41,7 @@ class Emu:
     def qp(self, kernel, xs, us, x0, lin):
         stats = np.zeros((self.B, 12))
         if kernel == 1:
-            ws = np.zeros((self.B, self.ws_stride))
+            ws = np.full((self.B, self.ws_stride), np.nan)   # device memory is not zero either
             self.E.emu_qp(C.byref(self.cp), self.B, p(xs), p(us), p(x0), p(lin), p(self.Df), p(ws), p(stats))
         else:
             f = self.E.emu_qp2 if kernel == 2 else self.E.emu_qp3

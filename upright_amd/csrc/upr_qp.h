@@ -322,30 +322,30 @@ static inline UPR_HD void upr_qp_assemble(upr_qp_state& S, int k) {
             double c = upr_ineq_value(P, d, j, L + o.Xk, L + o.Uk, L + o.ob, L + o.dxk);
             double rp = c - t;
             w = lam / t;
-            if (d.soft && upr_slot_soft(P, d, j)) {
+            // (the mode is uniform over the workgroup: it is tested OUTSIDE the per-lane soft / hard distinction -- with the
+            // per-lane test outermost, lanes of a wave that mixes softened and hard rows lost their mode-2 value on gfx950)
+            const bool is_soft = d.soft && upr_slot_soft(P, d, j);
+            const double sig = is_soft ? L[o.sgk + j] : 0.0, tau = is_soft ? L[o.tak + j] : 1.0, gam = is_soft ? L[o.gak + j] : 0.0;
+            rp += sig;
+            if (S.mode == 2) s = -lam;                         // plain Lagrangian gradient
+            else if (is_soft) {
                 // softened row: the slack is eliminated, leaving an effective weight and gradient multiplier
-                const double sig = L[o.sgk + j], tau = L[o.tak + j], gam = L[o.gak + j];
-                rp += sig;
-                if (S.mode == 2) s = -lam;
-                else {
-                    double* rcsg = S.ws + d.ws_rcs + (size_t)k * d.ni_stage;
-                    double rc = lam * t, rcs = gam * tau;
-                    if (S.mode == 1) {
-                        const upr_soft_row a0 = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
-                        const double gdz = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob);
-                        const double dsa = -(a0.a + a0.w * gdz) / a0.D;
-                        const double dta = gdz + rp + dsa, dtaua = dsa + a0.rps;
-                        const double dla = -lam - a0.w * dta, dga = -gam - a0.ws * dtaua;
-                        rc = lam * t + dta * dla - S.sigma_mu; rcs = gam * tau + dtaua * dga - S.sigma_mu;
-                        rcg[j] = rc; rcsg[j] = rcs;
-                    } else if (S.mode == 3) { rc = rcg[j]; rcs = rcsg[j]; }
-                    const upr_soft_row r = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
-                    s = (rc + lam * rp) / t - r.w * r.a / r.D - lam;
-                    w = r.w * (r.Z + r.ws) / r.D;
-                }
+                double* rcsg = S.ws + d.ws_rcs + (size_t)k * d.ni_stage;
+                double rc = lam * t, rcs = gam * tau;
+                if (S.mode == 1) {
+                    const upr_soft_row a0 = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
+                    const double gdz = upr_ineq_dir(P, d, j, L + o.sxk, L + o.suk, L + o.ob);
+                    const double dsa = -(a0.a + a0.w * gdz) / a0.D;
+                    const double dta = gdz + rp + dsa, dtaua = dsa + a0.rps;
+                    const double dla = -lam - a0.w * dta, dga = -gam - a0.ws * dtaua;
+                    rc = lam * t + dta * dla - S.sigma_mu; rcs = gam * tau + dtaua * dga - S.sigma_mu;
+                    rcg[j] = rc; rcsg[j] = rcs;
+                } else if (S.mode == 3) { rc = rcg[j]; rcs = rcsg[j]; }
+                const upr_soft_row r = upr_soft_terms(P, d, j, t, lam, sig, tau, gam, rp, rc, rcs);
+                s = (rc + lam * rp) / t - r.w * r.a / r.D - lam;
+                w = r.w * (r.Z + r.ws) / r.D;
             }
             else if (S.mode == 0) s = w * rp;                  // predictor: rc = lam t
-            else if (S.mode == 2) s = -lam;                    // plain Lagrangian gradient
             else {
                 double rc;
                 if (S.mode == 1) {                             // corrector: build and keep the target
@@ -703,7 +703,7 @@ static inline UPR_HD void upr_qp_forward(upr_qp_state& S, double* nu_new, double
         UPR_FOR(r, ne) {
             double v = L[o.snu + r];
             for (int m = 0; m <= r; ++m) v += L[o.Lsi + r * ne + m] * L[o.ee + m];
-            L[o.wv + r] = v;
+            L[o.gjr + r] = v;   // (ne entries: wv holds nx only)
         }
         // su_j = -Lji' tj
         UPR_FOR(j, nq) {
@@ -714,7 +714,7 @@ static inline UPR_HD void upr_qp_forward(upr_qp_state& S, double* nu_new, double
         UPR_SYNC();
         UPR_FOR(r, ne) {
             double v = 0.0;
-            for (int m = r; m < ne; ++m) v += L[o.Lsi + m * ne + r] * L[o.wv + m];
+            for (int m = r; m < ne; ++m) v += L[o.Lsi + m * ne + r] * L[o.gjr + m];
             L[o.nuv + r] = v;
             nu_new[k * ne + r] = v;
         }
