@@ -272,7 +272,8 @@ def time_extra(w, steps, warmup):
     mpc = make_engine(w)
     import torch
 
-    elapsed, _ = rank_main(args, mpc, w["P"], sync_device=torch.cuda.synchronize)
+    # (the engine's own stream sync closes the timed region; torch's is added when torch owns a context in this process)
+    elapsed, _ = rank_main(args, mpc, w["P"], sync_device=torch.cuda.synchronize if torch.cuda.is_initialized() else None)
     kt, st = mpc.kernel_times(), mpc.stats()
     B = mpc.B
     roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False)

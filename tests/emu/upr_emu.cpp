@@ -96,15 +96,22 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
              const double* Df, double* ws, long ws_stride, double* stats) {
     upr_qp_args A;
     A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
-    if (P->nq == 9 && P->nb == 1 && P->nc == 4 && P->nf == 3 && P->N == 20) {
-        typedef upr_qp3_cfg<9, 1, 4, 3, 20, 1> C;
-        if (!ws) return (long)upr_qp3_ws<C>::total;
-        A.d.ws_stride = (int)ws_stride;
-        upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
-        std::vector<double> L(upr_qp3_lds<C>::total + 16);
-        for (int b = 0; b < B; ++b) upr_qp3_solve<C>(ctx, A, b, L.data());
-        return 0;
-    }
+    if (P->N != 20) return -1;
+    const bool softb = P->soft_state_box || P->soft_input_box;
+    // the instantiations libupright_mi launches (upr_api.hip: headline, UPR_QP3_EXTRA), one thread per workgroup
+#define EMU_QP3(a, b, c, e, sf, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && (cond)) { \
+        typedef upr_qp3_cfg<a, b, c, e, 20, 1, true, sf> C; \
+        if (!ws) return (long)upr_qp3_ws<C>::total; \
+        A.d.ws_stride = (int)ws_stride; \
+        upr_ctx ctx; ctx.tid = 0; ctx.nt = 1; \
+        std::vector<double> L(upr_qp3_lds<C>::total + 16, std::nan("")); \
+        for (int bb = 0; bb < B; ++bb) upr_qp3_solve<C>(ctx, A, bb, L.data()); \
+        return 0; }
+    EMU_QP3(9, 1, 4, 3, false, !softb)
+    EMU_QP3(9, 1, 4, 3, true, softb)
+    EMU_QP3(9, 1, 4, 1, true, true)
+    EMU_QP3(9, 8, 32, 1, true, true)
+#undef EMU_QP3
     return -1;
 }
 long emu_qp3_lds_doubles() { return (long)upr_qp3_lds<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; }

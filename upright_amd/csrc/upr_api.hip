@@ -220,7 +220,8 @@ struct upr_batch {
     int sqp_iters_next = 0;   // > 0: SQP iterations of the next advance only (init_sqp_iteration of the first solve)
     double last_ms = 0.0;
     int qp_nt = 0;
-    bool use_qp2 = false, use_qp3 = false;
+    bool use_qp2 = false;
+    int use_qp3 = 0;   // 0: no; 1: headline instantiations; 2: one of UPR_QP3_EXTRA (qp3_variant)
     bool use_mfma = true;
     bool timing = false;
     double k_ms[3] = {0, 0, 0};
@@ -282,16 +283,34 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     return 0;
 }
 
-// generic (runtime-dimension) QP kernel
-int launch_qp_generic(upr_batch* h, const upr_qp_args& A) {
-    const int nt = 64;
-    const upr_qp_lds lay = upr_qp_lds_layout(A.d, nt);
+// generic (runtime-dimension) QP kernel.  Its LDS footprint (one knot's matrices) allows one or two workgroups per CU for
+// the multi-body shapes, so the workgroup size IS the occupancy: 64 lanes left 3 of 4 SIMDs of a CU idle.  NT is chosen by
+// the size of the per-knot phases (ne x nx, nx x nx, ne x ne items); UPR_QP_GENERIC_NT overrides it.
+template <int NT>
+int launch_qp_generic_nt(upr_batch* h, const upr_qp_args& A) {
+    const upr_qp_lds lay = upr_qp_lds_layout(A.d, NT);
     const size_t lds = (size_t)lay.total * sizeof(double);
     if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
-    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(upr_qp_kernel<64>, dim3(h->B), dim3(64), lds, h->stream, A);
+    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(upr_qp_kernel<NT>, dim3(h->B), dim3(NT), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
+}
+int generic_nt(const upr_batch* h) {
+    if (const char* e = getenv("UPR_QP_GENERIC_NT")) return atoi(e);
+    const upr_dims& d = h->d;
+    const int big = d.ne * d.nx > d.nx * d.nx ? d.ne * d.nx : d.nx * d.nx;
+    return big >= 1024 ? 512 : (big >= 512 ? 256 : 64);
+}
+int launch_qp_generic(upr_batch* h, const upr_qp_args& A) {
+    switch (generic_nt(h)) {
+        case 64: return launch_qp_generic_nt<64>(h, A);
+        case 128: return launch_qp_generic_nt<128>(h, A);
+        case 256: return launch_qp_generic_nt<256>(h, A);
+        case 512: return launch_qp_generic_nt<512>(h, A);
+        case 1024: return launch_qp_generic_nt<1024>(h, A);
+        default: return fail("UPR_QP_GENERIC_NT must be 64, 128, 256, 512 or 1024");
+    }
 }
 
 template <class D, int NT>
@@ -330,31 +349,68 @@ size_t qp2_ws_doubles(const upr_problem& P, const upr_dims& d) {
     return 0;
 }
 
-// third-structure kernel: instantiated for the headline shape (nq 9, nb 1, nc 4, nf 3, N 20)
-template <int NT, bool ROWS>
-int launch_qp3_rows(upr_batch* h, const upr_qp_args& A) {
-    typedef upr_qp3_cfg<9, 1, 4, 3, 20, NT, ROWS> C;
+// third-structure ("production") kernel.  The headline shape (nq 9, nb 1, nc 4, nf 3, N 20) in three workgroup sizes, with
+// and without state-polytopic rows; further (shape, SOFT) instantiations at 256 lanes for the configurations the
+// reference ships with HPIPM slacks: thing_demo (one body, frictionless) and the upright_robust 8-corner arrangement.
+template <class C>
+int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
     const size_t lds = (size_t)upr_qp3_lds<C>::total * sizeof(double);
+    if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
     if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((upr_qp3_kernel<C>), dim3(h->B), dim3(NT), lds, h->stream, A);
+    hipLaunchKernelGGL((upr_qp3_kernel<C>), dim3(h->B), dim3(C::NT), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
 }
+// (nq, nb, nc, nf, SOFT) instantiations besides the headline's
+#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, true) X(9, 1, 4, 1, true) X(9, 8, 32, 1, true)
+bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
+bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }
+// can the production kernel take this problem, and in which instantiation?  0: no; 1: headline (hard boxes); 2: one of
+// UPR_QP3_EXTRA
+int qp3_variant(const upr_problem& P, const upr_dims& d) {
+    if (P.N != 20 || P.nq != 9) return 0;
+    if (d.no > UPR_QP3_NOMAX) return 0;
+    if (P.soft_poly && (d.np > 0 || d.no > 0)) return 0;      // slacks on friction / collision rows: generic kernel
+    if (d.nfc < d.ne && !P.soft_eq) return 0;                 // rank-deficient hard equality (proximal treatment): other kernels
+    if (P.nb > 1) {
+        for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) return 0;   // bodies that share contacts: dense Schur complement
+        if (P.use_feedback_policy || d.no > 0) return 0;
+    }
+    if (qp3_is_headline(P) && !soft_boxes(P)) return 1;
+    if (d.no > 0) return 0;
+#define X(a, b, c, e, sf) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e && (soft_boxes(P) || !qp3_is_headline(P))) return 2;
+    UPR_QP3_EXTRA(X)
+#undef X
+    return 0;
+}
+template <int NT, bool ROWS>
+int launch_qp3_rows(upr_batch* h, const upr_qp_args& A) { return launch_qp3_cfg<upr_qp3_cfg<9, 1, 4, 3, 20, NT, ROWS>>(h, A); }
 // problems without state-polytopic rows run the instantiation that has none compiled in (upr_qp3.h, upr_qp3_cfg)
 template <int NT>
 int launch_qp3(upr_batch* h, const upr_qp_args& A) {
     return (h->d.no > 0) ? launch_qp3_rows<NT, true>(h, A) : launch_qp3_rows<NT, false>(h, A);
 }
-bool qp3_has_shape(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
+size_t qp3_ws_doubles(const upr_problem& P, int variant) {
+    if (variant == 1) return upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 512>>::total;   // (the far arrays grow with the lanes: largest NT)
+#define X(a, b, c, e, sf) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>>::total;
+    UPR_QP3_EXTRA(X)
+#undef X
+    return 0;
+}
 
 int launch_qp(upr_batch* h, const upr_qp_args& A) {
-    if (h->use_qp3) {
+    if (h->use_qp3 == 1) {
         switch (h->qp_nt) {
             case 128: return launch_qp3<128>(h, A);
             case 256: return launch_qp3<256>(h, A);
             case 512: return launch_qp3<512>(h, A);
             default: return fail("UPR_QP_NT must be 128, 256 or 512 for the headline-shape kernel");
         }
+    }
+    if (h->use_qp3 == 2) {
+#define X(a, b, c, e, sf) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp3_cfg<upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>>(h, A);
+        UPR_QP3_EXTRA(X)
+#undef X
     }
     if (h->use_qp2) {
 #define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp2<upr_qp2_dims<a, b, c, e>>(h, A);
@@ -410,9 +466,16 @@ upr_fb_src fb_source(const upr_batch* h) {
     upr_fb_src s;
     const upr_dims& d = h->d;
     if (h->use_qp3) {
-        typedef upr_qp3_cfg<9, 1, 4, 3, 20, 256> C; typedef upr_qp3_ws<C> W; typedef upr_qp3_far<C> F;
-        s.kind = 3; s.k_base = W::far + F::Ks; s.k_stride = C::NQ * C::NX; s.lji_base = 0; s.lji_stride = 0;
-        s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NE * C::NE;
+        auto fill = [&](auto cfg) {
+            typedef decltype(cfg) C; typedef upr_qp3_ws<C> W; typedef upr_qp3_far<C> F;
+            s.kind = 3; s.k_base = W::far + F::Ks; s.k_stride = C::NQ * C::NX; s.lji_base = 0; s.lji_stride = 0;
+            s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NLS;
+        };
+        // (these offsets lie in front of everything that depends on the workgroup size or on ROWS / SOFT)
+        if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
+#define X(a, b, c, e, sf) else if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) fill(upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>());
+        UPR_QP3_EXTRA(X)
+#undef X
         return s;
     }
     if (h->use_qp2) {
@@ -526,23 +589,25 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     // collision rows (state-polytopic inequalities) are implemented in the generic kernel only
     const bool soft = P->soft_state_box || P->soft_input_box || P->soft_poly || P->soft_eq;
     const bool plain = P->n_pairs + P->n_proj == 0 && !soft;   // rows only the generic kernel has
-    h->use_qp3 = qp3_has_shape(*P) && !soft && P->n_pairs + P->n_proj <= UPR_QP3_NOMAX;   // (the production kernel takes up to UPR_QP3_NOMAX state rows per knot)
+    h->use_qp3 = qp3_variant(*P, h->d);
     h->use_qp2 = qp2_has_shape(*P) && plain;
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
-    if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = false; if (v < 2) h->use_qp2 = false; }
-    if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = false; } }
+    if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = 0; if (v < 2) h->use_qp2 = false; }
+    if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = 0; } }
     h->qp_nt = h->use_qp3 ? 256 : 128;
     if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
-    {   // both QP kernels index the instance workspace with the same stride
+    if (h->use_qp3 == 2) h->qp_nt = 256;
+    {   // every QP kernel indexes the instance workspace with the same stride: the largest any selectable one needs
         size_t need = qp2_ws_doubles(*P, h->d);
         if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;
-        if (qp3_has_shape(*P)) { need = upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
+        if (h->use_qp3) { need = qp3_ws_doubles(*P, h->use_qp3); if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
     }
     {
         char buf[128];
-        if (h->use_qp3) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, %d, %s>>", P->nq, P->nb, P->nc, P->nf, P->N, h->qp_nt, h->d.no > 0 ? "true" : "false");
+        if (h->use_qp3) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, %d, %s, %s>>", P->nq, P->nb, P->nc, P->nf, P->N, h->qp_nt,
+                                 (h->use_qp3 == 1 && h->d.no > 0) ? "true" : "false", h->use_qp3 == 2 ? "true" : "false");
         else if (h->use_qp2) snprintf(buf, sizeof(buf), "upr_qp2_kernel<upr_qp2_dims<%d, %d, %d, %d>, %d>", P->nq, P->nb, P->nc, P->nf, h->qp_nt == 512 ? 128 : h->qp_nt);
-        else snprintf(buf, sizeof(buf), "upr_qp_kernel<64>");
+        else snprintf(buf, sizeof(buf), "upr_qp_kernel<%d>", generic_nt(h));
         h->qp_name = buf;
     }
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;

@@ -24,10 +24,19 @@
 // ROWS_: the instantiation takes state-polytopic rows (collision / projectile).  Problems without such rows run the
 // ROWS_ = false instantiation, in which every trace of them folds away (their runtime trip counts and the runtime
 // Hessian offset cost 1.8 % of the headline solve when they were compiled in unconditionally); layouts do not depend on it.
-template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true>
+// SOFT_: the instantiation carries HPIPM slacks on the lane-owned box rows (state and / or input boxes, selected at run
+// time by upr_problem::soft_state_box / soft_input_box): slack, its own barrier pair and the second corrector target
+// per row.  Hard problems run the SOFT_ = false instantiation.  (A softened object-dynamics equality, soft_eq, needs no
+// state of its own -- it is the runtime regularisation rho_s = 1 / Z of the Schur complement -- and works in both.)
+// NB_ > 1 ("star" arrangements: every contact point joins the tray and one balanced body, so no two bodies share a
+// contact): the Schur complement of the object-dynamics rows is block diagonal, one 6 x 6 block per (knot, body); all
+// Schur-related phases run one lane per block exactly as the single-body kernel runs one lane per knot.
+template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true, bool SOFT_ = false>
 struct upr_qp3_cfg {
     static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
-    static constexpr bool ROWS = ROWS_;
+    static constexpr bool ROWS = ROWS_, SOFT = SOFT_, MULTI = NB_ > 1;
+    static constexpr int SB = 6, NKB = N_ * NB_;                 // Schur block size; number of (knot, body) blocks
+    static constexpr int NLS = NB_ * 36;                         // doubles of the inverse Schur factor(s) of a knot
     static constexpr int N1 = N + 1;
     static constexpr int NX = 3 * NQ, NFC = NF * NC, NU = NQ + NFC, NE = 6 * NB;
     static constexpr int NP = (NF == 3) ? 5 * NC : 0;
@@ -55,14 +64,14 @@ struct upr_qp3_far {
     static constexpr int g0 = 0, e0 = g0 + r2(C::N * C::NQ), ek = e0 + r2(C::N * C::NE), yf = ek + r2(C::N * C::NE), hf = yf + r2(C::N * C::NFC),
                          ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE), cv = zt, nun = zt + r2(C::N * C::NE), lfi = nun + r2(C::N * C::NE),
                          Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * C::NH), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
-                         hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NE * C::NE),
+                         hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NLS),
                          // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
                          // set-up and its step: 20 registers less to carry through the sweeps)
-                         cxr = Ks + r2(C::N * C::NQ * C::NX), rows = cxr + r2((2 * C::QX + 2 * C::QU) * C::NT),   // rows: parked (t, lam) of the box rows
+                         cxr = Ks + r2(C::N * C::NQ * C::NX), rows = cxr + r2((C::SOFT ? 2 : 1) * (2 * C::QX + 2 * C::QU) * C::NT),   // rows: parked (t, lam) of the box rows (SOFT: + sigma, tau, gam; cxr: + the slack pairs' targets)
                          // state-polytopic (collision / projectile) rows of knots 1 .. N-1, at most UPR_QP3_NOMAX per knot: slack,
                          // multiplier, corrector target, affine part d - G xs_q; heew = hee + (1/h) sum_r w_r G_r G_r' (what the
                          // matrix sweep and the costates use in place of hee when such rows exist)
-                         ot = rows + r2((4 * C::QX + 4 * C::QU) * C::NT), ol = ot + (C::N - 1) * UPR_QP3_NOMAX, oc = ol + (C::N - 1) * UPR_QP3_NOMAX,
+                         ot = rows + r2((C::SOFT ? 10 : 4) * (C::QX + C::QU) * C::NT), ol = ot + (C::N - 1) * UPR_QP3_NOMAX, oc = ol + (C::N - 1) * UPR_QP3_NOMAX,
                          od0 = oc + (C::N - 1) * UPR_QP3_NOMAX, heew = od0 + (C::N - 1) * UPR_QP3_NOMAX,
                          total = heew + r2(C::N * C::NH);
 };
@@ -95,7 +104,7 @@ struct upr_qp3_lds {
                          yN = ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
-                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NE * C::NE), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX), total = gee + r2(C::N * C::NQ);   // gee: end-effector part of the cost gradient
 };
 
@@ -208,7 +217,17 @@ struct upr_qp3 {
     // lane-owned box rows: [item][0 = lower, 1 = upper]
     double tx[C::QX][2], lx[C::QX][2];
     double tu[C::QU][2], lu[C::QU][2];
-    static constexpr int NCT = 2 * C::QX + 2 * C::QU;   // corrector targets per lane (F::cxr)
+    // SOFT: slack sigma of a softened box row, its own barrier pair (tau, gam); untouched otherwise
+    static constexpr int QXS = C::SOFT ? C::QX : 1, QUS = C::SOFT ? C::QU : 1;
+    double sgx[QXS][2], tax[QXS][2], gax[QXS][2];
+    double sgu[QUS][2], tau_[QUS][2], gau[QUS][2];
+    bool softx, softu;      // which box classes carry slacks (uniform over the workgroup)
+    double ZL, ZU, zL, zU;  // L2 / L1 penalties of lower / upper rows
+    double rho_s;           // regularisation of the Schur complement: UPR_QP_RHO_S, or 1 / Z for a softened equality
+    double rho_eq;          // 1 / Z for a softened equality (the row's residual is C dz + e - rho_eq nu), else 0
+    double soft_stat;       // running max of the slack stationarity |Z sigma + z - lam - gam| (residuals)
+    static constexpr int NCT0 = 2 * C::QX + 2 * C::QU;                // corrector targets of the rows per lane (F::cxr)
+    static constexpr int NCT = (C::SOFT ? 2 : 1) * NCT0;             // SOFT: + the targets of the slack pairs, behind them
     struct zero_targets_t { double v[NCT]; };
     UPR_HDI static const double (&zero_targets())[NCT] { static constexpr zero_targets_t z = {}; return z.v; }
     UPR_HDI void load_targets(double (&ctm)[NCT]) const {
@@ -224,6 +243,17 @@ struct upr_qp3 {
     UPR_HDI void store_rows() const {
         const int tid_ = tid();
         double* R = G + F::rows + tid_;
+        if (C::SOFT) {
+            double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int q = 0; q < QXS; ++q)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { Q[(6 * q + 3 * s2) * NT] = sgx[q][s2]; Q[(6 * q + 3 * s2 + 1) * NT] = tax[q][s2]; Q[(6 * q + 3 * s2 + 2) * NT] = gax[q][s2]; }
+#pragma unroll
+            for (int q = 0; q < QUS; ++q)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { Q[(6 * QXS + 6 * q + 3 * s2) * NT] = sgu[q][s2]; Q[(6 * QXS + 6 * q + 3 * s2 + 1) * NT] = tau_[q][s2]; Q[(6 * QXS + 6 * q + 3 * s2 + 2) * NT] = gau[q][s2]; }
+        }
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) { R[(4 * q) * NT] = tx[q][0]; R[(4 * q + 1) * NT] = tx[q][1]; R[(4 * q + 2) * NT] = lx[q][0]; R[(4 * q + 3) * NT] = lx[q][1]; }
 #pragma unroll
@@ -232,6 +262,17 @@ struct upr_qp3 {
     UPR_HDI void load_rows() {
         const int tid_ = tid();
         const double* R = G + F::rows + tid_;
+        if (C::SOFT) {
+            const double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int q = 0; q < QXS; ++q)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { sgx[q][s2] = Q[(6 * q + 3 * s2) * NT]; tax[q][s2] = Q[(6 * q + 3 * s2 + 1) * NT]; gax[q][s2] = Q[(6 * q + 3 * s2 + 2) * NT]; }
+#pragma unroll
+            for (int q = 0; q < QUS; ++q)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { sgu[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2) * NT]; tau_[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2 + 1) * NT]; gau[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2 + 2) * NT]; }
+        }
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) { tx[q][0] = R[(4 * q) * NT]; tx[q][1] = R[(4 * q + 1) * NT]; lx[q][0] = R[(4 * q + 2) * NT]; lx[q][1] = R[(4 * q + 3) * NT]; }
 #pragma unroll
@@ -304,6 +345,32 @@ struct upr_qp3 {
         }
     }
 
+    // The same for a softened row c + sigma >= 0, sigma >= 0 with cost 1/2 Z sigma^2 + z sigma (HPIPM slack; the
+    // arithmetic of upr_soft_terms, upr_qp.h): the slack step is eliminated from the Newton system, which leaves the
+    // effective weight w (Z + w_s) / D and the gradient multiplier (rc + lam rp) / t - w a / D - lam.  cterm / cterm_s
+    // carry rc - lam t and rc_s - gam tau (0 in the predictor).
+    UPR_HDI void row_soft(double c, double ds, double t, double lam, double sig, double tau, double gam, double Zp, double zp,
+                          double& cterm, double& cterm_s, double& s, double& w) const {
+        const double rp = c + sig - t, rps = sig - tau;
+        const double rt = upr_rcp(t), rtau = upr_rcp(tau);
+        const double w0 = lam * rt, ws_ = gam * rtau;
+        if (mode == 2) { s = -lam; w = w0; return; }
+        const double D = Zp + w0 + ws_, rD = upr_rcp(D);
+        const double base = (Zp * sig + zp - lam - gam);
+        if (mode == 0) { cterm = 0.0; cterm_s = 0.0; }
+        else if (mode == 1) {
+            const double a0 = base + (lam * t + lam * rp) * rt + (gam * tau + gam * rps) * rtau;
+            const double dsa = -(a0 + w0 * ds) * rD;
+            const double dta = ds + rp + dsa, dtaua = dsa + rps;
+            const double dla = -lam - w0 * dta, dga = -gam - ws_ * dtaua;
+            cterm = dta * dla - sigma_mu; cterm_s = dtaua * dga - sigma_mu;
+        }
+        const double g0 = (lam * t + cterm + lam * rp) * rt;
+        const double a = base + g0 + (gam * tau + cterm_s + gam * rps) * rtau;
+        s = g0 - w0 * a * rD - lam;
+        w = w0 * (Zp + ws_) * rD;
+    }
+
     // ---- flat phases: per-knot vectors and factors out of the lane-owned rows -------------------------------
     // level 0: reduced gradients + residuals only (KKT check); 1: + back-substitution vectors; 2: + factors
     UPR_HDI void prep(int level) {
@@ -341,8 +408,10 @@ struct upr_qp3 {
         }
 #ifndef UPR_HOST_EMU
         constexpr int CH = (NX + 3) / 4, QR = (N * NE * 4 + NT - 1) / NT;
-        double ckr[QR][CH], e0r[QR];
-        if (fresh) {
+        // (multi-body shapes have too many rows of C for a register prefetch: they read them where they are used)
+        constexpr bool PRE_C = QR <= 4;
+        double ckr[PRE_C ? QR : 1][CH], e0r[PRE_C ? QR : 1];
+        if (PRE_C && fresh) {
 #pragma unroll
             for (int q = 0; q < QR; ++q) {
                 const int e4 = tid_ + q * NT;
@@ -350,8 +419,8 @@ struct upr_qp3 {
                     const int e = e4 >> 2, part = e4 & 3;
                     const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) ckr[q][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
-                    e0r[q] = G[F::e0 + e];
+                    for (int c = 0; c < CH; ++c) ckr[q % (PRE_C ? QR : 1)][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                    e0r[q % (PRE_C ? QR : 1)] = G[F::e0 + e];
                 }
             }
         }
@@ -377,8 +446,15 @@ struct upr_qp3 {
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
                 double s0, s1, w0, w1;
                 double c0 = 0.0, c1 = 0.0;
-                row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], c0, s0, w0);
-                row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], c1, s1, w1);
+                if (C::SOFT && softx) {
+                    double d0 = 0.0, d1 = 0.0;
+                    row_soft(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, c0, d0, s0, w0);
+                    row_soft(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, c1, d1, s1, w1);
+                    if (mode == 1) { G[F::cxr + (NCT0 + 2 * q) * NT + tid_] = d0; G[F::cxr + (NCT0 + 2 * q + 1) * NT + tid_] = d1; }
+                } else {
+                    row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], c0, s0, w0);
+                    row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], c1, s1, w1);
+                }
                 if (mode == 1) { G[F::cxr + (2 * q) * NT + tid_] = c0; G[F::cxr + (2 * q + 1) * NT + tid_] = c1; }
                 const double g = (k < N) ? h * L[O::qd + i] * (X - L[O::xd + i]) : 0.0;   // (the end-effector part is added behind the barrier)
                 L[O::gxs + zo] = g + s0 - s1;
@@ -393,8 +469,15 @@ struct upr_qp3 {
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
                 double s0, s1, w0, w1;
                 double c0 = 0.0, c1 = 0.0;
-                row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], c0, s0, w0);
-                row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], c1, s1, w1);
+                if (C::SOFT && softu) {
+                    double d0 = 0.0, d1 = 0.0;
+                    row_soft(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, c0, d0, s0, w0);
+                    row_soft(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, c1, d1, s1, w1);
+                    if (mode == 1) { G[F::cxr + (NCT0 + 2 * C::QX + 2 * q) * NT + tid_] = d0; G[F::cxr + (NCT0 + 2 * C::QX + 2 * q + 1) * NT + tid_] = d1; }
+                } else {
+                    row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], c0, s0, w0);
+                    row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], c1, s1, w1);
+                }
                 if (mode == 1) { G[F::cxr + (2 * C::QX + 2 * q) * NT + tid_] = c0; G[F::cxr + (2 * C::QX + 2 * q + 1) * NT + tid_] = c1; }
                 L[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
                 L[O::wu + iu] = w0 + w1;
@@ -438,6 +521,7 @@ struct upr_qp3 {
             G[F::heew + k * C::NH + t] = G[F::hee + k * C::NH + t] + v / h;
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
+        if (C::MULTI && no > 0) UPR_SYNC();   // (Z of the multi-body shapes extends over the LDS the row multipliers above were staged in)
         for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
             if (ic < C::NCI) {
@@ -464,12 +548,24 @@ struct upr_qp3 {
                         if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
                         for (int a = 0; a < 9; ++a) Bk[a] = Hc[a];
                         // Z = Lf^-1 Df' of this contact (S = Z'Z + rho I is assembled in phase C); staged where the sweeps keep P
+                        if (C::MULTI) {
+                            // star arrangement: the contact loads one body only, Z keeps that body's six rows, [knot][force][6]
+                            const int b2 = P->contact_body2[ci];
+#pragma unroll
+                            for (int r6 = 0; r6 < 6; ++r6) {
+                                const double* dr = L + O::df + (6 * b2 + r6) * NFC + 3 * ci;
+                                const double d0 = dr[0], d1 = dr[1], d2 = dr[2];
+                                double* zr = L + O::Pa + (k * NFC + 3 * ci) * 6 + r6;
+                                zr[0] = Hc[0] * d0; zr[6] = Hc[3] * d0 + Hc[4] * d1; zr[12] = Hc[6] * d0 + Hc[7] * d1 + Hc[8] * d2;
+                            }
+                        } else {
 #pragma unroll
                         for (int r = 0; r < NE; ++r) {
                             const double* dr = L + O::df + r * NFC + 3 * ci;
                             const double d0 = dr[0], d1 = dr[1], d2 = dr[2];
                             double* zr = L + O::Pa + (k * NE + r) * NFC + 3 * ci;
                             zr[0] = Hc[0] * d0; zr[1] = Hc[3] * d0 + Hc[4] * d1; zr[2] = Hc[6] * d0 + Hc[7] * d1 + Hc[8] * d2;
+                        }
                         }
                     }
                     double yv[3], hv[3];
@@ -482,7 +578,8 @@ struct upr_qp3 {
                     if (factor) {
                         const double lf0 = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
                         G[F::lfi + k * C::NLF + ci] = lf0;
-                        for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
+                        if (C::MULTI) { const int b2 = P->contact_body2[ci]; for (int r6 = 0; r6 < 6; ++r6) L[O::Pa + (k * NFC + ci) * 6 + r6] = lf0 * L[O::df + (6 * b2 + r6) * NFC + ci]; }
+                        else for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
                     }
                     const double lf = G[F::lfi + k * C::NLF + ci];
                     const double yv = lf * L[O::gus + uo];
@@ -500,14 +597,22 @@ struct upr_qp3 {
                 const int e4 = tid_ + q * NT;
                 const bool act = e4 < N * NE * 4;
                 const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
-                double v = 0.0;
+                double v = 0.0, e0v = 0.0;
                 if (act) {
                     const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+                    if (PRE_C) {
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q][c] * zx[c];
+                        for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q % (PRE_C ? QR : 1)][c] * zx[c];
+                        e0v = e0r[q % (PRE_C ? QR : 1)];
+                    } else {
+                        const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) if (part * CH + c < NX) v += Ck[c] * zx[c];
+                        e0v = G[F::e0 + e];
+                    }
                 }
                 v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                if (act && part == 0) L[O::ek + e] = v + e0r[q];
+                if (act && part == 0) L[O::ek + e] = v + e0v;
             }
             UPR_SYNC_LDS();
         }
@@ -536,11 +641,11 @@ struct upr_qp3 {
             L[O::ys + e] = v - v2;
         }
 #endif
-        if (factor) {
+        if (factor && !C::MULTI) {
             UPR_FORT(e, N * NE * NE) {
                 const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
                 if (c > r) continue;
-                double acc = (r == c) ? UPR_QP_RHO_S : 0.0;
+                double acc = (r == c) ? rho_s : 0.0;
                 const double* zr = L + O::Pa + (k * NE + r) * NFC; const double* zc = L + O::Pa + (k * NE + c) * NFC;
 #pragma unroll
                 for (int i = 0; i < NFC; ++i) acc += zr[i] * zc[i];
@@ -551,43 +656,72 @@ struct upr_qp3 {
         if (level == 0) return;
         // (phase E's rows of C come out of global memory: fetched here, consumed behind phase D)
         constexpr int QE = (N * NX + NT - 1) / NT;
-        double ckp[QE][NE];
+        constexpr bool PRE_E = QE * NE <= 24;
+        double ckp[PRE_E ? QE : 1][PRE_E ? NE : 1];
+        if (PRE_E) {
 #pragma unroll
-        for (int q = 0; q < QE; ++q) {
-            const int e = tid_ + q * NT;
-            if (e < N * NX) {
-                const double* Ck = rec(e / NX) + lin_gx + e % NX;
+            for (int q = 0; q < QE; ++q) {
+                const int e = tid_ + q * NT;
+                if (e < N * NX) {
+                    const double* Ck = rec(e / NX) + lin_gx + e % NX;
 #pragma unroll
-                for (int r = 0; r < NE; ++r) ckp[q][r] = Ck[r * NX];
+                    for (int r = 0; r < NE; ++r) ckp[q % (PRE_E ? QE : 1)][r % (PRE_E ? NE : 1)] = Ck[r * NX];
+                }
             }
         }
-        // D: one lane per knot: Schur factor (LDS staging -> global), ys = Lsi ee, zt = Lsi' ys
-        UPR_FORT(k, N) {
-            double* Ls = G + F::lsi + k * NE * NE;
-            double Lr[NE * NE];                                   // the inverse factor stays in registers for the two products
+        // D: one lane per Schur block (a knot; a (knot, body) pair of the multi-body shapes): factor (LDS staging -> global),
+        // ys = Lsi ee, zt = Lsi' ys
+        constexpr int SB = C::SB;
+        UPR_FORT(kb, C::NKB) {
+            double* Ls = G + F::lsi + kb * SB * SB;
+            double Lr[SB * SB];                                   // the inverse factor stays in registers for the two products
             if (factor) {
-                if (!upr_chol_inv_serial<NE>(L + O::hux + k * NE * NE, Lr)) L[O::misc] = 1.0;
+                bool ok;
+                if (C::MULTI) {
+                    // S_b = rho I + sum over the forces of this body z z' out of the staged Z (nothing else touches the block)
+                    const int k = kb / C::NB, b = kb % C::NB;
+                    double Sm[SB * SB];
 #pragma unroll
-                for (int e = 0; e < NE * NE; ++e) Ls[e] = Lr[e];
+                    for (int r = 0; r < SB; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) Sm[r * SB + c] = (r == c) ? rho_s : 0.0;
+                    for (int ci = 0; ci < NC; ++ci) {
+                        if (P->contact_body2[ci] != b) continue;
+                        for (int a = 0; a < NF; ++a) {
+                            const double* z = L + O::Pa + (k * NFC + NF * ci + a) * 6;
+                            double zv[SB];
+#pragma unroll
+                            for (int r = 0; r < SB; ++r) zv[r] = z[r];
+#pragma unroll
+                            for (int r = 0; r < SB; ++r)
+#pragma unroll
+                                for (int c = 0; c <= r; ++c) Sm[r * SB + c] += zv[r] * zv[c];
+                        }
+                    }
+                    ok = upr_chol_inv_serial<SB>(Sm, Lr);
+                } else ok = upr_chol_inv_serial<SB>(L + O::hux + kb * SB * SB, Lr);
+                if (!ok) L[O::misc] = 1.0;
+#pragma unroll
+                for (int e = 0; e < SB * SB; ++e) Ls[e] = Lr[e];
             } else {
 #pragma unroll
-                for (int r = 0; r < NE; ++r)
+                for (int r = 0; r < SB; ++r)
 #pragma unroll
-                    for (int m = 0; m <= r; ++m) Lr[r * NE + m] = Ls[r * NE + m];
+                    for (int m = 0; m <= r; ++m) Lr[r * SB + m] = Ls[r * SB + m];
             }
-            double ee[NE], yv[NE];
+            double ee[SB], yv[SB];
 #pragma unroll
-            for (int r = 0; r < NE; ++r) ee[r] = L[O::ys + k * NE + r];
+            for (int r = 0; r < SB; ++r) ee[r] = L[O::ys + kb * SB + r];
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = 0.0;
+            for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = 0; m <= r; ++m) v += Lr[r * NE + m] * ee[m];
+                for (int m = 0; m <= r; ++m) v += Lr[r * SB + m] * ee[m];
                 yv[r] = v; }
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = 0.0;
+            for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = r; m < NE; ++m) v += Lr[m * NE + r] * yv[m];
-                L[O::ys + k * NE + r] = yv[r]; L[O::zt + k * NE + r] = v; }
+                for (int m = r; m < SB; ++m) v += Lr[m * SB + r] * yv[m];
+                L[O::ys + kb * SB + r] = yv[r]; L[O::zt + kb * SB + r] = v; }
         }
         UPR_SYNC(); toc(4);
         // E: cs = C' zt
@@ -597,8 +731,14 @@ struct upr_qp3 {
             if (e < N * NX) {
                 const int k = e / NX;
                 double v = 0.0;
+                if (PRE_E) {
 #pragma unroll
-                for (int r = 0; r < NE; ++r) v += ckp[q][r] * L[O::zt + k * NE + r];
+                    for (int r = 0; r < NE; ++r) v += ckp[q % (PRE_E ? QE : 1)][r % (PRE_E ? NE : 1)] * L[O::zt + k * NE + r];
+                } else {
+                    const double* Ck = rec(k) + lin_gx + e % NX;
+#pragma unroll 8
+                    for (int r = 0; r < NE; ++r) v += Ck[r * NX] * L[O::zt + k * NE + r];
+                }
                 L[O::cs + e] = v;
             }
         }
@@ -643,7 +783,7 @@ struct upr_qp3 {
         {
             const double* Ck = rec(N - 1) + lin_gx;
             UPR_FORT(e, NE * NX) L[O::ck + e] = Ck[e];
-            UPR_FORT(e, NE * NE) L[O::lsik + e] = G[F::lsi + (N - 1) * NE * NE + e];
+            UPR_FORT(e, C::NLS) L[O::lsik + e] = G[F::lsi + (N - 1) * C::NLS + e];
             UPR_FORT(e, C::NH) L[O::heek + ((N - 1) & 1) * O::r2(C::NH) + e] = G[hee_w + (N - 1) * C::NH + e];
         }
         UPR_FORT(e, NX * NX) {
@@ -665,7 +805,7 @@ struct upr_qp3 {
         for (int k = N - 1; k >= 0; --k) {
             // next knot's C, Lsi, Hee: global -> registers now, -> LDS after the barrier (their readers are in phase 1 /
             // in the accumulator preload of the NEXT knot)
-            constexpr int NPF = NE * NX + NE * NE + C::NH, CKQ = (NPF + NT - 1) / NT;
+            constexpr int NLS = C::NLS, NPF = NE * NX + NLS + C::NH, CKQ = (NPF + NT - 1) / NT;
             double ckn[CKQ];
             const int tid_ = tid();
 #pragma unroll
@@ -674,8 +814,8 @@ struct upr_qp3 {
                 double v = 0.0;
                 if (k > 0) {
                     if (f < NE * NX) v = rec(k - 1)[lin_gx + f];
-                    else if (f < NE * NX + NE * NE) v = G[F::lsi + (k - 1) * NE * NE + (f - NE * NX)];
-                    else if (f < NPF) v = G[hee_w + (k - 1) * C::NH + (f - NE * NX - NE * NE)];
+                    else if (f < NE * NX + NLS) v = G[F::lsi + (k - 1) * NLS + (f - NE * NX)];
+                    else if (f < NPF) v = G[hee_w + (k - 1) * C::NH + (f - NE * NX - NLS)];
                 }
                 ckn[q] = v;
             }
@@ -686,13 +826,14 @@ struct upr_qp3 {
             // (a wave that holds two job kinds runs them one after the other: the 27-term dot products must not share
             // a wave with anything else)
             constexpr int PB0 = (NT >= 256) ? NT - 64 : ((NQ * NQ + NVC + 1) & ~1);
-            static_assert(VC0 >= NQ * NQ && PB0 >= VC0 + NVC && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
+            static_assert(VC0 >= NQ * NQ && PB0 > VC0 && (C::MULTI || PB0 >= VC0 + NVC) && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
 #ifndef UPR_HOST_EMU
             constexpr int NPB = 2 * NX;   // P+ b: a lane pair per row (two halves of the 27 terms, summed by DPP): it was the late wave of phase 1
 #else
             constexpr int NPB = NX;
 #endif
-            static_assert(N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux, "prep stages Z and S in the sweeps' working set");
+            static_assert(C::MULTI || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux), "prep stages Z and S in the sweeps' working set");
+            static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
             UPR_FORT(e, PB0 + NPB) {
                 if (e < NQ * NQ) {
@@ -727,17 +868,19 @@ struct upr_qp3 {
                     if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
                     // lower triangle, packed: the factoring wave reads it with paired 128-bit loads (it is the wave phase 2 waits for)
                     if (jj <= ii) L[O::hjj + ii * (ii + 1) / 2 + jj] = v;
-                } else if (e >= VC0 && e < VC0 + NVC) {
-                    if (k > 0) {
-                        const int f = e - VC0, g = f / NX, c = f % NX, r0 = 3 * g;
-                        const double* Ls = L + O::lsik;
+                } else if (e >= VC0 && e < ((NVC <= PB0 - VC0) ? VC0 + NVC : PB0)) {
+                    // (the multi-body shapes have more jobs than lanes between VC0 and PB0: those lanes take several)
+                    if (k > 0) for (int f = e - VC0; f < NVC; f += PB0 - VC0) {
+                        // three rows (r0 .. r0 + 2 of the knot) of the block of body g / 2: Vc = blockdiag(Lsi_b) C
+                        const int g = f / NX, c = f % NX, r0 = 3 * g, bo = 6 * (g >> 1), q0 = r0 - bo;
+                        const double* Ls = L + O::lsik + 36 * (g >> 1);
                         double v0 = 0.0, v1 = 0.0, v2 = 0.0;
                         // full-length rows with the entries above the diagonal masked: no lane-dependent trip count
 #pragma unroll
-                        for (int m = 0; m < NE; ++m) {
-                            const double cm = L[O::ck + m * NX + c];
-                            const double l0 = Ls[r0 * NE + m], l1 = Ls[(r0 + 1) * NE + m], l2 = Ls[(r0 + 2) * NE + m];
-                            v0 += ((m <= r0) ? l0 : 0.0) * cm; v1 += ((m <= r0 + 1) ? l1 : 0.0) * cm; v2 += ((m <= r0 + 2) ? l2 : 0.0) * cm;
+                        for (int m = 0; m < 6; ++m) {
+                            const double cm = L[O::ck + (bo + m) * NX + c];
+                            const double l0 = Ls[q0 * 6 + m], l1 = Ls[(q0 + 1) * 6 + m], l2 = Ls[(q0 + 2) * 6 + m];
+                            v0 += ((m <= q0) ? l0 : 0.0) * cm; v1 += ((m <= q0 + 1) ? l1 : 0.0) * cm; v2 += ((m <= q0 + 2) ? l2 : 0.0) * cm;
                         }
                         L[O::vc + r0 * NX + c] = v0; L[O::vc + (r0 + 1) * NX + c] = v1; L[O::vc + (r0 + 2) * NX + c] = v2;
                     }
@@ -777,7 +920,7 @@ struct upr_qp3 {
             // receives D[(l >> 4) + 4 r][l & 15].  Tile t belongs to wave 1 + t % (nwaves - 1) (wave 0 is busy
             // with the factorisation), which keeps the accumulator in registers across the barrier.
             typedef double v4d __attribute__((ext_vector_type(4)));
-            constexpr bool MFMA = (NX <= 32 && NQ <= 12 && NE <= 8);
+            constexpr bool MFMA = (NX <= 32 && NQ <= 12);
             constexpr int nwaves = NT >> 6;
             const int wave = wb >> 6, lane = this->lane();
             v4d acc[3];
@@ -929,8 +1072,8 @@ struct upr_qp3 {
                 for (int q = 0; q < CKQ; ++q) {
                     const int f = tid_ + q * NT;
                     if (f < NE * NX) L[O::ck + f] = ckn[q];
-                    else if (f < NE * NX + NE * NE) L[O::lsik + (f - NE * NX)] = ckn[q];
-                    else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NE * NE)] = ckn[q];
+                    else if (f < NE * NX + NLS) L[O::lsik + (f - NE * NX)] = ckn[q];
+                    else if (f < NPF) L[O::heek + ((k - 1) & 1) * O::r2(C::NH) + (f - NE * NX - NLS)] = ckn[q];
                 }
             }
             mtoc(4);
@@ -1066,12 +1209,15 @@ struct upr_qp3 {
         // call: the waves that idle during the serial sweep fetch them into registers meanwhile, and the tail runs on
         // those waves (lane index tl) out of registers and LDS.
         constexpr int NTL = NT - 64, CH = (NX + 3) / 4, QV = (N * NE * 4 + NTL - 1) / NTL, QCT = (C::NCI + NTL - 1) / NTL;
-        static_assert(N <= NTL && NTL % 4 == 0, "tail lanes");
+        static_assert(C::NKB <= NTL && NTL % 4 == 0, "tail lanes: one per Schur block");
         const int tl = tid() - 64;
-        double ckq[QV][CH], lsr[NE * NE], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
         constexpr int QCS = (N * NX + NTL - 1) / NTL;
         constexpr int QH = (N * NQ + NTL - 1) / NTL;
-        double heeq[QH][NQ], ckc[QCS][NE];
+        // (register prefetch of the rows of C only where they fit: the multi-body shapes read them behind the sweep)
+        constexpr bool PRE_V = QV <= 6, PRE_K = QCS * NE <= 24;
+        constexpr int SB = C::SB;
+        double ckq[PRE_V ? QV : 1][CH], lsr[SB * SB], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
+        double heeq[QH][NQ], ckc[PRE_K ? QCS : 1][PRE_K ? NE : 1];
 #endif
         if (wave0()) {
             // knot 0: sx_0 = 0
@@ -1159,21 +1305,23 @@ struct upr_qp3 {
 #ifndef UPR_HOST_EMU
         else {
             load_rows();
+            if (PRE_V) {
 #pragma unroll
-            for (int q = 0; q < QV; ++q) {
-                const int e4 = tl + q * NTL;
-                if (e4 < N * NE * 4) {
-                    const int e = e4 >> 2, part = e4 & 3;
-                    const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+                for (int q = 0; q < QV; ++q) {
+                    const int e4 = tl + q * NTL;
+                    if (e4 < N * NE * 4) {
+                        const int e = e4 >> 2, part = e4 & 3;
+                        const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) ckq[q][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                        for (int c = 0; c < CH; ++c) ckq[q % (PRE_V ? QV : 1)][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                    }
                 }
             }
-            if (tl < N) {
+            if (tl < C::NKB) {
 #pragma unroll
-                for (int r = 0; r < NE; ++r)
+                for (int r = 0; r < SB; ++r)
 #pragma unroll
-                    for (int m = 0; m <= r; ++m) lsr[r * NE + m] = G[F::lsi + tl * NE * NE + r * NE + m];
+                    for (int m = 0; m <= r; ++m) lsr[r * SB + m] = G[F::lsi + tl * SB * SB + r * SB + m];
             }
             if (COST) {
 #pragma unroll
@@ -1185,13 +1333,15 @@ struct upr_qp3 {
                         for (int j = 0; j < NQ; ++j) heeq[q][j] = G[hee_w + k * C::NH + upr_tri(NQ, i, j)];
                     }
                 }
+                if (PRE_K) {
 #pragma unroll
-                for (int q = 0; q < QCS; ++q) {
-                    const int e = tl + q * NTL;
-                    if (e < N * NX) {
-                        const double* Ck = rec(e / NX) + lin_gx + e % NX;
+                    for (int q = 0; q < QCS; ++q) {
+                        const int e = tl + q * NTL;
+                        if (e < N * NX) {
+                            const double* Ck = rec(e / NX) + lin_gx + e % NX;
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) ckc[q][r] = Ck[r * NX];
+                            for (int r = 0; r < NE; ++r) ckc[q % (PRE_K ? QCS : 1)][r % (PRE_K ? NE : 1)] = Ck[r * NX];
+                        }
                     }
                 }
             }
@@ -1223,8 +1373,14 @@ struct upr_qp3 {
             double v = 0.0;
             if (act) {
                 const double* sx = Sx(e / NE) + part * CH;
+                if (PRE_V) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckq[q][c] * sx[c];
+                    for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckq[q % (PRE_V ? QV : 1)][c] * sx[c];
+                } else {
+                    const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) if (part * CH + c < NX) v += Ck[c] * sx[c];
+                }
             }
             v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
             if (act && part == 0) L[O::cv + e] = v;
@@ -1244,21 +1400,21 @@ struct upr_qp3 {
         }
         UPR_SYNC_LDS();
         // nu+ of a knot by its lane: in place over cv (LDS, what the contact step and the costates read) and to global
-        if (tl >= 0 && tl < N) {
-            const int k = tl;
-            double cvr[NE], t1[NE];
+        if (tl >= 0 && tl < C::NKB) {
+            const int kb = tl;   // Schur block: a knot, or a (knot, body) pair
+            double cvr[SB], t1[SB];
 #pragma unroll
-            for (int r = 0; r < NE; ++r) cvr[r] = L[O::cv + k * NE + r];
+            for (int r = 0; r < SB; ++r) cvr[r] = L[O::cv + kb * SB + r];
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = L[O::ys + k * NE + r];
+            for (int r = 0; r < SB; ++r) { double v = L[O::ys + kb * SB + r];
 #pragma unroll
-                for (int m = 0; m <= r; ++m) v += lsr[r * NE + m] * cvr[m];
+                for (int m = 0; m <= r; ++m) v += lsr[r * SB + m] * cvr[m];
                 t1[r] = v; }
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = 0.0;
+            for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = r; m < NE; ++m) v += lsr[m * NE + r] * t1[m];
-                L[O::cv + k * NE + r] = v; G[F::nun + k * NE + r] = v; }
+                for (int m = r; m < SB; ++m) v += lsr[m * SB + r] * t1[m];
+                L[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
         }
         UPR_SYNC_LDS();
 #pragma unroll
@@ -1268,10 +1424,11 @@ struct upr_qp3 {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
                     double dfn[3], tf[3];
+                    const int rb = C::MULTI ? 6 * P->contact_body2[ci] : 0;   // the six rows of the body this contact loads
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = 0.0;
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * L[O::cv + k * NE + r];
+                        for (int r = 0; r < 6; ++r) v += L[O::df + (rb + r) * NFC + 3 * ci + a] * L[O::cv + k * NE + rb + r];
                         dfn[a] = v; }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = yfq[q][a];
@@ -1285,8 +1442,9 @@ struct upr_qp3 {
                         Su(k)[NQ + 3 * ci + a] = -v; }
                 } else {
                     double dfn = 0.0;
+                    const int rb = C::MULTI ? 6 * P->contact_body2[ci] : 0;
 #pragma unroll
-                    for (int r = 0; r < NE; ++r) dfn += L[O::df + r * NFC + ci] * L[O::cv + k * NE + r];
+                    for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb + r) * NFC + ci] * L[O::cv + k * NE + rb + r];
                     const double lf = bkq[q][0];
                     Su(k)[NQ + ci] = -lf * (yfq[q][0] + lf * dfn);
                 }
@@ -1301,19 +1459,20 @@ struct upr_qp3 {
             L[O::cv + e] = v;
         }
         UPR_SYNC();
-        UPR_FORT(k, N) {
-            const double* Ls = G + F::lsi + k * NE * NE;
-            double t1[NE];
+        UPR_FORT(kb, C::NKB) {
+            constexpr int SB = C::SB;
+            const double* Ls = G + F::lsi + kb * SB * SB;
+            double t1[SB];
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = L[O::ys + k * NE + r];
+            for (int r = 0; r < SB; ++r) { double v = L[O::ys + kb * SB + r];
 #pragma unroll
-                for (int m = 0; m <= r; ++m) v += Ls[r * NE + m] * L[O::cv + k * NE + m];
+                for (int m = 0; m <= r; ++m) v += Ls[r * SB + m] * L[O::cv + kb * SB + m];
                 t1[r] = v; }
 #pragma unroll
-            for (int r = 0; r < NE; ++r) { double v = 0.0;
+            for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
-                for (int m = r; m < NE; ++m) v += Ls[m * NE + r] * t1[m];
-                L[O::cv + k * NE + r] = v; G[F::nun + k * NE + r] = v; }
+                for (int m = r; m < SB; ++m) v += Ls[m * SB + r] * t1[m];
+                L[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
@@ -1354,8 +1513,14 @@ struct upr_qp3 {
                     const double sxi = Sx(k)[i];
                     double v = L[O::gxs + e] + L[O::wx + e] * sxi + h * L[O::qd + i] * sxi;
                     if (i < NQ) v += L[O::gee + k * NQ + i];
+                    if (PRE_K) {
 #pragma unroll
-                    for (int r = 0; r < NE; ++r) v += ckc[q][r] * L[O::cv + k * NE + r];
+                        for (int r = 0; r < NE; ++r) v += ckc[q % (PRE_K ? QCS : 1)][r % (PRE_K ? NE : 1)] * L[O::cv + k * NE + r];
+                    } else {
+                        const double* Ck = rec(k) + lin_gx + i;
+#pragma unroll 8
+                        for (int r = 0; r < NE; ++r) v += Ck[r * NX] * L[O::cv + k * NE + r];
+                    }
                     pin[e] = v;
                 }
             }
@@ -1431,6 +1596,28 @@ struct upr_qp3 {
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
         else { t += alpha * dt; lam += alpha * dl; }
     }
+    // softened row (see row_soft): what 3 also folds the slack pair into the residuals (|sigma - tau| into acc, gam tau into
+    // aux, the slack stationarity into soft_stat)
+    UPR_HDI void sweep_row_soft(int what, double alpha, double c, double ds, double& t, double& lam, double& sig, double& tau, double& gam,
+                                double Zp, double zp, double cterm, double cterm_s, double& acc, double* aux) {
+        const double rp = c + sig - t, rps = sig - tau;
+        if (what == 3) {
+            const double a = fmax(fabs(rp), fabs(rps)); if (a > acc) acc = a;
+            *aux += lam * t + gam * tau;
+            soft_stat = fmax(soft_stat, fabs(Zp * sig + zp - lam - gam));
+            return;
+        }
+        const double rc = (mode == 0) ? lam * t : lam * t + cterm, rcs = (mode == 0) ? gam * tau : gam * tau + cterm_s;
+        const double rt = upr_rcp(t), rtau = upr_rcp(tau);
+        const double w0 = lam * rt, ws_ = gam * rtau, rD = upr_rcp(Zp + w0 + ws_);
+        const double a = (Zp * sig + zp - lam - gam) + (rc + lam * rp) * rt + (rcs + gam * rps) * rtau;
+        const double dsg = -(a + w0 * ds) * rD;
+        const double dt = ds + rp + dsg, dtau = dsg + rps;
+        const double dl = -(rc + lam * dt) * rt, dg = -(rcs + gam * dtau) * rtau;
+        if (what == 0) acc = fmax(fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam))), fmax(-dtau * rtau, -dg * upr_rcp(gam)));
+        else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
+        else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
+    }
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
         double acc = 0.0;
         const int tid_ = tid();
@@ -1440,8 +1627,13 @@ struct upr_qp3 {
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
-                sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], acc, aux);
-                sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], acc, aux);
+                if (C::SOFT && softx) {
+                    sweep_row_soft(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, ctm[2 * q], ctm[(NCT0 + 2 * q) % NCT], acc, aux);
+                    sweep_row_soft(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, ctm[2 * q + 1], ctm[(NCT0 + 2 * q + 1) % NCT], acc, aux);
+                } else {
+                    sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], acc, aux);
+                    sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], acc, aux);
+                }
             }
         }
 #pragma unroll
@@ -1450,8 +1642,13 @@ struct upr_qp3 {
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
-                sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q], acc, aux);
-                sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1], acc, aux);
+                if (C::SOFT && softu) {
+                    sweep_row_soft(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, ctm[2 * C::QX + 2 * q], ctm[(NCT0 + 2 * C::QX + 2 * q) % NCT], acc, aux);
+                    sweep_row_soft(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, ctm[2 * C::QX + 2 * q + 1], ctm[(NCT0 + 2 * C::QX + 2 * q + 1) % NCT], acc, aux);
+                } else {
+                    sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q], acc, aux);
+                    sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1], acc, aux);
+                }
             }
         }
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
@@ -1528,12 +1725,14 @@ struct upr_qp3 {
             r_eq = fmax(r_eq, fabs(v + h * a + h2 * u - Xn[NQ + j]));
             r_eq = fmax(r_eq, fabs(a + h * u - Xn[2 * NQ + j]));
         }
-        UPR_FORT(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e]));
+        UPR_FORT(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e] - rho_eq * nu[e]));
         terminal_residual();
         UPR_SYNC();
         if (neN > 0) UPR_FORT(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
         double lt = 0.0;
+        soft_stat = 0.0;
         const double r_in = ineq_sweep(3, 0.0, &lt, zero_targets());
+        if (C::SOFT) r_stat = fmax(r_stat, soft_stat);
         res[0] = r_stat; res[1] = r_eq; res[2] = r_in; res[3] = lt;
         reduce4(res);
         res[3] /= (ntot > 0 ? ntot : 1);
@@ -1585,6 +1784,9 @@ struct upr_qp3 {
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
+        softx = C::SOFT && P->soft_state_box != 0; softu = C::SOFT && P->soft_input_box != 0;
+        ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
+        rho_eq = upr_qp_rho_soft(P); rho_s = P->soft_eq ? rho_eq : UPR_QP_RHO_S;
         prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
         if (prof) UPR_FORT(i, 64) L[O::prf + i] = 0.0;
         tic();
@@ -1640,6 +1842,7 @@ struct upr_qp3 {
                 tx[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tx[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
                 lx[q][0] = UPR_QP_MU0 / tx[q][0]; lx[q][1] = UPR_QP_MU0 / tx[q][1];
             }
+            if (C::SOFT) for (int s2 = 0; s2 < 2; ++s2) { sgx[q % QXS][s2] = 0.0; tax[q % QXS][s2] = (softx && ix < C::NXI) ? UPR_QP_THR : 1.0; gax[q % QXS][s2] = (softx && ix < C::NXI) ? UPR_QP_MU0 / UPR_QP_THR : 0.0; }
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
@@ -1651,6 +1854,7 @@ struct upr_qp3 {
                 tu[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tu[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
                 lu[q][0] = UPR_QP_MU0 / tu[q][0]; lu[q][1] = UPR_QP_MU0 / tu[q][1];
             }
+            if (C::SOFT) for (int s2 = 0; s2 < 2; ++s2) { sgu[q % QUS][s2] = 0.0; tau_[q % QUS][s2] = (softu && iu < C::NUI) ? UPR_QP_THR : 1.0; gau[q % QUS][s2] = (softu && iu < C::NUI) ? UPR_QP_MU0 / UPR_QP_THR : 0.0; }
         }
         store_rows();
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
@@ -1667,7 +1871,7 @@ struct upr_qp3 {
             }
         }
         UPR_SYNC();
-        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no;
+        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no + (softx ? N * 2 * NX : 0) + (softu ? N * 2 * NU : 0);   // each softened row adds the pair (tau, gam)
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
@@ -1764,7 +1968,7 @@ static UPR_HDI void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int 
 
 #ifndef UPR_HOST_EMU
 template <class C>
-__global__ void __launch_bounds__(C::NT, (C::NT <= 256) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
+__global__ void __launch_bounds__(C::NT, (C::NT <= 256 && !C::MULTI) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
     upr_qp3_solve<C>(ctx, A, blockIdx.x, smem);
