@@ -748,7 +748,7 @@ def test_config3_shape_three_objects_and_static_obstacles(arrangements):
         assert rows.min() > -1e-6
         assert np.abs(O.ee_kinematics(xs[b, P.N])[:3] - way[b, 0]).max() < 1e-5
         # both reach the same local solution although the early (infeasible) QPs are not well defined
-        assert np.abs(xs[b] - xo).max() < 5e-3
+        assert np.abs(xs[b] - xo).max() < P.delta_tol   # the SQP's own step tolerance (controller.yaml:58)
     mpc.close()
 
 
@@ -794,7 +794,7 @@ def test_dynamic_obstacle_and_projectile_constraint(arrangements):
         O = Oracle(P); O.set_dynamic_obstacle(dyn[b], 1.0)
         xo, uo, so, rc = O.solve(0.0, x0r[b], xs0r[b], us0[b])
         assert rc == 0 and st["qp_status_last"][b] == 0 and st["constraint_violation"][b] < 1e-3
-        assert np.abs(xs[b, :, :27] - xo).max() < 5e-3
+        assert np.abs(xs[b, :, :27] - xo).max() < P.delta_tol
         rows = np.array([O.obstacle_rows(xs[b, k, :27], jac=False, tau=k * P.dt) for k in range(1, P.N)])
         rows_free = np.array([O.obstacle_rows(xf[b, k, :27], jac=False, tau=k * P.dt) for k in range(1, P.N)])
         assert rows.min() > -1e-4 and rows[:, 3].min() < 1e-4          # the projectile row is active, nothing violated (SQP tolerance)

@@ -5,7 +5,7 @@ TAG=${1:-mf}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU --output-format csv -d $OUT/prof_${TAG}_mf -o ${TAG} -- python3 $ARGS > $OUT/prof_${TAG}_mf.log 2>&1
 python3 - <<PY
 import csv,glob,collections
