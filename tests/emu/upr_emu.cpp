@@ -99,8 +99,9 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
     if (P->N != 20) return -1;
     const bool softb = P->soft_state_box || P->soft_input_box;
     // the instantiations libupright_mi launches (upr_api.hip: headline, UPR_QP3_EXTRA), one thread per workgroup
-#define EMU_QP3(a, b, c, e, sf, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && (cond)) { \
-        typedef upr_qp3_cfg<a, b, c, e, 20, 1, true, sf> C; \
+#define EMU_QP3(a, b, c, e, sf, cond) EMU_QP3D(a, b, c, e, sf, false, cond)
+#define EMU_QP3D(a, b, c, e, sf, dense, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && (cond)) { \
+        typedef upr_qp3_cfg<a, b, c, e, 20, 1, true, sf, dense> C; \
         if (!ws) return (long)upr_qp3_ws<C>::total; \
         A.d.ws_stride = (int)ws_stride; \
         upr_ctx ctx; ctx.tid = 0; ctx.nt = 1; \
@@ -111,7 +112,9 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
     EMU_QP3(9, 1, 4, 3, true, softb)
     EMU_QP3(9, 1, 4, 1, true, true)
     EMU_QP3(9, 8, 32, 1, true, true)
+    EMU_QP3D(9, 3, 16, 3, false, true, !softb)
 #undef EMU_QP3
+#undef EMU_QP3D
     return -1;
 }
 long emu_qp3_lds_doubles() { return (long)upr_qp3_lds<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; }

@@ -1226,14 +1226,14 @@ def test_production_kernel_soft_boxes_headline_shape(arrangements):
     P.slacks = dict(state_box=True, input_box=True, poly_ineq=False, lower_L2_penalty=100.0, upper_L2_penalty=50.0, upper_L1_penalty=0.5)
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
     mpc = BatchMPC(P, B, way_p=way)
-    assert "upr_qp3_kernel<upr_qp3_cfg<9, 1, 4, 3, 20, 256, false, true>" in mpc.kernel_times()["qp_kernel"]
+    assert "upr_qp3_kernel<upr_qp3_cfg<9, 1, 4, 3, 20, 256, false, true, false>>" in mpc.kernel_times()["qp_kernel"]
     mpc.set_observation(0.0, x0); mpc.set_guess(xs0, us0)
     dxs, dus = mpc.qp_step()
     dxe, due, _ = _emu_qp3(P, B, x0, xs0, us0, mpc.lin_records(), np.broadcast_to(P.body_params, (B,) + P.body_params.shape))
     # (a race shows up at 1e-3 and above; the violated instance's weights span many decades after six iterations, which
     #  amplifies the device's reciprocal / rsqrt rounding: measured 4e-7)
     ok = np.arange(B) != 2
-    assert np.abs(dxs - dxe)[ok].max() < 1e-8 * max(1.0, np.abs(dxe).max()) and np.abs(dus - due)[ok].max() < 1e-8 * max(1.0, np.abs(due).max())
+    assert np.abs(dxs - dxe)[ok].max() < 1e-7 * max(1.0, np.abs(dxe).max()) and np.abs(dus - due)[ok].max() < 1e-7 * max(1.0, np.abs(due).max())
     assert np.abs(dxs - dxe).max() < 1e-5 * max(1.0, np.abs(dxe).max()) and np.abs(dus - due).max() < 1e-5 * max(1.0, np.abs(due).max())
     mpc.close()
     P.qp_tol, P.qp_iter_max = 1e-8, 40
@@ -1247,4 +1247,45 @@ def test_production_kernel_soft_boxes_headline_shape(arrangements):
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert rc == 0 and st["qp_status_last"][b] == 0
         assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+    mpc.close()
+
+
+def test_production_kernel_coupled_bodies(arrangements):
+    """The production-structure QP kernel on BASELINE config 3's shape (upr_qp3_cfg<9, 3, 16, 3, ., ., ROWS, ., DENSE>: three
+    stacked bodies that share contact points -- one dense 18 x 18 Schur complement per knot -- 80 friction rows and 20
+    collision rows per knot): it is the kernel the engine selects; host-emulation screen after fixed iterations; the
+    converged QP of a feasible linearisation point against the oracle."""
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME
+
+    B = 4
+    P = thing_problem(arrangements["box_arch"], qp_tol=0.0, qp_iter_max=6)
+    for k, v in robots.collision_model(P.chain, robots.SIMPLE_COLLISION_PAIRS).items():
+        setattr(P, k, v)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] = [0.3, 0.25, 0.32, 0.28]
+    way = waypoints_for(P, x0, offset=(-0.3, 0.3, 0.0))
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    assert "upr_qp3_kernel<upr_qp3_cfg<9, 3, 16, 3, 20, 256, true, false, true>>" in mpc.kernel_times()["qp_kernel"]
+    mpc.set_observation(0.0, x0); mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    dxe, due, _ = _emu_qp3(P, B, x0, xs0, us0, mpc.lin_records(), np.broadcast_to(P.body_params, (B,) + P.body_params.shape))
+    # (a race shows up at 1e-3 and above; measured 2e-8: 100 inequality rows per knot, device reciprocal / rsqrt rounding)
+    assert np.abs(dxs - dxe).max() < 1e-7 * max(1.0, np.abs(dxe).max()) and np.abs(dus - due).max() < 1e-7 * max(1.0, np.abs(due).max())
+    mpc.close()
+    P.qp_tol, P.qp_iter_max = 1e-8, 60
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0); mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    st = mpc.stats()
+    n_ok = 0
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert (rc == 0) == (st["qp_status_last"][b] == 0)
+        if rc == 0:
+            n_ok += 1
+            assert np.abs(dxs[b] - dxo).max() < 2e-5 * max(1.0, np.abs(dxo).max()) and np.abs(dus[b] - duo).max() < 2e-5 * max(1.0, np.abs(duo).max())
+    assert n_ok >= 2
     mpc.close()

@@ -361,8 +361,10 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
     UPR_HIP(hipGetLastError());
     return 0;
 }
-// (nq, nb, nc, nf, SOFT) instantiations besides the headline's
-#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, true) X(9, 1, 4, 1, true) X(9, 8, 32, 1, true)
+// (nq, nb, nc, nf, ROWS, SOFT, DENSE) instantiations besides the headline's: the headline shape with slacks on its boxes,
+// thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
+// (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
+#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false) X(9, 1, 4, 1, false, true, false) X(9, 8, 32, 1, false, true, false) X(9, 3, 16, 3, true, false, true)
 bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }
 // can the production kernel take this problem, and in which instantiation?  0: no; 1: headline (hard boxes); 2: one of
@@ -372,13 +374,12 @@ int qp3_variant(const upr_problem& P, const upr_dims& d) {
     if (d.no > UPR_QP3_NOMAX) return 0;
     if (P.soft_poly && (d.np > 0 || d.no > 0)) return 0;      // slacks on friction / collision rows: generic kernel
     if (d.nfc < d.ne && !P.soft_eq) return 0;                 // rank-deficient hard equality (proximal treatment): other kernels
-    if (P.nb > 1) {
-        for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) return 0;   // bodies that share contacts: dense Schur complement
-        if (P.use_feedback_policy || d.no > 0) return 0;
-    }
+    bool star = true;                                         // no two bodies share a contact point
+    for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) star = false;
     if (qp3_is_headline(P) && !soft_boxes(P)) return 1;
-    if (d.no > 0) return 0;
-#define X(a, b, c, e, sf) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e && (soft_boxes(P) || !qp3_is_headline(P))) return 2;
+#define X(a, b, c, e, rows, sf, dense) \
+    if (P.nq == a && P.nb == b && P.nc == c && P.nf == e && (rows || d.no == 0) && (sf || !soft_boxes(P)) && (dense || star) && \
+        !(b > 1 && !dense && P.use_feedback_policy)) return 2;
     UPR_QP3_EXTRA(X)
 #undef X
     return 0;
@@ -392,7 +393,7 @@ int launch_qp3(upr_batch* h, const upr_qp_args& A) {
 }
 size_t qp3_ws_doubles(const upr_problem& P, int variant) {
     if (variant == 1) return upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 512>>::total;   // (the far arrays grow with the lanes: largest NT)
-#define X(a, b, c, e, sf) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>>::total;
+#define X(a, b, c, e, rows, sf, dense) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>>::total;
     UPR_QP3_EXTRA(X)
 #undef X
     return 0;
@@ -408,7 +409,7 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
         }
     }
     if (h->use_qp3 == 2) {
-#define X(a, b, c, e, sf) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp3_cfg<upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>>(h, A);
+#define X(a, b, c, e, rows, sf, dense) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) return launch_qp3_cfg<upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>>(h, A);
         UPR_QP3_EXTRA(X)
 #undef X
     }
@@ -473,7 +474,7 @@ upr_fb_src fb_source(const upr_batch* h) {
         };
         // (these offsets lie in front of everything that depends on the workgroup size or on ROWS / SOFT)
         if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
-#define X(a, b, c, e, sf) else if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) fill(upr_qp3_cfg<a, b, c, e, 20, 256, false, sf>());
+#define X(a, b, c, e, rows, sf, dense) else if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) fill(upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>());
         UPR_QP3_EXTRA(X)
 #undef X
         return s;
@@ -604,8 +605,10 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     }
     {
         char buf[128];
-        if (h->use_qp3) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, %d, %s, %s>>", P->nq, P->nb, P->nc, P->nf, P->N, h->qp_nt,
-                                 (h->use_qp3 == 1 && h->d.no > 0) ? "true" : "false", h->use_qp3 == 2 ? "true" : "false");
+        if (h->use_qp3 == 1) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<9, 1, 4, 3, 20, %d, %s, false, false>>", h->qp_nt, h->d.no > 0 ? "true" : "false");
+#define X(a, b, c, e, rows, sf, dense) else if (h->use_qp3 == 2 && P->nq == a && P->nb == b && P->nc == c && P->nf == e) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, 20, 256, %s, %s, %s>>", a, b, c, e, #rows, #sf, #dense);
+        UPR_QP3_EXTRA(X)
+#undef X
         else if (h->use_qp2) snprintf(buf, sizeof(buf), "upr_qp2_kernel<upr_qp2_dims<%d, %d, %d, %d>, %d>", P->nq, P->nb, P->nc, P->nf, h->qp_nt == 512 ? 128 : h->qp_nt);
         else snprintf(buf, sizeof(buf), "upr_qp_kernel<%d>", generic_nt(h));
         h->qp_name = buf;

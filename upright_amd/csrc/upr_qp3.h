@@ -31,12 +31,15 @@
 // NB_ > 1 ("star" arrangements: every contact point joins the tray and one balanced body, so no two bodies share a
 // contact): the Schur complement of the object-dynamics rows is block diagonal, one 6 x 6 block per (knot, body); all
 // Schur-related phases run one lane per block exactly as the single-body kernel runs one lane per knot.
-template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true, bool SOFT_ = false>
+// DENSE_ (with NB_ > 1): arrangements whose bodies share contact points (stacked objects): the Schur complement of a
+// knot is one dense 6 NB x 6 NB matrix, assembled, factored and inverted by the knot's lane in registers (the
+// instantiation runs one workgroup per CU and may use all 512 registers of a lane).
+template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true, bool SOFT_ = false, bool DENSE_ = false>
 struct upr_qp3_cfg {
     static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
-    static constexpr bool ROWS = ROWS_, SOFT = SOFT_, MULTI = NB_ > 1;
-    static constexpr int SB = 6, NKB = N_ * NB_;                 // Schur block size; number of (knot, body) blocks
-    static constexpr int NLS = NB_ * 36;                         // doubles of the inverse Schur factor(s) of a knot
+    static constexpr bool ROWS = ROWS_, SOFT = SOFT_, COUPLED = DENSE_ && NB_ > 1, MULTI = NB_ > 1 && !DENSE_;
+    static constexpr int SB = COUPLED ? 6 * NB_ : 6, NKB = COUPLED ? N_ : N_ * NB_;   // Schur block size; number of blocks
+    static constexpr int NLS = COUPLED ? 36 * NB_ * NB_ : NB_ * 36;                   // doubles of the inverse Schur factor(s) of a knot
     static constexpr int N1 = N + 1;
     static constexpr int NX = 3 * NQ, NFC = NF * NC, NU = NQ + NFC, NE = 6 * NB;
     static constexpr int NP = (NF == 3) ? 5 * NC : 0;
@@ -56,7 +59,7 @@ struct upr_qp3_cfg {
 // store that the back-substitutions stream with a one-knot register prefetch.  They live in global memory
 // (L2-resident) so that two workgroups fit the 160 KB of LDS of a CU.
 #ifndef UPR_QP3_NOMAX
-#define UPR_QP3_NOMAX 16   // state-polytopic rows per knot this kernel takes (more: the generic kernel)
+#define UPR_QP3_NOMAX 20   // state-polytopic rows per knot this kernel takes (more: the generic kernel); obstacles/simple.yaml has 20 pairs
 #endif
 template <class C>
 struct upr_qp3_far {
@@ -558,7 +561,7 @@ struct upr_qp3 {
                                 double* zr = L + O::Pa + (k * NFC + 3 * ci) * 6 + r6;
                                 zr[0] = Hc[0] * d0; zr[6] = Hc[3] * d0 + Hc[4] * d1; zr[12] = Hc[6] * d0 + Hc[7] * d1 + Hc[8] * d2;
                             }
-                        } else {
+                        } else if (!C::COUPLED) {
 #pragma unroll
                         for (int r = 0; r < NE; ++r) {
                             const double* dr = L + O::df + r * NFC + 3 * ci;
@@ -579,7 +582,7 @@ struct upr_qp3 {
                         const double lf0 = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
                         G[F::lfi + k * C::NLF + ci] = lf0;
                         if (C::MULTI) { const int b2 = P->contact_body2[ci]; for (int r6 = 0; r6 < 6; ++r6) L[O::Pa + (k * NFC + ci) * 6 + r6] = lf0 * L[O::df + (6 * b2 + r6) * NFC + ci]; }
-                        else for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
+                        else if (!C::COUPLED) for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
                     }
                     const double lf = G[F::lfi + k * C::NLF + ci];
                     const double yv = lf * L[O::gus + uo];
@@ -641,7 +644,7 @@ struct upr_qp3 {
             L[O::ys + e] = v - v2;
         }
 #endif
-        if (factor && !C::MULTI) {
+        if (factor && !C::MULTI && !C::COUPLED) {
             UPR_FORT(e, N * NE * NE) {
                 const int k = e / (NE * NE), r = (e % (NE * NE)) / NE, c = e % NE;
                 if (c > r) continue;
@@ -699,10 +702,65 @@ struct upr_qp3 {
                         }
                     }
                     ok = upr_chol_inv_serial<SB>(Sm, Lr);
+                } else if (C::COUPLED) {
+                    // dense S of the knot straight from the inverse contact factors (G[lfi], written in phase B) and Df:
+                    // S = rho I + sum_c (Lf_c^-1 Df_c')' (Lf_c^-1 Df_c'); a contact loads the rows of at most two bodies, every
+                    // lane walks the same contact at the same time, so the body tests below do not diverge
+                    const int k = kb;
+                    double Sm[SB * SB];
+#pragma unroll
+                    for (int r = 0; r < SB; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) Sm[r * SB + c] = (r == c) ? rho_s : 0.0;
+                    for (int ci = 0; ci < NC; ++ci) {
+                        const int b1 = P->contact_body1[ci], b2 = P->contact_body2[ci];
+                        double Bk[NF == 3 ? 9 : 1];
+                        if (NF == 3) {
+#pragma unroll
+                            for (int a = 0; a < 9; ++a) Bk[a] = G[F::lfi + k * C::NLF + 9 * ci + a];
+                        } else Bk[0] = G[F::lfi + k * C::NLF + ci];
+                        double zb[C::NB][6][NF];
+#pragma unroll
+                        for (int bi = 0; bi < C::NB; ++bi) {
+                            if (bi != b1 && bi != b2) continue;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+                                const double* dr = L + O::df + (6 * bi + r) * NFC + NF * ci;
+                                if (NF == 3) { const double d0 = dr[0], d1 = dr[1], d2 = dr[2]; zb[bi][r][0] = Bk[0] * d0; zb[bi][r][1 % NF] = Bk[3 % (NF == 3 ? 9 : 1)] * d0 + Bk[4 % (NF == 3 ? 9 : 1)] * d1; zb[bi][r][2 % NF] = Bk[6 % (NF == 3 ? 9 : 1)] * d0 + Bk[7 % (NF == 3 ? 9 : 1)] * d1 + Bk[8 % (NF == 3 ? 9 : 1)] * d2; }
+                                else zb[bi][r][0] = Bk[0] * dr[0];
+                            }
+                        }
+#pragma unroll
+                        for (int bi = 0; bi < C::NB; ++bi) {
+                            if (bi != b1 && bi != b2) continue;
+#pragma unroll
+                            for (int bj = 0; bj <= bi; ++bj) {
+                                if (bj != b1 && bj != b2) continue;
+#pragma unroll
+                                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                                    for (int c = 0; c < 6; ++c) {
+                                        if (bi == bj && c > r) continue;
+                                        double v = 0.0;
+#pragma unroll
+                                        for (int a = 0; a < NF; ++a) v += zb[bi][r][a] * zb[bj][c][a];
+                                        Sm[(6 * bi + r) * SB + 6 * bj + c] += v;
+                                    }
+                            }
+                        }
+                    }
+                    ok = upr_chol_inv_serial<SB>(Sm, Ls);       // (the inverse goes to memory: factor and inverse together exceed the registers)
                 } else ok = upr_chol_inv_serial<SB>(L + O::hux + kb * SB * SB, Lr);
                 if (!ok) L[O::misc] = 1.0;
+                if (C::COUPLED) {
 #pragma unroll
-                for (int e = 0; e < SB * SB; ++e) Ls[e] = Lr[e];
+                    for (int r = 0; r < SB; ++r)
+#pragma unroll
+                        for (int m = 0; m <= r; ++m) Lr[r * SB + m] = Ls[r * SB + m];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < SB * SB; ++e) Ls[e] = Lr[e];
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
@@ -826,13 +884,13 @@ struct upr_qp3 {
             // (a wave that holds two job kinds runs them one after the other: the 27-term dot products must not share
             // a wave with anything else)
             constexpr int PB0 = (NT >= 256) ? NT - 64 : ((NQ * NQ + NVC + 1) & ~1);
-            static_assert(VC0 >= NQ * NQ && PB0 > VC0 && (C::MULTI || PB0 >= VC0 + NVC) && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
+            static_assert(VC0 >= NQ * NQ && PB0 > VC0 && (C::NB > 1 || PB0 >= VC0 + NVC) && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
 #ifndef UPR_HOST_EMU
             constexpr int NPB = 2 * NX;   // P+ b: a lane pair per row (two halves of the 27 terms, summed by DPP): it was the late wave of phase 1
 #else
             constexpr int NPB = NX;
 #endif
-            static_assert(C::MULTI || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux), "prep stages Z and S in the sweeps' working set");
+            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux), "prep stages Z and S in the sweeps' working set");
             static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
             UPR_FORT(e, PB0 + NPB) {
@@ -872,14 +930,15 @@ struct upr_qp3 {
                     // (the multi-body shapes have more jobs than lanes between VC0 and PB0: those lanes take several)
                     if (k > 0) for (int f = e - VC0; f < NVC; f += PB0 - VC0) {
                         // three rows (r0 .. r0 + 2 of the knot) of the block of body g / 2: Vc = blockdiag(Lsi_b) C
-                        const int g = f / NX, c = f % NX, r0 = 3 * g, bo = 6 * (g >> 1), q0 = r0 - bo;
-                        const double* Ls = L + O::lsik + 36 * (g >> 1);
+                        constexpr int SBV = C::SB;
+                        const int g = f / NX, c = f % NX, r0 = 3 * g, blk = r0 / SBV, bo = SBV * blk, q0 = r0 - bo;
+                        const double* Ls = L + O::lsik + SBV * SBV * blk;
                         double v0 = 0.0, v1 = 0.0, v2 = 0.0;
                         // full-length rows with the entries above the diagonal masked: no lane-dependent trip count
 #pragma unroll
-                        for (int m = 0; m < 6; ++m) {
+                        for (int m = 0; m < SBV; ++m) {
                             const double cm = L[O::ck + (bo + m) * NX + c];
-                            const double l0 = Ls[q0 * 6 + m], l1 = Ls[(q0 + 1) * 6 + m], l2 = Ls[(q0 + 2) * 6 + m];
+                            const double l0 = Ls[q0 * SBV + m], l1 = Ls[(q0 + 1) * SBV + m], l2 = Ls[(q0 + 2) * SBV + m];
                             v0 += ((m <= q0) ? l0 : 0.0) * cm; v1 += ((m <= q0 + 1) ? l1 : 0.0) * cm; v2 += ((m <= q0 + 2) ? l2 : 0.0) * cm;
                         }
                         L[O::vc + r0 * NX + c] = v0; L[O::vc + (r0 + 1) * NX + c] = v1; L[O::vc + (r0 + 2) * NX + c] = v2;
@@ -1424,12 +1483,19 @@ struct upr_qp3 {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
                     double dfn[3], tf[3];
-                    const int rb = C::MULTI ? 6 * P->contact_body2[ci] : 0;   // the six rows of the body this contact loads
+                    const int rb = (C::NB > 1) ? 6 * P->contact_body2[ci] : 0;   // the six rows of the body this contact loads
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = 0.0;
 #pragma unroll
                         for (int r = 0; r < 6; ++r) v += L[O::df + (rb + r) * NFC + 3 * ci + a] * L[O::cv + k * NE + rb + r];
                         dfn[a] = v; }
+                    if (C::COUPLED && P->contact_body1[ci] >= 0) {   // ... and of the body underneath
+                        const int rb1 = 6 * P->contact_body1[ci];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) dfn[a] += L[O::df + (rb1 + r) * NFC + 3 * ci + a] * L[O::cv + k * NE + rb1 + r];
+                    }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = yfq[q][a];
 #pragma unroll
@@ -1442,9 +1508,14 @@ struct upr_qp3 {
                         Su(k)[NQ + 3 * ci + a] = -v; }
                 } else {
                     double dfn = 0.0;
-                    const int rb = C::MULTI ? 6 * P->contact_body2[ci] : 0;
+                    const int rb = (C::NB > 1) ? 6 * P->contact_body2[ci] : 0;
 #pragma unroll
                     for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb + r) * NFC + ci] * L[O::cv + k * NE + rb + r];
+                    if (C::COUPLED && P->contact_body1[ci] >= 0) {
+                        const int rb1 = 6 * P->contact_body1[ci];
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb1 + r) * NFC + ci] * L[O::cv + k * NE + rb1 + r];
+                    }
                     const double lf = bkq[q][0];
                     Su(k)[NQ + ci] = -lf * (yfq[q][0] + lf * dfn);
                 }
@@ -1968,7 +2039,7 @@ static UPR_HDI void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int 
 
 #ifndef UPR_HOST_EMU
 template <class C>
-__global__ void __launch_bounds__(C::NT, (C::NT <= 256 && !C::MULTI) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
+__global__ void __launch_bounds__(C::NT, (C::NT <= 256 && C::NB == 1) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
     upr_qp3_solve<C>(ctx, A, blockIdx.x, smem);
