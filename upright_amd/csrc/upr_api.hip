@@ -222,6 +222,7 @@ struct upr_batch {
     int qp_nt = 0;
     bool use_qp2 = false;
     int use_qp3 = 0;   // 0: no; 1: headline instantiations; 2: one of UPR_QP3_EXTRA (qp3_variant)
+    bool fb_fused = false;   // the selected QP kernel writes the feedback gains itself (upr_qp_args::fb)
     bool use_mfma = true;
     bool timing = false;
     double k_ms[3] = {0, 0, 0};
@@ -378,8 +379,7 @@ int qp3_variant(const upr_problem& P, const upr_dims& d) {
     for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) star = false;
     if (qp3_is_headline(P) && !soft_boxes(P)) return 1;
 #define X(a, b, c, e, rows, sf, dense) \
-    if (P.nq == a && P.nb == b && P.nc == c && P.nf == e && (rows || d.no == 0) && (sf || !soft_boxes(P)) && (dense || star) && \
-        !(b > 1 && !dense && P.use_feedback_policy)) return 2;
+    if (P.nq == a && P.nb == b && P.nc == c && P.nf == e && (rows || d.no == 0) && (sf || !soft_boxes(P)) && (dense || star)) return 2;
     UPR_QP3_EXTRA(X)
 #undef X
     return 0;
@@ -424,7 +424,9 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
 template <int NQ>
 int launch_linesearch(upr_batch* h, const upr_ls_args& A) {
     const size_t lds = (size_t)(4 * 64 + 8) * sizeof(double);
-    hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64>), dim3(h->B), dim3(64), lds, h->stream, A);
+    // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
+    if (h->d.nfc <= 12 && h->d.nb == 1) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1>), dim3(h->B), dim3(64), lds, h->stream, A);
+    else hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64>), dim3(h->B), dim3(64), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
 }
@@ -506,13 +508,18 @@ int advance_impl(upr_batch* h) {
     h->sqp_iters_next = 0;
     for (int it = 0; it < sqp_iters; ++it) {
         { KernelTimer T(h, 0); if (do_linearize(h, traj_lin_args(h))) return 1; T.stop(); }
-        { KernelTimer T(h, 1); if (launch_qp(h, make_qp_args(h))) return 1; T.stop(); }
+        {
+            upr_qp_args Q = make_qp_args(h);
+            // the production kernel writes the feedback gains of the advance's LAST QP itself (no gather kernel afterwards)
+            if (h->fb && h->fb_fused && it == sqp_iters - 1) Q.fb = h->fb;
+            KernelTimer T(h, 1); if (launch_qp(h, Q)) return 1; T.stop();
+        }
         upr_ls_args L;
         L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
         L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
     }
-    if (h->fb) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
+    if (h->fb && !(h->fb_fused && sqp_iters > 0)) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
         if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
         else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
         UPR_HIP(hipGetLastError());
@@ -598,6 +605,8 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     h->qp_nt = h->use_qp3 ? 256 : 128;
     if (const char* e = getenv("UPR_QP_NT")) h->qp_nt = atoi(e);
     if (h->use_qp3 == 2) h->qp_nt = 256;
+    h->fb_fused = h->use_qp3 != 0;
+    if (const char* e = getenv("UPR_FB_FUSED")) h->fb_fused = h->fb_fused && atoi(e) != 0;
     {   // every QP kernel indexes the instance workspace with the same stride: the largest any selectable one needs
         size_t need = qp2_ws_doubles(*P, h->d);
         if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;

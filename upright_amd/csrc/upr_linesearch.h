@@ -29,7 +29,9 @@ struct upr_ls_args {
 };
 
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
-template <int NQ>
+// NFM / NBM: compile-time bounds of nf nc / nb (the per-lane input vector and body wrenches stay in registers for the
+// small shapes: with the library-wide maxima they lived in scratch, 2 KB per lane)
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
 static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
@@ -37,7 +39,7 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
     const double* xs = A.xs + (size_t)b * (N + 1) * nx; const double* us = A.us + (size_t)b * N * nu;
     const double* ws = A.ws + (size_t)b * d.ws_stride;
     const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
-    double X[3 * NQ], U[UPR_MAX_NU];
+    double X[3 * NQ], U[NQ + NFM];
     for (int i = 0; i < nx; ++i) X[i] = xs[k * nx + i] + alpha * dx[k * nx + i];
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
     const double wt = (k < N) ? h : 1.0;
@@ -73,7 +75,7 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
             dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
         }
         // object-dynamics equality
-        double Fw[6 * UPR_MAX_BODIES];
+        double Fw[6 * NBM];
         const double* bp = A.body_params + (size_t)b * d.nb * 10;
         upr_object_wrenches(P, bp, U + nq, Fw);
         const double sc = 1.0 / sqrt(6.0 * d.nb);
@@ -99,6 +101,53 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
     out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
 }
 
+// the same terms at the CURRENT iterate (alpha = 0), where the linearisation kernel has just been: the end-effector cost, the
+// object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
+// of walking the chain again
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS>
+static inline UPR_HD void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double* out) {
+    const upr_problem* P = A.P; const upr_dims& d = A.d;
+    const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
+    const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
+    const double* X = A.xs + ((size_t)b * (N + 1) + k) * nx;
+    const double* rec = A.lin + ((size_t)b * (N + 1) + k) * d.lin_stride;
+    double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
+    const double wt = (k < N) ? h : 1.0;
+    if (k == 0) for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
+    if (k >= 1) for (int i = 0; i < nx; ++i) {
+        double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
+        iq += wt * v * v;
+    }
+    if (d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
+    if (k < N) {
+        const double* U = A.us + ((size_t)b * N + k) * nu;
+        const double* xn = X + nx;
+        double c = rec[d.lin_cost];
+        for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
+        for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
+        cost += h * c;
+        for (int j = 0; j < nq; ++j) {
+            double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
+            double e0 = q + h * v + h2 * a + h3 * u - xn[j], e1 = v + h * a + h2 * u - xn[nq + j], e2 = a + h * u - xn[2 * nq + j];
+            dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
+        }
+        for (int r = 0; r < d.ne; ++r) eq += h * rec[d.lin_g + r] * rec[d.lin_g + r];
+        if (d.np > 0) for (int ci = 0; ci < d.nc; ++ci) {
+            double hr[5];
+            upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
+            for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+        }
+        for (int i = 0; i < nu; ++i) {
+            double v = fmin(0.0, fmin(U[i] - P->u_lb[i], P->u_ub[i] - U[i]));
+            iq += h * v * v;
+        }
+    } else if (d.neN > 0) {
+        for (int r = 0; r < 3; ++r) eq += rec[d.lin_grad + r] * rec[d.lin_grad + r];
+        for (int i = 0; i < 2 * nq; ++i) eq += X[nq + i] * X[nq + i];
+    }
+    out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
+}
+
 // block reduction of 4 partials; result broadcast in res[4]
 static inline UPR_HD void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double* part, double* res) {
     for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] = part[c];
@@ -113,7 +162,7 @@ static inline UPR_HD void upr_ls_reduce4(const upr_ctx& ctx, double* red, const 
 }
 
 // L: 4*nt + 8 doubles of workgroup scratch
-template <int NQ>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
 static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
@@ -127,7 +176,7 @@ static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args&
     const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
     // baseline, step norms and Armijo descent metric (cost gradient . step)
     double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
-    UPR_FOR(k, N + 1) upr_ls_knot<NQ>(A, b, k, 0.0, part);
+    UPR_FOR(k, N + 1) upr_ls_knot_base<NQ, NFM>(A, b, k, part);
     upr_ls_reduce4(ctx, L, part, base);
     UPR_FOR(k, N + 1) {
         for (int i = 0; i < nx; ++i) {
@@ -153,7 +202,7 @@ static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args&
     if (qp_status != 2.0) {
         do {
             double p2[4] = {0, 0, 0, 0};
-            UPR_FOR(k, N + 1) upr_ls_knot<NQ>(A, b, k, alpha, p2);
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM>(A, b, k, alpha, p2);
             upr_ls_reduce4(ctx, L, p2, perf);
             double viol = sqrt(perf[1] + perf[2] + perf[3]);
             if (viol > g_max) accepted = false;
@@ -180,11 +229,11 @@ static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args&
 }
 
 #ifndef UPR_HOST_EMU
-template <int NQ, int NT>
+template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
 __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
-    upr_ls_instance<NQ>(ctx, A, blockIdx.x, smem);
+    upr_ls_instance<NQ, NFM, NBM>(ctx, A, blockIdx.x, smem);
 }
 #endif
 

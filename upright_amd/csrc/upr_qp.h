@@ -58,6 +58,10 @@ struct upr_qp_args {
     // here): per instance [pi (N+1) nx][nu N ne][yN neN][lam (N+1) ni_stage], lam in the slot layout of upr_ineq_active
     double* kkt = nullptr;
     int kkt_stride = 0;
+    // optional: linear feedback gains of THIS QP written by the kernel at exit, fb[B][N][nu][nx] (ocs2 sign: u = bias + K x).
+    // Kernels that support it spare the separate gather kernel its launch and its re-read of the factors; the host sets
+    // it on the last QP of an advance only (upr_api.hip)
+    double* fb = nullptr;
 };
 static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + (d.N + 1) * d.ni_stage; }
 

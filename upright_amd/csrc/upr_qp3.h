@@ -1809,6 +1809,66 @@ struct upr_qp3 {
         res[3] /= (ntot > 0 ? ntot : 1);
     }
 
+    // Linear feedback gains of this QP (sqp.use_feedback_policy; what feedback_kernel of upr_api.hip gathers for the other QP
+    // kernels), out[N][nu][nx], ocs2 sign: jerk rows -K_k of the Riccati recursion; contact-force rows
+    // -Hff^-1 Df' S^-1 C_k (the forces follow the state through the object-dynamics rows).  A QP whose factorisation broke
+    // down (status 2) has no policy: zeros.
+    UPR_HDI void write_feedback(double* out, int status) {
+        UPR_SYNC();
+        if (status == 2) { UPR_FORT(e, N * NU * NX) out[e] = 0.0; return; }
+        UPR_FORT(e, N * NQ * NX) {
+            const int k = e / (NQ * NX), rem = e % (NQ * NX);
+            out[(size_t)k * NU * NX + rem] = -G[F::Ks + e];
+        }
+        constexpr int SB = C::SB, NBLK = NE / SB;
+        UPR_FORT(e, N * NX) {
+            const int k = e / NX, c = e % NX;
+            const double* Ck = rec(k) + lin_gx + c;
+            double t2[NE];
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const double* Ls = G + F::lsi + k * C::NLS + blk * SB * SB;
+                double t1[SB];
+#pragma unroll
+                for (int r = 0; r < SB; ++r) { double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) v += Ls[r * SB + m] * Ck[(blk * SB + m) * NX];
+                    t1[r] = v; }
+#pragma unroll
+                for (int r = 0; r < SB; ++r) { double v = 0.0;
+#pragma unroll
+                    for (int m = r; m < SB; ++m) v += Ls[m * SB + r] * t1[m];
+                    t2[blk * SB + r] = v; }
+            }
+            for (int ci = 0; ci < NC; ++ci) {
+                double t3[NF];
+#pragma unroll
+                for (int a = 0; a < NF; ++a) { double v = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + NF * ci + a] * t2[r];
+                    t3[a] = v; }
+                double* o = out + ((size_t)k * NU + NQ + NF * ci) * NX + c;
+                if (NF == 3) {
+                    const double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
+                    double y[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { double v = 0.0;
+#pragma unroll
+                        for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * t3[b2 % NF];
+                        y[a] = v; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { double v = 0.0;
+#pragma unroll
+                        for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * y[b2];
+                        o[(size_t)a * NX] = -v; }
+                } else {
+                    const double lf = G[F::lfi + k * C::NLF + ci];
+                    o[0] = -lf * lf * t3[0];
+                }
+            }
+        }
+    }
+
     double* prof; long long tlast;
     UPR_HDI void tic() {
 #ifndef UPR_HOST_EMU
@@ -2002,6 +2062,7 @@ struct upr_qp3 {
         UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
         UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
         if (prof) UPR_FORT(i, 64) prof[i] += L[O::prf + i];
+        if (A.fb) write_feedback(A.fb + (size_t)b * N * NU * NX, status);
         if (A.kkt) {   // multipliers for upr_batch_qp_kkt, in the generic kernel's slot layout
             double* K = A.kkt + (size_t)b * A.kkt_stride;
             const int ni = A.d.ni_stage, o_nu = N1 * NX, o_y = o_nu + N * NE, o_l = o_y + neN;
