@@ -61,7 +61,7 @@ typedef struct upr_problem {
     double Qdiag[UPR_MAX_NX];
     double Rdiag[UPR_MAX_NU];
     double xd[UPR_MAX_NX];
-    double Wee[6]; /* entries 3..5 (orientation) must be 0 */
+    double Wee[6]; /* diagonal of the end-effector pose weight: position (3), orientation error (3) */
 
     /* bounds: controller_interface.cpp:157-169,330-357 */
     double x_lb[UPR_MAX_NX], x_ub[UPR_MAX_NX];
@@ -152,6 +152,11 @@ void upr_batch_destroy(upr_batch* h);
  * the previous solution (next advance starts from the DefaultInitializer guess,
  * controller_interface.cpp:385-386). way_p may be NULL to keep targets. */
 int upr_batch_reset(upr_batch* h, const double* way_p);
+
+/* Target orientations (the quaternion part of ocs2::TargetTrajectories states, wrappers.py:31-43: Q_d = Q_EE(x0) (x) Q_offset):
+ * way_q[B][n_way][4], xyzw; between waypoints the target is their SLERP (reference_trajectory.h:18-47).  They enter the
+ * end-effector cost through its orientation error (cost/end_effector_cost.h:33-84) when Wee[3..5] != 0.  Default: identity. */
+int upr_batch_set_target_orientations(upr_batch* h, const double* way_q);
 
 /* ControllerInterface.setObservation (pybindings.cpp:369-370): t[B] (or t[1] broadcast if
  * t_stride == 0), x[B][nx_full], nx_full = 3 nq + 9 n_dyn. Host pointers.  Every x / xs argument of this interface has

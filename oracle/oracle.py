@@ -24,7 +24,7 @@ class OrcProblem(C.Structure):
         ("contact_normal", d * 3 * MAXC), ("contact_span", d * 6 * MAXC), ("contact_r1", d * 3 * MAXC), ("contact_r2", d * 3 * MAXC),
         ("Qdiag", d * MAXNX), ("Rdiag", d * MAXNU), ("xd", d * MAXNX), ("Wee", d * 6),
         ("x_lb", d * MAXNX), ("x_ub", d * MAXNX), ("u_lb", d * MAXNU), ("u_ub", d * MAXNU),
-        ("n_way", C.c_int), ("way_t", d * MAXW), ("way_p", d * 3 * MAXW),
+        ("n_way", C.c_int), ("way_t", d * MAXW), ("way_p", d * 3 * MAXW), ("way_q", d * 4 * MAXW),
         ("sqp_iters", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", d), ("delta_tol", d), ("cost_tol", d),
         ("terminal_constraint", C.c_int),
         ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", d * 3 * MAXS), ("sph_r", d * MAXS),
@@ -97,6 +97,8 @@ def to_orc(P):
     _fill(o.way_t, P.way_t)
     for i in range(o.n_way):
         _fill(o.way_p[i], P.way_p[i])
+        wq = getattr(P, "way_q", None)
+        _fill(o.way_q[i], wq[i] if wq is not None else [0.0, 0.0, 0.0, 1.0])
     o.sqp_iters, o.qp_iter_max, o.qp_tol = P.sqp_iters, P.qp_iter_max, P.qp_tol
     o.delta_tol, o.cost_tol, o.terminal_constraint = P.delta_tol, P.cost_tol, int(P.terminal_constraint)
     ns, npair = len(getattr(P, "sph_r", ())), len(getattr(P, "pair_a", ()))

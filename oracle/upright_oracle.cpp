@@ -324,6 +324,56 @@ void target_position(const orc_problem* P, double t, double* pd) {
     for (int i = 0; i < 3; ++i) pd[i] = alpha * P->way_p[idx][i] + (1.0 - alpha) * P->way_p[idx + 1][i];
 }
 
+// reference_trajectory.h:18-47 (orientation part): q_lhs.slerp(1 - alpha, q_rhs), Eigen's QuaternionBase::slerp (shortest
+// arc, linear interpolation of the coefficients where |q_lhs . q_rhs| >= 1 - eps).  Quaternions xyzw.
+void target_orientation(const orc_problem* P, double t, double* q) {
+    if (P->n_way <= 1) { for (int i = 0; i < 4; ++i) q[i] = P->way_q[0][i]; return; }
+    int n = P->n_way, idx; double alpha;
+    if (t <= P->way_t[0]) { idx = 0; alpha = 1.0; }
+    else if (t >= P->way_t[n - 1]) { idx = n - 2; alpha = 0.0; }
+    else {
+        idx = 0;
+        while (idx + 1 < n - 1 && t >= P->way_t[idx + 1]) ++idx;
+        alpha = (P->way_t[idx + 1] - t) / (P->way_t[idx + 1] - P->way_t[idx]);
+    }
+    const double* a = P->way_q[idx]; const double* b = P->way_q[idx + 1];
+    const double tt = 1.0 - alpha;
+    const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3], ad = std::fabs(d);
+    double s0, s1;
+    if (ad >= 1.0 - 2.220446049250313e-16) { s0 = 1.0 - tt; s1 = tt; }
+    else { const double th = std::acos(ad), st = std::sin(th); s0 = std::sin((1.0 - tt) * th) / st; s1 = std::sin(tt * th) / st; }
+    if (d < 0) s1 = -s1;
+    for (int i = 0; i < 4; ++i) q[i] = s0 * a[i] + s1 * b[i];
+}
+
+// Orientation error of the end-effector cost (cost/end_effector_cost.h:42-44; [UPSTREAM] ocs2
+// PinocchioEndEffectorKinematicsCppAd::getOrientationError = quaternionDistance(q, q_ref) =
+// q_w r_v - r_w q_v + q_v x r_v) with q the quaternion of the end-effector rotation, extracted branch by branch on the
+// largest of trace / diagonal entries (Eigen / Pinocchio assignment), in the arithmetic type T.
+template <class T>
+void orientation_error(const M3<T>& C, const double* r /*xyzw*/, T* e) {
+    const T m00 = C(0, 0), m11 = C(1, 1), m22 = C(2, 2);
+    const double t = val(m00) + val(m11) + val(m22);
+    T q[4];  // xyzw
+    if (t > 0) {
+        T s = sqrt(m00 + m11 + m22 + T(1.0)) * T(2.0);
+        q[3] = s * T(0.25); q[0] = (C(2, 1) - C(1, 2)) / s; q[1] = (C(0, 2) - C(2, 0)) / s; q[2] = (C(1, 0) - C(0, 1)) / s;
+    } else if (val(m00) > val(m11) && val(m00) > val(m22)) {
+        T s = sqrt(T(1.0) + m00 - m11 - m22) * T(2.0);
+        q[3] = (C(2, 1) - C(1, 2)) / s; q[0] = s * T(0.25); q[1] = (C(0, 1) + C(1, 0)) / s; q[2] = (C(0, 2) + C(2, 0)) / s;
+    } else if (val(m11) > val(m22)) {
+        T s = sqrt(T(1.0) + m11 - m00 - m22) * T(2.0);
+        q[3] = (C(0, 2) - C(2, 0)) / s; q[0] = (C(0, 1) + C(1, 0)) / s; q[1] = s * T(0.25); q[2] = (C(1, 2) + C(2, 1)) / s;
+    } else {
+        T s = sqrt(T(1.0) + m22 - m00 - m11) * T(2.0);
+        q[3] = (C(1, 0) - C(0, 1)) / s; q[0] = (C(0, 2) + C(2, 0)) / s; q[1] = (C(1, 2) + C(2, 1)) / s; q[2] = s * T(0.25);
+    }
+    const T rw = T(r[3]), rx = T(r[0]), ry = T(r[1]), rz = T(r[2]);
+    e[0] = q[3] * rx - rw * q[0] + (q[1] * rz - q[2] * ry);
+    e[1] = q[3] * ry - rw * q[1] + (q[2] * rx - q[0] * rz);
+    e[2] = q[3] * rz - rw * q[2] + (q[0] * ry - q[1] * rx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // small dense helpers (row-major)
 typedef std::vector<double> vec;
@@ -1059,24 +1109,34 @@ double orc_stage_cost(const orc_problem* P, double t, const double* x, const dou
     for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * u[i] * u[i];
     double pd[3]; target_position(P, t, pd);
     EEState<double> S = ee_kin<double>(P, x);
-    double e[3];
-    for (int r = 0; r < 3; ++r) { e[r] = S.p[r] - pd[r]; c += 0.5 * P->Wee[r] * e[r] * e[r]; }
+    const bool ori = P->Wee[3] != 0 || P->Wee[4] != 0 || P->Wee[5] != 0;
+    const int nr = ori ? 6 : 3;
+    double e[6] = {0, 0, 0, 0, 0, 0}, qd[4] = {0, 0, 0, 1};
+    for (int r = 0; r < 3; ++r) e[r] = S.p[r] - pd[r];
+    if (ori) {
+        target_orientation(P, t, qd);
+        const double nq_ = std::sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+        for (int i = 0; i < 4; ++i) qd[i] /= nq_;
+        orientation_error<double>(S.C, qd, e + 3);
+    }
+    for (int r = 0; r < nr; ++r) c += 0.5 * P->Wee[r] * e[r] * e[r];
     if (grad_x || Hxx) {
-        std::vector<double> J((size_t)3 * nx, 0.0);
+        std::vector<double> J((size_t)6 * nx, 0.0);
         std::vector<Dual> xd(nx);
         for (int i = 0; i < nx; ++i) xd[i] = Dual(x[i]);
-        for (int j = 0; j < P->nq; ++j) {  // position depends on q only
+        for (int j = 0; j < P->nq; ++j) {  // the pose depends on q only
             xd[j].d = 1.0; EEState<Dual> D = ee_kin<Dual>(P, xd.data()); xd[j].d = 0.0;
             for (int r = 0; r < 3; ++r) J[r * nx + j] = D.p[r].d;
+            if (ori) { Dual eo[3]; orientation_error<Dual>(D.C, qd, eo); for (int r = 0; r < 3; ++r) J[(3 + r) * nx + j] = eo[r].d; }
         }
         if (grad_x) for (int i = 0; i < nx; ++i) {
             double g = P->Qdiag[i] * (x[i] - P->xd[i]);
-            for (int r = 0; r < 3; ++r) g += J[r * nx + i] * P->Wee[r] * e[r];
+            for (int r = 0; r < nr; ++r) g += J[r * nx + i] * P->Wee[r] * e[r];
             grad_x[i] = g;
         }
         if (Hxx) for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) {
             double h = (i == j ? P->Qdiag[i] : 0.0);
-            for (int r = 0; r < 3; ++r) h += J[r * nx + i] * P->Wee[r] * J[r * nx + j];
+            for (int r = 0; r < nr; ++r) h += J[r * nx + i] * P->Wee[r] * J[r * nx + j];
             Hxx[i * nx + j] = h;
         }
     }

@@ -68,7 +68,7 @@ typedef struct {
     double Qdiag[ORC_MAX_NX];  /* state weight diagonal */
     double Rdiag[ORC_MAX_NU];  /* input weight diagonal (jerk weights then force_weight) */
     double xd[ORC_MAX_NX];     /* desired joint state */
-    double Wee[6];             /* EE pose weight diagonal; entries 3..5 must be 0 */
+    double Wee[6];             /* EE pose weight diagonal: position (3), orientation error (3) */
 
     /* ---- bounds (controller_interface.cpp:157-169,330-357) ---- */
     double x_lb[ORC_MAX_NX], x_ub[ORC_MAX_NX];
@@ -78,6 +78,7 @@ typedef struct {
     int n_way;
     double way_t[ORC_MAX_WAYPOINTS];
     double way_p[ORC_MAX_WAYPOINTS][3];
+    double way_q[ORC_MAX_WAYPOINTS][4]; /* target orientations, xyzw (reference_trajectory.h:14-16); used when Wee[3..5] != 0 */
 
     /* ---- solver settings (controller.yaml:54-72) ---- */
     int sqp_iters;

@@ -14,19 +14,23 @@
 #include "../../upright_amd/csrc/upr_qp2.h"
 #include "../../upright_amd/csrc/upr_qp3.h"
 
+template <int NQ, bool ORI>
+static void lin_all_o(const upr_lin_args& A);
 template <int NQ>
-static void lin_all(const upr_lin_args& A) {
+static void lin_all(const upr_lin_args& A) { if (A.way_q) lin_all_o<NQ, true>(A); else lin_all_o<NQ, false>(A); }
+template <int NQ, bool ORI>
+static void lin_all_o(const upr_lin_args& A) {
     std::vector<double> sh(upr_lin_lds_doubles(A.d, A.P->n_sph) + 8);
     for (int p = 0; p < A.npoints; ++p) {
         upr_lin_point q = upr_lin_locate(A, p);
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0b(A, q, l, sh.data());
-        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ>(A, q, l, sh.data());
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ, ORI>(A, q, l, sh.data());
         if (A.d.no > 0) {
             for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_a<NQ>(A, q, l, sh.data());
             for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_b<NQ>(A, q, l, sh.data());
         }
-        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase2<NQ>(A, q, l, sh.data());
+        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase2<NQ, ORI>(A, q, l, sh.data());
     }
 }
 
@@ -72,9 +76,13 @@ void emu_make_Df(const upr_problem* P, int B, const double* body_params, double*
 static const double* g_dyn = nullptr; static const double* g_pflag = nullptr;
 void emu_set_dynamic(const double* dyn, const double* pflag) { g_dyn = dyn; g_pflag = pflag; }
 
+static const double* g_way_q = nullptr;   // [B][n_way][4] target orientations (emu_set_way_q), NULL: none
+void emu_set_way_q(const double* q) { g_way_q = q; }
+
 void emu_linearize(const upr_problem* P, int B, const double* body_params, const double* way_p, const double* t0,
                    const double* xs, const double* us, double* lin) {
     upr_lin_args A;
+    A.way_q = upr_has_orientation_cost(P) ? g_way_q : nullptr;
     A.P = P; A.d = upr_make_dims(P); A.body_params = body_params; A.way_p = way_p; A.t0 = t0; A.xs = xs; A.us = us;
     A.inst = nullptr; A.lin = lin; A.ee_out = nullptr; A.npoints = B * (P->N + 1);
     if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
@@ -139,7 +147,7 @@ void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const d
                     int* done, int iter) {
     upr_ls_args A;
     A.P = P; A.d = upr_make_dims(P); if (ws_stride > 0) A.d.ws_stride = (int)ws_stride; A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
-    A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter;
+    A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter; A.way_q = upr_has_orientation_cost(P) ? g_way_q : nullptr;
     if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
     std::vector<double> L(64);

@@ -376,3 +376,59 @@ def test_kkt_conditions_checked_in_numpy(arrangements):
     sol = dict(dx=dx[0], du=du[0], **_emu_kkt(e, ws, 0))
     res = kkt_residuals(P, P.body_params, x0[0], xs[0], us[0], lin[0], sol)
     assert res.max() < 1e-7, res
+
+
+def test_end_effector_orientation_cost_kernel_source(arrangements):
+    """cost/end_effector_cost.h:33-84 with orientation weights and reference_trajectory.h:18-47 with two waypoints: the
+    linearisation kernel's orientation error (rotation-matrix form, tangents by the dual-number lanes) against the
+    oracle's quaternion form (ocs2 quaternionDistance of the extracted quaternion, SLERP'd target): cost, gradient and
+    Gauss-Newton Hessian at times inside, at and outside the waypoint interval; then an MPC solve with the line search."""
+    B = 2
+    P, x0, way, xs, us = _case(arrangements, B, 9)
+    P.Wee = np.array([1.0, 1.0, 1.0, 0.3, 0.5, 0.2])
+    P.way_t = np.array([0.4, 1.6])
+    rng = np.random.default_rng(4)
+    p0 = np.stack([P.chain.forward(x[:9])[0] for x in x0])
+    way = np.ascontiguousarray(np.stack([p0 + [0.2, 0.0, 0.05], p0 + [-0.4, 0.5, 0.0]], axis=1))
+    q = rng.normal(size=(B, 2, 4)); q /= np.linalg.norm(q, axis=2, keepdims=True)
+    from upright_amd.control import rot_to_quat_xyzw, quat_multiply_xyzw
+    for b in range(B):       # targets a moderate rotation away from the current orientation (theta < pi)
+        qe = rot_to_quat_xyzw(P.chain.forward(x0[b, :9])[1])
+        for w in range(2):
+            dq = np.concatenate([0.3 * q[b, w, :3], [1.0]]); dq /= np.linalg.norm(dq)
+            q[b, w] = quat_multiply_xyzw(qe, dq)
+    q = np.ascontiguousarray(q)
+    e = Emu(P, B)
+    e.E.emu_set_way_q(p(q))
+    xs = xs + rng.uniform(-0.2, 0.2, xs.shape); us = rng.uniform(-1, 1, us.shape)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    nq, nh = 9, 45
+    o_cost = 6 + 6 * 27
+    iu = np.triu_indices(nq)
+    for b in range(B):
+        P.way_p, P.way_q = way[b], q[b]
+        O = Oracle(P)
+        for k in (0, 3, 4, 10, 16, 19):
+            t = k * P.dt
+            c, gx, gu, H, R = O.stage_cost(t, xs[b, k], us[b, k])
+            c -= 0.5 * np.sum(P.Qdiag * (xs[b, k] - P.xd) ** 2) + 0.5 * np.sum(P.Rdiag * us[b, k] ** 2)
+            gx = gx - P.Qdiag * (xs[b, k] - P.xd)
+            H = H - np.diag(P.Qdiag)
+            rec = lin[b, k]
+            assert abs(rec[o_cost] - c) < 1e-12 * max(1.0, abs(c))
+            assert np.abs(rec[o_cost + 1:o_cost + 1 + nq] - gx[:nq]).max() < 1e-11
+            Hk = np.zeros((nq, nq)); Hk[iu] = rec[o_cost + 1 + nq:o_cost + 1 + nq + nh]; Hk = Hk + np.triu(Hk, 1).T
+            assert np.abs(Hk - H[:nq, :nq]).max() < 1e-11
+        # the orientation part is really there
+        P0 = thing_problem(arrangements["pink_bottle"]); P0.way_t, P0.way_p = P.way_t, way[b]
+        assert abs(Oracle(P0).stage_cost(1.0, xs[b, 10], us[b, 10])[0] - O.stage_cost(1.0, xs[b, 10], us[b, 10])[0]) > 1e-4
+    # one SQP iteration (QP + line search on the kernel source) against the oracle
+    xs0, us0 = stationary_guess(x0, P.N, P.nu); xs0 = np.ascontiguousarray(xs0); us0 = np.ascontiguousarray(us0)
+    lin = e.linearize(way, np.zeros(B), xs0, us0)
+    dx, du, stats, ws = e.qp(3, xs0, us0, x0, lin)
+    xs1, us1, done = e.linesearch(xs0, us0, x0, np.zeros(B), way, lin, ws, stats)
+    for b in range(B):
+        P.way_p, P.way_q = way[b], q[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and np.abs(xs1[b] - xo).max() < 2e-5 and np.abs(us1[b] - uo).max() < 2e-4
+    e.E.emu_set_way_q(None)

@@ -1289,3 +1289,76 @@ def test_production_kernel_coupled_bodies(arrangements):
             assert np.abs(dxs[b] - dxo).max() < 2e-5 * max(1.0, np.abs(dxo).max()) and np.abs(dus[b] - duo).max() < 2e-5 * max(1.0, np.abs(duo).max())
     assert n_ok >= 2
     mpc.close()
+
+
+def test_end_effector_orientation_cost(arrangements):
+    """Row a14 in full: cost/end_effector_cost.h:33-84 with orientation weights, two waypoints with different target
+    orientations (SLERP, reference_trajectory.h:18-47).  Kernel terms against the oracle's quaternion form, a converged SQP
+    solve against the oracle, and the reference's call sequence (TargetTrajectories.from_config: Q_d = Q_EE(x0) (x) Q_offset)
+    through ControllerManager with an orientation weight in the config."""
+    from upright_amd.control import quat_multiply_xyzw, rot_to_quat_xyzw
+
+    B = 3
+    P, x0, _ = _setup(arrangements, B, seed=17, sqp_iters=8)
+    P.Wee = np.array([1.0, 1.0, 1.0, 0.4, 0.4, 0.2])
+    P.way_t = np.array([0.5, 1.5])
+    rng = np.random.default_rng(1)
+    p0 = np.stack([P.chain.forward(x[:9])[0] for x in x0])
+    way = np.stack([p0 + [0.1, 0.0, 0.02], p0 + [-0.3, 0.3, 0.0]], axis=1)
+    q = np.zeros((B, 2, 4))
+    for b in range(B):
+        qe = rot_to_quat_xyzw(P.chain.forward(x0[b, :9])[1])
+        for w in range(2):      # yaw offsets about the vertical: the tray can follow them and stay level
+            a = (0.2 + 0.2 * w) * (1 if b % 2 else -1)
+            q[b, w] = quat_multiply_xyzw(np.array([0.0, 0.0, np.sin(a / 2), np.cos(a / 2)]), qe)
+    P.way_p, P.way_q = way[0], q[0]
+    mpc = BatchMPC(P, B, way_p=way, way_q=q)
+    ts = np.array([0.0, 0.5, 0.9, 1.5, 1.9])
+    xr = x0[:, None, :] + rng.uniform(-0.2, 0.2, (B, len(ts), 27))
+    for b in range(B):
+        P.way_p, P.way_q = way[b], q[b]
+        O = Oracle(P)
+        out = mpc.linearize_points(xr[b], np.zeros((len(ts), P.nu)), ts, inst=np.full(len(ts), b))
+        for i, t in enumerate(ts):
+            c, gx, gu, H, R = O.stage_cost(t, xr[b, i], np.zeros(P.nu))
+            c -= 0.5 * np.sum(P.Qdiag * (xr[b, i] - P.xd) ** 2)
+            assert abs(out["cost"][i] - c) < 1e-12 * max(1.0, abs(c))
+            assert np.abs(out["grad"][i] - (gx - P.Qdiag * (xr[b, i] - P.xd))[:9]).max() < 1e-11
+            assert np.abs(out["hess"][i] - (H - np.diag(P.Qdiag))[:9, :9]).max() < 1e-11
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    for b in range(B):
+        P.way_p, P.way_q = way[b], q[b]
+        xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and st["qp_status_last"][b] == 0 and st["sqp_iters_done"][b] == so.sqp_iters_done
+        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b] - uo).max() < 1e-3
+        # the orientation term acts: the plan is not the position-only plan
+        P0 = thing_problem(arrangements["pink_bottle"], sqp_iters=8); P0.way_t, P0.way_p = P.way_t, way[b]
+        xp, _, _, _ = Oracle(P0).solve(0.0, x0[b], xs0[b], us0[b])
+        assert np.abs(xp - xo).max() > 1e-3
+    mpc.close()
+    # through the reference's call sequence: an orientation weight and an orientation offset in the controller config
+    import copy
+    import json
+    from pathlib import Path
+
+    from upright_amd import control
+
+    cfg = copy.deepcopy(json.load(open(Path(__file__).parent / "golden" / "configs.json"))["full_bottle_point1"]["controller"])
+    cfg["weights"]["end_effector"]["diag"] = [1, 1, 1, 0.5, 0.5, 0.5]
+    cfg["waypoints"][0]["orientation"] = [0.0, 0.0, float(np.sin(0.15)), float(np.cos(0.15))]
+    bodies, contacts = control.objects_from_fixture(arrangements["pink_bottle"])
+    m = control.ControllerManager.from_config(cfg, bodies=bodies, contacts=contacts)
+    Pm = m.mpc.problem
+    assert np.allclose(Pm.Wee, [1, 1, 1, 0.5, 0.5, 0.5]) and Pm.way_q.shape == (1, 4)
+    xm = np.array(m.settings.initial_state)
+    qe = rot_to_quat_xyzw(Pm.chain.forward(xm[:9])[1])
+    assert np.allclose(Pm.way_q[0], quat_multiply_xyzw(qe, np.array(cfg["waypoints"][0]["orientation"])))   # wrappers.py:31-43
+    m.warmstart()
+    _, xsm, usm = m.get_mpc_trajectory()
+    xs0, us0 = stationary_guess(xm[None], Pm.N, Pm.nu)
+    xo, uo, so, rc = Oracle(Pm).solve(0.0, xm, xs0[0], us0[0])
+    assert rc == 0 and np.abs(xsm - xo).max() < 2e-5 and np.abs(usm[:-1] - uo).max() < 2e-4

@@ -116,6 +116,7 @@ PROTOTYPES = [
     ("upr_batch_create", C.c_void_p, [C.POINTER(UprProblem), C.c_int, dp, dp]),
     ("upr_batch_destroy", None, [C.c_void_p]),
     ("upr_batch_reset", C.c_int, [C.c_void_p, dp]),
+    ("upr_batch_set_target_orientations", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_set_observation", C.c_int, [C.c_void_p, dp, C.c_int, dp]),
     ("upr_batch_set_guess", C.c_int, [C.c_void_p, dp, dp]),
     ("upr_batch_advance", C.c_int, [C.c_void_p]),

@@ -385,9 +385,11 @@ class ControllerInterface:
         self._target = target
         ts = np.array(list(target.ts), dtype=np.float64)
         ps = np.array([np.asarray(x)[:3] for x in target.xs], dtype=np.float64).reshape(len(ts), 3)
-        self.problem.way_t, self.problem.way_p = ts, ps
+        qs = np.array([np.asarray(x)[3:7] if np.asarray(x).size >= 7 else [0.0, 0.0, 0.0, 1.0] for x in target.xs], dtype=np.float64).reshape(len(ts), 4)
+        self.problem.way_t, self.problem.way_p, self.problem.way_q = ts, ps, qs
         if self._mpc is not None and len(self._mpc.problem.way_t) == len(ts) and np.array_equal(self._mpc.problem.way_t, ts):
             self._mpc.reset(ps.reshape(1, len(ts), 3))
+            self._mpc.set_target_orientations(qs.reshape(1, len(ts), 4))
         else:
             if self._mpc is not None:
                 self._mpc.close()

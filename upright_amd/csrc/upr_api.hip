@@ -204,7 +204,7 @@ struct upr_batch {
     int B = 0;
     hipStream_t stream = nullptr;
     upr_problem* dP = nullptr;
-    double *body_params = nullptr, *way_p = nullptr, *t0 = nullptr, *x0 = nullptr;
+    double *body_params = nullptr, *way_p = nullptr, *way_q = nullptr, *t0 = nullptr, *x0 = nullptr;
     double *xs = nullptr, *us = nullptr, *xs_prev = nullptr, *us_prev = nullptr, *tprev = nullptr;
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr, *has_prev = nullptr;
@@ -244,7 +244,7 @@ int check_problem(const upr_problem* P) {
     if (P->N < 1 || P->N > 1000) return fail("N out of range");
     if (!(P->dt > 0)) return fail("dt must be positive");
     if (P->n_way < 1 || P->n_way > UPR_MAX_WAYPOINTS) return fail("n_way out of range");
-    if (P->Wee[3] != 0 || P->Wee[4] != 0 || P->Wee[5] != 0) return fail("end-effector orientation weights are not supported");
+    for (int i = 0; i < 6; ++i) if (!(P->Wee[i] >= 0)) return fail("end-effector weights must be non-negative");
     if (P->n_sph < 0 || P->n_sph > UPR_MAX_SPHERES) return fail("n_sph out of range");
     if (P->n_pairs < 0 || P->n_pairs > UPR_MAX_PAIRS) return fail("n_pairs out of range");
     if (P->n_dyn < 0 || P->n_dyn > 1) return fail("n_dyn must be 0 or 1");
@@ -278,8 +278,15 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     const int blocks = (A.npoints + 7) / 8;
     const size_t lds = (size_t)8 * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double);
     if (lds > 64 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
-    if (h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true>), dim3(blocks), dim3(256), lds, h->stream, A);
-    else hipLaunchKernelGGL((upr_linearize_kernel<NQ, false>), dim3(blocks), dim3(256), lds, h->stream, A);
+    static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 2;   // (measured: 2 -> 0.130 ms, 3 -> 0.142 ms, 4 -> 0.32 ms with spills)
+    if (A.way_q) {   // end-effector cost with orientation weights
+        if (h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true, 2, true>), dim3(blocks), dim3(256), lds, h->stream, A);
+        else hipLaunchKernelGGL((upr_linearize_kernel<NQ, false, 2, true>), dim3(blocks), dim3(256), lds, h->stream, A);
+    }
+    else if (!h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, false>), dim3(blocks), dim3(256), lds, h->stream, A);
+    else if (occ == 3) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true, 3>), dim3(blocks), dim3(256), lds, h->stream, A);
+    else if (occ == 4) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true, 4>), dim3(blocks), dim3(256), lds, h->stream, A);
+    else hipLaunchKernelGGL((upr_linearize_kernel<NQ, true>), dim3(blocks), dim3(256), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;
 }
@@ -433,7 +440,7 @@ int launch_linesearch(upr_batch* h, const upr_ls_args& A) {
 
 upr_lin_args traj_lin_args(upr_batch* h) {
     upr_lin_args A;
-    A.P = h->dP; A.d = h->d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = h->t0;
+    A.P = h->dP; A.d = h->d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = h->t0;
     A.xs = h->xs; A.us = h->us; A.inst = nullptr; A.lin = h->lin; A.ee_out = nullptr;
     A.npoints = h->B * (h->d.N + 1);
     A.dyn = h->dyn0; A.pflag = h->pflag;
@@ -516,7 +523,7 @@ int advance_impl(upr_batch* h) {
         }
         upr_ls_args L;
         L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
-        L.way_p = h->way_p; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
+        L.way_p = h->way_p; L.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
     }
     if (h->fb && !(h->fb_fused && sqp_iters > 0)) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
@@ -628,7 +635,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (hipMalloc((void**)&h->dP, sizeof(upr_problem)) != hipSuccess) { fail("hipMalloc failed"); return bad(); }
     hipMemcpy(h->dP, P, sizeof(upr_problem), hipMemcpyHostToDevice);
     const size_t n1 = d.N + 1;
-    if (dev_alloc(&h->body_params, (size_t)B * d.nb * 10) || dev_alloc(&h->way_p, (size_t)B * P->n_way * 3) || dev_alloc(&h->t0, B) ||
+    if (dev_alloc(&h->body_params, (size_t)B * d.nb * 10) || dev_alloc(&h->way_p, (size_t)B * P->n_way * 3) || dev_alloc(&h->way_q, (size_t)B * P->n_way * 4) || dev_alloc(&h->t0, B) ||
         dev_alloc(&h->x0, (size_t)B * d.nx) || dev_alloc(&h->xs, (size_t)B * n1 * d.nx) || dev_alloc(&h->us, (size_t)B * d.N * d.nu) ||
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
@@ -638,6 +645,11 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         return bad();
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
     hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
+    {   // target orientations default to the identity quaternion (xyzw) until upr_batch_set_target_orientations
+        std::vector<double> qi((size_t)B * P->n_way * 4, 0.0);
+        for (size_t i = 3; i < qi.size(); i += 4) qi[i] = 1.0;
+        hipMemcpy(h->way_q, qi.data(), sizeof(double) * qi.size(), hipMemcpyHostToDevice);
+    }
     // constant d(object_dynamics)/d(forces): unit forces through the wrench map (contact_constraints.h:107-157),
     // divided by the body mass and sqrt(6 nb) (balancing_constraints.cpp:144-151), sign of (GIF - F)
     h->hDf.assign((size_t)B * d.ne * d.nfc, 0.0);
@@ -660,7 +672,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
 
 void upr_batch_destroy(upr_batch* h) {
     if (!h) return;
-    hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
+    hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->way_q); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
     if (h->fb) hipFree(h->fb);
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
@@ -677,6 +689,20 @@ int upr_batch_reset(upr_batch* h, const double* way_p) {
     UPR_HIP(hipMemsetAsync(h->has_prev, 0, sizeof(int) * h->B, h->stream));
     UPR_HIP(hipStreamSynchronize(h->stream));
     h->guess_set = false;
+    return 0;
+}
+
+int upr_batch_set_target_orientations(upr_batch* h, const double* way_q) {
+    if (!h) return fail("null batch");
+    if (!way_q) return fail("upr_batch_set_target_orientations: way_q is NULL");
+    std::vector<double> q(way_q, way_q + (size_t)h->B * h->P.n_way * 4);
+    for (size_t i = 0; i < q.size(); i += 4) {   // unit quaternions (the reference builds Quatd from the target's coefficients)
+        const double n = std::sqrt(q[i] * q[i] + q[i + 1] * q[i + 1] + q[i + 2] * q[i + 2] + q[i + 3] * q[i + 3]);
+        if (!(n > 0)) return fail("upr_batch_set_target_orientations: zero quaternion");
+        for (int c = 0; c < 4; ++c) q[i + c] /= n;
+    }
+    UPR_HIP(hipMemcpyAsync(h->way_q, q.data(), sizeof(double) * q.size(), hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -810,7 +836,7 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     UPR_HIP(hipMemcpy(dx, x, sizeof(double) * n * d.nx, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(du, u, sizeof(double) * n * d.nu, hipMemcpyHostToDevice));
     upr_lin_args A;
-    A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
+    A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
     A.lin = dlin; A.ee_out = dee; A.npoints = n;
     double* ddyn = nullptr;
     if (h->P.n_dyn) {   // points mode: the obstacle state of every point as given

@@ -152,3 +152,38 @@ static inline UPR_HD void upr_target_position(const upr_problem* P, const double
     }
     for (int i = 0; i < 3; ++i) pd[i] = alpha * way_p[3 * idx + i] + (1.0 - alpha) * way_p[3 * (idx + 1) + i];
 }
+
+// reference_trajectory.h:18-47 (orientation part): the target orientation is the SLERP of the waypoint quaternions
+// (xyzw), q_lhs.slerp(1 - alpha, q_rhs) with Eigen's rule (shortest arc; linear where the two nearly coincide); out: the
+// rotation matrix (row-major) of the interpolated unit quaternion
+static inline UPR_HD void upr_quat_to_rot(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+static inline UPR_HD void upr_target_rotation(const upr_problem* P, const double* way_q, double t, double* R) {
+    const int n = P->n_way;
+    if (n <= 1) { upr_quat_to_rot(way_q, R); return; }
+    int idx; double alpha;
+    if (t <= P->way_t[0]) { idx = 0; alpha = 1.0; }
+    else if (t >= P->way_t[n - 1]) { idx = n - 2; alpha = 0.0; }
+    else {
+        idx = 0;
+        while (idx + 1 < n - 1 && t >= P->way_t[idx + 1]) ++idx;
+        alpha = (P->way_t[idx + 1] - t) / (P->way_t[idx + 1] - P->way_t[idx]);
+    }
+    const double* a = way_q + 4 * idx; const double* b = way_q + 4 * (idx + 1);
+    const double s = 1.0 - alpha;
+    const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3], ad = fabs(d);
+    double s0, s1;
+    if (ad >= 1.0 - 2.220446049250313e-16) { s0 = 1.0 - s; s1 = s; }
+    else { const double th = acos(ad), st = sin(th); s0 = sin((1.0 - s) * th) / st; s1 = sin(s * th) / st; }
+    if (d < 0.0) s1 = -s1;
+    double q[4];
+    for (int i = 0; i < 4; ++i) q[i] = s0 * a[i] + s1 * b[i];
+    const double nrm = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] *= nrm;
+    upr_quat_to_rot(q, R);
+}
+static inline UPR_HD bool upr_has_orientation_cost(const upr_problem* P) { return P->Wee[3] != 0.0 || P->Wee[4] != 0.0 || P->Wee[5] != 0.0; }

@@ -15,40 +15,60 @@
 struct upr_dd {  // value + one tangent
     double v, d;
 };
-static inline UPR_HD upr_dd operator+(upr_dd a, upr_dd b) { return {a.v + b.v, a.d + b.d}; }
-static inline UPR_HD upr_dd operator-(upr_dd a, upr_dd b) { return {a.v - b.v, a.d - b.d}; }
-static inline UPR_HD upr_dd operator*(upr_dd a, upr_dd b) { return {a.v * b.v, fma(a.d, b.v, a.v * b.d)}; }
-static inline UPR_HD upr_dd operator*(double a, upr_dd b) { return {a * b.v, a * b.d}; }
-static inline UPR_HD upr_dd operator*(upr_dd b, double a) { return {a * b.v, a * b.d}; }
-static inline UPR_HD upr_dd upr_lift(double a, upr_dd*) { return {a, 0.0}; }
-static inline UPR_HD double upr_lift(double a, double*) { return a; }
-static inline UPR_HD double upr_seed(double v, bool on, double*) { return v; }
-static inline UPR_HD upr_dd upr_seed(double v, bool on, upr_dd*) { return {v, on ? 1.0 : 0.0}; }
-static inline UPR_HD void upr_sincos(double th, double* s, double* c) { *s = sin(th); *c = cos(th); }
-static inline UPR_HD void upr_sincos(upr_dd th, upr_dd* s, upr_dd* c) {
+static UPR_HDI upr_dd operator+(upr_dd a, upr_dd b) { return {a.v + b.v, a.d + b.d}; }
+static UPR_HDI upr_dd operator-(upr_dd a, upr_dd b) { return {a.v - b.v, a.d - b.d}; }
+static UPR_HDI upr_dd operator*(upr_dd a, upr_dd b) { return {a.v * b.v, fma(a.d, b.v, a.v * b.d)}; }
+static UPR_HDI upr_dd operator*(double a, upr_dd b) { return {a * b.v, a * b.d}; }
+static UPR_HDI upr_dd operator*(upr_dd b, double a) { return {a * b.v, a * b.d}; }
+static UPR_HDI upr_dd upr_lift(double a, upr_dd*) { return {a, 0.0}; }
+static UPR_HDI double upr_lift(double a, double*) { return a; }
+static UPR_HDI double upr_seed(double v, bool on, double*) { return v; }
+static UPR_HDI upr_dd upr_seed(double v, bool on, upr_dd*) { return {v, on ? 1.0 : 0.0}; }
+static UPR_HDI void upr_sincos(double th, double* s, double* c) { *s = sin(th); *c = cos(th); }
+static UPR_HDI void upr_sincos(upr_dd th, upr_dd* s, upr_dd* c) {
     double sv = sin(th.v), cv = cos(th.v);
     *s = {sv, cv * th.d};
     *c = {cv, -sv * th.d};
 }
 
-template <class T> static inline UPR_HD void upr_cross(const T* a, const T* b, T* r) {
+static UPR_HDI double upr_sqrt_(double a) { return sqrt(a); }
+static UPR_HDI upr_dd upr_sqrt_(upr_dd a) { const double r = sqrt(a.v); return {r, 0.5 * a.d / r}; }
+static UPR_HDI double upr_recip_(double a) { return 1.0 / a; }
+static UPR_HDI upr_dd upr_recip_(upr_dd a) { const double r = 1.0 / a.v; return {r, -a.d * r * r}; }
+
+// Orientation error of the end-effector cost (cost/end_effector_cost.h:42-44,62-66; ocs2 quaternionDistance(q, q_ref) =
+// q_w r_v - r_w q_v + q_v x r_v): the vector part of the relative rotation r (x) q^-1, i.e. sin(theta / 2) axis of
+// R_d = R_ref C'.  Written on the rotation matrices, which the tangent lanes carry anyway:
+// e = vee(R_d - R_d') / (2 sqrt(1 + tr R_d)).  (The sign of a quaternion representative flips e, which cost, gradient
+// and Gauss-Newton Hessian do not see.)  C: world <- EE, row-major; Rr: desired, row-major.
+template <class T> static UPR_HDI void upr_orientation_error(const T* C, const double* Rr, T* e) {
+    T Rd[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rd[3 * i + j] = Rr[3 * i] * C[3 * j] + Rr[3 * i + 1] * C[3 * j + 1] + Rr[3 * i + 2] * C[3 * j + 2];
+    T tr1 = Rd[0] + Rd[4] + Rd[8];
+    tr1 = tr1 + upr_lift(1.0, (T*)nullptr);
+    const T inv = 0.5 * upr_recip_(upr_sqrt_(tr1));
+    e[0] = (Rd[7] - Rd[5]) * inv; e[1] = (Rd[2] - Rd[6]) * inv; e[2] = (Rd[3] - Rd[1]) * inv;
+}
+
+template <class T> static UPR_HDI void upr_cross(const T* a, const T* b, T* r) {
     T r0 = a[1] * b[2] - a[2] * b[1];
     T r1 = a[2] * b[0] - a[0] * b[2];
     T r2 = a[0] * b[1] - a[1] * b[0];
     r[0] = r0; r[1] = r1; r[2] = r2;
 }
 // r = R * c   (R row-major T, c constant)
-template <class T> static inline UPR_HD void upr_rot_const(const T* R, const double* c, T* r) {
+template <class T> static UPR_HDI void upr_rot_const(const T* R, const double* c, T* r) {
     for (int i = 0; i < 3; ++i) r[i] = R[3 * i] * c[0] + R[3 * i + 1] * c[1] + R[3 * i + 2] * c[2];
 }
 // R <- R * M  (M constant 3x3 row-major)
-template <class T> static inline UPR_HD void upr_rmul_const(T* R, const double* M) {
+template <class T> static UPR_HDI void upr_rmul_const(T* R, const double* M) {
     for (int i = 0; i < 3; ++i) {
         T a = R[3 * i], b = R[3 * i + 1], c = R[3 * i + 2];
         for (int j = 0; j < 3; ++j) R[3 * i + j] = a * M[j] + b * M[3 + j] + c * M[6 + j];
     }
 }
-template <class T> static inline UPR_HD void upr_rmul(T* R, const T* M) {
+template <class T> static UPR_HDI void upr_rmul(T* R, const T* M) {
     for (int i = 0; i < 3; ++i) {
         T a = R[3 * i], b = R[3 * i + 1], c = R[3 * i + 2];
         for (int j = 0; j < 3; ++j) R[3 * i + j] = a * M[j] + b * M[3 + j] + c * M[6 + j];
@@ -61,7 +81,7 @@ struct upr_ee {
 };
 
 // Rigidly carry the tracked point by the world-frame offset r (classical acceleration).
-template <class T> static inline UPR_HD void upr_carry(upr_ee<T>& E, const T* r) {
+template <class T> static UPR_HDI void upr_carry(upr_ee<T>& E, const T* r) {
     T wr[3], t[3];
     upr_cross(E.w, r, wr);
     for (int i = 0; i < 3; ++i) E.v[i] = E.v[i] + wr[i];
@@ -74,7 +94,7 @@ template <class T> static inline UPR_HD void upr_carry(upr_ee<T>& E, const T* r)
 // x: the knot's state [q, v, a] (plain values); dir: tangent direction of this lane (-1: none).
 // NQ is the compile-time joint count so that the chain loop unrolls and everything stays in registers.
 template <class T, int NQ>
-static inline UPR_HD void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E) {
+static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E) {
     T* tag = nullptr;
     for (int i = 0; i < 9; ++i) E.C[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
     for (int i = 0; i < 3; ++i) { E.p[i] = upr_lift(0.0, tag); E.v[i] = E.p[i]; E.w[i] = E.p[i]; E.a[i] = E.p[i]; E.al[i] = E.p[i]; }
@@ -133,7 +153,7 @@ static inline UPR_HD void upr_ee_kinematics(const upr_problem* P, const double* 
 // upright_assets/thing/xacro/collision_links.urdf.xacro ride on chain links, obstacle spheres are fixed in the
 // world): the same chain walk, positions only.  `put(s, c)` receives sphere s and its centre c[3].
 template <class T, int NQ, class F>
-static inline UPR_HD void upr_sphere_walk(const upr_problem* P, const double* x, int dir, F put) {
+static UPR_HDI void upr_sphere_walk(const upr_problem* P, const double* x, int dir, F put) {
     T* tag = nullptr;
     T R[9], o[3];
     for (int i = 0; i < 9; ++i) R[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
@@ -182,7 +202,7 @@ static inline UPR_HD void upr_sphere_walk(const upr_problem* P, const double* x,
 }
 // closest FUTURE time of a ballistic path r0 + t v0 + t^2/2 g to the point c (projectile_path_constraint.h:12-45:
 // stationary point of the squared distance by Newton on the cubic, 10 steps from t = 0, tolerance 1e-4)
-static inline UPR_HD double upr_projectile_closest_time(const double* c, const double* r0, const double* v0, const double* g) {
+static UPR_HDI double upr_projectile_closest_time(const double* c, const double* r0, const double* v0, const double* g) {
     const double dr[3] = {c[0] - r0[0], c[1] - r0[1], c[2] - r0[2]};
     const double a = g[0] * g[0] + g[1] * g[1] + g[2] * g[2], b = 3.0 * (v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2]);
     const double cc = 2.0 * (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] - (dr[0] * g[0] + dr[1] * g[1] + dr[2] * g[2]));
@@ -197,14 +217,14 @@ static inline UPR_HD double upr_projectile_closest_time(const double* c, const d
     return x > 0.0 ? x : 0.0;
 }
 // obstacle state tau seconds after its observation xo = [r, v, a]
-static inline UPR_HD void upr_obstacle_at(const double* xo, double tau, double* r, double* v, double* a) {
+static UPR_HDI void upr_obstacle_at(const double* xo, double tau, double* r, double* v, double* a) {
     for (int i = 0; i < 3; ++i) { a[i] = xo[6 + i]; v[i] = xo[3 + i] + tau * a[i]; r[i] = xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * a[i]; }
 }
 // one state row from the sphere centres: collision pair / ground row r < n_pairs, projectile row otherwise.
 // cen(s, i) returns coordinate i of the centre of sphere s; returns the value and the unit direction n (the row's
 // gradient is wgt * n . d c_a/dq - wgt * n . d c_b/dq, b < 0: no second sphere)
 template <class CEN>
-static inline UPR_HD double upr_state_row(const upr_problem* P, int r, CEN cen, const double* ro, const double* vo, const double* ao, double flag,
+static UPR_HDI double upr_state_row(const upr_problem* P, int r, CEN cen, const double* ro, const double* vo, const double* ao, double flag,
                                           int* sa, int* sb, double* n, double* wgt) {
     if (r < P->n_pairs) {
         const int a = P->pair_a[r], b = P->pair_b[r];
@@ -228,7 +248,7 @@ static inline UPR_HD double upr_state_row(const upr_problem* P, int r, CEN cen, 
 }
 // values of the state rows at a configuration (line search): d[n_pairs + n_proj]; xo: obstacle state at this knot
 template <int NQ>
-static inline UPR_HD void upr_obstacle_values(const upr_problem* P, const double* x, const double* xo, double flag, double* d) {
+static UPR_HDI void upr_obstacle_values(const upr_problem* P, const double* x, const double* xo, double flag, double* d) {
     double c[UPR_MAX_SPHERES][3];
     double ro[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
     if (xo) upr_obstacle_at(xo, 0.0, ro, vo, ao);
@@ -244,7 +264,7 @@ static inline UPR_HD void upr_obstacle_values(const upr_problem* P, const double
 // contact wrench (F, Tq) on the body (plain values: the wrench does not depend on the state).
 // bp = the body's 10 inertial parameters (rigid_body.h:36-51).
 template <class T>
-static inline UPR_HD void upr_body_residual(const upr_ee<T>& E, const double* bp, const double* g0, const double* F,
+static UPR_HDI void upr_body_residual(const upr_ee<T>& E, const double* bp, const double* g0, const double* F,
                                             const double* Tq, T* out) {
     T* tag = nullptr;
     const double m = bp[0];
@@ -279,7 +299,7 @@ static inline UPR_HD void upr_body_residual(const upr_ee<T>& E, const double* bp
 
 // contact_constraints.h:107-157: summed contact wrench on every balanced body.  forces = u tail.
 // Fw[nb][6] = [F(3), T(3)].  bodies: body_params[nb][10].
-static inline UPR_HD void upr_object_wrenches(const upr_problem* P, const double* body_params, const double* forces,
+static UPR_HDI void upr_object_wrenches(const upr_problem* P, const double* body_params, const double* forces,
                                               double* Fw) {
     for (int i = 0; i < 6 * P->nb; ++i) Fw[i] = 0.0;
     for (int i = 0; i < P->nc; ++i) {
@@ -305,7 +325,7 @@ static inline UPR_HD void upr_object_wrenches(const upr_problem* P, const double
 }
 
 // contact_constraints.h:50-77: the five pyramid rows of contact i
-static inline UPR_HD void upr_friction_rows_contact(const upr_problem* P, int i, const double* f, double* h) {
+static UPR_HDI void upr_friction_rows_contact(const upr_problem* P, int i, const double* f, double* h) {
     const double* n = P->contact_normal[i];
     const double* S = P->contact_span[i];
     double fn = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
@@ -319,7 +339,7 @@ static inline UPR_HD void upr_friction_rows_contact(const upr_problem* P, int i,
     h[4] = mu * fn + t0 + t1;
 }
 // row r (0..4) of the constant 5x3 Jacobian d h / d f of contact i
-static inline UPR_HD void upr_friction_row_jac(const upr_problem* P, int i, int r, double* e) {
+static UPR_HDI void upr_friction_row_jac(const upr_problem* P, int i, int r, double* e) {
     const double* n = P->contact_normal[i];
     const double* S = P->contact_span[i];
     double mu = P->contact_mu[i];

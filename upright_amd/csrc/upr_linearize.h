@@ -19,15 +19,18 @@
 
 #define UPR_LPK 32
 
-// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[3 nq] e[3] | sphere centres and their q-tangents [ns][3][1 + nq]
-static inline UPR_HD int upr_lin_lds_base(const upr_dims& d) { return (d.nx + d.nu + 6 * d.nb + 3 * d.nq + 3 + 1 + 1) & ~1; }
-static inline UPR_HD int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
+// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[6 nq] e[6] Rref[9] | sphere centres and their q-tangents [ns][3][1 + nq]
+// (J / e: position rows, then the orientation rows used when the end-effector cost weighs orientation)
+static UPR_HDI int upr_lin_lds_base(const upr_dims& d) { return (d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6 + 9 + 1 + 1) & ~1; }
+static UPR_HDI int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
 
 struct upr_lin_args {
     const upr_problem* P;
     upr_dims d;
     const double* body_params;  // [B][nb][10]
     const double* way_p;        // [B][n_way][3]
+    const double* way_q = nullptr;   // [B][n_way][4] target orientations (xyzw); NULL unless Wee[3..5] != 0 (set by the host: the
+                                     // kernel never looks the weights up to decide)
     const double* t0;           // [B] (trajectory mode) or per point (points mode)
     const double* xs;           // trajectory mode: [B][N+1][nx]; points mode: [n][nx]
     const double* us;           // trajectory mode: [B][N][nu];   points mode: [n][nu]
@@ -50,7 +53,7 @@ struct upr_lin_point {
     double* out;
 };
 
-static inline UPR_HD upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) {
+static UPR_HDI upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) {
     upr_lin_point q;
     const upr_dims& d = A.d;
     q.p = p;
@@ -69,30 +72,34 @@ static inline UPR_HD upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) 
 }
 
 // phase 0: stage x, u into LDS (coalesced: lane l loads element l) -- lanes 0..LPK-1 of the knot
-static inline UPR_HD void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_dims& d = A.d;
     double* sx = sh; double* su = sh + d.nx;
     for (int i = lane; i < d.nx; i += UPR_LPK) sx[i] = q.x[i];
     for (int i = lane; i < d.nu; i += UPR_LPK) su[i] = q.terminal ? 0.0 : q.u[i];
 }
 // phase 0b: summed contact wrench per body (contact x body loop out of the LDS-staged forces)
-static inline UPR_HD void upr_lin_phase0b(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+static UPR_HDI void upr_lin_phase0b(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_dims& d = A.d;
     if (lane == 0) {
         double* Fw = sh + d.nx + d.nu;
         upr_object_wrenches(A.P, A.body_params + (size_t)q.b * d.nb * 10, sh + d.nx + d.nq, Fw);
     }
+    if (lane == 1 && A.way_q != nullptr)   // desired orientation of this knot (SLERP of the waypoints)
+        upr_target_rotation(A.P, A.way_q + (size_t)q.b * A.P->n_way * 4, q.t, sh + d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6);
 }
 
-// phase 1: the tangent lanes
-template <int NQ>
-static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+// phase 1: the tangent lanes.  ORI: the end-effector cost weighs orientation (compile-time: the error-row loops keep
+// constant trip counts)
+template <int NQ, bool ORI = false>
+static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_dims& d = A.d;
     const upr_problem* P = A.P;
     const double* sx = sh;
     const double* Fw = sh + d.nx + d.nu;
     double* sJ = sh + d.nx + d.nu + 6 * d.nb;
-    double* se = sJ + 3 * d.nq;
+    double* se = sJ + 6 * d.nq;
+    constexpr bool ori = ORI;
     const int dir = (lane < d.nx) ? lane : -1;
     upr_ee<upr_dd> E;
     upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E);
@@ -110,6 +117,12 @@ static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_po
     }
     if (dir >= 0 && dir < NQ)
         for (int r = 0; r < 3; ++r) sJ[r * NQ + dir] = E.p[r].d;
+    if (ori && !q.terminal) {
+        upr_dd eo[3];
+        upr_orientation_error<upr_dd>(E.C, se + 6, eo);
+        if (dir >= 0 && dir < NQ) for (int r = 0; r < 3; ++r) sJ[(3 + r) * NQ + dir] = eo[r].d;
+        if (lane == 0) for (int r = 0; r < 3; ++r) se[3 + r] = eo[r].v;
+    }
     if (lane == 0) {
         double pd[3];
         upr_target_position(P, A.way_p + (size_t)q.b * P->n_way * 3, q.t, pd);
@@ -122,14 +135,14 @@ static inline UPR_HD void upr_lin_phase1(const upr_lin_args& A, const upr_lin_po
 //   a: lane l < nq walks the chain with the tangent along q_l and leaves every sphere centre's tangent in LDS
 //      (lane 0 also the values);  b: lane r owns pair r: distance and its gradient n . (dc_a/dq - dc_b/dq)
 // obstacle state at this point (trajectory mode: k dt after the observation)
-static inline UPR_HD void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point& q, double* ro, double* vo, double* ao) {
+static UPR_HDI void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point& q, double* ro, double* vo, double* ao) {
     for (int i = 0; i < 3; ++i) { ro[i] = 0.0; vo[i] = 0.0; ao[i] = 0.0; }
     if (!A.dyn) return;
     if (A.inst) upr_obstacle_at(A.dyn + (size_t)q.p * 9, 0.0, ro, vo, ao);
     else upr_obstacle_at(A.dyn + (size_t)q.b * 9, q.k * A.P->dt, ro, vo, ao);
 }
 template <int NQ>
-static inline UPR_HD void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+static UPR_HDI void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_problem* P = A.P;
     double* sc = sh + upr_lin_lds_base(A.d);
     if (q.terminal || lane >= NQ) return;
@@ -145,7 +158,7 @@ static inline UPR_HD void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_l
     });
 }
 template <int NQ>
-static inline UPR_HD void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
+static UPR_HDI void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const double* sc = sh + upr_lin_lds_base(d);
     if (q.terminal) return;
@@ -164,24 +177,25 @@ static inline UPR_HD void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_l
 }
 
 // phase 2 (VALU path): gradient, Gauss-Newton Hessian, cost from the LDS-staged position Jacobian
-template <int NQ>
-static inline UPR_HD void upr_lin_phase2(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
+template <int NQ, bool ORI = false>
+static UPR_HDI void upr_lin_phase2(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
     const upr_dims& d = A.d;
     const double* W = A.P->Wee;
     const double* sJ = sh + d.nx + d.nu + 6 * d.nb;
-    const double* se = sJ + 3 * d.nq;
+    const double* se = sJ + 6 * d.nq;
+    constexpr int nr = ORI ? 6 : 3;   // error rows: position (+ orientation)
     if (!q.terminal) {
         if (lane < NQ) {
             double g = 0.0;
-            for (int r = 0; r < 3; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
+            for (int r = 0; r < nr; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
             q.out[d.lin_grad + lane] = g;
             for (int m = lane; m < NQ; ++m) {
                 double h = 0.0;
-                for (int r = 0; r < 3; ++r) h += W[r] * sJ[r * NQ + lane] * sJ[r * NQ + m];
+                for (int r = 0; r < nr; ++r) h += W[r] * sJ[r * NQ + lane] * sJ[r * NQ + m];
                 q.out[d.lin_hess + upr_tri(NQ, lane, m)] = h;
             }
         }
-        if (lane == 0) q.out[d.lin_cost] = 0.5 * (W[0] * se[0] * se[0] + W[1] * se[1] * se[1] + W[2] * se[2] * se[2]);
+        if (lane == 0) { double c = 0.0; for (int r = 0; r < nr; ++r) c += 0.5 * W[r] * se[r] * se[r]; q.out[d.lin_cost] = c; }
     } else {
         if (lane < 3) q.out[d.lin_grad + lane] = -se[lane];
         if (lane < NQ) for (int r = 0; r < 3; ++r) q.out[d.lin_hess + r * NQ + lane] = sJ[r * NQ + lane];
@@ -191,8 +205,9 @@ static inline UPR_HD void upr_lin_phase2(const upr_lin_args& A, const upr_lin_po
 
 #ifndef UPR_HOST_EMU
 // 256 threads = 8 knots x 32 lanes.  USE_MFMA: Gauss-Newton Hessian through v_mfma_f64_16x16x4_f64.
-template <int NQ, bool USE_MFMA>
-__global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
+// OCC: waves per SIMD the register allocation is held to (the kernel is latency bound: more resident knots hide more of it)
+template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false>
+__global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int per = upr_lin_lds_doubles(A.d, A.P->n_sph);
     const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
@@ -204,7 +219,7 @@ __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
     __syncthreads();
     if (live) upr_lin_phase0b(A, q, lane, sh);
     __syncthreads();
-    if (live) upr_lin_phase1<NQ>(A, q, lane, sh);
+    if (live) upr_lin_phase1<NQ, ORI>(A, q, lane, sh);
     if (A.d.no > 0) {
         if (live) upr_lin_phase_obs_a<NQ>(A, q, lane, sh);
         __syncthreads();
@@ -212,7 +227,7 @@ __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
     }
     __syncthreads();
     if (!USE_MFMA) {
-        if (live) upr_lin_phase2<NQ>(A, q, lane, sh);
+        if (live) upr_lin_phase2<NQ, ORI>(A, q, lane, sh);
     } else {
         // One MFMA per knot-half: D(16x16) = A(16x4) B(4x16) with A[i][k] = sqrt(W_k) J[k][i],
         // B[k][j] = sqrt(W_k) J[k][j] (k < 3; k = 3 is zero padding).  Operand lane map (f64 16x16x4,
@@ -232,6 +247,11 @@ __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
             if (ph < A.npoints && k4 < 3 && i16 < NQ) a = sqrt(A.P->Wee[k4]) * sJ[k4 * NQ + i16];
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+            if (ORI) {   // the three orientation rows: one more rank-4 update
+                double a2 = 0.0;
+                if (ph < A.npoints && k4 < 3 && i16 < NQ) a2 = sqrt(A.P->Wee[3 + k4]) * sJ[(3 + k4) * NQ + i16];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc, 0, 0, 0);
+            }
             if (ph < A.npoints) {
                 upr_lin_point qh = upr_lin_locate(A, ph);
                 if (!qh.terminal) {
@@ -247,16 +267,17 @@ __global__ void __launch_bounds__(256) upr_linearize_kernel(upr_lin_args A) {
         if (live) {
             const double* W = A.P->Wee;
             const double* sJ = sh + A.d.nx + A.d.nu + 6 * A.d.nb;
-            const double* se = sJ + 3 * A.d.nq;
+            const double* se = sJ + 6 * A.d.nq;
+            constexpr int nr = ORI ? 6 : 3;
             if (!q.terminal) {
                 if (lane < NQ) {
                     double g = 0.0;
-                    for (int r = 0; r < 3; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
+                    for (int r = 0; r < nr; ++r) g += W[r] * se[r] * sJ[r * NQ + lane];
                     q.out[A.d.lin_grad + lane] = g;
                 }
-                if (lane == 0) q.out[A.d.lin_cost] = 0.5 * (W[0] * se[0] * se[0] + W[1] * se[1] * se[1] + W[2] * se[2] * se[2]);
+                if (lane == 0) { double c = 0.0; for (int r = 0; r < nr; ++r) c += 0.5 * W[r] * se[r] * se[r]; q.out[A.d.lin_cost] = c; }
             } else {
-                upr_lin_phase2<NQ>(A, q, lane, sh);
+                upr_lin_phase2<NQ, ORI>(A, q, lane, sh);
             }
         }
     }

@@ -26,13 +26,14 @@ struct upr_ls_args {
     int iter;              // SQP iteration index (0-based)
     const double* dyn = nullptr;    // [B][9] observed dynamic-obstacle state (NULL: none)
     const double* pflag = nullptr;  // [B] projectile activation flag
+    const double* way_q = nullptr;  // [B][n_way][4] target orientations; NULL unless Wee[3..5] != 0
 };
 
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
 // NFM / NBM: compile-time bounds of nf nc / nb (the per-lane input vector and body wrenches stay in registers for the
 // small shapes: with the library-wide maxima they lived in scratch, 2 KB per lane)
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
-static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
+static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
@@ -64,6 +65,12 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
         for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
         for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
         for (int r = 0; r < 3; ++r) { double e = E.p[r] - pd[r]; c += 0.5 * P->Wee[r] * e * e; }
+        if (A.way_q) {
+            double Rr[9], eo[3];
+            upr_target_rotation(P, A.way_q + (size_t)b * P->n_way * 4, A.t0[b] + k * h, Rr);
+            upr_orientation_error<double>(E.C, Rr, eo);
+            for (int r = 0; r < 3; ++r) c += 0.5 * P->Wee[3 + r] * eo[r] * eo[r];
+        }
         cost += h * c;
         // dynamics defect against the next trial state
         for (int j = 0; j < nq; ++j) {
@@ -105,7 +112,7 @@ static inline UPR_HD void upr_ls_knot(const upr_ls_args& A, int b, int k, double
 // object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
 // of walking the chain again
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS>
-static inline UPR_HD void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double* out) {
+static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
@@ -149,7 +156,7 @@ static inline UPR_HD void upr_ls_knot_base(const upr_ls_args& A, int b, int k, d
 }
 
 // block reduction of 4 partials; result broadcast in res[4]
-static inline UPR_HD void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double* part, double* res) {
+static UPR_HDI void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double* part, double* res) {
     for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] = part[c];
     UPR_SYNC();
     for (int s = 1; s < ctx.nt; s <<= 1) {
@@ -163,7 +170,7 @@ static inline UPR_HD void upr_ls_reduce4(const upr_ctx& ctx, double* red, const 
 
 // L: 4*nt + 8 doubles of workgroup scratch
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
-static inline UPR_HD void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
+static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
     if (A.done[b]) return;
@@ -240,7 +247,7 @@ __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
 // ---- warm start / policy evaluation ----------------------------------------------------------------
 // Linear interpolation of a stored solution (ts = tp0 + j dt) at time tau; beyond the stored horizon
 // the state is held and the input is zero (ocs2 DefaultInitializer, controller_interface.cpp:385-386).
-static inline UPR_HD void upr_interp(const upr_dims& d, double dt, double tp0, const double* xs, const double* us,
+static UPR_HDI void upr_interp(const upr_dims& d, double dt, double tp0, const double* xs, const double* us,
                                      double tau, int i_x, int i_u, double* xo, double* uo) {
     double s = (tau - tp0) / dt;
     int N = d.N;

@@ -13,7 +13,7 @@ from ._capi import check, cont, iptr, ptr
 
 
 class BatchMPC:
-    def __init__(self, problem, B=1, body_params=None, way_p=None):
+    def __init__(self, problem, B=1, body_params=None, way_p=None, way_q=None):
         self.problem = problem.validate()
         self.B = int(B)
         self.nx, self.nu, self.N = problem.nx, problem.nu, problem.N
@@ -30,6 +30,10 @@ class BatchMPC:
         self._h = self._lib.upr_batch_create(C.byref(self._c), self.B, ptr(self.body_params), ptr(self.way_p))
         if not self._h:
             raise RuntimeError(self._lib.upr_last_error().decode())
+        if way_q is None and getattr(problem, "way_q", None) is not None:
+            way_q = np.broadcast_to(np.asarray(problem.way_q, dtype=np.float64), (self.B, len(problem.way_t), 4))
+        if way_q is not None:
+            self.set_target_orientations(way_q)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -47,6 +51,11 @@ class BatchMPC:
         if way_p is not None:
             self.way_p = cont(way_p).reshape(self.B, len(self.problem.way_t), 3)
         check(self._lib.upr_batch_reset(self._h, ptr(self.way_p) if way_p is not None else None))
+
+    def set_target_orientations(self, way_q):
+        """Target orientations per instance and waypoint, (B, n_way, 4) quaternions xyzw."""
+        self.way_q = cont(way_q).reshape(self.B, len(self.problem.way_t), 4)
+        check(self._lib.upr_batch_set_target_orientations(self._h, ptr(self.way_q)))
 
     def set_observation(self, t, x):
         x = cont(x).reshape(self.B, self.nxf)

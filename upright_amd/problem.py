@@ -40,6 +40,7 @@ class Problem:
     u_ub: np.ndarray = None
     way_t: np.ndarray = field(default_factory=lambda: np.zeros(1))
     way_p: np.ndarray = field(default_factory=lambda: np.zeros((1, 3)))
+    way_q: np.ndarray = None  # (n_way, 4) target orientations, xyzw (None = identity); used when Wee[3:] != 0
     sqp_iters: int = 1
     qp_iter_max: int = 30
     qp_tol: float = 1e-8
@@ -99,8 +100,8 @@ class Problem:
                 raise ValueError(f"{name} has shape {a.shape}, expected ({n},)")
         if self.nf not in (1, 3):
             raise ValueError("nf must be 1 (frictionless) or 3")
-        if np.any(np.asarray(self.Wee)[3:] != 0):
-            raise ValueError("end-effector orientation weights are not supported (all shipped configs use 0)")
+        if np.asarray(self.Wee).shape != (6,) or np.any(np.asarray(self.Wee) < 0):
+            raise ValueError("Wee must hold six non-negative weights")
         if self.body_params.shape != (self.nb, 10):
             raise ValueError("body_params must be (nb, 10)")
         return self
