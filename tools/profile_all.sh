@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-2 evidence set on the GPU box (run through gpurun from the repo root): tools/profile_all.sh <tag>
+#   1. bench.py as the driver runs it (headline + extra workloads + CPU baseline)      -> gpurun_out/<tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the headline workload                        -> <tag>_kernel_stats.csv
+#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)                        -> <tag>_pmc_hbm.csv
+#   4. rocprofv3 --pmc instruction mix (tools/pmc_mfma.sh)                              -> <tag>_pmc_mfma.csv
+#   5. rocprofv3 --kernel-trace --stats of bench.py WITH the extra workloads            -> <tag>_kernel_stats_all.csv
+set -u
+TAG=${1:-r02}
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+python3 bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+bash tools/profile.sh $TAG > $OUT/prof_${TAG}.log 2>&1
+bash tools/pmc_mfma.sh $TAG > $OUT/prof_${TAG}_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_all -o ${TAG}all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_all.log 2>&1
+cp $(find $OUT/prof_${TAG}_all -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_all.csv
+head -c 600 $OUT/${TAG}_bench.json; echo
+head -8 $OUT/${TAG}_kernel_stats_all.csv
