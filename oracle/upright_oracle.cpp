@@ -956,7 +956,8 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
     if (!ric.Kx.empty()) for (int k = 0; k < N; ++k) {
         if (ric.Kx[k].empty()) continue;
         vec Kt = ric.Kx[k];
-        if (ne > 0 && !ric.Ls[k].empty()) {
+        // (a factorisation that broke down part-way leaves some knots without all of their factors: no gain there)
+        if (ne > 0 && !ric.Ls[k].empty() && !ric.Cbar[k].empty() && !ric.Y[k].empty()) {
             vec SC = ric.Cbar[k]; chol_solve(ric.Ls[k].data(), ne, SC.data(), nx);
             for (int i = 0; i < nu; ++i) for (int j = 0; j < nx; ++j) { double t = 0; for (int r = 0; r < ne; ++r) t += ric.Y[k][i * ne + r] * SC[r * nx + j]; Kt[i * nx + j] += t; }
         }
