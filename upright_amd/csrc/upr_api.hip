@@ -33,6 +33,22 @@ int fail(const std::string& msg) {
         if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
+// device scratch of one call: freed on every exit path (the early returns of UPR_HIP included)
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        UPR_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+        UPR_HIP(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+        return 0;
+    }
+    operator T*() const { return p; }
+};
+
 template <class T>
 int dev_alloc(T** p, size_t n) {
     UPR_HIP(hipMalloc((void**)p, n * sizeof(T)));
@@ -209,6 +225,7 @@ struct upr_batch {
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr, *has_prev = nullptr;
     double* prof = nullptr;
+    double *ev_t = nullptr, *ev_xo = nullptr, *ev_x = nullptr, *ev_u = nullptr;   // scratch of the evaluate / evaluate_policy calls
     double* kkt = nullptr;   // multiplier export of the register-resident QP kernel (upr_batch_qp_kkt), allocated on first use
     double *fb = nullptr, *xs_lin = nullptr;   // feedback gains of the last solve
     // dynamic obstacle (n_dyn == 1): observed state per instance (device + host copies, and the one the stored
@@ -557,21 +574,19 @@ int upr_core_object_dynamics(const upr_problem* P, const double* body_params, in
     if (!P || P->nb < 1 || P->nb > UPR_MAX_BODIES || P->nc < 0 || P->nc > UPR_MAX_CONTACTS) return fail("bad problem dims");
     if (n <= 0) return 0;
     const int nfc = P->nf * P->nc, nb = P->nb;
-    upr_problem* dP = nullptr; double *dbp, *df, *dC, *dw, *dal, *da, *dout;
-    UPR_HIP(hipMalloc((void**)&dP, sizeof(upr_problem)));
+    DevBuf<upr_problem> dP; DevBuf<double> dbp, df, dC, dw, dal, da, dout;
+    if (dP.alloc(1) || dbp.alloc((size_t)nb * 10) || df.alloc((size_t)n * nfc + 1) || dC.alloc((size_t)n * 9) || dw.alloc((size_t)n * 3) ||
+        dal.alloc((size_t)n * 3) || da.alloc((size_t)n * 3) || dout.alloc((size_t)n * 6 * nb)) return 1;
     UPR_HIP(hipMemcpy(dP, P, sizeof(upr_problem), hipMemcpyHostToDevice));
-    if (dev_alloc(&dbp, (size_t)nb * 10) || dev_alloc(&df, (size_t)n * nfc + 1) || dev_alloc(&dC, (size_t)n * 9) || dev_alloc(&dw, (size_t)n * 3) ||
-        dev_alloc(&dal, (size_t)n * 3) || dev_alloc(&da, (size_t)n * 3) || dev_alloc(&dout, (size_t)n * 6 * nb)) return 1;
     UPR_HIP(hipMemcpy(dbp, body_params, sizeof(double) * nb * 10, hipMemcpyHostToDevice));
     if (nfc) UPR_HIP(hipMemcpy(df, forces, sizeof(double) * n * nfc, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(dC, C, sizeof(double) * n * 9, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(dw, w, sizeof(double) * n * 3, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(dal, al, sizeof(double) * n * 3, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(da, a, sizeof(double) * n * 3, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(core_object_dynamics_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, dP, dbp, n, df, dC, dw, dal, da, dout);
+    hipLaunchKernelGGL(core_object_dynamics_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, dP.p, dbp.p, n, df.p, dC.p, dw.p, dal.p, da.p, dout.p);
     UPR_HIP(hipGetLastError());
     UPR_HIP(hipMemcpy(out, dout, sizeof(double) * n * 6 * nb, hipMemcpyDeviceToHost));
-    hipFree(dP); hipFree(dbp); hipFree(df); hipFree(dC); hipFree(dw); hipFree(dal); hipFree(da); hipFree(dout);
     return 0;
 }
 
@@ -579,15 +594,13 @@ int upr_core_friction_rows(const upr_problem* P, int n, const double* forces, do
     if (need_device()) return 1;
     if (!P || P->nc < 1 || P->nc > UPR_MAX_CONTACTS) return fail("bad problem dims");
     if (n <= 0) return 0;
-    upr_problem* dP = nullptr; double *df, *dout;
-    UPR_HIP(hipMalloc((void**)&dP, sizeof(upr_problem)));
+    DevBuf<upr_problem> dP; DevBuf<double> df, dout;
+    if (dP.alloc(1) || df.alloc((size_t)n * 3 * P->nc) || dout.alloc((size_t)n * 5 * P->nc)) return 1;
     UPR_HIP(hipMemcpy(dP, P, sizeof(upr_problem), hipMemcpyHostToDevice));
-    if (dev_alloc(&df, (size_t)n * 3 * P->nc) || dev_alloc(&dout, (size_t)n * 5 * P->nc)) return 1;
     UPR_HIP(hipMemcpy(df, forces, sizeof(double) * n * 3 * P->nc, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(core_friction_rows_kernel, dim3((n * P->nc + 63) / 64), dim3(64), 0, 0, dP, n, df, dout);
+    hipLaunchKernelGGL(core_friction_rows_kernel, dim3((n * P->nc + 63) / 64), dim3(64), 0, 0, dP.p, n, df.p, dout.p);
     UPR_HIP(hipGetLastError());
     UPR_HIP(hipMemcpy(out, dout, sizeof(double) * n * 5 * P->nc, hipMemcpyDeviceToHost));
-    hipFree(dP); hipFree(df); hipFree(dout);
     return 0;
 }
 
@@ -678,6 +691,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
     hipFree(h->done); hipFree(h->has_prev); hipFree(h->prof); hipFree(h->kkt);
+    hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -770,17 +784,16 @@ static int get_solution_core(upr_batch* h, double* ts, double* xs, double* us) {
 static int evaluate_core(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
     if (!h) return fail("null batch");
     const upr_dims& d = h->d;
-    double *dt_ = nullptr, *dx = nullptr, *du = nullptr;
-    if (dev_alloc(&dt_, h->B) || dev_alloc(&dx, (size_t)h->B * d.nx) || dev_alloc(&du, (size_t)h->B * d.nu)) return 1;
+    // (per-tick path of the closed loop: scratch preallocated in the handle on first use)
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
-    UPR_HIP(hipMemcpy(dt_, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, dt_, 1, dx, du);
+    UPR_HIP(hipMemcpyAsync(h->ev_t, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->ev_t, 1, h->ev_x, h->ev_u);
     UPR_HIP(hipGetLastError());
+    UPR_HIP(hipMemcpyAsync(x_out, h->ev_x, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost, h->stream));
+    UPR_HIP(hipMemcpyAsync(u_out, h->ev_u, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost, h->stream));
     UPR_HIP(hipStreamSynchronize(h->stream));
-    UPR_HIP(hipMemcpy(x_out, dx, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost));
-    UPR_HIP(hipMemcpy(u_out, du, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost));
-    hipFree(dt_); hipFree(dx); hipFree(du);
     return 0;
 }
 
@@ -788,18 +801,16 @@ static int evaluate_policy_core(upr_batch* h, const double* t, int t_stride, con
     if (!h) return fail("null batch");
     if (!h->fb) return fail("upr_batch_evaluate_policy: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
-    double *dt_ = nullptr, *dxo = nullptr, *dx = nullptr, *du = nullptr;
-    if (dev_alloc(&dt_, h->B) || dev_alloc(&dxo, (size_t)h->B * d.nx) || dev_alloc(&dx, (size_t)h->B * d.nx) || dev_alloc(&du, (size_t)h->B * d.nu)) return 1;
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
-    UPR_HIP(hipMemcpy(dt_, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice));
-    UPR_HIP(hipMemcpy(dxo, x_obs, sizeof(double) * h->B * d.nx, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, dt_, dxo, dx, du);
+    UPR_HIP(hipMemcpyAsync(h->ev_t, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->ev_xo, x_obs, sizeof(double) * h->B * d.nx, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, h->ev_t, h->ev_xo, h->ev_x, h->ev_u);
     UPR_HIP(hipGetLastError());
+    UPR_HIP(hipMemcpyAsync(x_out, h->ev_x, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost, h->stream));
+    UPR_HIP(hipMemcpyAsync(u_out, h->ev_u, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost, h->stream));
     UPR_HIP(hipStreamSynchronize(h->stream));
-    UPR_HIP(hipMemcpy(x_out, dx, sizeof(double) * h->B * d.nx, hipMemcpyDeviceToHost));
-    UPR_HIP(hipMemcpy(u_out, du, sizeof(double) * h->B * d.nu, hipMemcpyDeviceToHost));
-    hipFree(dt_); hipFree(dxo); hipFree(dx); hipFree(du);
     return 0;
 }
 
@@ -828,9 +839,9 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
                                  std::vector<double>& rec, double* ee, const double* dyn_pts = nullptr) {
     const upr_dims& d = h->d;
     for (int i = 0; i < n; ++i) if (inst[i] < 0 || inst[i] >= h->B) return fail("instance index out of range");
-    int* dinst = nullptr; double *dt_, *dx, *du, *dlin, *dee;
-    if (dev_alloc(&dinst, n) || dev_alloc(&dt_, n) || dev_alloc(&dx, (size_t)n * d.nx) || dev_alloc(&du, (size_t)n * d.nu) ||
-        dev_alloc(&dlin, (size_t)n * d.lin_stride) || dev_alloc(&dee, (size_t)n * 3)) return 1;
+    DevBuf<int> dinst; DevBuf<double> dt_, dx, du, dlin, dee, ddyn;
+    if (dinst.alloc(n) || dt_.alloc(n) || dx.alloc((size_t)n * d.nx) || du.alloc((size_t)n * d.nu) ||
+        dlin.alloc((size_t)n * d.lin_stride) || dee.alloc((size_t)n * 3)) return 1;
     UPR_HIP(hipMemcpy(dinst, inst, sizeof(int) * n, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(dt_, t, sizeof(double) * n, hipMemcpyHostToDevice));
     UPR_HIP(hipMemcpy(dx, x, sizeof(double) * n * d.nx, hipMemcpyHostToDevice));
@@ -838,9 +849,8 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     upr_lin_args A;
     A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
     A.lin = dlin; A.ee_out = dee; A.npoints = n;
-    double* ddyn = nullptr;
     if (h->P.n_dyn) {   // points mode: the obstacle state of every point as given
-        if (dev_alloc(&ddyn, (size_t)n * 9)) return 1;
+        if (ddyn.alloc((size_t)n * 9)) return 1;
         if (dyn_pts) UPR_HIP(hipMemcpy(ddyn, dyn_pts, sizeof(double) * n * 9, hipMemcpyHostToDevice));
         A.dyn = ddyn; A.pflag = h->pflag;
     }
@@ -849,7 +859,6 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     rec.assign((size_t)n * d.lin_stride, 0.0);
     UPR_HIP(hipMemcpy(rec.data(), dlin, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
     if (ee) UPR_HIP(hipMemcpy(ee, dee, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
-    hipFree(dinst); hipFree(dt_); hipFree(dx); hipFree(du); hipFree(dlin); hipFree(dee); if (ddyn) hipFree(ddyn);
     return 0;
 }
 
