@@ -5,16 +5,22 @@ from upright_amd.engine import BatchMPC
 from upright_amd.problem import thing_problem
 from upright_amd.sampling import level_tray_states, waypoints_for
 arr=json.load(open('tests/golden/arrangements.json'))
-P=thing_problem(arr['pink_bottle'])
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
-x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
+# workload: "config3" / "config4" among the arguments selects bench.py's extra workloads, default the headline
+import bench
+bp=None
+if "config3" in sys.argv: w=bench.config3_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
+elif "config4" in sys.argv: w=bench.config4_workload(B); P,x0,way,bp=w["P"],w["x0"],w["way"],w["body_params"]; P.sqp_iters=1
+else:
+    P=thing_problem(arr['pink_bottle'])
+    x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
 names=["residuals","prep A: box rows","prep B: contacts","prep C: eq residual, S","prep D: Schur factor","prep E: C' zt","mat: phase 1","mat: aug. Cholesky","mat: V, K store","mat: P update","vec: sweep","vec/mat: flat parts","fwd: sweep","fwd: tail + costates","aff sweeps","update + init"]
 MAT = "mat" in sys.argv[2:]
 if MAT:
     names=["ph1 work","ph1 wait","ph2: after last pivot -> arrival (stores | mfma preload, feedback)","ph2 wait","ph3 work (P update)","ph3 wait","wave 0: operand loads (hjj, hux)","wave 0: pivots 7, 8","wave 0: pivot 0","wave 0: pivot 1","wave 0: pivot 2","wave 0: pivot 3","wave 0: pivot 4","wave 0: pivot 5","wave 0: pivot 6","outside the matrix sweep"]
-for nt in [a for a in sys.argv[2:] if a != "mat"] or ["256"]:
+for nt in [a for a in sys.argv[2:] if a.isdigit()] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
-    mpc=BatchMPC(P,B,way_p=way); mpc.set_observation(0.0,x0)
+    mpc=BatchMPC(P,B,way_p=way,body_params=bp); mpc.set_observation(0.0,x0)
     mpc.advance()
     mpc.qp_profile()   # arm
     mpc.reset(); mpc.advance()

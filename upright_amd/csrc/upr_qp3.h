@@ -108,7 +108,9 @@ struct upr_qp3_lds {
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
                          prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
-                         bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX), total = gee + r2(C::N * C::NQ);   // gee: end-effector part of the cost gradient
+                         bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
+                         // multi-body shapes: the contacts that load each body (indices as doubles) and their number
+                         clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0), total = ccnt + r2(C::NB > 1 ? C::NB : 0);
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -290,6 +292,21 @@ struct upr_qp3 {
     // h, h2, h3 on a lane-dependent index would be turned into an indexed load and pin the whole object in scratch
     UPR_HDI double coefA(int a, int b) const { return ((a == b) ? 1.0 : 0.0) + (((a == 0 && b == 1) || (a == 1 && b == 2)) ? 1.0 : 0.0) * h + ((a == 0 && b == 2) ? 1.0 : 0.0) * h2; }
     UPR_HDI double coefB(int a) const { return ((a == 0) ? 1.0 : 0.0) * h3 + ((a == 1) ? 1.0 : 0.0) * h2 + ((a == 2) ? 1.0 : 0.0) * h; }
+    // row r of Df times a force-indexed vector.  Multi-body shapes: the row of body r / 6 has entries at the contacts that
+    // load that body only (O::clist), four of 32 columns for the robust arrangement
+    UPR_HDI double df_dot(int r, const double* vf) const {
+        double v = 0.0;
+        if (C::NB == 1) { for (int i = 0; i < NFC; ++i) v += L[O::df + r * NFC + i] * vf[i]; }
+        else {
+            const int bb = r / 6, n = (int)L[O::ccnt + bb];
+            for (int j = 0; j < n; ++j) {
+                const int ci = (int)L[O::clist + bb * NC + j];
+#pragma unroll
+                for (int a = 0; a < NF; ++a) v += L[O::df + r * NFC + NF * ci + a] * vf[NF * ci + a];
+            }
+        }
+        return v;
+    }
 
     // workgroup reductions: butterfly inside each wave (ds_bpermute), one LDS slot per wave, two LDS-only barriers
     UPR_HDI static double comb(double a, double b, int op) { return (op == 0) ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
@@ -525,6 +542,7 @@ struct upr_qp3 {
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         if (C::MULTI && no > 0) UPR_SYNC();   // (Z of the multi-body shapes extends over the LDS the row multipliers above were staged in)
+#pragma unroll
         for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
             if (ic < C::NCI) {
@@ -595,27 +613,51 @@ struct upr_qp3 {
 #ifndef UPR_HOST_EMU
         if (fresh) {
             // C Zx by quads (four column chunks of a row, summed by DPP)
+            if (PRE_C) {
 #pragma unroll
-            for (int q = 0; q < QR; ++q) {
-                const int e4 = tid_ + q * NT;
-                const bool act = e4 < N * NE * 4;
-                const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
-                double v = 0.0, e0v = 0.0;
-                if (act) {
-                    const double* zx = L + O::Z + (e / NE) * NX + part * CH;
-                    if (PRE_C) {
+                for (int q = 0; q < QR; ++q) {
+                    const int e4 = tid_ + q * NT;
+                    const bool act = e4 < N * NE * 4;
+                    const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+                    double v = 0.0;
+                    if (act) {
+                        const double* zx = L + O::Z + (e / NE) * NX + part * CH;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q % (PRE_C ? QR : 1)][c] * zx[c];
-                        e0v = e0r[q % (PRE_C ? QR : 1)];
-                    } else {
+                    }
+                    v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+                    if (act && part == 0) L[O::ek + e] = v + e0r[q % (PRE_C ? QR : 1)];
+                }
+            } else {
+                // multi-body shapes: the rows of C come straight from the records, GQ rows of a lane requested together
+                // (one exposed latency per group instead of one per row)
+                constexpr int GQ = 5;
+#pragma unroll 1
+                for (int q0 = 0; q0 < QR; q0 += GQ) {
+                    double cb[GQ][CH], e0b[GQ];
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        const int e4 = tid_ + (q0 + g) * NT;
+                        const bool act = (q0 + g < QR) && e4 < N * NE * 4;
+                        const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
                         const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) if (part * CH + c < NX) v += Ck[c] * zx[c];
-                        e0v = G[F::e0 + e];
+                        for (int c = 0; c < CH; ++c) cb[g][c] = (act && part * CH + c < NX) ? Ck[c] : 0.0;
+                        e0b[g] = act ? G[F::e0 + e] : 0.0;
+                    }
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        const int e4 = tid_ + (q0 + g) * NT;
+                        const bool act = (q0 + g < QR) && e4 < N * NE * 4;
+                        const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+                        const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+                        double v = 0.0;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? zx[c] : 0.0);
+                        v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+                        if (act && part == 0) L[O::ek + e] = v + e0b[g];
                     }
                 }
-                v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                if (act && part == 0) L[O::ek + e] = v + e0v;
             }
             UPR_SYNC_LDS();
         }
@@ -623,10 +665,10 @@ struct upr_qp3 {
             const int k = e / NE, r = e % NE;
             double v = L[O::ek + e], v2 = 0.0;
             if (fresh) {
-                for (int i = 0; i < NFC; ++i) v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i];
+                v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
                 L[O::ek + e] = v;
             }
-            if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
+            if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
             L[O::ys + e] = v - v2;
         }
 #else
@@ -637,10 +679,10 @@ struct upr_qp3 {
             if (fresh) {
                 v = G[F::e0 + e];
                 for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
-                for (int i = 0; i < NFC; ++i) v += L[O::df + r * NFC + i] * L[O::Z + N1 * NX + k * NU + NQ + i];
+                v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
                 L[O::ek + e] = v;
             } else v = L[O::ek + e];
-            if (level > 0) for (int i = 0; i < NFC; ++i) v2 += L[O::df + r * NFC + i] * L[O::hf + k * NFC + i];
+            if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
             L[O::ys + e] = v - v2;
         }
 #endif
@@ -794,8 +836,11 @@ struct upr_qp3 {
                     for (int r = 0; r < NE; ++r) v += ckp[q % (PRE_E ? QE : 1)][r % (PRE_E ? NE : 1)] * L[O::zt + k * NE + r];
                 } else {
                     const double* Ck = rec(k) + lin_gx + e % NX;
-#pragma unroll 8
-                    for (int r = 0; r < NE; ++r) v += Ck[r * NX] * L[O::zt + k * NE + r];
+                    double cr[NE];   // (every row requested before the first product)
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) cr[r] = Ck[r * NX];
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) v += cr[r] * L[O::zt + k * NE + r];
                 }
                 L[O::cs + e] = v;
             }
@@ -859,7 +904,7 @@ struct upr_qp3 {
         // carries the overflow of the A'P+A jobs, and phase 1 waited for that wave (profiles/r01h_mat_waves.txt).
         static_assert(NE % 3 == 0, "three rows per Vc job");
         constexpr int NVC = (NE / 3) * NX;
-        constexpr int VC0 = (NT >= 256) ? 128 : NQ * NQ;   // first lane of the Vc jobs: a wave of their own where there is one
+        constexpr int VC0 = (NT >= 256) ? (C::NB > 1 ? 96 : 128) : NQ * NQ;   // first lane of the Vc jobs: a wave of their own where there is one (a wave and a half for the multi-body shapes)
         for (int k = N - 1; k >= 0; --k) {
             // next knot's C, Lsi, Hee: global -> registers now, -> LDS after the barrier (their readers are in phase 1 /
             // in the accumulator preload of the NEXT knot)
@@ -928,6 +973,21 @@ struct upr_qp3 {
                     if (jj <= ii) L[O::hjj + ii * (ii + 1) / 2 + jj] = v;
                 } else if (e >= VC0 && e < ((NVC <= PB0 - VC0) ? VC0 + NVC : PB0)) {
                     // (the multi-body shapes have more jobs than lanes between VC0 and PB0: those lanes take several)
+                    if (C::MULTI) {
+                        // star arrangements: a job is one column of one body's block, all six rows (static triangular loops)
+                        if (k > 0) for (int f = e - VC0; f < C::NB * NX; f += PB0 - VC0) {
+                            const int blk = f / NX, c = f % NX, bo = 6 * blk;
+                            const double* Ls = L + O::lsik + 36 * blk;
+                            double cm[6];
+#pragma unroll
+                            for (int m = 0; m < 6; ++m) cm[m] = L[O::ck + (bo + m) * NX + c];
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) { double v = 0.0;
+#pragma unroll
+                                for (int m = 0; m <= r; ++m) v += Ls[r * 6 + m] * cm[m];
+                                L[O::vc + (bo + r) * NX + c] = v; }
+                        }
+                    } else
                     if (k > 0) for (int f = e - VC0; f < NVC; f += PB0 - VC0) {
                         // three rows (r0 .. r0 + 2 of the knot) of the block of body g / 2: Vc = blockdiag(Lsi_b) C
                         constexpr int SBV = C::SB;
@@ -1424,25 +1484,48 @@ struct upr_qp3 {
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
 #ifndef UPR_HOST_EMU
         // cv: a quad per row of C (four column chunks), summed by DPP
+        if (PRE_V) {
 #pragma unroll
-        for (int q = 0; q < QV; ++q) {
-            const int e4 = tl + q * NTL;
-            const bool act = tl >= 0 && e4 < N * NE * 4;
-            const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
-            double v = 0.0;
-            if (act) {
-                const double* sx = Sx(e / NE) + part * CH;
-                if (PRE_V) {
+            for (int q = 0; q < QV; ++q) {
+                const int e4 = tl + q * NTL;
+                const bool act = tl >= 0 && e4 < N * NE * 4;
+                const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+                double v = 0.0;
+                if (act) {
+                    const double* sx = Sx(e / NE) + part * CH;
 #pragma unroll
                     for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckq[q % (PRE_V ? QV : 1)][c] * sx[c];
-                } else {
+                }
+                v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+                if (act && part == 0) L[O::cv + e] = v;
+            }
+        } else {
+            constexpr int GQ = 5;   // (as in prep: GQ rows of a lane requested together)
+#pragma unroll 1
+            for (int q0 = 0; q0 < QV; q0 += GQ) {
+                double cb[GQ][CH];
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    const int e4 = tl + (q0 + g) * NTL;
+                    const bool act = tl >= 0 && (q0 + g < QV) && e4 < N * NE * 4;
+                    const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
                     const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) if (part * CH + c < NX) v += Ck[c] * sx[c];
+                    for (int c = 0; c < CH; ++c) cb[g][c] = (act && part * CH + c < NX) ? Ck[c] : 0.0;
+                }
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    const int e4 = tl + (q0 + g) * NTL;
+                    const bool act = tl >= 0 && (q0 + g < QV) && e4 < N * NE * 4;
+                    const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
+                    const double* sx = Sx(e / NE) + part * CH;
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? sx[c] : 0.0);
+                    v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
+                    if (act && part == 0) L[O::cv + e] = v;
                 }
             }
-            v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-            if (act && part == 0) L[O::cv + e] = v;
         }
         if (COST) {   // end-effector Hessian part of the costates (the gee slot is free after the corrector's prep)
 #pragma unroll
@@ -1589,8 +1672,11 @@ struct upr_qp3 {
                         for (int r = 0; r < NE; ++r) v += ckc[q % (PRE_K ? QCS : 1)][r % (PRE_K ? NE : 1)] * L[O::cv + k * NE + r];
                     } else {
                         const double* Ck = rec(k) + lin_gx + i;
-#pragma unroll 8
-                        for (int r = 0; r < NE; ++r) v += Ck[r * NX] * L[O::cv + k * NE + r];
+                        double cr[NE];
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) cr[r] = Ck[r * NX];
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) v += cr[r] * L[O::cv + k * NE + r];
                     }
                     pin[e] = v;
                 }
@@ -1785,7 +1871,12 @@ struct upr_qp3 {
             const int k = e / NU, i = e % NU;
             double v = L[O::gus + e];
             if (i < NQ) { const double* pn = pi + (k + 1) * NX; v += h3 * pn[i] + h2 * pn[NQ + i] + h * pn[2 * NQ + i]; }
-            else for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q];
+            else if (C::NB == 1) { for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q]; }
+            else {   // (the column of a force has entries in the rows of the bodies its contact loads only)
+                const int ci = (i - NQ) / NF, b2 = P->contact_body2[ci], b1 = P->contact_body1[ci];
+                for (int q = 0; q < 6; ++q) v += L[O::df + (6 * b2 + q) * NFC + (i - NQ)] * nu[k * NE + 6 * b2 + q];
+                if (b1 >= 0) for (int q = 0; q < 6; ++q) v += L[O::df + (6 * b1 + q) * NFC + (i - NQ)] * nu[k * NE + 6 * b1 + q];
+            }
             r_stat = fmax(r_stat, fabs(v));
         }
         UPR_FORT(e, N * NQ) {
@@ -1926,6 +2017,11 @@ struct upr_qp3 {
         UPR_FORT(i, NU) { L[O::ulb + i] = P->u_lb[i]; L[O::uub + i] = P->u_ub[i]; L[O::rd + i] = P->Rdiag[i]; }
         if (NF == 3) UPR_FORT(e, C::NP) { double e3[3]; upr_friction_row_jac(P, e / 5, e % 5, e3); L[O::erow + 3 * e] = e3[0]; L[O::erow + 3 * e + 1] = e3[1]; L[O::erow + 3 * e + 2] = e3[2]; }
         UPR_FORT(e, NE * NFC) L[O::df + e] = Dfg[e];
+        if (C::NB > 1) UPR_FORT(bb, C::NB) {
+            int n = 0;
+            for (int ci = 0; ci < NC; ++ci) if (P->contact_body2[ci] == bb || P->contact_body1[ci] == bb) L[O::clist + bb * NC + n++] = (double)ci;
+            L[O::ccnt + bb] = (double)n;
+        }
         UPR_FORT(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
         UPR_FORT(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
         UPR_FORT(e, N * C::NH) { const int k = e / C::NH; G[F::hee + e] = rec(k)[lin_hess + e % C::NH]; }
