@@ -165,6 +165,19 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_KSTAGES
 #define UPR_QP3_KSTAGES 6
 #endif
+// issue priority of the calling wave (0 .. 3): the wave that carries a serial recursion is raised above the co-resident
+// workgroup's waves on its SIMD for the duration (UPR_QP3_PRIO=0 at compile time switches it off for A/B runs)
+#ifndef UPR_QP3_PRIO
+#define UPR_QP3_PRIO 1
+#endif
+#ifndef UPR_QP3_PRIO_MAT
+#define UPR_QP3_PRIO_MAT 0   // every wave during the matrix sweep: 2 measured no different from 0 (3.235 vs 3.230 ms)
+#endif
+#if defined(UPR_HOST_EMU) || !UPR_QP3_PRIO
+#define UPR_SETPRIO(p) ((void)0)
+#else
+#define UPR_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 template <class C>
 #define UPR_FORT(i, n) for (int i = tid(); i < (n); i += stride())
 
@@ -881,6 +894,7 @@ struct upr_qp3 {
         for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + c] = kk[i];
     }
     UPR_HDI void backward_mat() {
+        UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
         {
@@ -1085,6 +1099,7 @@ struct upr_qp3 {
             // exchanged between lanes.  (The one-column-per-lane form of the same elimination broadcast each multiplier
             // through a v_readlane pair: 94 of them per knot at ~20 cycles of latency each, 4.4 k cycles per knot.)
             if (wave0()) {
+                UPR_SETPRIO(3);
 #ifndef UPR_HOST_EMU
                 static_assert(NX <= 64, "one lane per column of Hux");
                 const int c = tid();
@@ -1147,6 +1162,7 @@ struct upr_qp3 {
                 }
 #endif
             }
+            UPR_SETPRIO(UPR_QP3_PRIO_MAT);
             if (k == 0) break;
             mtoc(2);
             UPR_SYNC_LDS();
@@ -1199,6 +1215,7 @@ struct upr_qp3 {
             UPR_SYNC_LDS();
             toc(9);
         }
+        UPR_SETPRIO(0);
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
         if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
@@ -1220,6 +1237,7 @@ struct upr_qp3 {
         UPR_SYNC();
         toc(11);
         if (wave0()) {
+            UPR_SETPRIO(3);
             UPR_FORT(i, NX) {
                 double v = L[O::gxs + N * NX + i];
                 if (neN > 0) {
@@ -1293,6 +1311,7 @@ struct upr_qp3 {
                 }
             }
 #endif
+            UPR_SETPRIO(0);
         }
         UPR_SYNC();
         toc(10);
@@ -1339,6 +1358,7 @@ struct upr_qp3 {
         double heeq[QH][NQ], ckc[PRE_K ? QCS : 1][PRE_K ? NE : 1];
 #endif
         if (wave0()) {
+            UPR_SETPRIO(3);
             // knot 0: sx_0 = 0
             UPR_FORT(i, NX) {
                 const int b = i / NQ, j = i % NQ;
@@ -1417,6 +1437,7 @@ struct upr_qp3 {
                 }
             }
 #endif
+            UPR_SETPRIO(0);
 #ifndef UPR_HOST_EMU
             load_rows();   // (wave 0: in flight while the other waves run the tail)
 #endif
