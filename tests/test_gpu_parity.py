@@ -1362,3 +1362,20 @@ def test_end_effector_orientation_cost(arrangements):
     xs0, us0 = stationary_guess(xm[None], Pm.N, Pm.nu)
     xo, uo, so, rc = Oracle(Pm).solve(0.0, xm, xs0[0], us0[0])
     assert rc == 0 and np.abs(xsm - xo).max() < 2e-5 and np.abs(usm[:-1] - uo).max() < 2e-4
+
+
+def test_closed_loop_goal_sweep_workload_of_the_bench():
+    """BASELINE configs[4] as bench.py times it (a goal sweep under a thrown ball, 100 Hz closed loop): a short run at a
+    small batch stays finite, moves every tray towards its goal, and reports a rate and the non-converged share."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    w = bench.config5_workload(16)
+    p0 = np.array([w["P"].chain.forward(w["x0"][b, :9])[0] for b in range(16)])
+    d0 = np.linalg.norm(p0 - w["way"][:, 0], axis=1)
+    out = bench.time_closed_loop(w, 60)
+    assert out["finite"] and out["value"] > 0 and out["ticks"] == 60 and out["kernel_ms"]["launches"] == [60, 60, 60]
+    assert out["qp_not_converged_fraction"] < 0.05
+    assert out["tray_to_goal_m_after_run"]["max"] < d0.min() - 0.05   # 0.6 s in: every tray is closer to its goal than at the start
