@@ -120,6 +120,11 @@ typedef struct upr_problem {
      * with hard rows they admit no motion ("config 4").  Requires soft_L2_lower == soft_L2_upper > 0 and zero
      * L1 penalties. */
     int soft_eq;
+    /* tolerance of the stationarity residual of the QP (HPIPM's tol_stat / res_g_max; ocs2's hpipm_interface::Settings
+     * keeps it at 1e-6 next to 1e-8 for the equality, inequality and complementarity residuals, which `qp_tol` carries:
+     * below ~1e-7 the stationarity residual of these problems is roundoff of the factorisation once the barrier
+     * parameter is small).  <= 0: use qp_tol. */
+    double qp_tol_stat;
 } upr_problem;
 
 const char* upr_last_error(void);

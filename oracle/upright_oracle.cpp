@@ -645,7 +645,8 @@ struct Riccati {
 // Mehrotra predictor-corrector primal-dual IPM (published algorithm; HPIPM [UPSTREAM] is the
 // reference's implementation of the same family, settings at upright_control/src/pybindings.cpp:183-188).
 // Unknown: z = (dx, du) with dx[0] fixed.  Inequalities c_i(z) >= 0 with slack t and dual lam.
-int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
+int ipm_solve(const QP& qp, int iter_max, double tol, double tol_stat, QPSol& sol) {
+    if (!(tol_stat > 0.0)) tol_stat = tol;
     const int N = qp.N, nx = qp.nx, nu = qp.nu, ne = qp.ne, np = qp.np, neN = qp.neN;
     // inequality layout per stage k<N: [x lower nx][x upper nx] (k>=1 only) [u lower nu][u upper nu][poly np]
     // terminal: [x lower][x upper]
@@ -790,7 +791,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, QPSol& sol) {
             r_stat = std::max(r_stat, std::fabs(pen_Z(k, (int)i) * sig[k][i] + pen_z(k, (int)i) - lam[k][i] - gam[k][i]));
                 sol.res[0] = r_stat; sol.res[1] = r_eq; sol.res[2] = r_ineq; sol.res[3] = mu;
         if (getenv("ORC_DEBUG")) printf("orc it %d res %.3e %.3e %.3e %.3e\n", it, r_stat, r_eq, r_ineq, mu);
-        if (it > 0 && r_stat < tol && r_eq < tol && r_ineq < tol && mu < tol) { sol.status = 0; break; }
+        if (it > 0 && r_stat < tol_stat && r_eq < tol && r_ineq < tol && mu < tol) { sol.status = 0; break; }
         if (it == iter_max) break;
 
         // effective barrier weight of every row: lam / t, and for a softened row the same after the elimination of its
@@ -1197,7 +1198,7 @@ void orc_performance(const orc_problem* P, double t0, const double* x0, const do
 int orc_qp_step(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us,
                 double* dxs, double* dus, orc_stats* stats) {
     QP qp; build_qp(P, t0, x0, xs, us, qp);
-    QPSol sol; int st = ipm_solve(qp, P->qp_iter_max, P->qp_tol, sol);
+    QPSol sol; int st = ipm_solve(qp, P->qp_iter_max, P->qp_tol, P->qp_tol_stat, sol);
     const int nx = qp.nx, nu = qp.nu;
     for (int k = 0; k <= qp.N; ++k) for (int i = 0; i < nx; ++i) dxs[(size_t)k * nx + i] = sol.dx[k][i];
     for (int k = 0; k < qp.N; ++k) for (int i = 0; i < nu; ++i) dus[(size_t)k * nu + i] = sol.du[k][i];
@@ -1209,7 +1210,7 @@ int orc_qp_step(const orc_problem* P, double t0, const double* x0, const double*
 int orc_qp_feedback(const orc_problem* P, double t0, const double* x0, const double* xs, const double* us,
                     double* dxs, double* dus, double* K, orc_stats* stats) {
     QP qp; build_qp(P, t0, x0, xs, us, qp);
-    QPSol sol; int st = ipm_solve(qp, P->qp_iter_max, P->qp_tol, sol);
+    QPSol sol; int st = ipm_solve(qp, P->qp_iter_max, P->qp_tol, P->qp_tol_stat, sol);
     const int nx = qp.nx, nu = qp.nu;
     for (int k = 0; k <= qp.N; ++k) for (int i = 0; i < nx; ++i) dxs[(size_t)k * nx + i] = sol.dx[k][i];
     for (int k = 0; k < qp.N; ++k) for (int i = 0; i < nu; ++i) dus[(size_t)k * nu + i] = sol.du[k][i];
@@ -1232,7 +1233,7 @@ int orc_solve(const orc_problem* P, double t0, const double* x0, double* xs, dou
         double base[4]; orc_performance(P, t0, x0, xs, us, base);
         double base_viol = std::sqrt(base[1] + base[2] + base[3]);
         QP qp; build_qp(P, t0, x0, xs, us, qp);
-        QPSol sol; st.qp_status_last = ipm_solve(qp, P->qp_iter_max, P->qp_tol, sol);
+        QPSol sol; st.qp_status_last = ipm_solve(qp, P->qp_iter_max, P->qp_tol, P->qp_tol_stat, sol);
         st.qp_iters_last = sol.iters; for (int i = 0; i < 4; ++i) st.qp_res[i] = sol.res[i];
         if (st.qp_status_last == 2) break;
         double descent = 0, dxn = 0, dun = 0;  // armijo descent metric: cost gradient . step

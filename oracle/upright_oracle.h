@@ -121,6 +121,7 @@ typedef struct {
      * defaults): the slack pair of a row eliminates to the quadratic penalty Z/2 |C dx + D du + e|^2, solved here as
      * the regularised equality C dx + D du + e = nu / Z. */
     int soft_eq;
+    double qp_tol_stat;  /* stationarity tolerance of the IPM (HPIPM tol_stat; ocs2 default 1e-6); <= 0: qp_tol */
 } orc_problem;
 
 int orc_nx(const orc_problem* P);

@@ -46,6 +46,7 @@ class UprProblem(C.Structure):
         ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
         ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
         ("soft_eq", C.c_int),
+        ("qp_tol_stat", d),
     ]
 
 
@@ -104,6 +105,7 @@ def problem_to_c(P):
     o.soft_L1_lower, o.soft_L1_upper = float(sl.get("lower_L1_penalty", 0.0)), float(sl.get("upper_L1_penalty", 0.0))
     # the object-dynamics equality reaches HPIPM as a general constraint with lg = ug: `poly_ineq` softens it too
     o.soft_eq = int(bool(sl.get("equality", sl.get("poly_ineq"))))
+    o.qp_tol_stat = float(getattr(P, "qp_tol_stat", 0.0) or 0.0)
     return o
 
 

@@ -62,7 +62,11 @@ struct upr_qp_args {
     // Kernels that support it spare the separate gather kernel its launch and its re-read of the factors; the host sets
     // it on the last QP of an advance only (upr_api.hip)
     double* fb = nullptr;
+    // optional dispatch order: workgroup i solves instance order[i] (a permutation of 0..B-1).  The host passes the
+    // instances sorted by the IPM iteration count of their previous QP, longest first (upr_api.hip, order_kernel)
+    const int* order = nullptr;
 };
+static UPR_HDI int upr_qp_instance(const upr_qp_args& A, int wg) { return A.order ? A.order[wg] : wg; }
 static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + (d.N + 1) * d.ni_stage; }
 
 // LDS layout (doubles)
@@ -991,12 +995,13 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
     double res[4] = {0, 0, 0, 0};
     int it = 0, status = 1;
     const double tol = P->qp_tol;
+    const double tol_stat = P->qp_tol_stat > 0.0 ? P->qp_tol_stat : tol;   // HPIPM tol_stat (upright_mi.h)
     for (;; ++it) {
         upr_qp_residuals(S, ntot, res);
 #ifdef UPR_HOST_EMU
         if (getenv("UPR_EMU_DEBUG")) printf("it %d res %.3e %.3e %.3e %.3e sigma_mu %.3e\n", it, res[0], res[1], res[2], res[3], S.sigma_mu);
 #endif
-        if (it > 0 && res[0] < tol && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
+        if (it > 0 && res[0] < tol_stat && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
         if (it >= P->qp_iter_max) break;
         const double mu = res[3];
         // ---- predictor
@@ -1046,6 +1051,6 @@ template <int NT>
 __global__ void __launch_bounds__(NT) upr_qp_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
-    upr_qp_solve(ctx, A, blockIdx.x, smem);
+    upr_qp_solve(ctx, A, upr_qp_instance(A, blockIdx.x), smem);
 }
 #endif

@@ -740,13 +740,14 @@ struct upr_qp2 {
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
+        const double tol_stat = P->qp_tol_stat > 0.0 ? P->qp_tol_stat : tol;   // HPIPM tol_stat (upright_mi.h)
         for (;; ++it) {
             residuals(ntot, res);
             toc(0);
 #ifdef UPR_HOST_EMU
             if (getenv("UPR_EMU_DEBUG")) printf("v2 it %d res %.3e %.3e %.3e %.3e\n", it, res[0], res[1], res[2], res[3]);
 #endif
-            if (it > 0 && res[0] < tol && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
+            if (it > 0 && res[0] < tol_stat && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
             if (it >= P->qp_iter_max) break;
             const double mu = res[3];
             // predictor
@@ -806,6 +807,6 @@ template <class D, int NT>
 __global__ void __launch_bounds__(NT, 4) upr_qp2_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
-    upr_qp2_solve<D>(ctx, A, blockIdx.x, smem);
+    upr_qp2_solve<D>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);
 }
 #endif

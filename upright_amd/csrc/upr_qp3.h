@@ -2123,6 +2123,7 @@ struct upr_qp3 {
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
+        const double tol_stat = P->qp_tol_stat > 0.0 ? P->qp_tol_stat : tol;   // HPIPM tol_stat (upright_mi.h)
         toc(15);
         for (;; ++it) {
             // the KKT test can only pass once the complementarity average and the inequality residual are below the
@@ -2136,7 +2137,7 @@ struct upr_qp3 {
 #ifdef UPR_HOST_EMU
             if (getenv("UPR_EMU_DEBUG")) printf("v3 it %d res %.3e %.3e %.3e %.3e\n", it, res[0], res[1], res[2], res[3]);
 #endif
-            if (it > 0 && res[0] < tol && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
+            if (it > 0 && res[0] < tol_stat && res[1] < tol && res[2] < tol && res[3] < tol) { status = 0; break; }
             if (it >= P->qp_iter_max) break;
             const double mu = res[3];
             mode = 0;
@@ -2220,6 +2221,6 @@ template <class C>
 __global__ void __launch_bounds__(C::NT, (C::NT <= 256 && C::NB == 1) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
-    upr_qp3_solve<C>(ctx, A, blockIdx.x, smem);
+    upr_qp3_solve<C>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);
 }
 #endif

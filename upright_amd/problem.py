@@ -43,7 +43,8 @@ class Problem:
     way_q: np.ndarray = None  # (n_way, 4) target orientations, xyzw (None = identity); used when Wee[3:] != 0
     sqp_iters: int = 1
     qp_iter_max: int = 30
-    qp_tol: float = 1e-8
+    qp_tol: float = 1e-8        # equality / inequality / complementarity residuals (HPIPM tol_eq, tol_ineq, tol_comp)
+    qp_tol_stat: float = 1e-6   # stationarity residual (HPIPM tol_stat; ocs2's hpipm_interface::Settings default)
     delta_tol: float = 1e-3
     cost_tol: float = 1e-4
     terminal_constraint: bool = True
