@@ -451,7 +451,9 @@ template <int NQ>
 int launch_linesearch(upr_batch* h, const upr_ls_args& A) {
     const size_t lds = (size_t)(4 * 64 + 8) * sizeof(double);
     // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
-    if (h->d.nfc <= 12 && h->d.nb == 1) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1>), dim3(h->B), dim3(64), lds, h->stream, A);
+    // exactly the headline's contact structure (one body on the tray, four frictional contacts): every bound a constant
+    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1, true>), dim3(h->B), dim3(64), lds, h->stream, A);
+    else if (h->d.nfc <= 12 && h->d.nb == 1) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1>), dim3(h->B), dim3(64), lds, h->stream, A);
     else hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64>), dim3(h->B), dim3(64), lds, h->stream, A);
     UPR_HIP(hipGetLastError());
     return 0;

@@ -32,24 +32,50 @@ struct upr_ls_args {
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
 // NFM / NBM: compile-time bounds of nf nc / nb (the per-lane input vector and body wrenches stay in registers for the
 // small shapes: with the library-wide maxima they lived in scratch, 2 KB per lane)
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
+// EXACT: the problem has exactly nf = 3, nc = NFM / 3 contacts, nb = NBM bodies and no collision rows (checked by the launcher): every
+// loop bound below is then a compile-time constant, the trial state, input and wrenches stay in registers (with
+// run-time bounds they were indexed dynamically: 1.2 KB of scratch per lane)
+// contact wrench on the single balanced body (contact_constraints.h:107-157 with nb = 1: every contact joins tray and body)
+template <int NCX>
+static UPR_HDI void upr_object_wrench_single(const upr_problem* P, const double* bp, const double* forces, double* W) {
+    const double com[3] = {bp[1] / bp[0], bp[2] / bp[0], bp[3] / bp[0]};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) W[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NCX; ++i) {
+        const double f0 = forces[3 * i], f1 = forces[3 * i + 1], f2 = forces[3 * i + 2];
+        const double l0 = P->contact_r2[i][0] - com[0], l1 = P->contact_r2[i][1] - com[1], l2 = P->contact_r2[i][2] - com[2];
+        W[0] -= f0; W[1] -= f1; W[2] -= f2;
+        W[3] -= l1 * f2 - l2 * f1; W[4] -= l2 * f0 - l0 * f2; W[5] -= l0 * f1 - l1 * f0;
+    }
+}
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
 static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
-    const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
+    const int N = d.N;
+    constexpr int nq = NQ, nx = 3 * NQ;
+    const int nu = EXACT ? NQ + NFM : d.nu;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
     const double* xs = A.xs + (size_t)b * (N + 1) * nx; const double* us = A.us + (size_t)b * N * nu;
     const double* ws = A.ws + (size_t)b * d.ws_stride;
     const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
     double X[3 * NQ], U[NQ + NFM];
+#pragma unroll
     for (int i = 0; i < nx; ++i) X[i] = xs[k * nx + i] + alpha * dx[k * nx + i];
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
     const double wt = (k < N) ? h : 1.0;
-    if (k == 0) for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
-    if (k >= 1) for (int i = 0; i < nx; ++i) {
-        double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
-        iq += wt * v * v;
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
     }
-    if (d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1)
+    if (k >= 1) {
+#pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
+            iq += wt * v * v;
+        }
+    }
+    if (!EXACT && d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1); EXACT: the problem has none
         double dd[UPR_MAX_PAIRS + 8], xo[9];
         if (A.dyn) { upr_obstacle_at(A.dyn + (size_t)b * 9, k * h, xo, xo + 3, xo + 6); }
         upr_obstacle_values<NQ>(P, X, A.dyn ? xo : nullptr, A.pflag ? A.pflag[b] : 0.0, dd);
@@ -60,10 +86,13 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
     double pd[3];
     upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * h, pd);
     if (k < N) {
-        for (int i = 0; i < nu; ++i) U[i] = us[k * nu + i] + alpha * du[k * nu + i];
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) U[i] = us[k * nu + i] + alpha * du[k * nu + i];
         double c = 0.0;
+#pragma unroll
         for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
-        for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
         for (int r = 0; r < 3; ++r) { double e = E.p[r] - pd[r]; c += 0.5 * P->Wee[r] * e * e; }
         if (A.way_q) {
             double Rr[9], eo[3];
@@ -73,6 +102,7 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
         }
         cost += h * c;
         // dynamics defect against the next trial state
+#pragma unroll
         for (int j = 0; j < nq; ++j) {
             double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
             const double* xn = xs + (k + 1) * nx; const double* dn = dx + (k + 1) * nx;
@@ -83,26 +113,34 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
         }
         // object-dynamics equality
         double Fw[6 * NBM];
-        const double* bp = A.body_params + (size_t)b * d.nb * 10;
-        upr_object_wrenches(P, bp, U + nq, Fw);
-        const double sc = 1.0 / sqrt(6.0 * d.nb);
-        for (int bb = 0; bb < d.nb; ++bb) {
+        const int nb = EXACT ? NBM : d.nb;
+        const double* bp = A.body_params + (size_t)b * nb * 10;
+        if (EXACT && NBM == 1) upr_object_wrench_single<NFM / 3>(P, bp, U + nq, Fw);
+        else upr_object_wrenches(P, bp, U + nq, Fw);
+        const double sc = 1.0 / sqrt(6.0 * nb);
+#pragma unroll
+        for (int bb = 0; bb < (EXACT ? NBM : nb); ++bb) {
             double g[6];
             upr_body_residual<double>(E, bp + 10 * bb, P->gravity, Fw + 6 * bb, Fw + 6 * bb + 3, g);
             for (int r = 0; r < 6; ++r) eq += h * (sc * g[r]) * (sc * g[r]);
         }
         // friction rows and input box
-        if (d.np > 0) for (int ci = 0; ci < d.nc; ++ci) {
-            double hr[5];
-            upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
-            for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+        if (EXACT || d.np > 0) {
+#pragma unroll
+            for (int ci = 0; ci < (EXACT ? NFM / 3 : d.nc); ++ci) {
+                double hr[5];
+                upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
+                for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+            }
         }
-        for (int i = 0; i < nu; ++i) {
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) {
             double v = fmin(0.0, fmin(U[i] - P->u_lb[i], P->u_ub[i] - U[i]));
             iq += h * v * v;
         }
     } else if (d.neN > 0) {
         for (int r = 0; r < 3; ++r) { double e = pd[r] - E.p[r]; eq += e * e; }
+#pragma unroll
         for (int i = 0; i < 2 * nq; ++i) eq += X[nq + i] * X[nq + i];
     }
     out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
@@ -168,8 +206,24 @@ static UPR_HDI void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double
     UPR_SYNC();
 }
 
+#ifndef UPR_HOST_EMU
+// one-wave workgroups: the same pairwise tree by cross-lane butterflies (no LDS, no barriers); every lane ends with the sum
+static __device__ __forceinline__ void upr_ls_reduce4_wave(const double* part, double* res) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double v = part[c];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+        res[c] = v;
+    }
+}
+#define UPR_LS_REDUCE4(part, res) do { if (ctx.nt == 64) upr_ls_reduce4_wave(part, res); else upr_ls_reduce4(ctx, L, part, res); } while (0)
+#else
+#define UPR_LS_REDUCE4(part, res) upr_ls_reduce4(ctx, L, part, res)
+#endif
+
 // L: 4*nt + 8 doubles of workgroup scratch
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
 static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
@@ -184,7 +238,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     // baseline, step norms and Armijo descent metric (cost gradient . step)
     double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
     UPR_FOR(k, N + 1) upr_ls_knot_base<NQ, NFM>(A, b, k, part);
-    upr_ls_reduce4(ctx, L, part, base);
+    UPR_LS_REDUCE4(part, base);
     UPR_FOR(k, N + 1) {
         for (int i = 0; i < nx; ++i) {
             double s = dx[k * nx + i];
@@ -201,7 +255,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
             aux[0] += P->dt * P->Rdiag[i] * us[k * nu + i] * s;
         }
     }
-    upr_ls_reduce4(ctx, L, aux, auxr);
+    UPR_LS_REDUCE4(aux, auxr);
     const double descent = auxr[0], dxn = sqrt(auxr[1]), dun = sqrt(auxr[2]);
     const double base_viol = sqrt(base[1] + base[2] + base[3]);
     double alpha = 1.0, perf[4] = {base[0], base[1], base[2], base[3]};
@@ -209,8 +263,8 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     if (qp_status != 2.0) {
         do {
             double p2[4] = {0, 0, 0, 0};
-            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM>(A, b, k, alpha, p2);
-            upr_ls_reduce4(ctx, L, p2, perf);
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT>(A, b, k, alpha, p2);
+            UPR_LS_REDUCE4(p2, perf);
             double viol = sqrt(perf[1] + perf[2] + perf[3]);
             if (viol > g_max) accepted = false;
             else if (viol < g_min) accepted = (descent < 0.0) ? (perf[0] < base[0] + armijo * alpha * descent) : true;
@@ -236,11 +290,11 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
 }
 
 #ifndef UPR_HOST_EMU
-template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES>
+template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
 __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
-    upr_ls_instance<NQ, NFM, NBM>(ctx, A, blockIdx.x, smem);
+    upr_ls_instance<NQ, NFM, NBM, EXACT>(ctx, A, blockIdx.x, smem);
 }
 #endif
 
