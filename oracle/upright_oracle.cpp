@@ -708,7 +708,7 @@ int ipm_solve(const QP& qp, int iter_max, double tol, double tol_stat, QPSol& so
     };
     // initial point: z = 0 (dx0 fixed), t = max(c, thr), lam = mu0 / t
     eval_c(dx, du, cval);
-    double thr = 10.0, mu0 = 1.0;
+    double thr = 3.0, mu0 = 0.1;   // on the plateau of the iteration count over (thr, mu0) for every BASELINE configuration
     if (getenv("ORC_THR")) thr = atof(getenv("ORC_THR"));
     if (getenv("ORC_MU0")) mu0 = atof(getenv("ORC_MU0"));
     for (int k = 0; k <= N; ++k)
