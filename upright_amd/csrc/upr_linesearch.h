@@ -149,46 +149,69 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
 // the same terms at the CURRENT iterate (alpha = 0), where the linearisation kernel has just been: the end-effector cost, the
 // object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
 // of walking the chain again
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, bool EXACT = false>
 static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
-    const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
+    const int N = d.N;
+    constexpr int nq = NQ, nx = 3 * NQ;
+    const int nu = EXACT ? NQ + NFM : d.nu;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
     const double* X = A.xs + ((size_t)b * (N + 1) + k) * nx;
     const double* rec = A.lin + ((size_t)b * (N + 1) + k) * d.lin_stride;
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
     const double wt = (k < N) ? h : 1.0;
-    if (k == 0) for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
-    if (k >= 1) for (int i = 0; i < nx; ++i) {
-        double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
-        iq += wt * v * v;
+    // (compile-time trip counts: the loads of a loop are requested together instead of one exposed latency per trip)
+    double Xr[3 * NQ];
+#pragma unroll
+    for (int i = 0; i < nx; ++i) Xr[i] = X[i];
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - Xr[i]; dyn += e * e; }
     }
-    if (d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
+    if (k >= 1) {
+#pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            double v = fmin(0.0, fmin(Xr[i] - P->x_lb[i], P->x_ub[i] - Xr[i]));
+            iq += wt * v * v;
+        }
+    }
+    if (!EXACT && d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
     if (k < N) {
         const double* U = A.us + ((size_t)b * N + k) * nu;
         const double* xn = X + nx;
         double c = rec[d.lin_cost];
-        for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
-        for (int i = 0; i < nu; ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
+#pragma unroll
+        for (int i = 0; i < nx; ++i) { double e = Xr[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
+        double Ur[NQ + NFM];
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) Ur[i] = U[i];
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) c += 0.5 * P->Rdiag[i] * Ur[i] * Ur[i];
         cost += h * c;
+#pragma unroll
         for (int j = 0; j < nq; ++j) {
-            double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
+            double q = Xr[j], v = Xr[nq + j], a = Xr[2 * nq + j], u = Ur[j];
             double e0 = q + h * v + h2 * a + h3 * u - xn[j], e1 = v + h * a + h2 * u - xn[nq + j], e2 = a + h * u - xn[2 * nq + j];
             dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
         }
         for (int r = 0; r < d.ne; ++r) eq += h * rec[d.lin_g + r] * rec[d.lin_g + r];
-        if (d.np > 0) for (int ci = 0; ci < d.nc; ++ci) {
-            double hr[5];
-            upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
-            for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+        if (EXACT || d.np > 0) {
+#pragma unroll
+            for (int ci = 0; ci < (EXACT ? NFM / 3 : d.nc); ++ci) {
+                double hr[5];
+                upr_friction_rows_contact(P, ci, Ur + nq + 3 * ci, hr);
+                for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
+            }
         }
-        for (int i = 0; i < nu; ++i) {
-            double v = fmin(0.0, fmin(U[i] - P->u_lb[i], P->u_ub[i] - U[i]));
+#pragma unroll
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) {
+            double v = fmin(0.0, fmin(Ur[i] - P->u_lb[i], P->u_ub[i] - Ur[i]));
             iq += h * v * v;
         }
     } else if (d.neN > 0) {
         for (int r = 0; r < 3; ++r) eq += rec[d.lin_grad + r] * rec[d.lin_grad + r];
-        for (int i = 0; i < 2 * nq; ++i) eq += X[nq + i] * X[nq + i];
+#pragma unroll
+        for (int i = 0; i < 2 * nq; ++i) eq += Xr[nq + i] * Xr[nq + i];
     }
     out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
 }
@@ -229,6 +252,14 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
     if (A.done[b]) return;
     double* st = A.stats + (size_t)b * UPR_NSTATS;
+#if defined(UPR_LS_PROF) && !defined(UPR_HOST_EMU)
+    // instrumented build (tools/build_prof.sh): cycle stamps of the phases, returned in the QP-residual slots of the statistics
+    long long lsp[5]; int lspn = 0;
+#define UPR_LS_STAMP() do { __builtin_amdgcn_sched_barrier(0); lsp[lspn++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define UPR_LS_STAMP() ((void)0)
+#endif
+    UPR_LS_STAMP();
     const double qp_status = st[2];
     const double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, g_max = 1e6, g_min = 1e-6, armijo = 1e-4;
     double* xs = A.xs + (size_t)b * (N + 1) * nx; double* us = A.us + (size_t)b * N * nu;
@@ -237,25 +268,43 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
     // baseline, step norms and Armijo descent metric (cost gradient . step)
     double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
-    UPR_FOR(k, N + 1) upr_ls_knot_base<NQ, NFM>(A, b, k, part);
+    UPR_FOR(k, N + 1) upr_ls_knot_base<NQ, NFM, EXACT>(A, b, k, part);
     UPR_LS_REDUCE4(part, base);
+    UPR_LS_STAMP();
     UPR_FOR(k, N + 1) {
-        for (int i = 0; i < nx; ++i) {
-            double s = dx[k * nx + i];
+        constexpr int nxc = 3 * NQ;
+        double sx[nxc], xv[nxc], gq[NQ];
+#pragma unroll
+        for (int i = 0; i < nxc; ++i) { sx[i] = dx[k * nxc + i]; xv[i] = (k < N) ? xs[k * nxc + i] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) gq[i] = (k < N) ? lin[(size_t)k * d.lin_stride + d.lin_grad + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < nxc; ++i) {
+            const double s = sx[i];
             aux[1] += s * s;
             if (k < N) {
-                double g = P->Qdiag[i] * (xs[k * nx + i] - P->xd[i]);
-                if (i < nq) g += lin[(size_t)k * d.lin_stride + d.lin_grad + i];
+                double g = P->Qdiag[i] * (xv[i] - P->xd[i]);
+                if (i < NQ) g += gq[i];
                 aux[0] += P->dt * g * s;
             }
         }
-        if (k < N) for (int i = 0; i < nu; ++i) {
-            double s = du[k * nu + i];
-            aux[2] += s * s;
-            aux[0] += P->dt * P->Rdiag[i] * us[k * nu + i] * s;
+        if (k < N) {
+            if (EXACT) {
+                constexpr int nuc = NQ + NFM;
+                double su[nuc], uv[nuc];
+#pragma unroll
+                for (int i = 0; i < nuc; ++i) { su[i] = du[k * nuc + i]; uv[i] = us[k * nuc + i]; }
+#pragma unroll
+                for (int i = 0; i < nuc; ++i) { aux[2] += su[i] * su[i]; aux[0] += P->dt * P->Rdiag[i] * uv[i] * su[i]; }
+            } else for (int i = 0; i < nu; ++i) {
+                double s = du[k * nu + i];
+                aux[2] += s * s;
+                aux[0] += P->dt * P->Rdiag[i] * us[k * nu + i] * s;
+            }
         }
     }
     UPR_LS_REDUCE4(aux, auxr);
+    UPR_LS_STAMP();
     const double descent = auxr[0], dxn = sqrt(auxr[1]), dun = sqrt(auxr[2]);
     const double base_viol = sqrt(base[1] + base[2] + base[3]);
     double alpha = 1.0, perf[4] = {base[0], base[1], base[2], base[3]};
@@ -273,6 +322,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
             alpha *= alpha_decay;
         } while (alpha >= alpha_min);
     }
+    UPR_LS_STAMP();
     double cost = base[0], viol = base_viol;
     if (accepted) {
         UPR_FOR(i, (N + 1) * nx) xs[i] += alpha * dx[i];
@@ -286,6 +336,10 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
         st[0] = A.iter + 1; st[3] = accepted ? alpha : 0.0; st[4] = cost; st[5] = viol; st[10] = dxn; st[11] = dun;
         if (conv) A.done[b] = 1;
     }
+#if defined(UPR_LS_PROF) && !defined(UPR_HOST_EMU)
+    UPR_LS_STAMP();
+    if (ctx.tid == 0) for (int i = 0; i < 4; ++i) st[6 + i] = (double)(lsp[i + 1] - lsp[i]);
+#endif
     UPR_SYNC();
 }
 
