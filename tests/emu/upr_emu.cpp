@@ -24,7 +24,6 @@ static void lin_all_o(const upr_lin_args& A) {
     for (int p = 0; p < A.npoints; ++p) {
         upr_lin_point q = upr_lin_locate(A, p);
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0(A, q, l, sh.data());
-        for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0b(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ, ORI>(A, q, l, sh.data());
         if (A.d.no > 0) {
             for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_a<NQ>(A, q, l, sh.data());
@@ -86,6 +85,11 @@ void emu_linearize(const upr_problem* P, int B, const double* body_params, const
     A.P = P; A.d = upr_make_dims(P); A.body_params = body_params; A.way_p = way_p; A.t0 = t0; A.xs = xs; A.us = us;
     A.inst = nullptr; A.lin = lin; A.ee_out = nullptr; A.npoints = B * (P->N + 1);
     if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
+    // the constant d g / d forces, as the engine hands it to the kernel (UPR_EMU_LIN_WRENCH=1: the wrench-sum form of the value)
+    upr_dims d = A.d;
+    std::vector<double> Df((size_t)B * d.ne * d.nfc);
+    emu_make_Df(P, B, body_params, Df.data());
+    if (!getenv("UPR_EMU_LIN_WRENCH")) A.Df = Df.data();
     if (P->nq == 6) lin_all<6>(A); else lin_all<9>(A);
 }
 

@@ -1,0 +1,23 @@
+"""Phase cycles of the linearisation kernel (instrumented build: hipcc ... -DUPR_LIN_PROF -o upright_amd/libupright_mi_prof.so;
+run with UPR_LIB=libupright_mi_prof.so)."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import numpy as np
+import bench
+from upright_amd import _capi
+w = bench.headline_workload(1024)
+mpc = bench.make_engine(w)
+lib = _capi.lib()
+out = np.zeros(8)
+mpc.reset(); mpc.advance()
+lib.upr_debug_lin_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
+mpc.enable_timing(True)
+for _ in range(3):
+    mpc.reset(); mpc.advance()
+mpc.sync()
+lib.upr_debug_lin_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 0)
+names = ["phase 0: stage x, u", "phase 0b: wrenches (lane 0)", "phase 1: chain walk, residual, stores", "barrier after phase 1", "phase 2: MFMA Hessian, gradient"]
+n = out[7]
+for i, l in enumerate(names):
+    print("%-42s %9.0f cycles / workgroup" % (l, out[i] / n))
+print("workgroups", n, mpc.kernel_times())

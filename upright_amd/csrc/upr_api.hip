@@ -464,7 +464,7 @@ upr_lin_args traj_lin_args(upr_batch* h) {
     A.P = h->dP; A.d = h->d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = h->t0;
     A.xs = h->xs; A.us = h->us; A.inst = nullptr; A.lin = h->lin; A.ee_out = nullptr;
     A.npoints = h->B * (h->d.N + 1);
-    A.dyn = h->dyn0; A.pflag = h->pflag;
+    A.dyn = h->dyn0; A.pflag = h->pflag; A.Df = h->Df;
     return A;
 }
 upr_qp_args make_qp_args(upr_batch* h) {
@@ -886,7 +886,7 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     UPR_HIP(hipMemcpy(du, u, sizeof(double) * n * d.nu, hipMemcpyHostToDevice));
     upr_lin_args A;
     A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
-    A.lin = dlin; A.ee_out = dee; A.npoints = n;
+    A.lin = dlin; A.ee_out = dee; A.npoints = n; A.Df = h->Df;
     if (h->P.n_dyn) {   // points mode: the obstacle state of every point as given
         if (ddyn.alloc((size_t)n * 9)) return 1;
         if (dyn_pts) UPR_HIP(hipMemcpy(ddyn, dyn_pts, sizeof(double) * n * 9, hipMemcpyHostToDevice));
@@ -1195,3 +1195,14 @@ int upr_batch_set_projectile_flag(upr_batch* h, const double* sflag) {
     return 0;
 }
 }  // extern "C"
+
+#ifdef UPR_LIN_PROF
+// instrumented build only: cycles per phase of the linearisation kernel summed over workgroups, [7] = workgroups counted
+extern "C" int upr_debug_lin_prof(double* out, int reset) {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(upr_lin_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(upr_lin_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

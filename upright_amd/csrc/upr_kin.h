@@ -324,6 +324,46 @@ static UPR_HDI void upr_object_wrenches(const upr_problem* P, const double* body
     }
 }
 
+// The same sums for arrangements with at most NCM contact points, every operand requested before the first use (the
+// loop above exposes one memory latency per contact and per operand group); same order of additions, bitwise the same result.
+template <int NCM>
+static UPR_HDI void upr_object_wrenches_small(const upr_problem* P, const double* body_params, const double* forces, double* Fw) {
+    const int nc = P->nc, nf = P->nf, nb = P->nb;
+    double f[NCM][3], r1[NCM][3], r2[NCM][3], c1[NCM][3], c2[NCM][3];
+    int b1[NCM], b2[NCM];
+#pragma unroll
+    for (int i = 0; i < NCM; ++i) {
+        const int ii = (i < nc) ? i : 0;
+        b1[i] = P->contact_body1[ii]; b2[i] = P->contact_body2[ii];
+        if (nf == 1) { const double s = forces[ii]; for (int a = 0; a < 3; ++a) f[i][a] = s * P->contact_normal[ii][a]; }
+        else { f[i][0] = forces[3 * ii]; f[i][1] = forces[3 * ii + 1]; f[i][2] = forces[3 * ii + 2]; }
+        for (int a = 0; a < 3; ++a) { r1[i][a] = P->contact_r1[ii][a]; r2[i][a] = P->contact_r2[ii][a]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NCM; ++i) {
+        const double* bq = body_params + 10 * b2[i];
+        const double* bp = body_params + 10 * (b1[i] >= 0 ? b1[i] : 0);
+        for (int a = 0; a < 3; ++a) { c2[i][a] = bq[1 + a] / bq[0]; c1[i][a] = bp[1 + a] / bp[0]; }
+    }
+    for (int i = 0; i < 6 * nb; ++i) Fw[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NCM; ++i) {
+        if (i >= nc) continue;
+        if (b1[i] >= 0) {
+            const double l[3] = {r1[i][0] - c1[i][0], r1[i][1] - c1[i][1], r1[i][2] - c1[i][2]};
+            double* W = Fw + 6 * b1[i];
+            W[0] += f[i][0]; W[1] += f[i][1]; W[2] += f[i][2];
+            W[3] += l[1] * f[i][2] - l[2] * f[i][1]; W[4] += l[2] * f[i][0] - l[0] * f[i][2]; W[5] += l[0] * f[i][1] - l[1] * f[i][0];
+        }
+        {
+            const double l[3] = {r2[i][0] - c2[i][0], r2[i][1] - c2[i][1], r2[i][2] - c2[i][2]};
+            double* W = Fw + 6 * b2[i];
+            W[0] -= f[i][0]; W[1] -= f[i][1]; W[2] -= f[i][2];
+            W[3] -= l[1] * f[i][2] - l[2] * f[i][1]; W[4] -= l[2] * f[i][0] - l[0] * f[i][2]; W[5] -= l[0] * f[i][1] - l[1] * f[i][0];
+        }
+    }
+}
+
 // contact_constraints.h:50-77: the five pyramid rows of contact i
 static UPR_HDI void upr_friction_rows_contact(const upr_problem* P, int i, const double* f, double* h) {
     const double* n = P->contact_normal[i];

@@ -42,6 +42,10 @@ struct upr_lin_args {
     // (points mode, taken as is); activation flag of the projectile rows per instance.  NULL when n_dyn == 0.
     const double* dyn = nullptr;
     const double* pflag = nullptr;
+    // optional: the constant d g / d forces of every instance, [B][ne][nfc] (the QP's Df).  The equality is affine in the
+    // forces, g = g(x; f = 0) + Df f, so with it the force part of the VALUE is ne short dot products spread over the
+    // lanes of the knot instead of one lane summing contact wrenches (a chain of dependent loads and 6 divisions per contact)
+    const double* Df = nullptr;
 };
 
 struct upr_lin_point {
@@ -71,21 +75,37 @@ static UPR_HDI upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) {
     return q;
 }
 
-// phase 0: stage x, u into LDS (coalesced: lane l loads element l) -- lanes 0..LPK-1 of the knot
+// phase 0: stage x, u into LDS (coalesced: lane l loads element l) -- lanes 0..LPK-1 of the knot.  Two of the lanes that
+// carry no tangent work from global memory at the same time: the summed contact wrench per body (its forces straight from
+// the input vector, so it does not wait for the staging) and the desired orientation of the knot (SLERP of the waypoints)
 static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_dims& d = A.d;
     double* sx = sh; double* su = sh + d.nx;
     for (int i = lane; i < d.nx; i += UPR_LPK) sx[i] = q.x[i];
     for (int i = lane; i < d.nu; i += UPR_LPK) su[i] = q.terminal ? 0.0 : q.u[i];
-}
-// phase 0b: summed contact wrench per body (contact x body loop out of the LDS-staged forces)
-static UPR_HDI void upr_lin_phase0b(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
-    const upr_dims& d = A.d;
-    if (lane == 0) {
+    if (A.Df != nullptr) {
+        if (!q.terminal) {
+            double* gf = sh + d.nx + d.nu;   // Df f of this knot, in the slot of the wrenches (6 nb doubles)
+            const double* f = q.u + d.nq;
+            for (int r = lane; r < d.ne; r += UPR_LPK) {
+                const double* D = A.Df + ((size_t)q.b * d.ne + r) * d.nfc;
+                double v = 0.0;
+                int j = 0;
+                for (; j + 4 <= d.nfc; j += 4) {   // four operands of each kind requested together
+                    const double d0 = D[j], d1 = D[j + 1], d2 = D[j + 2], d3 = D[j + 3], f0 = f[j], f1 = f[j + 1], f2 = f[j + 2], f3 = f[j + 3];
+                    v += d0 * f0; v += d1 * f1; v += d2 * f2; v += d3 * f3;
+                }
+                for (; j < d.nfc; ++j) v += D[j] * f[j];
+                gf[r] = v;
+            }
+        }
+    } else if (lane == UPR_LPK - 1 && !q.terminal) {
         double* Fw = sh + d.nx + d.nu;
-        upr_object_wrenches(A.P, A.body_params + (size_t)q.b * d.nb * 10, sh + d.nx + d.nq, Fw);
+        const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
+        if (d.nc <= 4) upr_object_wrenches_small<4>(A.P, bp, q.u + d.nq, Fw);
+        else upr_object_wrenches(A.P, bp, q.u + d.nq, Fw);
     }
-    if (lane == 1 && A.way_q != nullptr)   // desired orientation of this knot (SLERP of the waypoints)
+    if (lane == UPR_LPK - 2 && A.way_q != nullptr)
         upr_target_rotation(A.P, A.way_q + (size_t)q.b * A.P->n_way * 4, q.t, sh + d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6);
 }
 
@@ -106,12 +126,14 @@ static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q
     if (!q.terminal) {
         const double scale = 1.0 / sqrt(6.0 * d.nb);
         const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
+        const double zero3[3] = {0.0, 0.0, 0.0};
         for (int b = 0; b < d.nb; ++b) {
             upr_dd gb[6];
-            upr_body_residual<upr_dd>(E, bp + 10 * b, P->gravity, Fw + 6 * b, Fw + 6 * b + 3, gb);
+            if (A.Df != nullptr) upr_body_residual<upr_dd>(E, bp + 10 * b, P->gravity, zero3, zero3, gb);
+            else upr_body_residual<upr_dd>(E, bp + 10 * b, P->gravity, Fw + 6 * b, Fw + 6 * b + 3, gb);
             for (int r = 0; r < 6; ++r) {
                 if (dir >= 0) q.out[d.lin_gx + (6 * b + r) * d.nx + dir] = scale * gb[r].d;
-                if (lane == 0) q.out[d.lin_g + 6 * b + r] = scale * gb[r].v;
+                if (lane == 0) q.out[d.lin_g + 6 * b + r] = scale * gb[r].v + (A.Df != nullptr ? Fw[6 * b + r] : 0.0);
             }
         }
     }
@@ -204,6 +226,13 @@ static UPR_HDI void upr_lin_phase2(const upr_lin_args& A, const upr_lin_point& q
 }
 
 #ifndef UPR_HOST_EMU
+#ifdef UPR_LIN_PROF
+// instrumented build (-DUPR_LIN_PROF): cycles per phase, summed over the workgroups by lane 0 (upr_debug_lin_prof reads them)
+__device__ unsigned long long upr_lin_prof[8];
+#define UPR_LIN_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&upr_lin_prof[i], (unsigned long long)(now_ - t_prof)); t_prof = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define UPR_LIN_STAMP(i) ((void)0)
+#endif
 // 256 threads = 8 knots x 32 lanes.  USE_MFMA: Gauss-Newton Hessian through v_mfma_f64_16x16x4_f64.
 // OCC: waves per SIMD the register allocation is held to (the kernel is latency bound: more resident knots hide more of it)
 template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false>
@@ -215,17 +244,22 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     const bool live = p < A.npoints;
     double* sh = smem + sub * per;
     upr_lin_point q;
+#ifdef UPR_LIN_PROF
+    long long t_prof = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) atomicAdd(&upr_lin_prof[7], 1ull);
+#endif
     if (live) { q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, sh); }
     __syncthreads();
-    if (live) upr_lin_phase0b(A, q, lane, sh);
-    __syncthreads();
+    UPR_LIN_STAMP(0);
     if (live) upr_lin_phase1<NQ, ORI>(A, q, lane, sh);
+    UPR_LIN_STAMP(2);
     if (A.d.no > 0) {
         if (live) upr_lin_phase_obs_a<NQ>(A, q, lane, sh);
         __syncthreads();
         if (live) upr_lin_phase_obs_b<NQ>(A, q, lane, sh);
     }
     __syncthreads();
+    UPR_LIN_STAMP(3);
     if (!USE_MFMA) {
         if (live) upr_lin_phase2<NQ, ORI>(A, q, lane, sh);
     } else {
@@ -281,5 +315,6 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
             }
         }
     }
+    UPR_LIN_STAMP(4);
 }
 #endif
