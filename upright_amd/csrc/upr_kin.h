@@ -31,6 +31,10 @@ static UPR_HDI void upr_sincos(upr_dd th, upr_dd* s, upr_dd* c) {
     *c = {cv, -sv * th.d};
 }
 
+// the same with sin / cos of the VALUE supplied (computed once per knot instead of by every tangent lane)
+static UPR_HDI void upr_sincos_given(double, double sv, double cv, double* s, double* c) { *s = sv; *c = cv; }
+static UPR_HDI void upr_sincos_given(upr_dd th, double sv, double cv, upr_dd* s, upr_dd* c) { *s = {sv, cv * th.d}; *c = {cv, -sv * th.d}; }
+
 static UPR_HDI double upr_sqrt_(double a) { return sqrt(a); }
 static UPR_HDI upr_dd upr_sqrt_(upr_dd a) { const double r = sqrt(a.v); return {r, 0.5 * a.d / r}; }
 static UPR_HDI double upr_recip_(double a) { return 1.0 / a; }
@@ -93,8 +97,9 @@ template <class T> static UPR_HDI void upr_carry(upr_ee<T>& E, const T* r) {
 
 // x: the knot's state [q, v, a] (plain values); dir: tangent direction of this lane (-1: none).
 // NQ is the compile-time joint count so that the chain loop unrolls and everything stays in registers.
+// sc: optional [NQ][2] = (sin q_j, cos q_j) of the revolute joints, precomputed (NULL: computed here)
 template <class T, int NQ>
-static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E) {
+static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E, const double* sc = nullptr) {
     T* tag = nullptr;
     for (int i = 0; i < 9; ++i) E.C[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
     for (int i = 0; i < 3; ++i) { E.p[i] = upr_lift(0.0, tag); E.v[i] = E.p[i]; E.w[i] = E.p[i]; E.a[i] = E.p[i]; E.al[i] = E.p[i]; }
@@ -119,7 +124,7 @@ static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int
             // Rodrigues about the constant local axis
             const double* ax = P->joint_axis[j];
             T s, c;
-            upr_sincos(q, &s, &c);
+            if (sc) upr_sincos_given(q, sc[2 * j], sc[2 * j + 1], &s, &c); else upr_sincos(q, &s, &c);
             T omc = upr_lift(1.0, tag) - c;
             T M[9];
             for (int a = 0; a < 3; ++a)

@@ -19,9 +19,10 @@
 
 #define UPR_LPK 32
 
-// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[6 nq] e[6] Rref[9] | sphere centres and their q-tangents [ns][3][1 + nq]
+// LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[6 nq] e[6] Rref[9] sincos[2 nq] | sphere centres and their q-tangents [ns][3][1 + nq]
 // (J / e: position rows, then the orientation rows used when the end-effector cost weighs orientation)
-static UPR_HDI int upr_lin_lds_base(const upr_dims& d) { return (d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6 + 9 + 1 + 1) & ~1; }
+static UPR_HDI int upr_lin_lds_sc(const upr_dims& d) { return d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6 + 9; }   // (sin q_j, cos q_j) [nq][2]
+static UPR_HDI int upr_lin_lds_base(const upr_dims& d) { return (upr_lin_lds_sc(d) + 2 * d.nq + 1 + 1) & ~1; }
 static UPR_HDI int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
 
 struct upr_lin_args {
@@ -83,6 +84,8 @@ static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q
     double* sx = sh; double* su = sh + d.nx;
     for (int i = lane; i < d.nx; i += UPR_LPK) sx[i] = q.x[i];
     for (int i = lane; i < d.nu; i += UPR_LPK) su[i] = q.terminal ? 0.0 : q.u[i];
+    // sin / cos of the joint angles once per knot (lanes nq .. 2 nq - 1, straight from the input: no wait for the staging)
+    if (lane >= d.nq && lane < 2 * d.nq) { const int j = lane - d.nq; double s_, c_; upr_sincos(q.x[j], &s_, &c_); sh[upr_lin_lds_sc(d) + 2 * j] = s_; sh[upr_lin_lds_sc(d) + 2 * j + 1] = c_; }
     if (A.Df != nullptr) {
         if (!q.terminal) {
             double* gf = sh + d.nx + d.nu;   // Df f of this knot, in the slot of the wrenches (6 nb doubles)
@@ -122,7 +125,7 @@ static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q
     constexpr bool ori = ORI;
     const int dir = (lane < d.nx) ? lane : -1;
     upr_ee<upr_dd> E;
-    upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E);
+    upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E, sh + upr_lin_lds_sc(d));
     if (!q.terminal) {
         const double scale = 1.0 / sqrt(6.0 * d.nb);
         const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
