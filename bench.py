@@ -261,17 +261,22 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
     B, n1 = mpc.B, P.N + 1
-    loc_x = loc_u = None
+    loc = None
     counts = [B] * world
     if world > 1:
-        loc_x = torch.empty((B, n1, P.nx), dtype=torch.float64, device=device)
-        loc_u = torch.empty((B, P.N, P.nu), dtype=torch.float64, device=device)
+        # two sets of send buffers, used in turn: the collective of step i is enqueued on the backend's stream and runs
+        # while the engine's stream is already in step i + 1, whose copy-out must not land in a buffer still being sent
+        loc = [(torch.empty((B, n1, P.nx), dtype=torch.float64, device=device),
+                torch.empty((B, P.N, P.nu), dtype=torch.float64, device=device)) for _ in range(2)]
     gathered = [None]
+    turn = [0]
 
     def step():
         mpc.reset_async()      # cold start: DefaultInitializer guess
         mpc.advance_async()
         if world > 1:          # exchange step: all-gather of the solved trajectories
+            loc_x, loc_u = loc[turn[0] & 1]
+            turn[0] += 1
             mpc.copy_solution_device(loc_x.data_ptr(), loc_u.data_ptr())
             mpc.sync()
             gx, gu, _ = all_gather_solutions(loc_x, loc_u, counts=counts)
