@@ -361,7 +361,12 @@ int launch_qp2(upr_batch* h, const upr_qp_args& A) {
 }
 
 // shapes the production kernel is instantiated for: (nq, nb, nc, nf)
+// -DUPR_HEADLINE_ONLY: experiment builds of the headline kernel (a tenth of the compile time); never the production library
+#ifdef UPR_HEADLINE_ONLY
+#define UPR_QP2_SHAPES(X) X(9, 1, 4, 3)
+#else
 #define UPR_QP2_SHAPES(X) X(9, 1, 4, 3) X(9, 1, 4, 1) X(6, 1, 4, 1) X(6, 1, 4, 3) X(9, 2, 8, 3)
+#endif
 
 bool qp2_has_shape(const upr_problem& P) {
 #define X(a, b, c, e) if (P.nq == a && P.nb == b && P.nc == c && P.nf == e) return true;
@@ -391,7 +396,11 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 // (nq, nb, nc, nf, ROWS, SOFT, DENSE) instantiations besides the headline's: the headline shape with slacks on its boxes,
 // thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
 // (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
+#ifdef UPR_HEADLINE_ONLY
+#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false)
+#else
 #define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false) X(9, 1, 4, 1, false, true, false) X(9, 8, 32, 1, false, true, false) X(9, 3, 16, 3, true, false, true)
+#endif
 bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }
 // can the production kernel take this problem, and in which instantiation?  0: no; 1: headline (hard boxes); 2: one of
@@ -428,9 +437,11 @@ size_t qp3_ws_doubles(const upr_problem& P, int variant) {
 int launch_qp(upr_batch* h, const upr_qp_args& A) {
     if (h->use_qp3 == 1) {
         switch (h->qp_nt) {
-            case 128: return launch_qp3<128>(h, A);
             case 256: return launch_qp3<256>(h, A);
+#ifndef UPR_HEADLINE_ONLY
+            case 128: return launch_qp3<128>(h, A);
             case 512: return launch_qp3<512>(h, A);
+#endif
             default: return fail("UPR_QP_NT must be 128, 256 or 512 for the headline-shape kernel");
         }
     }
