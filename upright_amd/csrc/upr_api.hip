@@ -396,7 +396,9 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 // (nq, nb, nc, nf, ROWS, SOFT, DENSE) instantiations besides the headline's: the headline shape with slacks on its boxes,
 // thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
 // (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
-#ifdef UPR_HEADLINE_ONLY
+#if defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_CONFIG3)
+#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, true, false, true)
+#elif defined(UPR_HEADLINE_ONLY)
 #define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false)
 #else
 #define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false) X(9, 1, 4, 1, false, true, false) X(9, 8, 32, 1, false, true, false) X(9, 3, 16, 3, true, false, true)

@@ -921,7 +921,9 @@ struct upr_qp3 {
         constexpr int VC0 = (NT >= 256) ? (C::NB > 1 ? 96 : 128) : NQ * NQ;   // first lane of the Vc jobs: a wave of their own where there is one (a wave and a half for the multi-body shapes)
         for (int k = N - 1; k >= 0; --k) {
             // next knot's C, Lsi, Hee: global -> registers now, -> LDS after the barrier (their readers are in phase 1 /
-            // in the accumulator preload of the NEXT knot)
+            // in the accumulator preload of the NEXT knot).  (Multi-body shapes: requesting them behind the barrier of phase 1
+            // instead takes ~14 k cycles per iteration out of phase 1 -- every reload of a spilled register there waits for
+            // all memory operations in flight -- and puts them back into phases 2 and 3: measured no different.)
             constexpr int NLS = C::NLS, NPF = NE * NX + NLS + C::NH, CKQ = (NPF + NT - 1) / NT;
             double ckn[CKQ];
             const int tid_ = tid();
@@ -952,6 +954,62 @@ struct upr_qp3 {
             static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux), "prep stages Z and S in the sweeps' working set");
             static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
+#ifndef UPR_HOST_EMU
+            // dense Schur complement (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x 27) as 18
+            // v_mfma_f64_16x16x4_f64 on ONE wave -- as lane jobs it was 162 three-row dot products on a wave and a half,
+            // which the phase waited for (123 k of its 136 k cycles per iteration, the A'P+A lanes need 59 k)
+            constexpr bool VC_MFMA = C::COUPLED;
+            if (VC_MFMA && k > 0 && (wb >> 6) == 2) {
+                typedef double v4dv __attribute__((ext_vector_type(4)));
+                constexpr int SBV = C::SB, NTR = (SBV + 15) / 16, NTC = (NX + 15) / 16, NS = (SBV + 3) / 4;
+                const int ln = this->lane(), l15 = ln & 15, k4 = ln >> 4;
+                // every operand first (unconditional loads from clamped addresses, zeroed by select: a conditional load
+                // per step serialises load -> wait -> v_mfma), then the matrix instructions back to back, tiles interleaved
+                static_assert(!VC_MFMA || (NTR == 2 && NTC == 2 && NS == 5), "operand list of the load fence below");
+                double av[NTR][NS], bv[NTC][NS];
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const int m = 4 * s4 + k4, mc = (m < SBV) ? m : SBV - 1;
+#pragma unroll
+                    for (int tr = 0; tr < NTR; ++tr) { const int row = 16 * tr + l15, rc = (row < SBV) ? row : SBV - 1; av[tr][s4] = L[O::lsik + rc * SBV + mc]; }
+#pragma unroll
+                    for (int tc = 0; tc < NTC; ++tc) { const int col = 16 * tc + l15, cc = (col < NX) ? col : NX - 1; bv[tc][s4] = L[O::ck + mc * NX + cc]; }
+                }
+                // one fence behind ALL twenty loads: they stay unconditional (left alone the compiler sinks each into the
+                // branch of its select, with a wait of its own) and are in flight together
+                asm volatile("" : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(av[0][4]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(av[1][2]), "+v"(av[1][3]), "+v"(av[1][4]),
+                                  "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]), "+v"(bv[0][4]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3]), "+v"(bv[1][4]));
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const int m = 4 * s4 + k4;
+#pragma unroll
+                    for (int tr = 0; tr < NTR; ++tr) { const int row = 16 * tr + l15; av[tr][s4] = (row < SBV && m < SBV && m <= row) ? av[tr][s4] : 0.0; }
+#pragma unroll
+                    for (int tc = 0; tc < NTC; ++tc) { const int col = 16 * tc + l15; bv[tc][s4] = (m < SBV && col < NX) ? bv[tc][s4] : 0.0; }
+                }
+                v4dv dacc[NTR][NTC];
+#pragma unroll
+                for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < NTC; ++tc) dacc[tr][tc] = v4dv{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4)
+#pragma unroll
+                    for (int tr = 0; tr < NTR; ++tr) {
+                        if (4 * s4 > 16 * tr + 15) continue;   // the rows of this tile end before these columns of the factor begin
+#pragma unroll
+                        for (int tc = 0; tc < NTC; ++tc) dacc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr][s4], bv[tc][s4], dacc[tr][tc], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const int r = 16 * tr + k4 + 4 * q, col = 16 * tc + l15; if (r < NE && col < NX) L[O::vc + r * NX + col] = dacc[tr][tc][q]; }
+            }
+#else
+            constexpr bool VC_MFMA = false;
+#endif
             UPR_FORT(e, PB0 + NPB) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
@@ -1002,7 +1060,7 @@ struct upr_qp3 {
                                 L[O::vc + (bo + r) * NX + c] = v; }
                         }
                     } else
-                    if (k > 0) for (int f = e - VC0; f < NVC; f += PB0 - VC0) {
+                    if (!VC_MFMA && k > 0) for (int f = e - VC0; f < NVC; f += PB0 - VC0) {
                         // three rows (r0 .. r0 + 2 of the knot) of the block of body g / 2: Vc = blockdiag(Lsi_b) C
                         constexpr int SBV = C::SB;
                         const int g = f / NX, c = f % NX, r0 = 3 * g, blk = r0 / SBV, bo = SBV * blk, q0 = r0 - bo;
