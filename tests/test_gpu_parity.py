@@ -1428,3 +1428,39 @@ def test_longest_first_dispatch_only_permutes_the_workgroups(arrangements, monke
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
     assert len(set(out["1"][3].astype(int))) > 1    # the batch has different iteration counts to sort by
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at its stated batch (4096 instances of box_arch + 20 collision pairs, the bench's workload): after
+    12 SQP iterations from cold start every QP converges, the plans close the multiple-shooting defects and keep every
+    collision row, friction row and box; the object-dynamics equality holds along the plan."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    B = 4096
+    w = bench.config3_workload(B)
+    P = w["P"]
+    mpc = BatchMPC(P, B, way_p=w["way"])
+    mpc.set_sqp_iterations(12)
+    mpc.set_observation(0.0, w["x0"])
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    assert "DENSE" not in mpc.kernel_times()["qp_kernel"] and "9, 3, 16, 3" in mpc.kernel_times()["qp_kernel"]   # the production instantiation ran
+    assert np.all(st["qp_status_last"] == 0) and np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+    assert st["constraint_violation"].max() < 1e-4
+    h = P.dt
+    q, v, a, j = xs[:, :-1, :9], xs[:, :-1, 9:18], xs[:, :-1, 18:], us[:, :, :9]
+    pred = np.concatenate([q + h * v + 0.5 * h * h * a + h ** 3 / 6 * j, v + h * a + 0.5 * h * h * j, a + h * j], axis=2)
+    assert np.abs(pred - xs[:, 1:]).max() < 1e-5
+    assert np.all(us >= P.u_lb - 1e-6) and np.all(us <= P.u_ub + 1e-6) and np.all(xs[:, 1:] >= P.x_lb - 1e-6) and np.all(xs[:, 1:] <= P.x_ub + 1e-6)
+    O = Oracle(P)
+    for b in range(0, B, 512):           # rows of a sample of the plans, evaluated by the oracle
+        rows = np.array([O.obstacle_rows(xs[b, k], jac=False) for k in range(1, P.N)])
+        assert rows.min() > -1e-5
+        for k in (0, 7, 19):
+            assert np.abs(O.eq_constraint(xs[b, k], us[b, k], jac=False)).max() < 1e-5
+            assert O.ineq_constraint(us[b, k]).min() > -1e-6
+    mpc.close()
