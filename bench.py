@@ -430,7 +430,7 @@ def cpu_baseline(w, n_sample):
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
     O = Oracle(P)
     threads = usable_threads()
-    n1 = min(len(x0), 64)
+    n1 = min(len(x0), 256)   # ~2.7 s on one thread
     tc = time.perf_counter()
     O.solve_batch(0.0, x0[:n1], xs0[:n1], us0[:n1], way_p=way[:n1], nthreads=1)
     dt1 = time.perf_counter() - tc
@@ -479,7 +479,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="instances of the CPU-baseline sample (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances of the CPU-baseline sample (rank 0, N=1): ~11 core-seconds at the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3], configs[4])")
     ap.add_argument("--extra-steps", type=int, default=3)
