@@ -258,6 +258,7 @@ struct upr_qp3 {
     // are parked in global memory [slot][lane]: written once per iteration after the step, read back behind the two
     // forward sweeps (by the idle waves during the sweep, by wave 0 right after it).
     static constexpr int NROWV = 4 * C::QX + 4 * C::QU;
+    static constexpr int QO = ((C::N - 1) * UPR_QP3_NOMAX + C::NT - 1) / C::NT;   // state-polytopic rows per lane (at most)
     UPR_HDI void store_rows() const {
         const int tid_ = tid();
         double* R = G + F::rows + tid_;
@@ -460,15 +461,31 @@ struct upr_qp3 {
 #endif
         // state-polytopic rows d + G (q - q_lin) >= 0 of knots 1 .. N-1 (collision pairs, projectile path): multiplier s and
         // weight w of every row, staged in the LDS the sweeps use for Hux / V until the gradient and Hessian passes below
-        if (no > 0) UPR_FORT(e, (N - 1) * no) {
-            const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
-            const double* g = orow(k, r);
-            double c = G[F::od0 + ei], ds = 0.0;
-            for (int i = 0; i < NQ; ++i) { c += g[i] * L[O::Z + k * NX + i]; ds += g[i] * L[O::S + k * NX + i]; }
-            double sr, wr, ct_ = 0.0;
-            row(c, ds, G[F::ot + ei], G[F::ol + ei], ct_, sr, wr);
-            if (mode == 1) G[F::oc + ei] = ct_;
-            L[O::hux + ei] = sr; L[O::hux + (N - 1) * UPR_QP3_NOMAX + ei] = wr;
+        if (no > 0) {
+            // (the rows of a lane requested together: their Jacobian rows and far-array entries come out of global memory)
+            double gq[QO][NQ], od[QO], otv[QO], olv[QO];
+#pragma unroll
+            for (int q = 0; q < QO; ++q) {
+                const int e = tid_ + q * NT, ec = (e < (N - 1) * no) ? e : 0;
+                const int k = 1 + ec / no, r = ec % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                const double* g = orow(k, r);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) gq[q][i] = g[i];
+                od[q] = G[F::od0 + ei]; otv[q] = G[F::ot + ei]; olv[q] = G[F::ol + ei];
+            }
+#pragma unroll
+            for (int q = 0; q < QO; ++q) {
+                const int e = tid_ + q * NT;
+                if (e >= (N - 1) * no) continue;
+                const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                double c = od[q], ds = 0.0;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
+                double sr, wr, ct_ = 0.0;
+                row(c, ds, otv[q], olv[q], ct_, sr, wr);
+                if (mode == 1) G[F::oc + ei] = ct_;
+                L[O::hux + ei] = sr; L[O::hux + (N - 1) * UPR_QP3_NOMAX + ei] = wr;
+            }
         }
         // A: box rows (registers)
 #pragma unroll
@@ -539,8 +556,14 @@ struct upr_qp3 {
                     for (int j = 0; j < NQ; ++j) a += heeP[q][j] * L[O::Z + k * NX + j];
                     L[O::gee + e] = a;
                 } else a = L[O::gee + e];
-                double go = 0.0;   // G' s of the state-polytopic rows
-                for (int r = 0; r < no; ++r) go += orow(k, r)[i] * L[O::hux + (k - 1) * UPR_QP3_NOMAX + r];
+                double go = 0.0;   // G' s of the state-polytopic rows (five rows requested together: one exposed latency per group)
+                for (int r0 = 0; r0 < no; r0 += 5) {
+                    double gv[5], sv[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { const int r = r0 + u, rc = (r < no) ? r : no - 1; gv[u] = orow(k, rc)[i]; sv[u] = (r < no) ? L[O::hux + (k - 1) * UPR_QP3_NOMAX + rc] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) go += gv[u] * sv[u];
+                }
                 L[O::gxs + k * NX + i] += h * a + go;
             }
         }
@@ -550,8 +573,20 @@ struct upr_qp3 {
             while (rem >= NQ - i) { rem -= NQ - i; ++i; }
             const int j = i + rem;   // upr_tri(NQ, i, j) == t for i <= j
             double v = 0.0;
-            for (int r = 0; r < no; ++r) { const double* g = orow(k, r); v += L[O::hux + (N - 1) * UPR_QP3_NOMAX + (k - 1) * UPR_QP3_NOMAX + r] * g[i] * g[j]; }
-            G[F::heew + k * C::NH + t] = G[F::hee + k * C::NH + t] + v / h;
+            const double hee_kt = G[F::hee + k * C::NH + t];
+            for (int r0 = 0; r0 < no; r0 += 5) {
+                double gi[5], gj[5], wv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int r = r0 + u, rc = (r < no) ? r : no - 1;
+                    const double* g = orow(k, rc);
+                    gi[u] = g[i]; gj[u] = g[j];
+                    wv[u] = (r < no) ? L[O::hux + (N - 1) * UPR_QP3_NOMAX + (k - 1) * UPR_QP3_NOMAX + rc] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) v += wv[u] * gi[u] * gj[u];
+            }
+            G[F::heew + k * C::NH + t] = hee_kt + v / h;
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
         if (C::MULTI && no > 0) UPR_SYNC();   // (Z of the multi-body shapes extends over the LDS the row multipliers above were staged in)
@@ -1887,6 +1922,31 @@ struct upr_qp3 {
                 }
             }
         }
+        if (NF == 3 && C::QC > 1) {
+            // several contacts per lane (multi-body shapes): slack, multiplier and corrector term of all their rows requested
+            // together (one exposed latency for the lot instead of one per contact)
+            double ctv[C::QC][5], clv[C::QC][5], ccv[C::QC][5];
+#pragma unroll
+            for (int q = 0; q < C::QC; ++q) {
+                const int ic = tid_ + q * NT, icc = (ic < C::NCI) ? ic : 0;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) { ctv[q][r] = G[F::ct + 5 * icc + r]; clv[q][r] = G[F::cl + 5 * icc + r]; ccv[q][r] = G[F::cc + 5 * icc + r]; }
+            }
+#pragma unroll
+            for (int q = 0; q < C::QC; ++q) {
+                const int ic = tid_ + q * NT;
+                if (ic >= C::NCI) continue;
+                const int k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
+                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                    double t = ctv[q][r], lam = clv[q][r];
+                    sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, ccv[q][r], acc, aux);
+                    if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
+                }
+            }
+        } else
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
             const int ic = tid_ + q * NT;
             if (ic < C::NCI) {
@@ -1901,14 +1961,29 @@ struct upr_qp3 {
                 }
             }
         }
-        if (no > 0) UPR_FORT(e, (N - 1) * no) {
-            const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
-            const double* g = orow(k, r);
-            double c = G[F::od0 + ei], ds = 0.0;
-            for (int i = 0; i < NQ; ++i) { c += g[i] * L[O::Z + k * NX + i]; ds += g[i] * L[O::S + k * NX + i]; }
-            double t = G[F::ot + ei], lam = G[F::ol + ei];
-            sweep_row(what, alpha, c, ds, t, lam, G[F::oc + ei], acc, aux);
-            if (what == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
+        if (no > 0) {
+            double gq[QO][NQ], od[QO], otv[QO], olv[QO], ocv[QO];
+#pragma unroll
+            for (int q = 0; q < QO; ++q) {
+                const int e = tid_ + q * NT, ec = (e < (N - 1) * no) ? e : 0;
+                const int k = 1 + ec / no, r = ec % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                const double* g = orow(k, r);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) gq[q][i] = g[i];
+                od[q] = G[F::od0 + ei]; otv[q] = G[F::ot + ei]; olv[q] = G[F::ol + ei]; ocv[q] = G[F::oc + ei];
+            }
+#pragma unroll
+            for (int q = 0; q < QO; ++q) {
+                const int e = tid_ + q * NT;
+                if (e >= (N - 1) * no) continue;
+                const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                double c = od[q], ds = 0.0;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
+                double t = otv[q], lam = olv[q];
+                sweep_row(what, alpha, c, ds, t, lam, ocv[q], acc, aux);
+                if (what == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
+            }
         }
         if (what == 0) acc = acc > 1e-30 ? 1.0 / acc : 1e30;
         return acc;
