@@ -1464,3 +1464,38 @@ def test_config3_full_size_properties():
             assert np.abs(O.eq_constraint(xs[b, k], us[b, k], jac=False)).max() < 1e-5
             assert O.ineq_constraint(us[b, k]).min() > -1e-6
     mpc.close()
+
+
+@pytest.mark.parametrize("B,N", [(1, 20), (3, 10), (2, 30), (5, 5)])
+def test_edge_sizes_single_instances_and_other_horizons(arrangements, B, N):
+    """Edges of the batch / horizon sizes: one instance, odd batches, horizons other than the production kernel's 20
+    (BASELINE config 1 names horizon 10; those run the run-time-dimension kernels).  One SQP iteration against the oracle at
+    north_star's tolerance; an empty batch is refused."""
+    P = thing_problem(arrangements["pink_bottle"], N=N, use_feedback_policy=True)
+    x0 = level_tray_states(B, seed=90 + N)
+    # the terminal equality [p_d - p; v; a] = 0 must be reachable inside the horizon: 2.2 m for T >= 2 s, a short move otherwise
+    # (with the default target both solvers stop at the iteration cap for N = 5 and 10, status 1 on either side)
+    way = waypoints_for(P, x0) if N >= 20 else waypoints_for(P, x0, offset=(-0.004 * N * N, 0.002 * N * N, 0.0))
+    mpc = BatchMPC(P, B, way_p=way)
+    assert ("cfg<" in mpc.kernel_times()["qp_kernel"]) == (N == 20)     # production kernel only at its compiled horizon
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    K = mpc.feedback_gains()
+    assert xs.shape == (B, N + 1, 27) and us.shape == (B, N, 21) and K.shape == (B, N, 21, 27) and np.all(np.isfinite(K))
+    xs0, us0 = stationary_guess(x0, N, P.nu)
+    xo, uo, so, _ = Oracle(P).solve_batch(0.0, x0, xs0, us0, way_p=way, nthreads=1)
+    nconv = 0
+    for b in range(B):
+        # (short horizons leave some of the random start states without a feasible first QP: the status must be the oracle's)
+        assert st["qp_status_last"][b] == so[b].qp_status_last
+        if so[b].qp_status_last != 0:
+            continue
+        nconv += 1
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo[b])) < 1e-4 and abs(np.linalg.norm(us[b]) - np.linalg.norm(uo[b])) < 1e-4
+        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-3
+    assert nconv >= (B + 1) // 2
+    mpc.close()
+    with pytest.raises(Exception):
+        BatchMPC(P, 0, way_p=way[:0])
