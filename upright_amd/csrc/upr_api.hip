@@ -397,7 +397,7 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 // thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
 // (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
 #if defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_CONFIG3)
-#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, true, false, true)
+#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, true, false, true) X(9, 8, 32, 1, false, true, false)
 #elif defined(UPR_HEADLINE_ONLY)
 #define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false)
 #else
