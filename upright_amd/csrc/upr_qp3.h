@@ -47,6 +47,9 @@ struct upr_qp3_cfg {
     static constexpr int NH = NQ * (NQ + 1) / 2;
     static constexpr int NZ = N1 * NX + N * NU;
     static constexpr int NEN = 3 + 2 * NQ;
+    // SW: the matrix part of the backward sweep runs on ONE wave with the cost-to-go in registers (one-body shapes: a lane
+    // per 3 x 3 block (joint i, joint j), i <= j, of P; a lane per column of Hux): no workgroup barrier inside the sweep
+    static constexpr bool SW = NB_ == 1 && NH <= 64 && 4 * NQ <= 64;
     // lane-owned inequality items
     static constexpr int NXI = N * NX, QX = (NXI + NT - 1) / NT;   // state boxes, knots 1..N
     static constexpr int NUI = N * NU, QU = (NUI + NT - 1) / NT;   // input boxes, knots 0..N-1
@@ -66,7 +69,8 @@ struct upr_qp3_far {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
     static constexpr int g0 = 0, e0 = g0 + r2(C::N * C::NQ), ek = e0 + r2(C::N * C::NE), yf = ek + r2(C::N * C::NE), hf = yf + r2(C::N * C::NFC),
                          ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE), cv = zt, nun = zt + r2(C::N * C::NE), lfi = nun + r2(C::N * C::NE),
-                         Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * C::NH), cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
+                         Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * (C::SW ? C::NQ * C::NQ : C::NH)),   // SW: the dense inverse factor of Hjj
+                          cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
                          hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NLS),
                          // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
                          // set-up and its step: 20 registers less to carry through the sweeps)
@@ -104,7 +108,12 @@ struct upr_qp3_lds {
                          // K = Lj^-T V of the previous knot is formed by an idle wave while wave 0 factors the next)
                          vm = hux + r2(C::NQ * C::NX), lk = vm + 2 * r2(C::NQ * C::NX),
                          hjj = lk + 2 * r2(C::NH), vc = hjj + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
-                         yN = ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
+                         // single-wave sweep (C::SW): Vc = Lsi C of knots 1 .. N-1, [col][ne] each -- the first KS of them in the step array
+                         // (dead between prep and the vector sweep), the rest from Pa on -- then the sweep's staging: packed Hjj,
+                         // Hux / V by columns [nx][HXS], the partial sums of P+ b [nx][HXS]
+                         VCN = C::NE * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
+                         sw0 = Pa + (C::N - 1 - KS) * VCN, sw_hj = sw0, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_end = sw_pb + C::NX * HXS,
+                         yN = (C::SW && sw_end > ck + r2(C::NE * C::NX)) ? sw_end : ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
                          prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
@@ -857,6 +866,19 @@ struct upr_qp3 {
 #pragma unroll
                     for (int m = 0; m <= r; ++m) Lr[r * SB + m] = Ls[r * SB + m];
             }
+#ifndef UPR_HOST_EMU
+            if (C::SW && factor) {
+                // single-wave sweep: phase E forms Vc = Lsi C of every knot; it reads the factor out of LDS (packed lower
+                // triangle, in the sweep's staging area).  That area overlaps the S blocks of the last knots, which other
+                // lanes of THIS wave read at the top of their factorisation: all Schur blocks sit on one wave (lockstep),
+                // so every read precedes every write.
+                static_assert(!C::SW || (C::NKB <= 64 && C::NKB * (SB * (SB + 1) / 2) <= O::sw_end - O::sw0), "Lsi staging of phase D");
+#pragma unroll
+                for (int r = 0; r < SB; ++r)
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) L[O::sw0 + kb * (SB * (SB + 1) / 2) + r * (r + 1) / 2 + m] = Lr[r * SB + m];
+            }
+#endif
             double ee[SB], yv[SB];
 #pragma unroll
             for (int r = 0; r < SB; ++r) ee[r] = L[O::ys + kb * SB + r];
@@ -879,17 +901,31 @@ struct upr_qp3 {
             if (e < N * NX) {
                 const int k = e / NX;
                 double v = 0.0;
+                double cr[NE];   // (every row requested before the first product)
                 if (PRE_E) {
 #pragma unroll
-                    for (int r = 0; r < NE; ++r) v += ckp[q % (PRE_E ? QE : 1)][r % (PRE_E ? NE : 1)] * L[O::zt + k * NE + r];
+                    for (int r = 0; r < NE; ++r) cr[r] = ckp[q % (PRE_E ? QE : 1)][r % (PRE_E ? NE : 1)];
                 } else {
                     const double* Ck = rec(k) + lin_gx + e % NX;
-                    double cr[NE];   // (every row requested before the first product)
 #pragma unroll
                     for (int r = 0; r < NE; ++r) cr[r] = Ck[r * NX];
-#pragma unroll
-                    for (int r = 0; r < NE; ++r) v += cr[r] * L[O::zt + k * NE + r];
                 }
+#pragma unroll
+                for (int r = 0; r < NE; ++r) v += cr[r] * L[O::zt + k * NE + r];
+#ifndef UPR_HOST_EMU
+                if (C::SW && factor && k >= 1) {
+                    // column e % NX of Vc_k = Lsi_k C_k for the single-wave matrix sweep (its lanes read whole columns)
+                    const double* Ls = L + O::sw0 + k * (NE * (NE + 1) / 2);
+                    double* vo = L + vca(k) + (e % NX) * NE;
+#pragma unroll
+                    for (int r = 0; r < NE; ++r) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int m = 0; m <= r; ++m) w += Ls[r * (r + 1) / 2 + m] * cr[m];
+                        vo[r] = w;
+                    }
+                }
+#endif
                 L[O::cs + e] = v;
             }
         }
@@ -928,7 +964,215 @@ struct upr_qp3 {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + c] = kk[i];
     }
+#ifndef UPR_HOST_EMU
+    // ---- backward sweep, matrix part, on ONE wave (C::SW: one-body shapes) ---------------------------------------------------
+    // The four-wave form below spends a knot in three workgroup barriers and five LDS round trips, with eight waves of two
+    // co-resident workgroups hitting the LDS at the same moments (~9 k cycles per knot).  Here wave 0 carries the whole
+    // recursion and the other waves wait at the end:
+    //   * lane (bi, bj), bi <= bj (nq (nq + 1) / 2 = 45 lanes) keeps the 3 x 3 block P+[(a, bi)][(c, bj)] in REGISTERS: A'P+A, its
+    //     rows of Hux = B'P+A (for both (bi, bj) and the mirrored block), its entry of Hjj = B'P+B + R + W and its partial sums of
+    //     P+ b are in-lane arithmetic on nine values (block-scalar structure of the triple integrator, system_dynamics.h:15-22);
+    //   * Hjj (packed), Hux (by columns) and the partial sums cross the lanes through LDS once (wave-local: LDS operations of a
+    //     wave execute in order, no barrier); every lane then factors Hjj for itself (9 dependent pivots) and lane c < nx carries
+    //     column c of Hux through the eliminations: V = Lj^-1 Hux; lanes nx .. nx + nq - 1 carry the columns of the identity instead
+    //     and end with Lj^-1, which the feed-forward phase multiplies with (kff = Lj^-T Lj^-1 r);
+    //   * the same lanes back-substitute their column of the feedback K = Lj^-T V in registers and store it (coalesced);
+    //   * V goes back through LDS by columns, and lane (bi, bj) updates its block: P = A'P+A + Q~ + Vc'Vc - V'V with the six
+    //     columns of V and of Vc = Lsi C it needs (Vc of every knot was left in LDS by prep's phase E).
+    UPR_HDI static int vca(int k) { return (k <= O::KS) ? O::S + (k - 1) * O::VCN : O::Pa + (k - 1 - O::KS) * O::VCN; }
+    UPR_HDI void backward_mat_sw() {
+        constexpr int NBK = C::NH, HXS = O::HXS;
+        static_assert(!C::SW || (O::sw_end <= O::yN && (O::VCN % 2) == 0 && O::KS * O::VCN <= O::r2(C::NZ)), "staging of the single-wave sweep");
+        if (wave0()) {
+            UPR_SETPRIO(3);
+            const double irho = 1.0 / UPR_QP_RHO_N;
+            const int l = lane();
+            const bool blk = l < NBK;
+            const int lc = blk ? l : NBK - 1;      // = upr_tri(NQ, bi, bj)
+            int bi = 0, b0 = 0;
+#pragma unroll
+            for (int i = 1; i < NQ; ++i) { const int st = i * NQ - i * (i - 1) / 2; if (lc >= st) { bi = i; b0 = st; } }
+            const int bj = bi + (lc - b0);
+            const bool dg = bi == bj;
+            const bool vl = l < NX;                // lanes that carry a column of Hux
+            const int vcl = (l < NX + NQ) ? l : 0;  // (lanes nx .. nx + nq - 1 read a column of the identity, kept behind Hux)
+            if (l >= NX && l < NX + NQ) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) L[O::sw_hx + l * HXS + i] = (l - NX == i) ? 1.0 : 0.0;
+            }
+            double p[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[a][c] = 0.0;
+            {
+                double v = dg ? L[O::wx + N * NX + bi] : 0.0;
+                if (neN > 0) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + bi] * L[O::jN + q * NQ + bj]; }
+                p[0][0] = v;
+                const double d1 = L[O::wx + N * NX + NQ + bi] + ((neN > 0) ? irho : 0.0), d2 = L[O::wx + N * NX + 2 * NQ + bi] + ((neN > 0) ? irho : 0.0);
+                p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
+            }
+            bool ok = true;
+            // heek: the knot's entry of the end-effector Hessian, requested a knot ahead (the only global operand of the loop)
+            double heek = G[hee_w + (N - 1) * C::NH + lc];
+#pragma nounroll
+            for (int k = N - 1; k >= 0; --k) {
+                // operands that do not depend on the recursion
+                const double wuk = L[O::wu + k * NU + bi], rdk = L[O::rd + bi];
+                double bjv[3], biv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
+                // in-lane: T = P+ A, B'T (both orientations of the block), B'P+B, P+ b
+                double hxa[3], hxb[3], up[3], r1[3], r2[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double t0 = (c == 0) ? p[0][0] : ((c == 1) ? h * p[0][0] + p[0][1] : h2 * p[0][0] + h * p[0][1] + p[0][2]);
+                    const double t1 = (c == 0) ? p[1][0] : ((c == 1) ? h * p[1][0] + p[1][1] : h2 * p[1][0] + h * p[1][1] + p[1][2]);
+                    const double t2 = (c == 0) ? p[2][0] : ((c == 1) ? h * p[2][0] + p[2][1] : h2 * p[2][0] + h * p[2][1] + p[2][2]);
+                    hxa[c] = h3 * t0 + h2 * t1 + h * t2;                                // Hux[bi][(c, bj)]
+                    up[c] = h3 * p[c][0] + h2 * p[c][1] + h * p[c][2];
+                    r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
+                    r2[c] = p[0][c] * biv[0] + p[1][c] * biv[1] + p[2][c] * biv[2];     // -> (P+ b)[(c, bj)]   (bi < bj)
+                }
+                hxb[0] = up[0]; hxb[1] = h * up[0] + up[1]; hxb[2] = h2 * up[0] + h * up[1] + up[2];   // Hux[bj][(c, bi)]
+                double hj = h3 * up[0] + h2 * up[1] + h * up[2];
+                if (dg) hj += h * rdk + wuk;
+                if (blk) {
+                    L[O::sw_hj + bj * (bj + 1) / 2 + bi] = hj;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { L[O::sw_hx + (c * NQ + bj) * HXS + bi] = hxa[c]; L[O::sw_pb + (c * NQ + bi) * HXS + bj] = r1[c]; }
+                    if (!dg) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c]; L[O::sw_pb + (c * NQ + bj) * HXS + bi] = r2[c]; }
+                    }
+                }
+                UPR_WSYNC();
+                // everything of the new block that does not wait for the factorisation, in the shadow of that LDS round trip:
+                // p1 = sym(A'P+A) + Q~ + Vc'Vc (block (bi, bj); Vc = Lsi C of this knot was left in LDS by prep's phase E)
+                double p1[3][3];
+                if (k > 0) {
+                    double wxk[3], qdk[3], o2[3][3], cj[3][NE], ci[3][NE];
+                    const double* Vk = L + vca(k);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * NE + r]; ci[c][r] = Vk[(c * NQ + bi) * NE + r]; }
+                    }
+                    {
+                        double t[3][3];
+#pragma unroll
+                        for (int a3 = 0; a3 < 3; ++a3) { t[a3][0] = p[a3][0]; t[a3][1] = h * p[a3][0] + p[a3][1]; t[a3][2] = h2 * p[a3][0] + h * p[a3][1] + p[a3][2]; }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { o2[0][c] = t[0][c]; o2[1][c] = h * t[0][c] + t[1][c]; o2[2][c] = h2 * t[0][c] + h * t[1][c] + t[2][c]; }
+                        if (dg) { o2[1][0] = o2[0][1]; o2[2][0] = o2[0][2]; o2[2][1] = o2[1][2]; }   // a diagonal block stays exactly symmetric
+                    }
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double acc = o2[a3][c];
+                            if (a3 == c) acc += dg ? (h * qdk[a3] + wxk[a3]) : 0.0;
+                            if (a3 == 0 && c == 0) acc += h * heek;
+#pragma unroll
+                            for (int r = 0; r < NE; ++r) acc += ci[a3][r] * cj[c][r];
+                            p1[a3][c] = acc;
+                        }
+                    if (k > 1) heek = G[hee_w + (k - 1) * C::NH + lc];
+                }
+                toc(6);
+                // every lane: Hjj; lanes < nx: their column of Hux; lanes nx .. nx + nq - 1: a column of the identity
+                double a[NQ][NQ], hx[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
+                if (vl) {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; q += 3) { s0 += L[O::sw_pb + l * HXS + q]; if (q + 1 < NQ) s1 += L[O::sw_pb + l * HXS + q + 1]; if (q + 2 < NQ) s2 += L[O::sw_pb + l * HXS + q + 2]; }
+                    L[O::Pbs + k * NX + l] = (s0 + s1) + s2;
+                }
+#pragma unroll
+                for (int p2 = 0; p2 < NQ; ++p2) {
+                    const double piv = a[p2][p2];
+                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
+                    const double idg = upr_rsqrt(piv);
+#pragma unroll
+                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
+                    hx[p2] *= idg;
+#pragma unroll
+                    for (int j = p2 + 1; j < NQ; ++j) {
+#pragma unroll
+                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
+                        hx[j] -= a[j][p2] * hx[p2];
+                    }
+                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal
+                }
+                toc(7);
+                // V to LDS first (the update waits for it); its round trip is covered by the back substitution of the feedback column
+                if (k > 0) {
+                    UPR_WSYNC();
+                    if (vl) {
+#pragma unroll
+                        for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
+                    }
+                    UPR_WSYNC();
+                }
+                int bio = bi, bjo = bj;
+                {
+                    double kk[NQ];
+#pragma unroll
+                    for (int i = NQ - 1; i >= 0; --i) {
+                        double tt = hx[i];
+#pragma unroll
+                        for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
+                        kk[i] = tt * a[i][i];
+                    }
+                    // (the loads of the update are tied to the end of the back substitution: requested earlier, their 108 registers
+                    // overlap the factor's 90 and the loop's invariants are spilled -- every reload then waits for the stores below)
+                    asm volatile("" : "+v"(kk[0]), "+v"(bio), "+v"(bjo));
+                    double* dst = vl ? (G + F::Ks + k * NQ * NX + l) : (G + F::Ljis + k * NQ * NQ + (l - NX));
+                    const int str = vl ? NX : NQ;
+                    if (l < NX + NQ) {
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i) dst[i * str] = vl ? kk[i] : hx[i];
+                    }
+                }
+                toc(8);
+                if (k == 0) break;
+                // P = p1 - V'V
+                {
+                    double vj[3][NQ], vi[3][NQ];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int m = 0; m < NQ; ++m) { vj[c][m] = L[O::sw_hx + (c * NQ + bjo) * HXS + m]; vi[c][m] = L[O::sw_hx + (c * NQ + bio) * HXS + m]; }
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double acc = p1[a3][c];
+#pragma unroll
+                            for (int m = 0; m < NQ; ++m) acc -= vi[a3][m] * vj[c][m];
+                            p[a3][c] = acc;
+                        }
+                }
+                UPR_WSYNC();
+                toc(9);
+            }
+            if (!ok && l == 0) L[O::misc] = 1.0;
+            UPR_SETPRIO(0);
+        }
+        UPR_SYNC();
+    }
+#endif
     UPR_HDI void backward_mat() {
+#ifndef UPR_HOST_EMU
+        if constexpr (C::SW) { backward_mat_sw(); return; }
+#endif
         UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
@@ -1409,6 +1653,32 @@ struct upr_qp3 {
         UPR_SYNC();
         toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
+#ifndef UPR_HOST_EMU
+        if constexpr (C::SW) {
+            // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
+            UPR_FORT(k, N) {
+                const double* Li = G + F::Ljis + k * NQ * NQ;
+                const double* w = Wk(k);
+                double li[NQ][NQ], tv[NQ], y[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int m = 0; m <= i; ++m) li[i][m] = Li[i * NQ + m];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) tv[i] = L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { double t = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= i; ++m) t += li[i][m] * tv[m];
+                    y[i] = t; }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) { double t = 0.0;
+#pragma unroll
+                    for (int m = i; m < NQ; ++m) t += li[m][i] * y[m];
+                    L[O::kffs + k * NQ + i] = t; }
+            }
+        } else
+#endif
         UPR_FORT(k, N) {
             const double* Lp = G + F::Ljis + k * C::NH;
             const double* w = Wk(k);
@@ -2277,7 +2547,13 @@ struct upr_qp3 {
             prep(2);
             backward_mat(); toc(11);
             backward_vec(); toc(11);
-            if (L[O::misc] != 0.0) { status = 2; break; }
+            if (L[O::misc] != 0.0) {
+                status = 2;
+#ifndef UPR_HOST_EMU
+                load_rows();   // (the exit reads the multipliers of the box rows: with this reload they are dead across the sweeps)
+#endif
+                break;
+            }
             { double unused[NCT]; forward<false>(unused); } toc(13);
             double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
             if (a_aff > 1.0) a_aff = 1.0;
