@@ -1013,8 +1013,15 @@ struct upr_qp3 {
                 p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
             }
             bool ok = true;
-            // heek: the knot's entry of the end-effector Hessian, requested a knot ahead (the only global operand of the loop)
-            double heek = G[hee_w + (N - 1) * C::NH + lc];
+            // every global load issued so far has landed before the loop: a first use inside it would put a wait for ALL memory
+            // operations in flight into every trip (behind the back edge those are the stores of the previous knot)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            // The column of K (of Lj^-1) a lane ends a knot with is STORED AT THE TOP OF THE NEXT KNOT, right behind that knot's one
+            // global load: loads and stores share a counter that the compiler can only wait out completely once both kinds are in
+            // flight, so stores issued at the end of a knot were waited for at the register copies of the loop's back edge.
+            double ks[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) ks[i] = 0.0;
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 // operands that do not depend on the recursion
@@ -1022,6 +1029,15 @@ struct upr_qp3 {
                 double bjv[3], biv[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
+                // (the knot's entry of the end-effector Hessian: the only global operand of the loop, used at the very end of the
+                // knot -- a value requested for the NEXT knot would be waited for at the loop's back edge)
+                const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;
+                if (k < N - 1 && l < NX + NQ) {
+                    double* const dst = vl ? (G + F::Ks + (k + 1) * NQ * NX + l) : (G + F::Ljis + (k + 1) * NQ * NQ + (l - NX));
+                    const int str = vl ? NX : NQ;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
+                }
                 // in-lane: T = P+ A, B'T (both orientations of the block), B'P+B, P+ b
                 double hxa[3], hxb[3], up[3], r1[3], r2[3];
 #pragma unroll
@@ -1073,12 +1089,10 @@ struct upr_qp3 {
                         for (int c = 0; c < 3; ++c) {
                             double acc = o2[a3][c];
                             if (a3 == c) acc += dg ? (h * qdk[a3] + wxk[a3]) : 0.0;
-                            if (a3 == 0 && c == 0) acc += h * heek;
 #pragma unroll
                             for (int r = 0; r < NE; ++r) acc += ci[a3][r] * cj[c][r];
                             p1[a3][c] = acc;
                         }
-                    if (k > 1) heek = G[hee_w + (k - 1) * C::NH + lc];
                 }
                 toc(6);
                 // every lane: Hjj; lanes < nx: their column of Hux; lanes nx .. nx + nq - 1: a column of the identity
@@ -1122,25 +1136,19 @@ struct upr_qp3 {
                     UPR_WSYNC();
                 }
                 int bio = bi, bjo = bj;
-                {
-                    double kk[NQ];
+                double kk[NQ];
 #pragma unroll
-                    for (int i = NQ - 1; i >= 0; --i) {
-                        double tt = hx[i];
+                for (int i = NQ - 1; i >= 0; --i) {
+                    double tt = hx[i];
 #pragma unroll
-                        for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
-                        kk[i] = tt * a[i][i];
-                    }
-                    // (the loads of the update are tied to the end of the back substitution: requested earlier, their 108 registers
-                    // overlap the factor's 90 and the loop's invariants are spilled -- every reload then waits for the stores below)
-                    asm volatile("" : "+v"(kk[0]), "+v"(bio), "+v"(bjo));
-                    double* dst = vl ? (G + F::Ks + k * NQ * NX + l) : (G + F::Ljis + k * NQ * NQ + (l - NX));
-                    const int str = vl ? NX : NQ;
-                    if (l < NX + NQ) {
-#pragma unroll
-                        for (int i = 0; i < NQ; ++i) dst[i * str] = vl ? kk[i] : hx[i];
-                    }
+                    for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
+                    kk[i] = vl ? tt * a[i][i] : hx[i];   // (lanes nx ..: their column of Lj^-1 is what is stored)
                 }
+                // (the loads of the update are tied to the end of the back substitution: requested earlier, their 108 registers
+                // overlap the factor's 90 and the loop's invariants are spilled -- every reload then waits for all stores in flight)
+                asm volatile("" : "+v"(kk[0]), "+v"(bio), "+v"(bjo));
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) ks[i] = kk[i];
                 toc(8);
                 if (k == 0) break;
                 // P = p1 - V'V
@@ -1157,11 +1165,18 @@ struct upr_qp3 {
                             double acc = p1[a3][c];
 #pragma unroll
                             for (int m = 0; m < NQ; ++m) acc -= vi[a3][m] * vj[c][m];
+                            if (a3 == 0 && c == 0) acc += h * heek;
                             p[a3][c] = acc;
                         }
                 }
                 UPR_WSYNC();
                 toc(9);
+            }
+            if (l < NX + NQ) {   // knot 0's column
+                double* const dst = vl ? (G + F::Ks + l) : (G + F::Ljis + (l - NX));
+                const int str = vl ? NX : NQ;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
             UPR_SETPRIO(0);
