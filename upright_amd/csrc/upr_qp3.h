@@ -69,7 +69,7 @@ struct upr_qp3_far {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
     static constexpr int g0 = 0, e0 = g0 + r2(C::N * C::NQ), ek = e0 + r2(C::N * C::NE), yf = ek + r2(C::N * C::NE), hf = yf + r2(C::N * C::NFC),
                          ys = hf + r2(C::N * C::NFC), zt = ys + r2(C::N * C::NE), cv = zt, nun = zt + r2(C::N * C::NE), lfi = nun + r2(C::N * C::NE),
-                         Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * (C::SW ? C::NQ * C::NQ : C::NH)),   // SW: the dense inverse factor of Hjj
+                         Ljis = lfi + r2(C::N * C::NLF), ct = Ljis + r2(C::N * (C::SW ? C::NQ * C::NX : C::NH)),   // SW: the dense inverse factor of Hjj, rows strided like K's
                           cl = ct + r2(5 * C::NCI), cc = cl + r2(5 * C::NCI),
                          hee = cc + r2(5 * C::NCI), lsi = hee + r2(C::N * C::NH), Ks = lsi + r2(C::N * C::NLS),
                          // corrector targets of the lane-owned box rows, [slot][lane] (parked here between the corrector's
@@ -178,6 +178,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 // workgroup's waves on its SIMD for the duration (UPR_QP3_PRIO=0 at compile time switches it off for A/B runs)
 #ifndef UPR_QP3_PRIO
 #define UPR_QP3_PRIO 1
+#endif
+#ifndef UPR_QP3_SW2
+#define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
 #endif
 #ifndef UPR_QP3_PRIO_MAT
 #define UPR_QP3_PRIO_MAT 0   // every wave during the matrix sweep: 2 measured no different from 0 (3.235 vs 3.230 ms)
@@ -1033,8 +1036,8 @@ struct upr_qp3 {
                 // knot -- a value requested for the NEXT knot would be waited for at the loop's back edge)
                 const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;
                 if (k < N - 1 && l < NX + NQ) {
-                    double* const dst = vl ? (G + F::Ks + (k + 1) * NQ * NX + l) : (G + F::Ljis + (k + 1) * NQ * NQ + (l - NX));
-                    const int str = vl ? NX : NQ;
+                    double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + (k + 1) * NQ * NX;
+                    constexpr int str = NX;
 #pragma unroll
                     for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
                 }
@@ -1173,8 +1176,8 @@ struct upr_qp3 {
                 toc(9);
             }
             if (l < NX + NQ) {   // knot 0's column
-                double* const dst = vl ? (G + F::Ks + l) : (G + F::Ljis + (l - NX));
-                const int str = vl ? NX : NQ;
+                double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX));
+                constexpr int str = NX;
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
             }
@@ -1183,10 +1186,212 @@ struct upr_qp3 {
         }
         UPR_SYNC();
     }
+
+    // ---- the same sweep on TWO waves (UPR_QP3_SW2, default): the single wave above is bound by instruction issue (~960 per knot, a
+    // third of them the factorisation).  Here wave 1 keeps the blocks of P (A'P+A, Hux, Hjj, P+ b partial sums; the Vc'Vc part of
+    // the update while wave 0 factors; then the V'V part) and wave 0 the columns (factorisation, V, K).  Two LDS-only workgroup
+    // barriers per knot hand Hjj / Hux over (A) and V back (B); the remaining waves only take part in the barriers.
+    UPR_HDI void backward_mat_sw2() {
+        constexpr int NBK = C::NH, HXS = O::HXS;
+        static_assert(!C::SW || NT >= 128, "two waves");
+        const int wave = wb >> 6;
+        const int l = lane();
+        if (wave == 1) {
+            UPR_SETPRIO(3);
+            const double irho = 1.0 / UPR_QP_RHO_N;
+            const bool blk = l < NBK;
+            const int lc = blk ? l : NBK - 1;      // = upr_tri(NQ, bi, bj)
+            int bi = 0, b0 = 0;
+#pragma unroll
+            for (int i = 1; i < NQ; ++i) { const int st = i * NQ - i * (i - 1) / 2; if (lc >= st) { bi = i; b0 = st; } }
+            const int bj = bi + (lc - b0);
+            const bool dg = bi == bj;
+            double p[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[a][c] = 0.0;
+            {
+                double v = dg ? L[O::wx + N * NX + bi] : 0.0;
+                if (neN > 0) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + bi] * L[O::jN + q * NQ + bj]; }
+                p[0][0] = v;
+                const double d1 = L[O::wx + N * NX + NQ + bi] + ((neN > 0) ? irho : 0.0), d2 = L[O::wx + N * NX + 2 * NQ + bi] + ((neN > 0) ? irho : 0.0);
+                p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no wait for earlier global loads inside the loop
+#pragma nounroll
+            for (int k = N - 1; k >= 0; --k) {
+                const double wuk = L[O::wu + k * NU + bi], rdk = L[O::rd + bi];
+                double bjv[3], biv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
+                const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;   // (used at the very end of the knot)
+                double hxa[3], hxb[3], up[3], r1[3], r2[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double t0 = (c == 0) ? p[0][0] : ((c == 1) ? h * p[0][0] + p[0][1] : h2 * p[0][0] + h * p[0][1] + p[0][2]);
+                    const double t1 = (c == 0) ? p[1][0] : ((c == 1) ? h * p[1][0] + p[1][1] : h2 * p[1][0] + h * p[1][1] + p[1][2]);
+                    const double t2 = (c == 0) ? p[2][0] : ((c == 1) ? h * p[2][0] + p[2][1] : h2 * p[2][0] + h * p[2][1] + p[2][2]);
+                    hxa[c] = h3 * t0 + h2 * t1 + h * t2;                                // Hux[bi][(c, bj)]
+                    up[c] = h3 * p[c][0] + h2 * p[c][1] + h * p[c][2];
+                    r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
+                    r2[c] = p[0][c] * biv[0] + p[1][c] * biv[1] + p[2][c] * biv[2];     // -> (P+ b)[(c, bj)]   (bi < bj)
+                }
+                hxb[0] = up[0]; hxb[1] = h * up[0] + up[1]; hxb[2] = h2 * up[0] + h * up[1] + up[2];   // Hux[bj][(c, bi)]
+                double hj = h3 * up[0] + h2 * up[1] + h * up[2];
+                if (dg) hj += h * rdk + wuk;
+                if (blk) {
+                    L[O::sw_hj + bj * (bj + 1) / 2 + bi] = hj;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) L[O::sw_hx + (c * NQ + bj) * HXS + bi] = hxa[c];
+                    if (!dg) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bi) * HXS + bj] = r1[c];
+                    if (!dg) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bj) * HXS + bi] = r2[c];
+                    }
+                }
+                UPR_SYNC_LDS();   // A: Hjj, Hux, partial sums of P+ b are in LDS
+                toc(6);
+                // while wave 0 factors: p1 = sym(A'P+A) + Q~ + Vc'Vc
+                double p1[3][3];
+                if (k > 0) {
+                    double wxk[3], qdk[3], o2[3][3], cj[3][NE], ci[3][NE];
+                    const double* Vk = L + vca(k);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
+#pragma unroll
+                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * NE + r]; ci[c][r] = Vk[(c * NQ + bi) * NE + r]; }
+                    }
+                    {
+                        double t[3][3];
+#pragma unroll
+                        for (int a3 = 0; a3 < 3; ++a3) { t[a3][0] = p[a3][0]; t[a3][1] = h * p[a3][0] + p[a3][1]; t[a3][2] = h2 * p[a3][0] + h * p[a3][1] + p[a3][2]; }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { o2[0][c] = t[0][c]; o2[1][c] = h * t[0][c] + t[1][c]; o2[2][c] = h2 * t[0][c] + h * t[1][c] + t[2][c]; }
+                        if (dg) { o2[1][0] = o2[0][1]; o2[2][0] = o2[0][2]; o2[2][1] = o2[1][2]; }   // a diagonal block stays exactly symmetric
+                    }
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double acc = o2[a3][c];
+                            if (a3 == c) acc += dg ? (h * qdk[a3] + wxk[a3]) : 0.0;
+                            if (a3 == 0 && c == 0) acc += h * heek;
+#pragma unroll
+                            for (int r = 0; r < NE; ++r) acc += ci[a3][r] * cj[c][r];
+                            p1[a3][c] = acc;
+                        }
+                }
+                toc(7);
+                UPR_SYNC_LDS();   // B: V is in LDS
+                toc(8);
+                if (k == 0) break;
+                {
+                    double vj[3][NQ], vi[3][NQ];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int m = 0; m < NQ; ++m) { vj[c][m] = L[O::sw_hx + (c * NQ + bj) * HXS + m]; vi[c][m] = L[O::sw_hx + (c * NQ + bi) * HXS + m]; }
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double acc = p1[a3][c];
+#pragma unroll
+                            for (int m = 0; m < NQ; ++m) acc -= vi[a3][m] * vj[c][m];
+                            p[a3][c] = acc;
+                        }
+                }
+                UPR_WSYNC();   // (the reads of V precede the next knot's stores of Hux: same wave, in order)
+                toc(9);
+            }
+            UPR_SETPRIO(0);
+        } else if (wave == 0) {
+            UPR_SETPRIO(3);
+            const bool vl = l < NX;                // lanes that carry a column of Hux
+            const int vcl = (l < NX + NQ) ? l : 0;  // (lanes nx .. nx + nq - 1 read a column of the identity, kept behind Hux)
+            if (l >= NX && l < NX + NQ) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) L[O::sw_hx + l * HXS + i] = (l - NX == i) ? 1.0 : 0.0;
+            }
+            bool ok = true;
+#pragma nounroll
+            for (int k = N - 1; k >= 0; --k) {
+                UPR_SYNC_LDS();   // A
+                toc(6);
+                double a[NQ][NQ], hx[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
+                double pbv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
+#pragma unroll
+                for (int p2 = 0; p2 < NQ; ++p2) {
+                    const double piv = a[p2][p2];
+                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
+                    const double idg = upr_rsqrt(piv);
+#pragma unroll
+                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
+                    hx[p2] *= idg;
+#pragma unroll
+                    for (int j = p2 + 1; j < NQ; ++j) {
+#pragma unroll
+                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
+                        hx[j] -= a[j][p2] * hx[p2];
+                    }
+                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal
+                }
+                if (k > 0 && vl) {
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
+                }
+                toc(7);
+                UPR_SYNC_LDS();   // B
+                toc(8);
+                // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
+                if (vl) {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
+                    L[O::Pbs + k * NX + l] = (s0 + s1) + s2;
+                }
+                double kk[NQ];
+#pragma unroll
+                for (int i = NQ - 1; i >= 0; --i) {
+                    double tt = hx[i];
+#pragma unroll
+                    for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
+                    kk[i] = vl ? tt * a[i][i] : hx[i];   // (lanes nx ..: their column of Lj^-1 is what is stored)
+                }
+                if (l < NX + NQ) {
+                    double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + k * NQ * NX;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) dst[i * NX] = kk[i];
+                }
+                toc(9);
+            }
+            if (!ok && l == 0) L[O::misc] = 1.0;
+            UPR_SETPRIO(0);
+        } else {
+#pragma nounroll
+            for (int k = N - 1; k >= 0; --k) { UPR_SYNC_LDS(); UPR_SYNC_LDS(); }
+        }
+        UPR_SYNC();
+    }
 #endif
     UPR_HDI void backward_mat() {
 #ifndef UPR_HOST_EMU
-        if constexpr (C::SW) { backward_mat_sw(); return; }
+        if constexpr (C::SW) { if (UPR_QP3_SW2 && NT >= 128) backward_mat_sw2(); else backward_mat_sw(); return; }
 #endif
         UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
@@ -1672,13 +1877,13 @@ struct upr_qp3 {
         if constexpr (C::SW) {
             // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
             UPR_FORT(k, N) {
-                const double* Li = G + F::Ljis + k * NQ * NQ;
+                const double* Li = G + F::Ljis + k * NQ * NX;
                 const double* w = Wk(k);
                 double li[NQ][NQ], tv[NQ], y[NQ];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
 #pragma unroll
-                    for (int m = 0; m <= i; ++m) li[i][m] = Li[i * NQ + m];
+                    for (int m = 0; m <= i; ++m) li[i][m] = Li[i * NX + m];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) tv[i] = L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
 #pragma unroll
