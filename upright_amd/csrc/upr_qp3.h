@@ -112,7 +112,7 @@ struct upr_qp3_lds {
                          // (dead between prep and the vector sweep), the rest from Pa on -- then the sweep's staging: packed Hjj,
                          // Hux / V by columns [nx][HXS], the partial sums of P+ b [nx][HXS]
                          VCN = C::NE * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
-                         sw0 = Pa + (C::N - 1 - KS) * VCN, sw_hj = sw0, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_end = sw_pb + C::NX * HXS,
+                         sw0 = Pa + (C::N - 1 - KS) * VCN, sw_hj = sw0, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */, sw_end = sw_w + r2(C::NX),
                          yN = (C::SW && sw_end > ck + r2(C::NE * C::NX)) ? sw_end : ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
@@ -178,6 +178,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 // workgroup's waves on its SIMD for the duration (UPR_QP3_PRIO=0 at compile time switches it off for A/B runs)
 #ifndef UPR_QP3_PRIO
 #define UPR_QP3_PRIO 1
+#endif
+#ifndef UPR_QP3_FUSEVEC
+#define UPR_QP3_FUSEVEC 1   // the predictor's vector sweep rides on wave 0 of the two-wave matrix sweep (K_k out of registers)
 #endif
 #ifndef UPR_QP3_SW2
 #define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
@@ -1187,6 +1190,8 @@ struct upr_qp3 {
         UPR_SYNC();
     }
 
+    // (P+ b: wave 1 writes its partial sums BEHIND barrier A and wave 0 reads them behind barrier B of the same knot, i.e. before it
+    // arrives at the next barrier A, behind which wave 1 writes the next ones.)
     // ---- the same sweep on TWO waves (UPR_QP3_SW2, default): the single wave above is bound by instruction issue (~960 per knot, a
     // third of them the factorisation).  Here wave 1 keeps the blocks of P (A'P+A, Hux, Hjj, P+ b partial sums; the Vc'Vc part of
     // the update while wave 0 factors; then the V'V part) and wave 0 the columns (factorisation, V, K).  Two LDS-only workgroup
@@ -1196,9 +1201,11 @@ struct upr_qp3 {
         static_assert(!C::SW || NT >= 128, "two waves");
         const int wave = wb >> 6;
         const int l = lane();
+        constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
+        const double irho = 1.0 / UPR_QP_RHO_N;
+        if (FUSE) { terminal_residual(); UPR_SYNC_LDS(); }
         if (wave == 1) {
             UPR_SETPRIO(3);
-            const double irho = 1.0 / UPR_QP_RHO_N;
             const bool blk = l < NBK;
             const int lc = blk ? l : NBK - 1;      // = upr_tri(NQ, bi, bj)
             int bi = 0, b0 = 0;
@@ -1219,14 +1226,11 @@ struct upr_qp3 {
                 p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no wait for earlier global loads inside the loop
+            double hjd = h * L[O::rd + bi] + L[O::wu + (N - 1) * NU + bi];
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
-                const double wuk = L[O::wu + k * NU + bi], rdk = L[O::rd + bi];
-                double bjv[3], biv[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
-                const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;   // (used at the very end of the knot)
-                double hxa[3], hxb[3], up[3], r1[3], r2[3];
+                // critical path first: Hux (both orientations of the block) and Hjj, straight from the registers of P+
+                double hxa[3], hxb[3], up[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double t0 = (c == 0) ? p[0][0] : ((c == 1) ? h * p[0][0] + p[0][1] : h2 * p[0][0] + h * p[0][1] + p[0][2]);
@@ -1234,12 +1238,10 @@ struct upr_qp3 {
                     const double t2 = (c == 0) ? p[2][0] : ((c == 1) ? h * p[2][0] + p[2][1] : h2 * p[2][0] + h * p[2][1] + p[2][2]);
                     hxa[c] = h3 * t0 + h2 * t1 + h * t2;                                // Hux[bi][(c, bj)]
                     up[c] = h3 * p[c][0] + h2 * p[c][1] + h * p[c][2];
-                    r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
-                    r2[c] = p[0][c] * biv[0] + p[1][c] * biv[1] + p[2][c] * biv[2];     // -> (P+ b)[(c, bj)]   (bi < bj)
                 }
                 hxb[0] = up[0]; hxb[1] = h * up[0] + up[1]; hxb[2] = h2 * up[0] + h * up[1] + up[2];   // Hux[bj][(c, bi)]
                 double hj = h3 * up[0] + h2 * up[1] + h * up[2];
-                if (dg) hj += h * rdk + wuk;
+                if (dg) hj += hjd;   // h R + W of this knot (requested during the previous knot's update)
                 if (blk) {
                     L[O::sw_hj + bj * (bj + 1) / 2 + bi] = hj;
 #pragma unroll
@@ -1248,16 +1250,30 @@ struct upr_qp3 {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c];
                     }
+                }
+                UPR_SYNC_LDS();   // A: Hjj, Hux are in LDS
+                toc(6);
+                // while wave 0 factors: the partial sums of P+ b (wave 0 adds them up behind barrier B) ...
+                const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;   // (used at the very end of the knot)
+                {
+                    double bjv[3], biv[3], r1[3], r2[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bi) * HXS + bj] = r1[c];
-                    if (!dg) {
+                    for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bj) * HXS + bi] = r2[c];
+                    for (int c = 0; c < 3; ++c) {
+                        r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
+                        r2[c] = p[0][c] * biv[0] + p[1][c] * biv[1] + p[2][c] * biv[2];     // -> (P+ b)[(c, bj)]   (bi < bj)
+                    }
+                    if (blk) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bi) * HXS + bj] = r1[c];
+                        if (!dg) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) L[O::sw_pb + (c * NQ + bj) * HXS + bi] = r2[c];
+                        }
                     }
                 }
-                UPR_SYNC_LDS();   // A: Hjj, Hux, partial sums of P+ b are in LDS
-                toc(6);
-                // while wave 0 factors: p1 = sym(A'P+A) + Q~ + Vc'Vc
+                // ... and p1 = sym(A'P+A) + Q~ + Vc'Vc
                 double p1[3][3];
                 if (k > 0) {
                     double wxk[3], qdk[3], o2[3][3], cj[3][NE], ci[3][NE];
@@ -1292,6 +1308,7 @@ struct upr_qp3 {
                 UPR_SYNC_LDS();   // B: V is in LDS
                 toc(8);
                 if (k == 0) break;
+                hjd = h * L[O::rd + bi] + L[O::wu + (k - 1) * NU + bi];
                 {
                     double vj[3][NQ], vi[3][NQ];
 #pragma unroll
@@ -1321,6 +1338,18 @@ struct upr_qp3 {
                 for (int i = 0; i < NQ; ++i) L[O::sw_hx + l * HXS + i] = (l - NX == i) ? 1.0 : 0.0;
             }
             bool ok = true;
+            // fused predictor sweep (backward_vec's recursion, mode 0): lane c < nx carries w~_k[c] = w_k[c] - (P+ b)_k[c]
+            const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
+            const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
+            double wt = 0.0;
+            if (FUSE && vl) {
+                double v = L[O::gxs + N * NX + l];
+                if (neN > 0) {
+                    if (l < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + l] * (L[O::yN + q] + irho * L[O::eN + q]); }
+                    else v += L[O::yN + 3 + (l - NQ)] + irho * L[O::eN + 3 + (l - NQ)];
+                }
+                wt = v;
+            }
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 UPR_SYNC_LDS();   // A
@@ -1332,9 +1361,6 @@ struct upr_qp3 {
                     for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
-                double pbv[NQ];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
 #pragma unroll
                 for (int p2 = 0; p2 < NQ; ++p2) {
                     const double piv = a[p2][p2];
@@ -1359,12 +1385,9 @@ struct upr_qp3 {
                 UPR_SYNC_LDS();   // B
                 toc(8);
                 // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
-                if (vl) {
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                double pbv[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
-                    L[O::Pbs + k * NX + l] = (s0 + s1) + s2;
-                }
+                for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
                 double kk[NQ];
 #pragma unroll
                 for (int i = NQ - 1; i >= 0; --i) {
@@ -1377,6 +1400,34 @@ struct upr_qp3 {
                     double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + k * NQ * NX;
 #pragma unroll
                     for (int i = 0; i < NQ; ++i) dst[i * NX] = kk[i];
+                }
+                double pbs;
+                {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
+                    pbs = (s0 + s1) + s2;
+                    if (vl) L[O::Pbs + k * NX + l] = pbs;
+                }
+                if (FUSE) {
+                    // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
+                    const double gk = (k >= 1) ? L[O::gxs + k * NX + (vl ? l : 0)] + L[O::cs + k * NX + (vl ? l : 0)] : 0.0;
+                    const double uk = L[O::gus + k * NU + vj_];
+                    const double wk = wt + pbs;
+                    if (vl) L[O::sw_w + l] = wk;
+                    UPR_WSYNC();
+                    const double w0 = L[O::sw_w + vj_], w1 = L[O::sw_w + NQ + vj_], w2 = L[O::sw_w + 2 * NQ + vj_];
+                    const double rq = ((h3 * w0 + h2 * w1) + h * w2) + uk;
+                    if (l < NQ) L[O::kffs + k * NQ + l] = rq;
+                    double v0 = gk + ca0 * w0, v1 = ca1 * w1, v2 = ca2 * w2;
+#pragma unroll
+                    for (int m = 0; m < NQ; m += 3) {
+                        v0 -= kk[m] * upr_readlane(rq, m);
+                        if (m + 1 < NQ) v1 -= kk[m + 1] * upr_readlane(rq, m + 1);
+                        if (m + 2 < NQ) v2 -= kk[m + 2] * upr_readlane(rq, m + 2);
+                    }
+                    wt = (v0 + v1) + v2;
+                    UPR_WSYNC();
                 }
                 toc(9);
             }
@@ -1788,12 +1839,16 @@ struct upr_qp3 {
     // knot ahead).  w_k is kept (in the step array, which the forward sweep overwrites afterwards) for the
     // feed-forward  kff_k = Hjj_k^-1 (gu_k[jerk] + B'w_k)  of all knots at once.
     UPR_HDI double* Wk(int k) const { return L + O::S + (k + 1) * NX; }
-    UPR_HDI void backward_vec() {
+    // fused: the recursion ran on wave 0 of the two-wave matrix sweep (backward_mat_sw2) and left rq_k = gu_k[jerk] + B'w_k in the
+    // feed-forward slots: only the feed-forward phase is left
+    UPR_HDI void backward_vec(bool fused = false) {
         const double irho = 1.0 / UPR_QP_RHO_N;
+        if (!fused) {
         terminal_residual();
         UPR_SYNC();
+        }
         toc(11);
-        if (wave0()) {
+        if (!fused && wave0()) {
             UPR_SETPRIO(3);
             UPR_FORT(i, NX) {
                 double v = L[O::gxs + N * NX + i];
@@ -1885,7 +1940,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int m = 0; m <= i; ++m) li[i][m] = Li[i * NX + m];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) tv[i] = L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+                for (int i = 0; i < NQ; ++i) tv[i] = fused ? L[O::kffs + k * NQ + i] : L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) { double t = 0.0;
 #pragma unroll
@@ -2766,7 +2821,11 @@ struct upr_qp3 {
             mode = 0;
             prep(2);
             backward_mat(); toc(11);
+#ifndef UPR_HOST_EMU
+            backward_vec(C::SW && UPR_QP3_SW2 && UPR_QP3_FUSEVEC && NT >= 128); toc(11);
+#else
             backward_vec(); toc(11);
+#endif
             if (L[O::misc] != 0.0) {
                 status = 2;
 #ifndef UPR_HOST_EMU
