@@ -14,6 +14,8 @@ Outputs (tests/golden/):
   configs.json        merged controller dicts (numeric fields the ControllerSettings mirror reads)
                       for the BASELINE.json configs, via the reference's include resolver
   parse_dsl.json      parse_number / parse_array known answers
+  grasp.json          upright_robust.modelling.compute_grasp_matrix (contact forces -> body wrenches) for three arrangements:
+                      a statement of the wrench map that is independent of the C++ (second reference-held answer for a1 / a2)
 
 Run:  python tests/golden/make_fixtures.py
 """
@@ -140,6 +142,11 @@ def install_stubs():
     b.RigidBody = _RigidBody
     b.ContactPoint = _ContactPoint
     sys.modules["upright_core.bindings"] = b
+    # upright_robust.modelling (grasp matrix): rigeo is touched inside methods the fixtures never call, upright_control only by
+    # upright_robust.parsing (imported by the package's __init__, not used here)
+    for name in ("rigeo", "upright_control"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.path.insert(0, str(REF / "upright_robust" / "src"))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -254,6 +261,21 @@ def main():
 
     with open(OUT / "arrangements.json", "w") as f:
         json.dump(arrangements, f, indent=1)
+
+    # --- grasp matrices (upright_robust/modelling.py:83-103): contact forces -> body wrenches about the EE origin ----------
+    import upright_robust.modelling as mdl
+
+    grasp = {}
+    for name, c in (("pink_bottle", cfg), ("box_arch", cfg), ("robust_8corner", rcfg)):
+        c2 = copy.deepcopy(c)
+        c2.setdefault("balancing", {})["arrangement"] = name
+        bodies, contacts = core.parsing.parse_control_objects(c2)
+        names = sorted(bodies)            # the body order of the stacked residual (contact_constraints.h:179-192)
+        index = mdl.compute_object_name_index(names)
+        G = mdl.compute_grasp_matrix(index, [mdl.RobustContactPoint(cp) for cp in contacts])
+        grasp[name] = {"names": names, "G": G.tolist()}
+    with open(OUT / "grasp.json", "w") as f:
+        json.dump(grasp, f, indent=1)
 
     # --- merged configs for the BASELINE configs ------------------------------------------------
     configs = {}

@@ -161,3 +161,24 @@ def kkt_residuals(P, body_params, x0, xs, us, lin, sol, lin_layout=None):
             eN = np.concatenate([rec[o_grad:o_grad + 3] - Jp @ (X[N][:nq] - xs[N][:nq]), X[N][nq:]])
             r_eq = max(r_eq, np.abs(eN).max())
     return np.array([r_stat, r_eq, r_in, r_comp])
+
+
+def force_jacobian_from_grasp(G, masses, coms, nb, contact_normals=None):
+    """The same Jacobian out of the reference's GRASP MATRIX (tests/golden/grasp.json: upright_robust/modelling.py:83-103,
+    contact forces -> body wrenches about the END-EFFECTOR origin, +G1 on object 1 unless it is "ee", -G2 on object 2):
+    d(object_dynamics)/d(forces) = -[G_F ; G_T - S(c_b) G_F] / (m_b sqrt(6 nb)) per body -- the torque rows shifted to the
+    centre of mass (contact_constraints.h:126-154 takes moments about c) and the residual's scaling
+    (contact_constraints.h:96-101, balancing_constraints.cpp:144-151).  contact_normals: frictionless problems (one
+    normal-force coordinate per contact, contact_constraints.h:111-120)."""
+    G = np.asarray(G, dtype=float)
+    D = np.zeros_like(G)
+    scale = 1.0 / np.sqrt(6.0 * nb)
+    for b in range(nb):
+        c = np.asarray(coms[b], dtype=float)
+        S = np.array([[0, -c[2], c[1]], [c[2], 0, -c[0]], [-c[1], c[0], 0]])
+        GF, GT = G[6 * b:6 * b + 3], G[6 * b + 3:6 * b + 6]
+        D[6 * b:6 * b + 3] = -scale * GF / masses[b]
+        D[6 * b + 3:6 * b + 6] = -scale * (GT - S @ GF) / masses[b]
+    if contact_normals is not None:
+        D = np.stack([D[:, 3 * i:3 * i + 3] @ np.asarray(n, dtype=float) for i, n in enumerate(contact_normals)], axis=1)
+    return D

@@ -3,7 +3,9 @@ same seeded inputs.  Tolerances: BASELINE.json's north_star asks for 1e-4 on sta
 against the reference solver; kernel-level terms are checked to 1e-9 .. 1e-12, QP steps to 1e-7,
 fixed-iteration QP steps (same iterate path) to 1e-9, converged QP / MPC solves to the ball the
 1e-8 KKT tolerance allows (2e-5 relative), converged SQP solves to 1e-4."""
+import json
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -1499,3 +1501,38 @@ def test_edge_sizes_single_instances_and_other_horizons(arrangements, B, N):
     mpc.close()
     with pytest.raises(Exception):
         BatchMPC(P, 0, way_p=way[:0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nf", [("pink_bottle", 3), ("box_arch", 3), ("robust_8corner", 1)])
+def test_force_jacobian_against_reference_grasp_matrix(arrangements, name, nf):
+    """The engine's constant d(object_dynamics)/d(forces) (upr_batch_eq_input_jacobian; what the QP kernels eliminate the
+    equality with) against the reference's own grasp matrix (tests/golden/grasp.json, generated from
+    upright_robust/modelling.py:83-103 by tests/golden/make_fixtures.py): -G / (m sqrt(6 nb)) with the torque rows taken
+    about each body's centre of mass.  With per-instance inertial parameters (upright_robust) every instance gets its own."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from kkt_check import force_jacobian_from_grasp
+
+    arr = arrangements[name]
+    gr = json.load(open(Path(__file__).resolve().parent / "golden" / "grasp.json"))[name]
+    assert gr["names"] == [b["name"] for b in arr["bodies"]]
+    P = thing_problem(arr, nf=nf)
+    normals = [c["normal"] for c in arr["contacts"]] if nf == 1 else None
+    B = 3
+    rng = np.random.default_rng(4)
+    bp = np.tile(np.asarray(P.body_params, dtype=np.float64)[None], (B, 1, 1))
+    for b in range(1, B):                       # other masses and centres of mass for the later instances
+        m = rng.uniform(0.5, 2.0, P.nb)
+        com = bp[0, :, 1:4] / bp[0, :, :1] + rng.uniform(-0.02, 0.02, (P.nb, 3))
+        bp[b, :, 0] = m; bp[b, :, 1:4] = m[:, None] * com
+    x0 = level_tray_states(B, seed=1)
+    mpc = BatchMPC(P, B, way_p=waypoints_for(P, x0), body_params=bp)
+    for b in range(B):
+        masses = bp[b, :, 0]; coms = bp[b, :, 1:4] / bp[b, :, :1]
+        D_ref = force_jacobian_from_grasp(gr["G"], masses, coms, P.nb, normals)
+        gu = mpc.eq_input_jacobian(b)
+        assert gu.shape == (6 * P.nb, P.nu)
+        assert np.abs(gu[:, 9:] - D_ref).max() < 1e-13 * max(1.0, np.abs(D_ref).max())
+        assert np.abs(gu[:, :9]).max() == 0.0
+    mpc.close()

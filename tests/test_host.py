@@ -312,3 +312,39 @@ def test_cpp_header_twin_compiles_and_fails_loudly_without_gpu(arrangements, tmp
         assert r.returncode == 1 and "runtime_error" in r.stdout and "no HIP device" in r.stdout
     else:
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_system_pinocchio_mapping_obstacle_coordinates_first():
+    """Row a12.  bindings.SystemPinocchioMapping (pybindings.cpp:57-65) against hand-built vectors: the generalised
+    position / velocity / acceleration of the Pinocchio model carry the dynamic obstacles' coordinates FIRST
+    (dynamics/system_pinocchio_mapping.h:84-97, 104-116, 125-137), the robot's behind them, and the state is laid out
+    [robot q, v, a | obstacle 0: r, v, a | obstacle 1: ...] (dimensions.h:32-45).  Then the call pattern of the
+    reference's robot model (upright_control/robot.py:232-234: position from x alone, velocity and acceleration from (x, u))."""
+    from upright_amd import control_bindings as cb
+
+    for n_obs in (0, 1, 2):
+        dims = cb.OptimizationDimensions()
+        dims.robot.q, dims.robot.v, dims.robot.x, dims.robot.u = 9, 9, 27, 9
+        dims.o, dims.c, dims.b, dims.nf = n_obs, 4, 1, 3
+        assert dims.q() == 9 + 3 * n_obs and dims.v() == 9 + 3 * n_obs and dims.x() == 27 + 9 * n_obs
+        m = cb.SystemPinocchioMapping(dims)
+        q = 1.0 + np.arange(9.0); v = 10.0 + np.arange(9.0); a = 20.0 + np.arange(9.0)
+        obs = [100.0 * (i + 1) + np.arange(9.0) for i in range(n_obs)]   # [r(3), v(3), a(3)] of obstacle i
+        x = np.concatenate([q, v, a] + obs)
+        u = np.concatenate([np.full(9, 7.0), np.zeros(dims.f())])        # jerk, forces: neither enters the mapping
+        qp = m.get_pinocchio_joint_position(x)
+        vp = m.get_pinocchio_joint_velocity(x, u)
+        ap = m.get_pinocchio_joint_acceleration(x, u)
+        assert qp.shape == (dims.q(),) and vp.shape == (dims.v(),) and ap.shape == (dims.v(),)
+        for i in range(n_obs):
+            assert np.array_equal(qp[3 * i: 3 * i + 3], obs[i][0:3])
+            assert np.array_equal(vp[3 * i: 3 * i + 3], obs[i][3:6])
+            assert np.array_equal(ap[3 * i: 3 * i + 3], obs[i][6:9])
+        assert np.array_equal(qp[3 * n_obs:], q) and np.array_equal(vp[3 * n_obs:], v) and np.array_equal(ap[3 * n_obs:], a)
+        # robot.py:225-234 -- forward_xu(x, u=None) substitutes a zero input of the model's velocity dimension
+        u0 = np.zeros(dims.v())
+        assert np.array_equal(m.get_pinocchio_joint_velocity(x, u0), vp)
+        assert np.array_equal(m.get_pinocchio_joint_acceleration(x, u0), ap)
+        # a state of the wrong length is an error (Eigen would read out of bounds: the mirror refuses)
+        with pytest.raises(ValueError):
+            m.get_pinocchio_joint_position(x[:-1])

@@ -297,3 +297,37 @@ def test_qp_statistics_of_headline_sample(arrangements):
         assert rc == 0 and max(st.qp_res) < P.qp_tol
         its.append(st.qp_iters_last)
     assert max(its) <= 20
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "box_arch", "robust_8corner"])
+@pytest.mark.parametrize("nf", [3, 1])
+def test_wrench_map_against_reference_grasp_matrix(arrangements, name, nf):
+    """Second reference-held answer for a1 / a2: the contact-force -> body-wrench map as upright_robust/modelling.py:83-103
+    states it (compute_grasp_matrix, imported by tests/golden/make_fixtures.py: signs, body order, object 1 = "ee"
+    skipped), independent of the C++ headers.  The oracle's d(object_dynamics)/d(forces) must equal
+    -G / (m sqrt(6 nb)) with the torque rows shifted to each body's centre of mass."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from kkt_check import force_jacobian, force_jacobian_from_grasp
+
+    arr = arrangements[name]
+    gr = json.load(open(Path(__file__).resolve().parent / "golden" / "grasp.json"))[name]
+    assert gr["names"] == [b["name"] for b in arr["bodies"]]
+    P = thing_problem(arr, nf=nf)
+    masses = [b["mass"] for b in arr["bodies"]]; coms = [b["com"] for b in arr["bodies"]]
+    normals = [c["normal"] for c in arr["contacts"]] if nf == 1 else None
+    D_ref = force_jacobian_from_grasp(gr["G"], masses, coms, P.nb, normals)
+    O = Oracle(P)
+    rng = np.random.default_rng(11)
+    x = np.concatenate([THING_HOME, np.zeros(18)]) + rng.uniform(-0.1, 0.1, 27)
+    u = rng.uniform(-1, 1, P.nu)
+    gu = O.eq_constraint(x, u)[2]
+    assert gu.shape == (6 * P.nb, P.nu)
+    assert np.abs(gu[:, 9:] - D_ref).max() < 1e-13 * max(1.0, np.abs(D_ref).max())
+    assert np.abs(gu[:, :9]).max() == 0.0                      # the jerk does not enter the rows
+    assert np.abs(force_jacobian(P, P.body_params) - D_ref).max() < 1e-13 * max(1.0, np.abs(D_ref).max())   # the numpy twin of tests/kkt_check.py
+    # the rows are affine in the forces: g(u + df) - g(u) = D df exactly (to rounding)
+    df = rng.uniform(-1, 1, P.nu - 9)
+    u2 = u.copy(); u2[9:] += df
+    g0 = O.eq_constraint(x, u, jac=False); g1 = O.eq_constraint(x, u2, jac=False)
+    assert np.abs((g1 - g0) - D_ref @ df).max() < 1e-12 * max(1.0, np.abs(D_ref).max())
