@@ -12,9 +12,14 @@ when --gpus > 1).  One JSON line is printed by rank 0 (contract in the task desc
     python bench.py --gpus 8                       # launches 8 ranks itself (torch.distributed.run, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-The other BASELINE configurations that fit one GPU are timed as `extra_workloads` of the same line (N = 1 only),
-each with its own roofline object: configs[2] (Thing + 3 stacked objects + static obstacles, batch 4096) and
-configs[3] (upright_robust 8-corner arrangement with per-instance inertial parameters, 1024 per GPU).
+The other BASELINE configurations are timed as `extra_workloads` of the same line, each with its own roofline object:
+configs[2] (Thing + 3 stacked objects + static obstacles, batch 4096; N = 1 only), configs[3] (upright_robust 8-corner
+arrangement with per-instance inertial parameters, 1024 per GPU: with --gpus N the N x 1024 scenarios are sharded over the
+ranks and the solved trajectories all-gathered), configs[4] (thrown ball, closed loop at 100 Hz: the goal sweep is sharded
+over the ranks and only the first input u_0 of every instance is gathered per tick), and the headline problem on the start
+distribution of SURVEY.md section 8(d) as written (U(+-0.25) on all nine joints; N = 1 only).
+
+    python bench.py --gpus 2 --dry-run             # the N-rank control flow over gloo with stand-in engines (no GPU, no numbers)
 """
 import argparse
 import json
@@ -57,45 +62,52 @@ def _latest_profile(pattern):
     return files[-1] if files else None
 
 
-def pmc_traffic():
-    """Per-launch HBM bytes of the headline kernels from the newest committed rocprofv3 PMC passes (profiles/):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  Measured at the default
-    workload (B = 1024); {} when no profile is committed."""
+def _pmc_rows(patterns):
+    """(kernel, counter) -> per-dispatch mean of the newest committed counter file matching one of `patterns`."""
     import csv
 
-    best = _latest_profile("r*_pmc_hbm.csv")
-    if best is None:
-        return {}, None
-    vals = {}
-    for row in csv.reader(l for l in open(best) if not l.startswith("#")):
-        if len(row) == 4 and row[0] != "kernel":
-            vals[(row[0], row[1])] = float(row[3])
-    out = {}
-    for key, tag in (("upr_qp", "qp"), ("upr_linearize_kernel", "linearize")):
-        fe = [v for (k, c), v in vals.items() if key in k and c == "FETCH_SIZE"]
-        wr = [v for (k, c), v in vals.items() if key in k and c == "WRITE_SIZE"]
-        if fe and wr:
-            out[tag] = (2.0 * fe[0] + wr[0]) * 1024.0
-    return out, best.name
+    for pat in patterns:
+        best = _latest_profile(pat)
+        if best is None:
+            continue
+        vals = {}
+        for row in csv.reader(l for l in open(best) if not l.startswith("#")):
+            if len(row) == 4 and row[0] != "kernel":
+                vals[(row[0], row[1])] = float(row[3])
+        yield vals, best.name
 
 
-def pmc_issued_flops():
+def pmc_traffic(kernel=None):
+    """Per-launch HBM bytes from the newest committed rocprofv3 PMC passes (profiles/): (2 * FETCH_SIZE + WRITE_SIZE) * 1024,
+    the gfx950 correction of MI355X_MICROARCH.md.  kernel None: the headline workload's QP and linearise kernels
+    (r*_pmc_hbm.csv, B = 1024); a kernel name: that QP kernel out of the all-workloads pass (r*_pmc_hbm_all.csv, mean over
+    the dispatches of that pass).  {} when nothing is committed."""
+    pats = ("r*_pmc_hbm.csv",) if kernel is None else ("r*_pmc_hbm_all.csv", "r*_pmc_hbm.csv")
+    for vals, name in _pmc_rows(pats):
+        out = {}
+        for key, tag in ((kernel or "upr_qp", "qp"), ("upr_linearize_kernel", "linearize")):
+            fe = [v for (k, c), v in vals.items() if key in k and c == "FETCH_SIZE"]
+            wr = [v for (k, c), v in vals.items() if key in k and c == "WRITE_SIZE"]
+            if fe and wr:
+                out[tag] = (2.0 * fe[0] + wr[0]) * 1024.0
+        if "qp" in out:
+            return out, name
+    return {}, None
+
+
+def pmc_issued_flops(kernel=None):
     """fp64 flops the QP kernel ISSUED per launch according to the newest committed instruction-mix pass
-    (profiles/r*_pmc_mfma.csv; wave instructions x 64 lanes: FMA 2 flops, MUL / ADD 1, one v_mfma_f64_16x16x4 = 2048)."""
-    import csv
-
-    best = _latest_profile("r*_pmc_mfma.csv")
-    if best is None:
-        return None, None
-    c = {}
-    for row in csv.reader(l for l in open(best) if not l.startswith("#")):
-        if len(row) == 4 and "upr_qp" in row[0]:
-            c[row[1]] = float(row[3])
-    if "SQ_INSTS_VALU_FMA_F64" not in c:
-        return None, best.name
-    flops = 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)) \
-        + 2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
-    return flops, best.name
+    (profiles/r*_pmc_mfma.csv, or r*_pmc_mfma_all.csv for a named kernel of the other workloads; wave instructions x 64
+    lanes: FMA 2 flops, MUL / ADD 1, one v_mfma_f64_16x16x4 = 2048)."""
+    pats = ("r*_pmc_mfma.csv",) if kernel is None else ("r*_pmc_mfma_all.csv", "r*_pmc_mfma.csv")
+    for vals, name in _pmc_rows(pats):
+        c = {cn: v for (k, cn), v in vals.items() if (kernel or "upr_qp") in k}
+        if "SQ_INSTS_VALU_FMA_F64" not in c:
+            continue
+        flops = 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)) \
+            + 2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+        return flops, name
+    return None, None
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------
@@ -136,31 +148,36 @@ def config3_workload(B):
                      f"N=20, batch={B}, cold start, sqp_iteration=1")
 
 
-def config4_workload(B):
+def config4_workload(B, rank=0, world=1):
     """configs[3]: the upright_robust 8-corner arrangement (planning_sim_loop.py:454-534), frictionless, per-instance
     inertial parameters (CoM uniform in the CoM box, inertia scaled by {1, 0.5, 0.1}, :559), HPIPM slacks on the state
     boxes and the general constraints, init_sqp_iteration 3 (upright_robust/config/demos/_base.yaml:62-75), waypoint
-    [-2, 1, 0], seed 2."""
+    [-2, 1, 0], seed 2.  Rank r owns scenarios [r B, (r+1) B) of the global sample of world x B (8 x 1024 = BASELINE's 8192;
+    planning_sim_loop.py:613-655 runs them one after the other)."""
+    from upright_amd.distributed import shard_range
     from upright_amd.problem import THING_HOME, thing_problem
     from upright_amd.sampling import waypoints_for
 
     P = thing_problem(_arrangements()["robust_8corner"], nf=1, force_weight=0.0, sqp_iters=3)
     P.slacks = dict(state_box=True, input_box=False, poly_ineq=True)
     rng = np.random.default_rng(2)
-    bp = np.zeros((B, 8, 10))
-    for b in range(B):
+    Bg = B * world
+    bp = np.zeros((Bg, 8, 10))
+    for b in range(Bg):
         sc = (1.0, 0.5, 0.1)[b % 3]
         for i in range(8):
             com = rng.uniform([-0.06, -0.06, -0.15], [0.06, 0.06, 0.15])
             bp[b, i] = [1.0, *com, sc * 0.009375, 0, 0, sc * 0.009375, 0, sc * 0.00375]
-    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
-    x0[:, :2] += rng.uniform(-0.25, 0.25, (B, 2))
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (Bg, 1))
+    x0[:, :2] += rng.uniform(-0.25, 0.25, (Bg, 2))
+    lo, hi = shard_range(Bg, rank, world)
+    x0, bp = x0[lo:hi], bp[lo:hi]
     return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0)), body_params=bp,
                 name=f"configs[3]: upright_robust 8-corner arrangement (8 bodies, 32 frictionless contacts: nx 27, nu 41, 48 soft eq rows/knot), "
                      f"per-instance inertial parameters, N=20, batch={B} per GPU, cold start, init_sqp_iteration=3")
 
 
-def config5_workload(B):
+def config5_workload(B, rank=0, world=1):
     """configs[4]: Thing + pink_bottle with a thrown ball (dynamic obstacle, obstacles/dynamic.yaml:5-17; rows as in
     ral23/experiments/projectile/_base.yaml:81-87: two self-collision pairs, wrist-vs-ground, forearm-vs-ball and the
     projectile-path row on the tray's link), closed loop at 100 Hz; goal sweep: goals on a 1.2 m circle around the
@@ -177,7 +194,7 @@ def config5_workload(B):
     robots.add_projectile_rows(P, ["balanced_object_collision_link"], [0.35], 0.2)
     x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
     p, _ = P.chain.forward(THING_HOME)
-    ang = 2.0 * np.pi * np.arange(B) / B
+    ang = 2.0 * np.pi * (rank * B + np.arange(B)) / (B * world)   # (rank r owns goals [r B, (r+1) B) of the sweep of world x B)
     goal = np.stack([1.2 * np.cos(ang), 1.2 * np.sin(ang), np.zeros(B)], axis=1)
     T = 1.0
     a0 = np.array([0.0, 0.0, -9.81])
@@ -193,22 +210,45 @@ def config5_workload(B):
                      f"(one warm-started SQP iteration per tick, linear feedback policy at the observed state), goal sweep of {B} goals per GPU")
 
 
-def time_closed_loop(w, ticks):
+def contract_workload(B):
+    """The headline problem on the start distribution of SURVEY.md section 8(d) AS WRITTEN: x_home + U(-0.25, 0.25) on all nine
+    joints, U(-0.2, 0.2) on the velocities, zero accelerations, seed 0.  Most of these starts tilt the tray beyond the
+    friction cone at the fixed first knot (upright_amd/sampling.py): their hard-constrained QPs are infeasible, for the
+    reference's formulation as for this one, and are reported per instance."""
+    from upright_amd.problem import thing_problem
+    from upright_amd.sampling import contract_states, waypoints_for
+
+    P = thing_problem(_arrangements()["pink_bottle"], use_feedback_policy=True)
+    x0 = contract_states(B, seed=0)
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0), body_params=None,
+                name=f"configs[1] on SURVEY 8(d)'s start distribution as written (U(+-0.25) on all nine joints, U(+-0.2) velocities, seed 0), "
+                     f"batch={B}, cold start, sqp_iteration=1: most starts are infeasible at the fixed first knot (tray tilted beyond the friction cone)")
+
+
+def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     """configs[4]: `ticks` control periods of 10 ms for the whole batch: observation in (host -> device), one warm-started
     SQP iteration, policy out (device -> host), exact triple-integrator plant and ballistic ball on the host.  The
     plant's states come from outside the engine every tick, so this rate includes both PCIe hops by construction."""
-    mpc = make_engine(w)
+    mpc = engine if engine is not None else make_engine(w)
     P, B = w["P"], mpc.B
+    world = dist.get_world_size() if dist is not None else 1
     mpc.set_projectile_flag(1.0)
     x, t, dt = w["x0"].copy(), 0.0, 0.01
     failed = 0
     lat = []
+    u0_all = [None]
 
     def tick(x, t):
         tc = time.perf_counter()
         mpc.set_observation(t, x)
         mpc.advance()
         _, u = mpc.evaluate(t, x_obs=x)
+        if world > 1:   # exchange step of the closed loop (SURVEY.md 8e): only u_0 of every instance, [B, nu] per rank
+            import torch
+
+            from upright_amd.distributed import all_gather_first_inputs
+
+            u0_all[0] = all_gather_first_inputs(torch.as_tensor(np.ascontiguousarray(u), device=device))
         lat.append(time.perf_counter() - tc)
         j = u[:, :9]
         q, v, a = x[:, :9], x[:, 9:18], x[:, 18:27]
@@ -224,18 +264,29 @@ def time_closed_loop(w, ticks):
         x = tick(x, t); t += dt
         failed += int(np.sum(mpc.stats()["qp_status_last"] != 0))
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+
+        tt = torch.tensor([elapsed, float(failed)], dtype=torch.float64, device=device)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)      # the slowest rank's clock
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        elapsed, failed = float(tt[0].item()), int(tt[1].item())
+        assert u0_all[0].shape == (world * B, P.nu)
     kt = mpc.kernel_times()
     goal_err = np.linalg.norm(np.array([P.chain.forward(x[b, :9])[0] for b in range(0, B, max(1, B // 64))])
                               - w["way"][::max(1, B // 64), 0], axis=1)
     out = {
-        "workload": w["name"], "value": B * ticks / elapsed, "unit": "solves/s", "ms_per_tick": 1e3 * elapsed / ticks,
+        "workload": w["name"], "value": B * world * ticks / elapsed, "unit": "solves/s", "n_gpus": world, "ms_per_tick": 1e3 * elapsed / ticks,
         "ms_per_tick_p99_engine": 1e3 * float(np.quantile(lat, 0.99)), "control_period_ms": 10.0, "ticks": ticks,
         "real_time_factor": 0.01 * ticks / elapsed,
-        "qp_not_converged_fraction": failed / (B * ticks),
+        "exchange": "all-gather of u_0 per tick" if world > 1 else None,
+        "qp_not_converged_fraction": failed / (B * world * ticks),
         "tray_to_goal_m_after_run": {"mean": float(goal_err.mean()), "max": float(goal_err.max())},
         "finite": bool(np.all(np.isfinite(x))),
         "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
     }
+    if u0_all[0] is not None:
+        out["u0_gathered"] = u0_all[0]        # (for the tests; dropped before the line is printed)
     mpc.close()
     return out
 
@@ -249,10 +300,15 @@ def make_engine(w):
 
 
 # ---- the timed loop of one rank -----------------------------------------------------------------------------------
-def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None):
+def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_exchange=False):
     """W untimed + K timed steps on this rank.  `mpc` is the engine (or a stand-in with the same methods: the gloo test
     drives this function with fake solutions); `dist` a torch.distributed module with an initialised group or None.
-    Returns (max-over-ranks seconds of the timed region, gathered trajectories of the last step or None)."""
+    Returns (max-over-ranks seconds of the timed region, gathered trajectories of the last step or None).
+    Exchange step (world > 1; force_exchange: also at world size 1, for the one-GPU test of the nccl branch): the copy-out of
+    step i runs on the engine's stream, the collective's stream waits for it through an event -- no host synchronisation --
+    and the collective runs while the engine is already in step i + 1.  Two send-buffer pairs are used in turn; before pair
+    i & 1 is overwritten the handles of the collective that last read it are waited for and the engine's stream is ordered
+    behind them."""
     import torch
 
     from upright_amd.distributed import all_gather_solutions
@@ -260,29 +316,47 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None):
     world = dist.get_world_size() if dist is not None else 1
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    exchange = world > 1 or (force_exchange and dist is not None)
     B, n1 = mpc.B, P.N + 1
     loc = None
     counts = [B] * world
-    if world > 1:
-        # two sets of send buffers, used in turn: the collective of step i is enqueued on the backend's stream and runs
-        # while the engine's stream is already in step i + 1, whose copy-out must not land in a buffer still being sent
+    ext = None
+    if exchange:
         loc = [(torch.empty((B, n1, P.nx), dtype=torch.float64, device=device),
                 torch.empty((B, P.N, P.nu), dtype=torch.float64, device=device)) for _ in range(2)]
+        if device != "cpu" and hasattr(mpc, "stream_ptr") and mpc.stream_ptr():
+            ext = torch.cuda.ExternalStream(mpc.stream_ptr())
     gathered = [None]
+    pending = [None, None]
     turn = [0]
+
+    def retire(i):
+        if pending[i] is not None:
+            for hd in pending[i]:
+                hd.wait()                    # nccl: torch's current stream waits for the collective; gloo: the host does
+            pending[i] = None
+            if ext is not None:
+                ext.wait_stream(torch.cuda.current_stream())
 
     def step():
         mpc.reset_async()      # cold start: DefaultInitializer guess
         mpc.advance_async()
-        if world > 1:          # exchange step: all-gather of the solved trajectories
-            loc_x, loc_u = loc[turn[0] & 1]
+        if exchange:           # exchange step: all-gather of the solved trajectories
+            i = turn[0] & 1
             turn[0] += 1
+            retire(i)
+            loc_x, loc_u = loc[i]
             mpc.copy_solution_device(loc_x.data_ptr(), loc_u.data_ptr())
-            mpc.sync()
-            gx, gu, _ = all_gather_solutions(loc_x, loc_u, counts=counts)
+            if ext is not None:
+                torch.cuda.current_stream().wait_stream(ext)
+            else:
+                mpc.sync()
+            gx, gu, _, hs = all_gather_solutions(loc_x, loc_u, counts=counts, async_op=True)
+            pending[i] = hs
             gathered[0] = (gx, gu)
 
     def fence():
+        retire(0); retire(1)
         mpc.sync()
         if sync_device is not None:
             sync_device()
@@ -313,25 +387,37 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
     # IPM iterations of the LAST QP launch of the step, per instance (the launches of a step run similar counts)
     qp_flops = qp_flops_per_iter(P) * float(np.sum(st["qp_iters_last"]))
     qp_tflops = qp_flops / (kt["qp_ms"] * 1e-3) / 1e12 if kt["qp_ms"] > 0 else 0.0
-    traffic, traffic_src = pmc_traffic() if (headline and B == 1024) else ({}, None)
-    issued, issued_src = pmc_issued_flops() if (headline and B == 1024) else (None, None)
+    kname = kt.get("qp_kernel", "upr_qp3_kernel")
+    # counters: the headline workload's own pass; for the other workloads the all-workloads pass, looked up by kernel name
+    # (template arguments as rocprofv3 prints them)
+    kkey = None if headline else kname.split("upr_qp3_kernel<")[-1].rstrip(">").strip() if "upr_qp3_kernel<" in kname else kname
+    traffic, traffic_src = pmc_traffic(kkey) if (not headline or B == 1024) else ({}, None)
+    issued, issued_src = pmc_issued_flops(kkey) if (not headline or B == 1024) else (None, None)
+    frac = qp_tflops / PEAK_FP64_TFLOPS
+    frac_hbm = (traffic["qp"] / (kt["qp_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic.get("qp") and kt["qp_ms"] > 0) else None
     roof = {
-        "kernel": kt.get("qp_kernel", "upr_qp3_kernel"),
-        # fp64 FMA / matrix-core bound; `achieved` prices the SURVEY.md 8(d) classical dense Riccati count x the IPM
-        # iterations of the launch against its HIP-event duration -- an algorithmic-model rate, not executed flops
-        "bound": "mfma",
+        "kernel": kname,
+        # `achieved` prices the SURVEY.md 8(d) classical dense Riccati count x the IPM iterations of the launch against its
+        # HIP-event duration: an algorithmic-model rate (the contract's definition), not executed flops -- those are
+        # `achieved_issued`.  `bound` names the roofline the kernel sits closer to (fp64 "mfma" = vector = matrix peak, or
+        # "hbm" by the counter traffic); it reaches neither: `bound_detail`.
+        "bound": "hbm" if (frac_hbm is not None and frac_hbm > frac) else "mfma",
+        "bound_detail": "latency / issue bound: dependent fp64 chains of the Riccati recursion (one or two waves per instance carry "
+                        "the serial sweeps), far from both the fp64 and the HBM roofline",
         "achieved": qp_tflops,
         "peak": PEAK_FP64_TFLOPS,
         "unit": "TFLOP/s",
-        "frac": qp_tflops / PEAK_FP64_TFLOPS,
+        "frac": frac,
         "traffic": traffic.get("qp"),
         "traffic_source": traffic_src,
+        "frac_hbm": frac_hbm,
         "avg_launch_ms": kt["qp_ms"],
         "algorithmic_flops_per_launch": qp_flops,
     }
     if issued is not None and kt["qp_ms"] > 0:
-        # flops the kernel actually issued (committed instruction-mix counters of the same workload): the block
-        # structure removes about half of the classical count
+        # flops the kernel actually issued (committed instruction-mix counters of the same kernel; for workloads whose
+        # launches differ in IPM iterations, e.g. configs[2] cold / warm, the mean over the dispatches of the counter pass):
+        # the block structure removes about half of the classical count
         roof["issued_flops_per_launch"] = issued
         roof["achieved_issued"] = issued / (kt["qp_ms"] * 1e-3) / 1e12
         roof["frac_issued"] = roof["achieved_issued"] / PEAK_FP64_TFLOPS
@@ -343,7 +429,7 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
         "peak": PEAK_HBM_GBS,
         "unit": "GB/s",
         "frac": lin_gbs / PEAK_HBM_GBS,
-        "traffic": traffic.get("linearize"),
+        "traffic": traffic.get("linearize") if headline else None,
         "algorithmic_bytes": lin_bytes,
         "avg_launch_ms": kt["linearize_ms"],
         "bytes_per_knot": bytes_per_knot(P),
@@ -351,26 +437,35 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
     return roof, lin
 
 
-def time_extra(w, steps, warmup, warm=None):
+def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=None):
     """One more BASELINE configuration on this GPU: solves/s + its own roofline objects.  warm = (n_settle, n_timed):
     after the cold-start steps, n_settle further SQP iterations from the plan found so far (no reset) and n_timed timed
     ones -- the closed-loop regime, in which the sub-problems are feasible and converge."""
-    args = argparse.Namespace(gpus=1, steps=steps, warmup=warmup)
-    mpc = make_engine(w)
+    world = dist.get_world_size() if dist is not None else 1
+    args = argparse.Namespace(gpus=world, steps=steps, warmup=warmup)
+    mpc = engine if engine is not None else make_engine(w)
     import torch
 
     # (the engine's own stream sync closes the timed region; torch's is added when torch owns a context in this process)
-    elapsed, _ = rank_main(args, mpc, w["P"], sync_device=torch.cuda.synchronize if torch.cuda.is_initialized() else None)
+    elapsed, gathered = rank_main(args, mpc, w["P"], dist=dist, device=device,
+                                  sync_device=torch.cuda.synchronize if (device != "cpu" and torch.cuda.is_initialized()) else None)
     kt, st = mpc.kernel_times(), mpc.stats()
     B = mpc.B
+    if world > 1:
+        assert gathered is not None and gathered[0].shape[0] == world * B
     roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False)
     out = {
-        "workload": w["name"], "value": B * steps / elapsed, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / steps,
+        "workload": w["name"], "value": B * world * steps / elapsed, "unit": "solves/s", "n_gpus": world,
+        "exchange": "all-gather of solved trajectories" if world > 1 else None, "ms_per_step": 1e3 * elapsed / steps,
         "ms_per_sqp_iter": 1e3 * elapsed / steps / max(1, kt["launches"][1] // steps), "steps": steps, "warmup": warmup,
         "qp_converged_fraction": float(np.mean(st["qp_status_last"] == 0)), "qp_iters_mean": float(np.mean(st["qp_iters_last"])),
         "roofline": roof, "roofline_linearize": lin,
         "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
     }
+    if gathered is not None:
+        out["gathered"] = gathered            # (for the tests; dropped before the line is printed)
+    if st["qp_iters_last"].size and float(np.mean(st["qp_status_last"] == 0)) == 0.0 and float(np.mean(st["qp_iters_last"])) >= w["P"].qp_iter_max:
+        out["note"] = "QPs AT THE ITERATION CAP: this figure times capped interior-point iterations of sub-problems that do not converge (not a solve rate)"
     if warm is not None:
         n_settle, n_timed = warm
         mpc.enable_timing(False)
@@ -473,6 +568,30 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def contract_entry(w, steps, warmup):
+    """extra_workloads entry for the SURVEY 8(d) start distribution: converged fraction, status counts, the rate of the
+    whole batch and the rate of the converged subset (instances / time of the batch: a batch is as slow as its slowest
+    instances, and the infeasible ones run to the iteration cap)."""
+    out = time_extra(w, steps, warmup)
+    out.pop("gathered", None)
+    mpc = make_engine(w)
+    mpc.advance()
+    st = mpc.stats()
+    mpc.close()
+    status = st["qp_status_last"].astype(int)
+    conv = int(np.sum(status == 0))
+    out["qp_status_counts"] = {"converged": conv, "iteration_cap": int(np.sum(status == 1)), "factorisation_broke_down": int(np.sum(status == 2))}
+    out["value_converged_subset"] = out["value"] * conv / len(status)
+    out["note"] = ("rate of the whole batch, infeasible instances included (they run to the iteration cap and are reported per instance); "
+                   "value_converged_subset = converged instances / the same time; the headline's level-tray distribution is upright_amd/sampling.py")
+    return out
+
+
+def _strip(e):
+    e.pop("gathered", None); e.pop("u0_gathered", None)
+    return e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -484,6 +603,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3], configs[4])")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--closed-loop-ticks", type=int, default=150, help="control periods of the configs[4] closed-loop run")
+    ap.add_argument("--dry-run", action="store_true", help="control flow only: gloo on the CPU, stand-in engines with fake solutions; prints a line marked dry_run (never a measurement)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -496,30 +616,59 @@ def main():
 
     import torch
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_run
+    device = "cpu" if dry else "cuda"
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
 
     import __graft_entry__ as g
 
-    if not g.LIB.exists():
+    if not dry and not g.LIB.exists():
         g.build()
+
+    def engine_for(w):
+        if not dry:
+            return make_engine(w)
+        from upright_amd.distributed import StandInEngine
+
+        Pw = w["P"]
+        return StandInEngine(len(w["x0"]), rank * len(w["x0"]), Pw.N, Pw.nx, Pw.nu, nxf=w["x0"].shape[1])
 
     w = headline_workload(args.batch, rank, world)
     P, B = w["P"], args.batch
-    mpc = make_engine(w)
-    elapsed, gathered = rank_main(args, mpc, P, dist=dist, sync_device=torch.cuda.synchronize)
+    mpc = engine_for(w)
+    elapsed, gathered = rank_main(args, mpc, P, dist=dist, device=device, sync_device=None if dry else torch.cuda.synchronize)
     if gathered is not None:
         assert gathered[0].shape[0] == world * B and bool(torch.isfinite(gathered[0]).all())
     kt = mpc.kernel_times()
     st = mpc.stats()
     mpc.enable_timing(False)
+    mpc.close()
+
+    # the other BASELINE configurations: every rank takes part in the sharded ones (configs[3], configs[4]); rank 0 alone
+    # prints.  configs[2] and the SURVEY start distribution are single-GPU workloads (N = 1 only).
+    extra = []
+    if not args.no_extra:
+        if world == 1 and not dry:
+            extra.append(time_extra(config3_workload(4096), args.extra_steps, 1, warm=(9, 3)))
+        w4 = config4_workload(args.batch if dry else 1024, rank, world)
+        extra.append(time_extra(w4, args.extra_steps, 1, dist=dist, device=device, engine=engine_for(w4)))
+        w5 = config5_workload(args.batch if dry else 1024, rank, world)
+        extra.append(time_closed_loop(w5, args.closed_loop_ticks, dist=dist, device=device, engine=engine_for(w5)))
+        if world == 1 and not dry:
+            extra.append(contract_entry(contract_workload(1024), args.extra_steps, 1))
+        extra = [_strip(e) for e in extra]
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -549,12 +698,13 @@ def main():
             "roofline_linearize": lin,
             "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
         }
-        if world == 1 and not args.no_extra:
-            mpc.close()
-            out["extra_workloads"] = [time_extra(config3_workload(4096), args.extra_steps, 1, warm=(9, 3)),
-                                      time_extra(config4_workload(1024), args.extra_steps, 1),
-                                      time_closed_loop(config5_workload(1024), args.closed_loop_ticks)]
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            out["dry_run"] = True
+            out["value"] = 0.0; out["ms_per_step"] = 0.0; out["ms_per_sqp_iter"] = 0.0
+            out["data"] = "none: --dry-run exercises the control flow with stand-in engines; no number of this line is a measurement"
+        if extra:
+            out["extra_workloads"] = extra
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
         print(json.dumps(out))
     if world > 1:

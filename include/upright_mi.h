@@ -264,6 +264,9 @@ const char* upr_batch_qp_kernel_name(const upr_batch* h);
  * all-gather of solved trajectories): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the
  * engine's stream, follow with upr_batch_sync. */
 int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst);
+/* the engine's HIP stream (a hipStream_t): for callers that order their own streams against it with events instead of
+ * upr_batch_sync -- the RCCL exchange step of bench.py makes the collective's stream wait for the copy-out, no host sync */
+void* upr_batch_stream(upr_batch* h);
 
 /* debug / test accessors: per-phase cycle counters of the production QP kernel (first call arms it,
  * later calls read and clear prof[B][4][16]: 16 phases as seen by lane 0 of each of the first four waves); per-knot linearisation records lin[B][N+1][*stride] */

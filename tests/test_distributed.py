@@ -1,5 +1,7 @@
 """N > 1 path on CPU: two processes over gloo shard a batch and all-gather 'solved trajectories'
-(stand-in arrays: the solve itself needs a GPU), including a ragged split."""
+(stand-in arrays: the solve itself needs a GPU), including a ragged split; bench.py's rank functions for the headline
+workload, for configs[3] (sharded upright_robust scenarios, all-gather of trajectories) and for configs[4] (sharded goal
+sweep in closed loop, all-gather of u_0 per tick) with stand-in engines; and bench.py --gpus 2 --dry-run end to end."""
 import os
 import socket
 
@@ -57,26 +59,7 @@ def test_all_gather_ragged_split():
     _run(7)
 
 
-class _StandInEngine:
-    """The methods bench.rank_main calls on the engine, with deterministic 'solutions' (the solve needs a GPU)."""
-
-    def __init__(self, B, lo, n1, nx, N, nu):
-        self.B = B
-        ids = np.arange(lo, lo + B, dtype=np.float64)
-        self.xs = np.ascontiguousarray(ids[:, None, None] + np.zeros((B, n1, nx)))
-        self.us = np.ascontiguousarray(-ids[:, None, None] + np.zeros((B, N, nu)))
-        self.calls = []
-
-    def reset_async(self): self.calls.append("reset")
-    def advance_async(self): self.calls.append("advance")
-    def sync(self): pass
-    def enable_timing(self, on): pass
-
-    def copy_solution_device(self, xp, up):
-        import ctypes
-
-        ctypes.memmove(xp, self.xs.ctypes.data, self.xs.nbytes)
-        ctypes.memmove(up, self.us.ctypes.data, self.us.nbytes)
+from upright_amd.distributed import StandInEngine
 
 
 def _bench_worker(rank, world, port, q):
@@ -90,7 +73,7 @@ def _bench_worker(rank, world, port, q):
 
     B, n1, nx, N, nu = 5, 21, 27, 20, 21
     P = types.SimpleNamespace(N=N, nx=nx, nu=nu)
-    eng = _StandInEngine(B, rank * B, n1, nx, N, nu)
+    eng = StandInEngine(B, rank * B, N, nx, nu)
     args = argparse.Namespace(gpus=world, steps=3, warmup=1)
     elapsed, (gx, gu) = bench.rank_main(args, eng, P, dist=dist, device="cpu")
     ok = elapsed > 0 and gx.shape == (world * B, n1, nx) and gu.shape == (world * B, N, nu)
@@ -131,3 +114,74 @@ def test_bench_self_launch_refuses_mismatched_world(monkeypatch):
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(Path(__file__).resolve().parents[1] / "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def _extra_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    B = 4
+    ok = True
+    # configs[3]: rank r owns scenarios [r B, (r + 1) B) of the global sample; per-instance parameters travel with the shard
+    w4 = bench.config4_workload(B, rank, world)
+    wg = bench.config4_workload(B * world, 0, 1)
+    ok = ok and np.array_equal(w4["body_params"], wg["body_params"][rank * B:(rank + 1) * B]) and np.array_equal(w4["x0"], wg["x0"][rank * B:(rank + 1) * B])
+    P = w4["P"]
+    eng = StandInEngine(B, rank * B, P.N, P.nx, P.nu)
+    out = bench.time_extra(w4, 2, 1, dist=dist, device="cpu", engine=eng)
+    gx, gu = out["gathered"]
+    ok = ok and out["n_gpus"] == world and gx.shape == (world * B, P.N + 1, P.nx) and gu.shape == (world * B, P.N, P.nu)
+    ok = ok and bool(torch.all(gx[:, 0, 0] == torch.arange(world * B, dtype=torch.float64)))   # rank order = instance order
+    ok = ok and eng.calls == ["reset", "advance"] * 3 and out["exchange"] == "all-gather of solved trajectories"
+    # configs[4]: the goal sweep is sharded (rank r owns goals [r B, (r + 1) B) of one circle); per tick only u_0 is gathered
+    w5 = bench.config5_workload(B, rank, world)
+    w5g = bench.config5_workload(B * world, 0, 1)
+    ok = ok and np.allclose(w5["way"], w5g["way"][rank * B:(rank + 1) * B]) and np.allclose(w5["x0"], w5g["x0"][rank * B:(rank + 1) * B])
+    P5 = w5["P"]
+    eng5 = StandInEngine(B, rank * B, P5.N, P5.nx, P5.nu, nxf=w5["x0"].shape[1])
+    ticks = 3
+    out5 = bench.time_closed_loop(w5, ticks, dist=dist, device="cpu", engine=eng5)
+    u0 = out5["u0_gathered"]
+    t_last = 0.01 * ticks                       # (one untimed tick at t = 0, then `ticks` timed ones)
+    ok = ok and u0.shape == (world * B, P5.nu) and out5["n_gpus"] == world and out5["exchange"] == "all-gather of u_0 per tick"
+    ok = ok and bool(torch.allclose(u0[:, 0], -(torch.arange(world * B, dtype=torch.float64) + t_last)))
+    ok = ok and eng5.calls.count("advance") == ticks + 1 and eng5.calls.count("obs") == ticks + 1 and out5["finite"]
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bench_extra_workloads_two_ranks():
+    """configs[3] and configs[4] under two gloo ranks: shards are slices of the one global sample, trajectories (u_0 in the
+    closed loop) come back in instance order on every rank, every rank solves once per step / tick."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_extra_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_dry_run_two_ranks():
+    """`python bench.py --gpus 2 --dry-run`: bench.py launches its two ranks itself, runs the headline loop and both sharded
+    extra workloads over gloo with stand-in engines and exits 0 with one line that says it is not a measurement."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parents[1] / "bench.py"), "--gpus", "2", "--dry-run", "--no-cpu-baseline",
+                        "--batch", "5", "--steps", "2", "--warmup", "1", "--closed-loop-ticks", "2", "--extra-steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["value"] == 0.0
+    names = [e["workload"][:10] for e in out["extra_workloads"]]
+    assert names == ["configs[3]", "configs[4]"] and all(e["n_gpus"] == 2 for e in out["extra_workloads"])

@@ -143,6 +143,7 @@ PROTOTYPES = [
     ("upr_batch_qp_kernel_name", C.c_char_p, [C.c_void_p]),
     ("upr_batch_copy_solution_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("upr_batch_reset_async", C.c_int, [C.c_void_p]),
+    ("upr_batch_stream", C.c_void_p, [C.c_void_p]),
     ("upr_batch_qp_profile", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_get_lin", C.c_int, [C.c_void_p, dp, ip]),
 ]

@@ -1091,6 +1091,8 @@ int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst) {
     return 0;
 }
 
+void* upr_batch_stream(upr_batch* h) { return h ? (void*)h->stream : nullptr; }
+
 /* forget the previous solution without a host synchronisation (cold start for the next advance) */
 int upr_batch_reset_async(upr_batch* h) {
     if (!h) return fail("null batch");

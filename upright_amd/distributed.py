@@ -16,10 +16,12 @@ def shard_range(total, rank, world):
     return lo, hi
 
 
-def all_gather_solutions(xs_local, us_local, counts=None, group=None):
+def all_gather_solutions(xs_local, us_local, counts=None, group=None, async_op=False):
     """All-gather per-rank solution blocks [B_r, ...] into [sum B_r, ...] on every rank.
     Tensors may be torch CPU (gloo) or CUDA (nccl) tensors; ragged B_r is handled by padding to the
-    largest shard (all_gather needs equal sizes) and trimming afterwards."""
+    largest shard (all_gather needs equal sizes) and trimming afterwards.
+    async_op (equal shards only): the collectives are only enqueued; returns (xs, us, counts, handles) -- the outputs
+    are valid, and the INPUT buffers free to be overwritten, once every handle's wait() has returned."""
     import torch
     import torch.distributed as dist
 
@@ -32,12 +34,19 @@ def all_gather_solutions(xs_local, us_local, counts=None, group=None):
     bmax = max(counts)
     if min(counts) == bmax:
         # equal shards (the benchmark's weak-scaling case): one collective per array, no padding, no copies
+        handles = []
+
         def gather_even(t):
             out = torch.empty((world * bmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+            h = dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=async_op)
+            if async_op:
+                handles.append(h)
             return out
 
-        return gather_even(xs_local), gather_even(us_local), counts
+        gx, gu = gather_even(xs_local), gather_even(us_local)
+        return (gx, gu, counts, handles) if async_op else (gx, gu, counts)
+    if async_op:
+        raise ValueError("async_op needs equal shards")
 
     def gather(t):
         pad = torch.zeros((bmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -48,3 +57,58 @@ def all_gather_solutions(xs_local, us_local, counts=None, group=None):
         return torch.cat(parts, dim=0)
 
     return gather(xs_local), gather(us_local), counts
+
+
+def all_gather_first_inputs(u0_local, group=None):
+    """Closed loop (BASELINE configs[4]): per control tick only the first input u_0 of every instance
+    is exchanged, [B, nu] per rank -> [world B, nu] on every rank (equal shards).  u0_local: torch tensor (CPU for gloo,
+    CUDA for nccl)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = torch.empty((world * u0_local.shape[0],) + tuple(u0_local.shape[1:]), dtype=u0_local.dtype, device=u0_local.device)
+    dist.all_gather_into_tensor(out, u0_local.contiguous(), group=group)
+    return out
+
+
+class StandInEngine:
+    """The methods bench.py's rank functions call on the engine, with deterministic 'solutions' (instance b's trajectory is
+    filled with +-b) -- the solve itself needs a GPU.  Used by the gloo world-size-2 tests and by `bench.py --dry-run`;
+    never by a measurement."""
+
+    def __init__(self, B, lo, N, nx, nu, nxf=None):
+        self.B, self.N, self.nx, self.nu, self.lo = B, N, nx, nu, lo
+        self.nxf = nxf or nx
+        ids = np.arange(lo, lo + B, dtype=np.float64)
+        self.xs = np.ascontiguousarray(ids[:, None, None] + np.zeros((B, N + 1, nx)))
+        self.us = np.ascontiguousarray(-ids[:, None, None] + np.zeros((B, N, nu)))
+        self.calls = []
+        self.t = 0.0
+
+    def reset_async(self): self.calls.append("reset")
+    def advance_async(self): self.calls.append("advance")
+    def advance(self): self.calls.append("advance")
+    def sync(self): pass
+    def enable_timing(self, on=True): pass
+    def close(self): pass
+    def set_projectile_flag(self, s): self.calls.append("flag")
+    def set_observation(self, t, x): self.calls.append("obs"); self.t = float(np.max(t))
+
+    def evaluate(self, t, x_obs=None):
+        """'policy': u_0[b] = -(global id of b) - t in every component."""
+        ids = np.arange(self.lo, self.lo + self.B, dtype=np.float64)
+        u = -(ids[:, None] + float(np.max(t))) + np.zeros((self.B, self.nu))
+        return np.zeros((self.B, self.nxf)), u
+
+    def stats(self):
+        return dict(qp_status_last=np.zeros(self.B), qp_iters_last=np.full(self.B, 10.0), constraint_violation=np.zeros(self.B))
+
+    def kernel_times(self):
+        return dict(linearize_ms=0.0, qp_ms=0.0, linesearch_ms=0.0, launches=[0, 0, 0], qp_kernel="stand-in")
+
+    def copy_solution_device(self, xp, up):
+        import ctypes
+
+        ctypes.memmove(xp, self.xs.ctypes.data, self.xs.nbytes)
+        ctypes.memmove(up, self.us.ctypes.data, self.us.nbytes)

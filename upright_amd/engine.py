@@ -176,6 +176,10 @@ class BatchMPC:
     def copy_solution_device(self, xs_ptr, us_ptr):
         check(self._lib.upr_batch_copy_solution_device(self._h, C.c_void_p(xs_ptr), C.c_void_p(us_ptr)))
 
+    def stream_ptr(self):
+        """The engine's HIP stream (hipStream_t) as an integer, e.g. for torch.cuda.ExternalStream."""
+        return int(self._lib.upr_batch_stream(self._h) or 0)
+
     def reset_async(self):
         check(self._lib.upr_batch_reset_async(self._h))
 

@@ -31,6 +31,16 @@ def level_tray_states(B, seed=0, dq=0.25, dv=0.2):
     return x
 
 
+def contract_states(B, seed=0, dq=0.25, dv=0.2):
+    """SURVEY.md section 8(d) as written: x_home + U(-dq, dq) on ALL nine joints, U(-dv, dv) on the velocities, zero
+    accelerations.  69 % of these starts have no feasible contact force at the fixed first knot (see above)."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros((B, 27))
+    x[:, :9] = THING_HOME + rng.uniform(-dq, dq, (B, 9))
+    x[:, 9:18] = rng.uniform(-dv, dv, (B, 9))
+    return x
+
+
 def stationary_guess(x0, N, nu):
     """ocs2 DefaultInitializer (controller_interface.cpp:385-386): hold the state, zero input."""
     x0 = np.atleast_2d(x0)
