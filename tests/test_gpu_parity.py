@@ -1591,3 +1591,74 @@ def test_force_jacobian_against_reference_grasp_matrix(arrangements, name, nf):
         assert np.abs(gu[:, 9:] - D_ref).max() < 1e-13 * max(1.0, np.abs(D_ref).max())
         assert np.abs(gu[:, :9]).max() == 0.0
     mpc.close()
+
+
+@pytest.mark.parametrize("shape", ["robust_8corner", "pink_bottle", "box_arch"])
+def test_fused_and_gathered_feedback_gains_agree(arrangements, shape, monkeypatch):
+    """The production QP kernel writes the gains of the linear policy at its exit (fused); UPR_FB_FUSED=0 makes the separate
+    gather kernel form them from the factors the QP kernel left in its workspace.  Both must give the same policy -- for the
+    star arrangement the inverse Schur factor is stored as one 6 x 6 block per body (upr_fb_src::lsi_sb), for stacked bodies
+    as one dense factor per knot."""
+    import copy
+
+    B = 3
+    if shape == "robust_8corner":
+        P, bp, x0, way = _robust_problem(arrangements, B)
+    else:
+        P = thing_problem(arrangements[shape], use_feedback_policy=True)
+        bp = None
+        x0 = level_tray_states(B, seed=9)
+        way = waypoints_for(P, x0)
+    P = copy.copy(P); P.use_feedback_policy = True
+    gains = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UPR_FB_FUSED", fused)
+        mpc = BatchMPC(P, B, body_params=bp, way_p=way)
+        mpc.set_observation(0.0, x0)
+        mpc.advance()
+        assert np.all(mpc.stats()["qp_status_last"] != 2)
+        gains[fused] = mpc.feedback_gains()
+        mpc.close()
+    scale = np.abs(gains["1"]).max()
+    assert scale > 1e-3 and np.all(np.isfinite(gains["0"]))
+    assert np.abs(gains["1"] - gains["0"]).max() < 1e-9 * max(1.0, scale)
+
+
+def test_orientation_error_near_a_half_turn(arrangements):
+    """The end-effector orientation error at relative rotations around 180 degrees, where the scalar-part form of the
+    quaternion extraction divides by zero: cost, gradient and Gauss-Newton Hessian of the kernel stay finite and agree with
+    the oracle's branchy quaternion form (ocs2 quaternionDistance); a solve towards such a target does not poison the
+    instance."""
+    from upright_amd.control import quat_multiply_xyzw, rot_to_quat_xyzw
+
+    B = 4
+    P, x0, _ = _setup(arrangements, B, seed=21, sqp_iters=1)
+    P.Wee = np.array([1.0, 1.0, 1.0, 0.3, 0.3, 0.3])
+    p0 = np.stack([P.chain.forward(x[:9])[0] for x in x0])
+    way = (p0 + [0.2, 0.1, 0.0])[:, None, :]
+    q = np.zeros((B, 1, 4))
+    axes = [np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0]), np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)]
+    angles = [np.pi, np.pi - 1e-9, np.pi + 1e-7, 0.9 * np.pi]
+    for b in range(B):
+        qe = rot_to_quat_xyzw(P.chain.forward(x0[b, :9])[1])
+        q[b, 0] = quat_multiply_xyzw(np.concatenate([np.sin(angles[b] / 2) * axes[b], [np.cos(angles[b] / 2)]]), qe)
+    P.way_p, P.way_q = way[0], q[0]
+    mpc = BatchMPC(P, B, way_p=way, way_q=q)
+    rng = np.random.default_rng(5)
+    for b in range(B):
+        P.way_p, P.way_q = way[b], q[b]
+        O = Oracle(P)
+        xr = np.concatenate([x0[b][None], x0[b][None] + rng.uniform(-0.05, 0.05, (3, 27))])
+        out = mpc.linearize_points(xr, np.zeros((len(xr), P.nu)), np.zeros(len(xr)), inst=np.full(len(xr), b))
+        for i in range(len(xr)):
+            c, gx, gu, H, R = O.stage_cost(0.0, xr[i], np.zeros(P.nu))
+            c -= 0.5 * np.sum(P.Qdiag * (xr[i] - P.xd) ** 2)
+            assert np.isfinite(out["cost"][i]) and np.all(np.isfinite(out["grad"][i])) and np.all(np.isfinite(out["hess"][i]))
+            assert abs(out["cost"][i] - c) < 1e-10 * max(1.0, abs(c))
+            assert np.abs(out["grad"][i] - (gx - P.Qdiag * (xr[i] - P.xd))[:9]).max() < 1e-8
+            assert np.abs(out["hess"][i] - (H - np.diag(P.Qdiag))[:9, :9]).max() < 1e-8
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+    mpc.close()

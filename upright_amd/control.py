@@ -318,7 +318,13 @@ class BatchControllerManager:
             offs = np.array([w["position"] for w in way], dtype=np.float64)
             targets = np.stack([chain.forward(x[: self.problem.nq])[0] + offs for x in x0])
         self.problem.way_p = np.asarray(targets[0], dtype=np.float64).reshape(len(way), 3)
-        self.mpc = BatchMPC(self.problem, self.B, body_params=body_params, way_p=np.asarray(targets, dtype=np.float64))
+        # target orientations per instance: Q_EE(x0) (x) Q_offset of every waypoint (wrappers.py:31-43); they enter the cost only
+        # with non-zero orientation weights (weights.end_effector[3:6])
+        chain = self.problem.chain
+        way_q = np.stack([[quat_multiply_xyzw(rot_to_quat_xyzw(chain.forward(x[: self.problem.nq])[1]),
+                                              np.asarray(w.get("orientation", [0, 0, 0, 1]), dtype=np.float64)) for w in way] for x in x0])
+        self.problem.way_q = way_q[0]
+        self.mpc = BatchMPC(self.problem, self.B, body_params=body_params, way_p=np.asarray(targets, dtype=np.float64), way_q=way_q)
         self.schedule = ReplanSchedule(config["tracking"]["min_policy_update_time"])
         self.x_opt = np.zeros((self.B, self.problem.nx_full))
         self.u_opt = np.zeros((self.B, self.problem.nu))

@@ -486,7 +486,8 @@ class ControllerInterface:
             return float(self._lin(t, x, u)["cost"][0])
         if name == "state_input_cost":
             P = self.problem
-            return float(0.5 * np.sum(P.Qdiag * (x - P.xd) ** 2) + 0.5 * np.sum(P.Rdiag * u ** 2))
+            xr = x[: P.nx]   # (the robot's part of the state: dynamic obstacles carry no cost, controller_interface.cpp:400-420)
+            return float(0.5 * np.sum(P.Qdiag * (xr - P.xd) ** 2) + 0.5 * np.sum(P.Rdiag * u ** 2))
         raise RuntimeError(f"no cost named '{name}'")
 
     def stateInputEqualityConstraint(self, t, x, u):

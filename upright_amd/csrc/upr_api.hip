@@ -125,6 +125,7 @@ struct upr_fb_src {
     long lji_base; int lji_stride;  // kinds 1, 2
     long lfi_base; int lfi_stride;  // inverse Cholesky factor of the contact-force blocks of Hff
     long lsi_base; int lsi_stride;  // inverse Cholesky factor of S = Df Hff^-1 Df'
+    int lsi_sb;                     // its block size: ne (one dense factor per knot) or 6 (star arrangements of the production kernel: one 6 x 6 block per body)
 };
 
 // Linear feedback gains of the last QP, ocs2 sign convention (u = bias + K x): fb[B][N][nu][nx].
@@ -163,8 +164,10 @@ __global__ void feedback_kernel(const upr_problem* P, upr_dims d, upr_fb_src src
         const double* Lsi = w + src.lsi_base + (long)k * src.lsi_stride;
         const double* Lfi = w + src.lfi_base + (long)k * src.lfi_stride;
         double t1[NEM], t2[NEM], t3[NFM];
-        for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = 0; m <= r; ++m) v += Lsi[r * ne + m] * Ck[m * nx + c]; t1[r] = v; }
-        for (int r = 0; r < ne; ++r) { double v = 0.0; for (int m = r; m < ne; ++m) v += Lsi[m * ne + r] * t1[m]; t2[r] = v; }
+        // S^-1 C = Lsi' (Lsi C), block by block (a dense factor is one block of ne rows)
+        const int sb = src.lsi_sb;
+        for (int r = 0; r < ne; ++r) { const int b0 = (r / sb) * sb; const double* Lb = Lsi + (b0 / sb) * sb * sb; double v = 0.0; for (int m = b0; m <= r; ++m) v += Lb[(r - b0) * sb + (m - b0)] * Ck[m * nx + c]; t1[r] = v; }
+        for (int r = 0; r < ne; ++r) { const int b0 = (r / sb) * sb; const double* Lb = Lsi + (b0 / sb) * sb * sb; double v = 0.0; for (int m = r; m < b0 + sb; ++m) v += Lb[(m - b0) * sb + (r - b0)] * t1[m]; t2[r] = v; }
         for (int i = 0; i < nfc; ++i) { double v = 0.0; for (int r = 0; r < ne; ++r) v += Dfb[r * nfc + i] * t2[r]; t3[i] = v; }
         for (int ci = 0; ci < d.nc; ++ci) {
             if (nf == 3) {
@@ -513,7 +516,7 @@ upr_fb_src fb_source(const upr_batch* h) {
         auto fill = [&](auto cfg) {
             typedef decltype(cfg) C; typedef upr_qp3_ws<C> W; typedef upr_qp3_far<C> F;
             s.kind = 3; s.k_base = W::far + F::Ks; s.k_stride = C::NQ * C::NX; s.lji_base = 0; s.lji_stride = 0;
-            s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NLS;
+            s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NLS; s.lsi_sb = C::SB;
         };
         // (these offsets lie in front of everything that depends on the workgroup size or on ROWS / SOFT)
         if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
@@ -525,12 +528,12 @@ upr_fb_src fb_source(const upr_batch* h) {
     if (h->use_qp2) {
 #define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) { typedef upr_qp2_dims<a, b, c, e> D; upr_qp2_ws<D> w(d.N, d.neN); \
         s.kind = 2; s.k_base = w.store + D::SS_V; s.k_stride = D::SS_STRIDE; s.lji_base = w.store + D::SS_LJI; s.lji_stride = D::SS_STRIDE; \
-        s.lfi_base = w.pre + D::PR_LFI; s.lfi_stride = D::PR_STRIDE; s.lsi_base = w.pre + D::PR_LSI; s.lsi_stride = D::PR_STRIDE; return s; }
+        s.lfi_base = w.pre + D::PR_LFI; s.lfi_stride = D::PR_STRIDE; s.lsi_base = w.pre + D::PR_LSI; s.lsi_stride = D::PR_STRIDE; s.lsi_sb = d.ne; return s; }
         UPR_QP2_SHAPES(X)
 #undef X
     }
     s.kind = 1; s.k_base = d.ws_store + d.ss_kx; s.k_stride = d.ss_stride; s.lji_base = d.ws_store + d.ss_hjj; s.lji_stride = d.ss_stride;
-    s.lfi_base = d.ws_store + d.ss_hff; s.lfi_stride = d.ss_stride; s.lsi_base = d.ws_store + d.ss_sinv; s.lsi_stride = d.ss_stride;
+    s.lfi_base = d.ws_store + d.ss_hff; s.lfi_stride = d.ss_stride; s.lsi_base = d.ws_store + d.ss_sinv; s.lsi_stride = d.ss_stride; s.lsi_sb = d.ne;
     return s;
 }
 

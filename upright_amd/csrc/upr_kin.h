@@ -45,14 +45,39 @@ static UPR_HDI upr_dd upr_recip_(upr_dd a) { const double r = 1.0 / a.v; return 
 // R_d = R_ref C'.  Written on the rotation matrices, which the tangent lanes carry anyway:
 // e = vee(R_d - R_d') / (2 sqrt(1 + tr R_d)).  (The sign of a quaternion representative flips e, which cost, gradient
 // and Gauss-Newton Hessian do not see.)  C: world <- EE, row-major; Rr: desired, row-major.
+static UPR_HDI double upr_val(double a) { return a; }
+static UPR_HDI double upr_val(upr_dd a) { return a.v; }
+static UPR_HDI double upr_neg(double a) { return -a; }
+static UPR_HDI upr_dd upr_neg(upr_dd a) { return {-a.v, -a.d}; }
+// vector part of the unit quaternion of Rd, largest-diagonal branch (I, J, K a cyclic permutation): finite where the
+// scalar-part branch divides by zero (a relative rotation of 180 degrees); representative with non-negative scalar part
+template <int I, int J, int K, class T> static UPR_HDI void upr_quat_vec_diag(const T* Rd, T* e) {
+    const T s2 = (Rd[4 * I] - Rd[4 * J]) - Rd[4 * K] + upr_lift(1.0, (T*)nullptr);
+    const T s = upr_sqrt_(s2);
+    const T is = 0.5 * upr_recip_(s);
+    T vi = 0.5 * s, vj = (Rd[3 * J + I] + Rd[3 * I + J]) * is, vk = (Rd[3 * K + I] + Rd[3 * I + K]) * is;
+    const T w = (Rd[3 * K + J] - Rd[3 * J + K]) * is;
+    if (upr_val(w) < 0.0) { vi = upr_neg(vi); vj = upr_neg(vj); vk = upr_neg(vk); }
+    e[I] = vi; e[J] = vj; e[K] = vk;
+}
 template <class T> static UPR_HDI void upr_orientation_error(const T* C, const double* Rr, T* e) {
     T Rd[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) Rd[3 * i + j] = Rr[3 * i] * C[3 * j] + Rr[3 * i + 1] * C[3 * j + 1] + Rr[3 * i + 2] * C[3 * j + 2];
     T tr1 = Rd[0] + Rd[4] + Rd[8];
-    tr1 = tr1 + upr_lift(1.0, (T*)nullptr);
-    const T inv = 0.5 * upr_recip_(upr_sqrt_(tr1));
-    e[0] = (Rd[7] - Rd[5]) * inv; e[1] = (Rd[2] - Rd[6]) * inv; e[2] = (Rd[3] - Rd[1]) * inv;
+    if (upr_val(tr1) > 0.0) {
+        tr1 = tr1 + upr_lift(1.0, (T*)nullptr);
+        const T inv = 0.5 * upr_recip_(upr_sqrt_(tr1));
+        e[0] = (Rd[7] - Rd[5]) * inv; e[1] = (Rd[2] - Rd[6]) * inv; e[2] = (Rd[3] - Rd[1]) * inv;
+    } else {
+        // relative rotation beyond 120 degrees (never in a tracking task; a target given upside down gets here): the
+        // quaternion by its largest diagonal entry, as ocs2 / Eigen extract it -- the value branch is uniform over the
+        // tangent lanes of a knot
+        const double d0 = upr_val(Rd[0]), d1 = upr_val(Rd[4]), d2 = upr_val(Rd[8]);
+        if (d0 >= d1 && d0 >= d2) upr_quat_vec_diag<0, 1, 2>(Rd, e);
+        else if (d1 >= d2) upr_quat_vec_diag<1, 2, 0>(Rd, e);
+        else upr_quat_vec_diag<2, 0, 1>(Rd, e);
+    }
 }
 
 template <class T> static UPR_HDI void upr_cross(const T* a, const T* b, T* r) {
