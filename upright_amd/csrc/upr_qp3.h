@@ -49,7 +49,10 @@ struct upr_qp3_cfg {
     static constexpr int NEN = 3 + 2 * NQ;
     // SW: the matrix part of the backward sweep runs on ONE wave with the cost-to-go in registers (one-body shapes: a lane
     // per 3 x 3 block (joint i, joint j), i <= j, of P; a lane per column of Hux): no workgroup barrier inside the sweep
-    static constexpr bool SW = NB_ == 1 && NH <= 64 && 4 * NQ <= 64;
+    static constexpr bool SW = NH <= 64 && 4 * NQ <= 64;
+    // VCPRE: Vc = Lsi C of EVERY knot is left in LDS by prep (one-body shapes: 6 x nx per knot).  Otherwise (multi-body shapes:
+    // 18 .. 48 rows per knot) the two waves that have no part in the sweep form Vc of the next knot into a double buffer
+    static constexpr bool VCPRE = SW && NB_ == 1;
     // lane-owned inequality items
     static constexpr int NXI = N * NX, QX = (NXI + NT - 1) / NT;   // state boxes, knots 1..N
     static constexpr int NUI = N * NU, QU = (NUI + NT - 1) / NT;   // input boxes, knots 0..N-1
@@ -112,7 +115,8 @@ struct upr_qp3_lds {
                          // (dead between prep and the vector sweep), the rest from Pa on -- then the sweep's staging: packed Hjj,
                          // Hux / V by columns [nx][HXS], the partial sums of P+ b [nx][HXS]
                          VCN = C::NE * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
-                         sw0 = Pa + (C::N - 1 - KS) * VCN, sw_hj = sw0, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */, sw_end = sw_w + r2(C::NX),
+                         sw0 = C::VCPRE ? Pa + (C::N - 1 - KS) * VCN : Pa, sw_vcb = sw0 /* (!VCPRE: Vc of the knot in work and of the next one) */,
+                         sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */, sw_end = sw_w + r2(C::NX),
                          yN = (C::SW && sw_end > ck + r2(C::NE * C::NX)) ? sw_end : ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
@@ -201,6 +205,13 @@ struct upr_qp3 {
     typedef upr_qp3_ws<C> W;
     typedef upr_qp3_far<C> F;
     static constexpr int NQ = C::NQ, NX = C::NX, NU = C::NU, NE = C::NE, NFC = C::NFC, NC = C::NC, NF = C::NF, N = C::N, N1 = C::N1, NT = C::NT;
+#ifndef UPR_HOST_EMU
+    // which form of the matrix sweep this instantiation runs: two waves (SW2), one wave (one-body shapes below 128 lanes, or
+    // UPR_QP3_SW2=0), or the four-wave form further down
+    static constexpr bool SW2 = C::SW && NT >= 128 && UPR_QP3_SW2 != 0, SWANY = SW2 || C::VCPRE;
+#else
+    static constexpr bool SW2 = false, SWANY = false;
+#endif
     upr_ctx ctx;
     int wb;   // first lane of this wave (uniform; lives in a scalar register)
     // Lane / work-item index recomputed from the hardware where it is needed: a work-item id kept in a vector
@@ -873,12 +884,12 @@ struct upr_qp3 {
                     for (int m = 0; m <= r; ++m) Lr[r * SB + m] = Ls[r * SB + m];
             }
 #ifndef UPR_HOST_EMU
-            if (C::SW && factor) {
+            if (C::VCPRE && factor) {
                 // single-wave sweep: phase E forms Vc = Lsi C of every knot; it reads the factor out of LDS (packed lower
                 // triangle, in the sweep's staging area).  That area overlaps the S blocks of the last knots, which other
                 // lanes of THIS wave read at the top of their factorisation: all Schur blocks sit on one wave (lockstep),
                 // so every read precedes every write.
-                static_assert(!C::SW || (C::NKB <= 64 && C::NKB * (SB * (SB + 1) / 2) <= O::sw_end - O::sw0), "Lsi staging of phase D");
+                static_assert(!C::VCPRE || (C::NKB <= 64 && C::NKB * (SB * (SB + 1) / 2) <= O::sw_end - O::sw0), "Lsi staging of phase D");
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -919,7 +930,7 @@ struct upr_qp3 {
 #pragma unroll
                 for (int r = 0; r < NE; ++r) v += cr[r] * L[O::zt + k * NE + r];
 #ifndef UPR_HOST_EMU
-                if (C::SW && factor && k >= 1) {
+                if (C::VCPRE && factor && k >= 1) {
                     // column e % NX of Vc_k = Lsi_k C_k for the single-wave matrix sweep (its lanes read whole columns)
                     const double* Ls = L + O::sw0 + k * (NE * (NE + 1) / 2);
                     double* vo = L + vca(k) + (e % NX) * NE;
@@ -988,7 +999,7 @@ struct upr_qp3 {
     UPR_HDI static int vca(int k) { return (k <= O::KS) ? O::S + (k - 1) * O::VCN : O::Pa + (k - 1 - O::KS) * O::VCN; }
     UPR_HDI void backward_mat_sw() {
         constexpr int NBK = C::NH, HXS = O::HXS;
-        static_assert(!C::SW || (O::sw_end <= O::yN && (O::VCN % 2) == 0 && O::KS * O::VCN <= O::r2(C::NZ)), "staging of the single-wave sweep");
+        static_assert(!C::VCPRE || (O::sw_end <= O::yN && (O::VCN % 2) == 0 && O::KS * O::VCN <= O::r2(C::NZ)), "staging of the single-wave sweep");
         if (wave0()) {
             UPR_SETPRIO(3);
             const double irho = 1.0 / UPR_QP_RHO_N;
@@ -1198,12 +1209,14 @@ struct upr_qp3 {
     // barriers per knot hand Hjj / Hux over (A) and V back (B); the remaining waves only take part in the barriers.
     UPR_HDI void backward_mat_sw2() {
         constexpr int NBK = C::NH, HXS = O::HXS;
-        static_assert(!C::SW || NT >= 128, "two waves");
+        static_assert(!SW2 || NT >= (C::VCPRE ? 128 : 256), "two waves (four where Vc is formed inside the sweep)");
         const int wave = wb >> 6;
         const int l = lane();
         constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
         const double irho = 1.0 / UPR_QP_RHO_N;
-        if (FUSE) { terminal_residual(); UPR_SYNC_LDS(); }
+        if (FUSE) terminal_residual();
+        if (!C::VCPRE && wave >= 2) form_vc(N - 1);
+        UPR_SYNC_LDS();
         if (wave == 1) {
             UPR_SETPRIO(3);
             const bool blk = l < NBK;
@@ -1276,13 +1289,18 @@ struct upr_qp3 {
                 // ... and p1 = sym(A'P+A) + Q~ + Vc'Vc
                 double p1[3][3];
                 if (k > 0) {
-                    double wxk[3], qdk[3], o2[3][3], cj[3][NE], ci[3][NE];
-                    const double* Vk = L + vca(k);
+                    // rows of Vc in chunks of RC: the columns (., bj) and (., bi) of the chunk in registers, the next chunk requested
+                    // before this one's products (the multi-body shapes have 18 .. 48 rows: all at once would be 576 registers)
+                    constexpr int RC = 6, NCH = NE / RC;
+                    static_assert(NE % RC == 0, "chunks of six rows");
+                    double wxk[3], qdk[3], o2[3][3], cj[2][3][RC], ci[2][3][RC];
+                    const double* Vk = L + (C::VCPRE ? vca(k) : O::sw_vcb + (k & 1) * O::VCN);
+                    int bic = bi, bjc = bj;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * NE + r]; ci[c][r] = Vk[(c * NQ + bi) * NE + r]; }
+                        for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * NE + r]; ci[0][c][r] = Vk[(c * NQ + bi) * NE + r]; }
                     }
                     {
                         double t[3][3];
@@ -1299,10 +1317,30 @@ struct upr_qp3 {
                             double acc = o2[a3][c];
                             if (a3 == c) acc += dg ? (h * qdk[a3] + wxk[a3]) : 0.0;
                             if (a3 == 0 && c == 0) acc += h * heek;
-#pragma unroll
-                            for (int r = 0; r < NE; ++r) acc += ci[a3][r] * cj[c][r];
                             p1[a3][c] = acc;
                         }
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        if (ch + 1 < NCH) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                                for (int r = 0; r < RC; ++r) {
+                                    cj[(ch + 1) & 1][c][r] = Vk[(c * NQ + bjc) * NE + (ch + 1) * RC + r];
+                                    ci[(ch + 1) & 1][c][r] = Vk[(c * NQ + bic) * NE + (ch + 1) * RC + r];
+                                }
+                        }
+#pragma unroll
+                        for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                double acc = p1[a3][c];
+#pragma unroll
+                                for (int r = 0; r < RC; ++r) acc += ci[ch & 1][a3][r] * cj[ch & 1][c][r];
+                                p1[a3][c] = acc;
+                            }
+                        if (NCH > 2) asm volatile("" : "+v"(p1[2][2]), "+v"(bic), "+v"(bjc));   // (the chunk after next is not requested before this one is consumed)
+                    }
                 }
                 toc(7);
                 UPR_SYNC_LDS();   // B: V is in LDS
@@ -1435,14 +1473,48 @@ struct upr_qp3 {
             UPR_SETPRIO(0);
         } else {
 #pragma nounroll
-            for (int k = N - 1; k >= 0; --k) { UPR_SYNC_LDS(); UPR_SYNC_LDS(); }
+            for (int k = N - 1; k >= 0; --k) {
+                UPR_SYNC_LDS();   // A
+                if (!C::VCPRE && k - 1 >= 1) form_vc(k - 1);   // (read by wave 1 behind the NEXT barrier A)
+                UPR_SYNC_LDS();   // B
+            }
         }
         UPR_SYNC();
+    }
+    // Vc_k = blockdiag(Lsi_k) C_k into the sweep's double buffer, by the waves from the third on (multi-body shapes): jobs of
+    // three rows of one column, operands straight from global memory (the rows of C of the linearisation record, the inverse
+    // Schur factor(s) prep left in the far array)
+    UPR_HDI void form_vc(int k) {
+        constexpr int SBV = C::SB, NJ = (NE / 3) * NX, NL = NT - 128;
+        static_assert(C::VCPRE || (SBV % 3 == 0 && NL >= 64), "three-row jobs; at least one wave to run them");
+        const int t = tid() - 128;
+        const double* Ck = rec(k) + lin_gx;
+        const double* Lk = G + F::lsi + k * C::NLS;
+        double* out = L + O::sw_vcb + (k & 1) * O::VCN;
+        for (int f = t; f < NJ; f += NL) {
+            const int g = f / NX, c = f % NX, r0 = 3 * g, blk = r0 / SBV, bo = SBV * blk, q0 = r0 - bo;
+            const double* Ls = Lk + SBV * SBV * blk;
+            double cm[SBV], l0[SBV], l1[SBV], l2[SBV];
+            // full-length rows with the entries above the diagonal masked: no lane-dependent trip count; every operand requested
+            // before the first product
+#pragma unroll
+            for (int m = 0; m < SBV; ++m) {
+                cm[m] = Ck[(bo + m) * NX + c];
+                l0[m] = Ls[q0 * SBV + m]; l1[m] = Ls[(q0 + 1) * SBV + m]; l2[m] = Ls[(q0 + 2) * SBV + m];
+            }
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < SBV; ++m) {
+                v0 += ((m <= q0) ? l0[m] : 0.0) * cm[m]; v1 += ((m <= q0 + 1) ? l1[m] : 0.0) * cm[m]; v2 += ((m <= q0 + 2) ? l2[m] : 0.0) * cm[m];
+            }
+            out[c * NE + r0] = v0; out[c * NE + r0 + 1] = v1; out[c * NE + r0 + 2] = v2;
+        }
     }
 #endif
     UPR_HDI void backward_mat() {
 #ifndef UPR_HOST_EMU
-        if constexpr (C::SW) { if (UPR_QP3_SW2 && NT >= 128) backward_mat_sw2(); else backward_mat_sw(); return; }
+        if constexpr (SW2) { backward_mat_sw2(); return; }
+        else if constexpr (C::VCPRE) { backward_mat_sw(); return; }
 #endif
         UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
@@ -1929,7 +2001,7 @@ struct upr_qp3 {
         toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
 #ifndef UPR_HOST_EMU
-        if constexpr (C::SW) {
+        if constexpr (SWANY) {
             // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
             UPR_FORT(k, N) {
                 const double* Li = G + F::Ljis + k * NQ * NX;
@@ -2822,7 +2894,7 @@ struct upr_qp3 {
             prep(2);
             backward_mat(); toc(11);
 #ifndef UPR_HOST_EMU
-            backward_vec(C::SW && UPR_QP3_SW2 && UPR_QP3_FUSEVEC && NT >= 128); toc(11);
+            backward_vec(SW2 && UPR_QP3_FUSEVEC); toc(11);
 #else
             backward_vec(); toc(11);
 #endif
