@@ -114,9 +114,11 @@ struct upr_qp3_lds {
                          // single-wave sweep (C::SW): Vc = Lsi C of knots 1 .. N-1, [col][ne] each -- the first KS of them in the step array
                          // (dead between prep and the vector sweep), the rest from Pa on -- then the sweep's staging: packed Hjj,
                          // Hux / V by columns [nx][HXS], the partial sums of P+ b [nx][HXS]
-                         VCN = C::NE * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
+                         VCS = (C::NE * 2 % 64 == 32 || C::NE * 2 % 64 == 0) ? C::NE + 2 : C::NE /* column stride of Vc: 48 rows = 96 dwords would put every column on the same two bank groups */,
+                         VCN = VCS * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
                          sw0 = C::VCPRE ? Pa + (C::N - 1 - KS) * VCN : Pa, sw_vcb = sw0 /* (!VCPRE: Vc of the knot in work and of the next one) */,
-                         sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */, sw_end = sw_w + r2(C::NX),
+                         sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */,
+                         sw_pq = sw_w + r2(C::NX) /* (!VCPRE: the shares of Vc'Vc of waves 2 and 3, [wave][entry][lane]) */, sw_end = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
                          yN = (C::SW && sw_end > ck + r2(C::NE * C::NX)) ? sw_end : ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
@@ -933,7 +935,7 @@ struct upr_qp3 {
                 if (C::VCPRE && factor && k >= 1) {
                     // column e % NX of Vc_k = Lsi_k C_k for the single-wave matrix sweep (its lanes read whole columns)
                     const double* Ls = L + O::sw0 + k * (NE * (NE + 1) / 2);
-                    double* vo = L + vca(k) + (e % NX) * NE;
+                    double* vo = L + vca(k) + (e % NX) * O::VCS;
 #pragma unroll
                     for (int r = 0; r < NE; ++r) {
                         double w = 0.0;
@@ -1090,7 +1092,7 @@ struct upr_qp3 {
                     for (int c = 0; c < 3; ++c) {
                         wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * NE + r]; ci[c][r] = Vk[(c * NQ + bi) * NE + r]; }
+                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * O::VCS + r]; ci[c][r] = Vk[(c * NQ + bi) * O::VCS + r]; }
                     }
                     {
                         double t[3][3];
@@ -1291,8 +1293,7 @@ struct upr_qp3 {
                 if (k > 0) {
                     // rows of Vc in chunks of RC: the columns (., bj) and (., bi) of the chunk in registers, the next chunk requested
                     // before this one's products (the multi-body shapes have 18 .. 48 rows: all at once would be 576 registers)
-                    constexpr int RC = 6, NCH = NE / RC;
-                    static_assert(NE % RC == 0, "chunks of six rows");
+                    constexpr int RC = VC_RC, NCH = VC_N1;   // (multi-body shapes: waves 2 and 3 take the other chunks, vc_share)
                     double wxk[3], qdk[3], o2[3][3], cj[2][3][RC], ci[2][3][RC];
                     const double* Vk = L + (C::VCPRE ? vca(k) : O::sw_vcb + (k & 1) * O::VCN);
                     int bic = bi, bjc = bj;
@@ -1300,7 +1301,7 @@ struct upr_qp3 {
                     for (int c = 0; c < 3; ++c) {
                         wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
 #pragma unroll
-                        for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * NE + r]; ci[0][c][r] = Vk[(c * NQ + bi) * NE + r]; }
+                        for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * O::VCS + r]; ci[0][c][r] = Vk[(c * NQ + bi) * O::VCS + r]; }
                     }
                     {
                         double t[3][3];
@@ -1326,8 +1327,8 @@ struct upr_qp3 {
                             for (int c = 0; c < 3; ++c)
 #pragma unroll
                                 for (int r = 0; r < RC; ++r) {
-                                    cj[(ch + 1) & 1][c][r] = Vk[(c * NQ + bjc) * NE + (ch + 1) * RC + r];
-                                    ci[(ch + 1) & 1][c][r] = Vk[(c * NQ + bic) * NE + (ch + 1) * RC + r];
+                                    cj[(ch + 1) & 1][c][r] = Vk[(c * NQ + bjc) * O::VCS + (ch + 1) * RC + r];
+                                    ci[(ch + 1) & 1][c][r] = Vk[(c * NQ + bic) * O::VCS + (ch + 1) * RC + r];
                                 }
                         }
 #pragma unroll
@@ -1358,6 +1359,7 @@ struct upr_qp3 {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             double acc = p1[a3][c];
+                            if (!C::VCPRE) acc += L[O::sw_pq + (3 * a3 + c) * 64 + l] + L[O::sw_pq + (9 + 3 * a3 + c) * 64 + l];
 #pragma unroll
                             for (int m = 0; m < NQ; ++m) acc -= vi[a3][m] * vj[c][m];
                             p[a3][c] = acc;
@@ -1472,43 +1474,189 @@ struct upr_qp3 {
             if (!ok && l == 0) L[O::misc] = 1.0;
             UPR_SETPRIO(0);
         } else {
+            vc_regs vq;
+            vcm_regs vm;
+            int bi = 0, bj = 0;
+            {
+                const int lc = (l < C::NH) ? l : C::NH - 1;
+                int b0 = 0;
+#pragma unroll
+                for (int i = 1; i < NQ; ++i) { const int st = i * NQ - i * (i - 1) / 2; if (lc >= st) { bi = i; b0 = st; } }
+                bj = bi + (lc - b0);
+            }
+            if (!C::VCPRE && N - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(N - 2, vm); } else form_vc_load(N - 2, vq); }
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 UPR_SYNC_LDS();   // A
-                if (!C::VCPRE && k - 1 >= 1) form_vc(k - 1);   // (read by wave 1 behind the NEXT barrier A)
+                toc(6);
+                // Vc of knot k - 1 goes into the buffer whose last readers (knot k + 1) finished before barrier B of that knot; its
+                // operands were requested behind that barrier.  Stacked bodies: wave 2 forms it on the matrix cores now, in the
+                // long interval; star arrangements: behind barrier B, the shares of Vc_k'Vc_k first
+                if (C::COUPLED && wave == 2 && k - 1 >= 1) form_vcm_store(k - 1, vm);
+                if (!C::VCPRE && k >= 1) { if (wave == 2) vc_share<0>(k, bi, bj); else vc_share<1>(k, bi, bj); }   // (added by wave 1 behind barrier B)
+                toc(7);
                 UPR_SYNC_LDS();   // B
+                toc(8);
+                if (!C::VCPRE && !C::COUPLED && k - 1 >= 1) form_vc_store(k - 1, vq);                                   // (read behind the NEXT barrier A)
+                if (!C::VCPRE && k - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(k - 2, vm); } else form_vc_load(k - 2, vq); }
+                toc(9);
             }
         }
         UPR_SYNC();
     }
+    // rows of Vc in chunks of VC_RC; wave 1 takes the first VC_N1 chunks of the products Vc'Vc, waves 2 and 3 the rest
+    static constexpr int VC_RC = 6, VC_NCH = NE / VC_RC;
+    // (star arrangements, 8 chunks: 4 | 2 | 2 -- waves 2 and 3 also form Vc of the next knot; stacked bodies, 3 chunks: 1 | 0 | 2 --
+    // wave 2 forms Vc on the matrix cores and takes no share)
+    static constexpr int VC_N1 = C::VCPRE ? VC_NCH : (C::COUPLED ? 1 : VC_NCH / 2), VC_N2 = (C::VCPRE || C::COUPLED) ? 0 : (VC_NCH - VC_N1) / 2;
+    static_assert(NE % VC_RC == 0 && VC_N1 >= 1 && VC_N1 + VC_N2 <= VC_NCH, "chunks of six rows, split over three waves");
+    // share WHICH (0: wave 2, 1: wave 3) of block (bi, bj)'s part of Vc_k'Vc_k, lane = block as on wave 1 -> sw_pq
+    template <int WHICH>
+    UPR_HDI void vc_share(int k, int bi, int bj) {
+        constexpr int RC = VC_RC, c0 = (WHICH == 0) ? VC_N1 : VC_N1 + VC_N2, c1 = (WHICH == 0) ? VC_N1 + VC_N2 : VC_NCH, NCHS = c1 - c0;
+        const int l = lane();
+        const double* Vk = L + O::sw_vcb + (k & 1) * O::VCN;
+        double acc[3][3], cj[2][3][RC], ci[2][3][RC];
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[a3][c] = 0.0;
+        if (NCHS > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * O::VCS + c0 * RC + r]; ci[0][c][r] = Vk[(c * NQ + bi) * O::VCS + c0 * RC + r]; }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCHS; ++ch) {
+            if (ch + 1 < NCHS) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < RC; ++r) {
+                        cj[(ch + 1) & 1][c][r] = Vk[(c * NQ + bj) * O::VCS + (c0 + ch + 1) * RC + r];
+                        ci[(ch + 1) & 1][c][r] = Vk[(c * NQ + bi) * O::VCS + (c0 + ch + 1) * RC + r];
+                    }
+            }
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < RC; ++r) acc[a3][c] += ci[ch & 1][a3][r] * cj[ch & 1][c][r];
+        }
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L[O::sw_pq + (9 * WHICH + 3 * a3 + c) * 64 + l] = acc[a3][c];
+    }
     // Vc_k = blockdiag(Lsi_k) C_k into the sweep's double buffer, by the waves from the third on (multi-body shapes): jobs of
     // three rows of one column, operands straight from global memory (the rows of C of the linearisation record, the inverse
     // Schur factor(s) prep left in the far array)
-    UPR_HDI void form_vc(int k) {
-        constexpr int SBV = C::SB, NJ = (NE / 3) * NX, NL = NT - 128;
-        static_assert(C::VCPRE || (SBV % 3 == 0 && NL >= 64), "three-row jobs; at least one wave to run them");
+    // jobs: VC_JR rows of one column; the rows of a job lie in one Schur block (six: a whole body of the star arrangements)
+    static constexpr int VC_JR = (C::SB % 6 == 0) ? 6 : 3, VC_NJ = (NE / VC_JR) * NX, VC_NL = (NT > 128) ? NT - 128 : 64, VC_R = (VC_NJ + VC_NL - 1) / VC_NL;
+    struct vc_regs { double cm[VC_R][C::SB], lr[VC_R][VC_JR][C::SB]; };
+    // (the operands are requested a phase ahead of their use: form_vc_load right behind barrier A, form_vc_store behind B)
+    UPR_HDI void form_vc_load(int k, vc_regs& q) const {
+        constexpr int SBV = C::SB;
+        static_assert(C::VCPRE || (SBV % VC_JR == 0 && NT >= 192), "jobs inside one block; at least one wave to run them");
         const int t = tid() - 128;
         const double* Ck = rec(k) + lin_gx;
         const double* Lk = G + F::lsi + k * C::NLS;
-        double* out = L + O::sw_vcb + (k & 1) * O::VCN;
-        for (int f = t; f < NJ; f += NL) {
-            const int g = f / NX, c = f % NX, r0 = 3 * g, blk = r0 / SBV, bo = SBV * blk, q0 = r0 - bo;
+#pragma unroll
+        for (int r = 0; r < VC_R; ++r) {
+            const int f = (t + r * VC_NL < VC_NJ) ? t + r * VC_NL : 0;
+            const int g = f / NX, c = f % NX, r0 = VC_JR * g, blk = r0 / SBV, bo = SBV * blk, q0 = r0 - bo;
             const double* Ls = Lk + SBV * SBV * blk;
-            double cm[SBV], l0[SBV], l1[SBV], l2[SBV];
-            // full-length rows with the entries above the diagonal masked: no lane-dependent trip count; every operand requested
-            // before the first product
 #pragma unroll
             for (int m = 0; m < SBV; ++m) {
-                cm[m] = Ck[(bo + m) * NX + c];
-                l0[m] = Ls[q0 * SBV + m]; l1[m] = Ls[(q0 + 1) * SBV + m]; l2[m] = Ls[(q0 + 2) * SBV + m];
-            }
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                q.cm[r][m] = Ck[(bo + m) * NX + c];
 #pragma unroll
-            for (int m = 0; m < SBV; ++m) {
-                v0 += ((m <= q0) ? l0[m] : 0.0) * cm[m]; v1 += ((m <= q0 + 1) ? l1[m] : 0.0) * cm[m]; v2 += ((m <= q0 + 2) ? l2[m] : 0.0) * cm[m];
+                for (int i = 0; i < VC_JR; ++i) if (SBV > VC_JR || m <= i) q.lr[r][i][m] = Ls[(q0 + i) * SBV + m];   // (one job per block: q0 = 0, the triangle only)
             }
-            out[c * NE + r0] = v0; out[c * NE + r0 + 1] = v1; out[c * NE + r0 + 2] = v2;
         }
+    }
+    UPR_HDI void form_vc_store(int k, const vc_regs& q) {
+        constexpr int SBV = C::SB;
+        const int t = tid() - 128;
+        double* out = L + O::sw_vcb + (k & 1) * O::VCN;
+#pragma unroll
+        for (int r = 0; r < VC_R; ++r) {
+            const int f = t + r * VC_NL;
+            const int fc = (f < VC_NJ) ? f : 0;
+            const int g = fc / NX, c = fc % NX, r0 = VC_JR * g, q0 = r0 - SBV * (r0 / SBV);
+            double v[VC_JR];
+#pragma unroll
+            for (int i = 0; i < VC_JR; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < SBV; ++m) {
+                    if (SBV > VC_JR) a += ((m <= q0 + i) ? q.lr[r][i][m] : 0.0) * q.cm[r][m];   // full-length rows, entries above the diagonal masked
+                    else if (m <= i) a += q.lr[r][i][m] * q.cm[r][m];
+                }
+                v[i] = a;
+            }
+            if (f < VC_NJ) {
+#pragma unroll
+                for (int i = 0; i < VC_JR; ++i) out[c * O::VCS + r0 + i] = v[i];
+            }
+        }
+    }
+    // Dense Schur factor (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x nx) as v_mfma_f64_16x16x4_f64 on ONE
+    // wave, operands straight from global memory (lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and receives
+    // D[(l >> 4) + 4 q][l & 15]): 20 loads per lane instead of the 126 of the lane-job form
+    static constexpr int VM_TR = (C::SB + 15) / 16, VM_TC = (NX + 15) / 16, VM_NS = (C::SB + 3) / 4;
+    struct vcm_regs { double av[VM_TR][VM_NS], bv[VM_TC][VM_NS]; };
+    UPR_HDI void form_vcm_load(int k, vcm_regs& q) const {
+        constexpr int SBV = C::SB;
+        const int ln = lane(), l15 = ln & 15, k4 = ln >> 4;
+        const double* Ck = rec(k) + lin_gx;
+        const double* Lk = G + F::lsi + k * C::NLS;
+#pragma unroll
+        for (int s4 = 0; s4 < VM_NS; ++s4) {
+            const int m = 4 * s4 + k4, mc = (m < SBV) ? m : SBV - 1;
+#pragma unroll
+            for (int tr = 0; tr < VM_TR; ++tr) { const int row = 16 * tr + l15, rc = (row < SBV) ? row : SBV - 1; q.av[tr][s4] = Lk[rc * SBV + mc]; }
+#pragma unroll
+            for (int tc = 0; tc < VM_TC; ++tc) { const int col = 16 * tc + l15, cc = (col < NX) ? col : NX - 1; q.bv[tc][s4] = Ck[mc * NX + cc]; }
+        }
+    }
+    UPR_HDI void form_vcm_store(int k, vcm_regs& q) {
+        typedef double v4dv __attribute__((ext_vector_type(4)));
+        constexpr int SBV = C::SB;
+        const int ln = lane(), l15 = ln & 15, k4 = ln >> 4;
+        double* out = L + O::sw_vcb + (k & 1) * O::VCN;
+#pragma unroll
+        for (int s4 = 0; s4 < VM_NS; ++s4) {
+            const int m = 4 * s4 + k4;
+#pragma unroll
+            for (int tr = 0; tr < VM_TR; ++tr) { const int row = 16 * tr + l15; q.av[tr][s4] = (row < SBV && m < SBV && m <= row) ? q.av[tr][s4] : 0.0; }
+#pragma unroll
+            for (int tc = 0; tc < VM_TC; ++tc) { const int col = 16 * tc + l15; q.bv[tc][s4] = (m < SBV && col < NX) ? q.bv[tc][s4] : 0.0; }
+        }
+        v4dv dacc[VM_TR][VM_TC];
+#pragma unroll
+        for (int tr = 0; tr < VM_TR; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < VM_TC; ++tc) dacc[tr][tc] = v4dv{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < VM_NS; ++s4)
+#pragma unroll
+            for (int tr = 0; tr < VM_TR; ++tr) {
+                if (4 * s4 > 16 * tr + 15) continue;   // the rows of this tile end before these columns of the factor begin
+#pragma unroll
+                for (int tc = 0; tc < VM_TC; ++tc) dacc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(q.av[tr][s4], q.bv[tc][s4], dacc[tr][tc], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tr = 0; tr < VM_TR; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < VM_TC; ++tc)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { const int r = 16 * tr + k4 + 4 * qq, col = 16 * tc + l15; if (r < NE && col < NX) out[col * O::VCS + r] = dacc[tr][tc][qq]; }
+    }
+    UPR_HDI void form_vc(int k) {
+        if constexpr (C::COUPLED) { if ((wb >> 6) == 2) { vcm_regs q; form_vcm_load(k, q); form_vcm_store(k, q); } }
+        else { vc_regs q; form_vc_load(k, q); form_vc_store(k, q); }
     }
 #endif
     UPR_HDI void backward_mat() {
