@@ -177,7 +177,7 @@ def config4_workload(B, rank=0, world=1):
                      f"per-instance inertial parameters, N=20, batch={B} per GPU, cold start, init_sqp_iteration=3")
 
 
-def config5_workload(B, rank=0, world=1):
+def config5_workload(B, rank=0, world=1, slacks=False):
     """configs[4]: Thing + pink_bottle with a thrown ball (dynamic obstacle, obstacles/dynamic.yaml:5-17; rows as in
     ral23/experiments/projectile/_base.yaml:81-87: two self-collision pairs, wrist-vs-ground, forearm-vs-ball and the
     projectile-path row on the tray's link), closed loop at 100 Hz; goal sweep: goals on a 1.2 m circle around the
@@ -192,6 +192,8 @@ def config5_workload(B, rank=0, world=1):
         setattr(P, k, v)
     P.n_dyn = 1
     robots.add_projectile_rows(P, ["balanced_object_collision_link"], [0.35], 0.2)
+    if slacks:   # sqp.hpipm.slacks.enabled with the reference's defaults (controller.yaml:68-72): boxes and polytopic rows softened
+        P.slacks = dict(state_box=True, input_box=True, poly_ineq=True)
     x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
     p, _ = P.chain.forward(THING_HOME)
     ang = 2.0 * np.pi * (rank * B + np.arange(B)) / (B * world)   # (rank r owns goals [r B, (r+1) B) of the sweep of world x B)
@@ -207,7 +209,8 @@ def config5_workload(B, rank=0, world=1):
         dyn[b] = np.concatenate([cross - v0 * T - 0.5 * a0 * T * T, v0, a0])
     return dict(P=P, x0=np.concatenate([x0, dyn], axis=1), way=(p + goal)[:, None, :], body_params=None,
                 name=f"configs[4]: Thing + pink_bottle + thrown ball (5 collision / projectile rows per knot), N=20, closed loop at 100 Hz "
-                     f"(one warm-started SQP iteration per tick, linear feedback policy at the observed state), goal sweep of {B} goals per GPU")
+                     f"(one warm-started SQP iteration per tick, linear feedback policy at the observed state), goal sweep of {B} goals per GPU"
+                     + (", sqp.hpipm.slacks.enabled (state_box, input_box, poly_ineq: the reference's remedy for rows one step cannot restore)" if slacks else ""))
 
 
 def contract_workload(B):
@@ -235,6 +238,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     mpc.set_projectile_flag(1.0)
     x, t, dt = w["x0"].copy(), 0.0, 0.01
     failed = 0
+    broke = [0]
     lat = []
     u0_all = [None]
 
@@ -262,15 +266,16 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     t0 = time.perf_counter()
     for _ in range(ticks):
         x = tick(x, t); t += dt
-        failed += int(np.sum(mpc.stats()["qp_status_last"] != 0))
+        stq = mpc.stats()["qp_status_last"]
+        failed += int(np.sum(stq != 0)); broke[0] += int(np.sum(stq == 2))
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch
 
-        tt = torch.tensor([elapsed, float(failed)], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed, float(failed), float(broke[0])], dtype=torch.float64, device=device)
         dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)      # the slowest rank's clock
         dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
-        elapsed, failed = float(tt[0].item()), int(tt[1].item())
+        elapsed, failed, broke[0] = float(tt[0].item()), int(tt[1].item()), int(tt[2].item())
         assert u0_all[0].shape == (world * B, P.nu)
     kt = mpc.kernel_times()
     goal_err = np.linalg.norm(np.array([P.chain.forward(x[b, :9])[0] for b in range(0, B, max(1, B // 64))])
@@ -281,6 +286,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         "real_time_factor": 0.01 * ticks / elapsed,
         "exchange": "all-gather of u_0 per tick" if world > 1 else None,
         "qp_not_converged_fraction": failed / (B * world * ticks),
+        "qp_factorisation_broke_down_fraction": broke[0] / (B * world * ticks),   # (status 2: no step, no feedback policy for that tick)
         "tray_to_goal_m_after_run": {"mean": float(goal_err.mean()), "max": float(goal_err.max())},
         "finite": bool(np.all(np.isfinite(x))),
         "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
@@ -666,6 +672,9 @@ def main():
         extra.append(time_extra(w4, args.extra_steps, 1, dist=dist, device=device, engine=engine_for(w4)))
         w5 = config5_workload(args.batch if dry else 1024, rank, world)
         extra.append(time_closed_loop(w5, args.closed_loop_ticks, dist=dist, device=device, engine=engine_for(w5)))
+        if not dry:
+            w5s = config5_workload(1024, rank, world, slacks=True)
+            extra.append(time_closed_loop(w5s, args.closed_loop_ticks, dist=dist, device=device, engine=engine_for(w5s)))
         if world == 1 and not dry:
             extra.append(contract_entry(contract_workload(1024), args.extra_steps, 1))
         extra = [_strip(e) for e in extra]

@@ -109,7 +109,7 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
     upr_qp_args A;
     A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
     if (P->N != 20) return -1;
-    const bool softb = P->soft_state_box || P->soft_input_box;
+    const bool softb = P->soft_state_box || P->soft_input_box || (P->soft_poly && (A.d.np > 0 || A.d.no > 0));   // upr_api.hip needs_soft
     // the instantiations libupright_mi launches (upr_api.hip: headline, UPR_QP3_EXTRA), one thread per workgroup
 #define EMU_QP3(a, b, c, e, sf, cond) EMU_QP3D(a, b, c, e, sf, false, cond)
 #define EMU_QP3D(a, b, c, e, sf, dense, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && (cond)) { \

@@ -311,15 +311,30 @@ def test_soft_rows_kernel_source(arrangements):
         assert rc == 0 and stats[b, 2] == 0 and abs(stats[b, 1] - so.qp_iters_last) <= 1
         assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
         assert np.abs(du[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max())
+    # the production kernel's source with the same slacks (SOFT instantiation: boxes in registers, friction rows in its far arrays)
+    dx3, du3, stats3, _ = e.qp(3, xs, us, x0, lin)
+    for b in range(B):
+        assert stats3[b, 2] == 0 and abs(stats3[b, 1] - stats[b, 1]) <= 1
+        assert np.abs(dx3[b] - dx[b]).max() < 2e-5 * max(1, np.abs(dx[b]).max()) and np.abs(du3[b] - du[b]).max() < 2e-5 * max(1, np.abs(du[b]).max())
     # only the polytopic rows softened: boxes stay hard (instance 1 then violates its acceleration box: not compared)
     P.slacks = dict(poly_ineq=True, equality=False)
     e = Emu(P, B)
-    dx, du, stats, ws = e.qp(1, xs, us, x0, lin)
-    for b in range(1):
-        P.way_p = way[b]
-        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
-        assert stats[b, 2] == 0 and rc == 0
-        assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
+    for kernel in (1, 3):
+        dx, du, stats, ws = e.qp(kernel, xs, us, x0, lin)
+        for b in range(1):
+            P.way_p = way[b]
+            dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+            assert stats[b, 2] == 0 and rc == 0
+            assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max())
+            assert np.abs(du[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max())
+    # fixed iteration count: the production kernel's soft friction rows follow the oracle's iterate path
+    P.qp_tol, P.qp_iter_max = 0.0, 6
+    e = Emu(P, B)
+    dx, du, stats, ws = e.qp(3, xs, us, x0, lin)
+    P.way_p = way[0]
+    dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[0], xs[0], us[0])
+    assert stats[0, 1] == 6 == so.qp_iters_last
+    assert np.abs(dx[0] - dxo).max() < 1e-7 * max(1, np.abs(dxo).max()) and np.abs(du[0] - duo).max() < 1e-7 * max(1, np.abs(duo).max())
 
 
 def _emu_kkt(e, ws, b):

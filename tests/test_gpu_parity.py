@@ -1662,3 +1662,104 @@ def test_orientation_error_near_a_half_turn(arrangements):
     _, xs, us = mpc.solution()
     assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
     mpc.close()
+
+
+def test_soft_polytopic_rows_in_the_production_kernel(arrangements):
+    """slacks.poly_ineq (pybindings.cpp:160-181) on the friction-pyramid, collision and projectile-path rows inside the
+    production QP kernel (SOFT instantiation with state-polytopic rows: upr_qp3_cfg<9, 1, 4, 3, 20, 256, true, true, false>;
+    until round 3 such problems fell back to the generic kernel).  (a) Static collision rows + friction rows, all softened:
+    the primal-dual point against the independent numpy assembly of the optimality conditions (tests/kkt_check.py, soft
+    rows included) and the step against the oracle; (b) the thrown-ball problem (BASELINE config 5: dynamic obstacle and
+    projectile-path row): QP step against the oracle; the kernel that ran."""
+    from kkt_check import kkt_residuals
+    from test_emu import _projectile_case
+    from upright_amd.problem import THING_HOME
+
+    soft = dict(state_box=False, input_box=False, poly_ineq=True, equality=False, lower_L2_penalty=100.0, upper_L2_penalty=100.0)
+    # (a)
+    B = 4
+    P = _with_collision_model(thing_problem(arrangements["pink_bottle"], qp_tol=1e-9, qp_iter_max=60))
+    P.slacks = soft
+    rng = np.random.default_rng(3)
+    x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
+    x0[:, 1] += rng.uniform(-0.1, 0.1, B)
+    way = waypoints_for(P, x0, offset=(1.0, 0.0, 0.0))
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    sol = mpc.qp_kkt()
+    lin = mpc.lin_records()
+    st = mpc.stats()
+    assert "true, true, false" in mpc.kernel_times()["qp_kernel"], mpc.kernel_times()["qp_kernel"]
+    assert np.all(st["qp_status_last"] == 0), st["qp_status_last"]
+    for b in range(B):
+        res = kkt_residuals(P, P.body_params, x0[b], xs0[b], us0[b], lin[b], {k: v[b] for k, v in sol.items()})
+        assert res.max() < 1e-7, (b, res)
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert rc == 0 and so.qp_status_last == 0
+        assert np.abs(sol["dx"][b] - dxo).max() < 2e-5 * max(1.0, np.abs(dxo).max())
+        assert np.abs(sol["du"][b] - duo).max() < 2e-5 * max(1.0, np.abs(duo).max())
+    mpc.close()
+    # (b)
+    P, x0r, way, _, _, dyn = _projectile_case(arrangements, B, use_feedback_policy=True, qp_tol=1e-9, qp_iter_max=60)
+    P.slacks = soft
+    x0 = np.concatenate([x0r, dyn], axis=1)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_projectile_flag(1.0)
+    mpc.set_observation(0.0, x0)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    xs0r, _ = stationary_guess(x0r, P.N, P.nu)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    st = mpc.stats()
+    assert "true, true, false" in mpc.kernel_times()["qp_kernel"] and np.all(st["qp_status_last"] == 0)
+    for b in range(B):
+        P.way_p = way[b]
+        O = Oracle(P)
+        O.set_dynamic_obstacle(dyn[b], 1.0)
+        dxo, duo, so, rc = O.qp_step(0.0, x0r[b], xs0r[b], us0[b])
+        assert rc == 0 and so.qp_status_last == 0
+        assert np.abs(dxs[b][:, :27] - dxo[:, :27]).max() < 2e-5 * max(1.0, np.abs(dxo).max())
+        assert np.abs(dus[b] - duo).max() < 2e-5 * max(1.0, np.abs(duo).max())
+    mpc.close()
+
+
+def test_closed_loop_thrown_ball_with_soft_rows(arrangements):
+    """The closed loop of test_closed_loop_thrown_ball with the reference's remedy for a hard row that one jerk-limited step
+    cannot restore: slacks.poly_ineq.  Every tick of every instance now ends with a converged QP (no iteration cap, no
+    broken factorisation, hence no tick without a feedback policy), on the production kernel; the tray still gives way
+    to the ball."""
+    from test_emu import _projectile_case
+
+    B = 4
+    P, x0r, way, _, _, dyn = _projectile_case(arrangements, B, use_feedback_policy=True)
+    P.slacks = dict(state_box=False, input_box=False, poly_ineq=True, equality=False, lower_L2_penalty=100.0, upper_L2_penalty=100.0)
+    O = Oracle(P)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_projectile_flag(1.0)
+    x = np.concatenate([x0r, dyn], axis=1)
+    t, dt = 0.0, 0.01
+    mind = np.full(B, np.inf)
+    failed = np.zeros((150, B), dtype=int)
+    for tick in range(150):
+        mpc.set_observation(t, x)
+        mpc.advance()
+        failed[tick] = mpc.stats()["qp_status_last"]
+        _, u = mpc.evaluate(t, x_obs=x)
+        assert np.all(np.isfinite(u))
+        j = u[:, :9]
+        q, v, a = x[:, :9], x[:, 9:18], x[:, 18:27]
+        ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
+        x = np.concatenate([q + dt * v + dt ** 2 / 2 * a + dt ** 3 / 6 * j, v + dt * a + dt ** 2 / 2 * j, a + dt * j,
+                            ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
+        t += dt
+        for b in range(B):
+            tray = O.sphere_centers(x[b, :27])[P.proj_sph[0]]
+            mind[b] = min(mind[b], np.linalg.norm(tray - x[b, 27:30]))
+    assert "true, true, false" in mpc.kernel_times()["qp_kernel"]
+    mpc.close()
+    assert not np.any(failed == 2), np.argwhere(failed == 2)            # no broken factorisation: every tick has a policy
+    assert np.mean(failed != 0) < 0.01, np.argwhere(failed != 0)        # (a stray tick at the iteration cap is not a failure of the loop)
+    assert mind.min() > 0.28

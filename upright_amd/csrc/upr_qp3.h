@@ -83,7 +83,12 @@ struct upr_qp3_far {
                          // matrix sweep and the costates use in place of hee when such rows exist)
                          ot = rows + r2((C::SOFT ? 10 : 4) * (C::QX + C::QU) * C::NT), ol = ot + (C::N - 1) * UPR_QP3_NOMAX, oc = ol + (C::N - 1) * UPR_QP3_NOMAX,
                          od0 = oc + (C::N - 1) * UPR_QP3_NOMAX, heew = od0 + (C::N - 1) * UPR_QP3_NOMAX,
-                         total = heew + r2(C::N * C::NH);
+                         // SOFT: slack, its own barrier pair and the pair's corrector target of the friction-pyramid rows (sfr: sigma,
+                         // + 1: tau, + 2: gam, + 3: target; 5 NCI each) and of the state-polytopic rows (sor, the same; (N - 1) NOMAX each)
+                         // when slacks.poly_ineq softens them (pybindings.cpp:160-181)
+                         sfr = heew + r2(C::N * C::NH), sor = sfr + (C::SOFT ? 4 * r2(5 * C::NCI) : 0),
+                         total = sor + ((C::SOFT && C::ROWS) ? 4 * (C::N - 1) * UPR_QP3_NOMAX : 0);
+    static constexpr int sfs = r2(5 * C::NCI), sos = (C::N - 1) * UPR_QP3_NOMAX;   // strides between the four arrays
 };
 
 // global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
@@ -268,6 +273,7 @@ struct upr_qp3 {
     double sgx[QXS][2], tax[QXS][2], gax[QXS][2];
     double sgu[QUS][2], tau_[QUS][2], gau[QUS][2];
     bool softx, softu;      // which box classes carry slacks (uniform over the workgroup)
+    bool softp;             // slacks on the polytopic rows (friction pyramid, collision / projectile rows): slacks.poly_ineq
     double ZL, ZU, zL, zU;  // L2 / L1 penalties of lower / upper rows
     double rho_s;           // regularisation of the Schur complement: UPR_QP_RHO_S, or 1 / Z for a softened equality
     double rho_eq;          // 1 / Z for a softened equality (the row's residual is C dz + e - rho_eq nu), else 0
@@ -458,6 +464,8 @@ struct upr_qp3 {
             }
         }
         double ctP[C::QC][5], clP[C::QC][5];
+        constexpr int QCS_ = C::SOFT ? C::QC : 1;
+        double csP[QCS_][5], caP[QCS_][5], cgP[QCS_][5];   // softened friction rows: slack, its barrier pair
         if (NF == 3) {
 #pragma unroll
             for (int q = 0; q < C::QC; ++q) {
@@ -465,6 +473,10 @@ struct upr_qp3 {
                 if (ic < C::NCI) {
 #pragma unroll
                     for (int r = 0; r < 5; ++r) { ctP[q][r] = G[F::ct + 5 * ic + r]; clP[q][r] = G[F::cl + 5 * ic + r]; }
+                    if (C::SOFT && softp) {
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) { csP[q % QCS_][r] = G[F::sfr + 5 * ic + r]; caP[q % QCS_][r] = G[F::sfr + F::sfs + 5 * ic + r]; cgP[q % QCS_][r] = G[F::sfr + 2 * F::sfs + 5 * ic + r]; }
+                    }
                 }
             }
         }
@@ -510,7 +522,11 @@ struct upr_qp3 {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
                 double sr, wr, ct_ = 0.0;
-                row(c, ds, otv[q], olv[q], ct_, sr, wr);
+                if (C::SOFT && C::ROWS && softp) {
+                    double cts_ = 0.0;
+                    row_soft(c, ds, otv[q], olv[q], G[F::sor + ei], G[F::sor + F::sos + ei], G[F::sor + 2 * F::sos + ei], ZL, zL, ct_, cts_, sr, wr);
+                    if (mode == 1) G[F::sor + 3 * F::sos + ei] = cts_;
+                } else row(c, ds, otv[q], olv[q], ct_, sr, wr);
                 if (mode == 1) G[F::oc + ei] = ct_;
                 L[O::hux + ei] = sr; L[O::hux + (N - 1) * UPR_QP3_NOMAX + ei] = wr;
             }
@@ -634,7 +650,11 @@ struct upr_qp3 {
                         const double c = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
                         const double ds = e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2];
                         double s, wgt, ct_ = 0.0;
-                        row(c, ds, ctP[q][r], clP[q][r], ct_, s, wgt);
+                        if (C::SOFT && softp) {
+                            double cts_ = 0.0;
+                            row_soft(c, ds, ctP[q][r], clP[q][r], csP[q % QCS_][r], caP[q % QCS_][r], cgP[q % QCS_][r], ZL, zL, ct_, cts_, s, wgt);
+                            if (mode == 1) G[F::sfr + 3 * F::sfs + 5 * ic + r] = cts_;
+                        } else row(c, ds, ctP[q][r], clP[q][r], ct_, s, wgt);
                         if (mode == 1) G[F::cc + 5 * ic + r] = ct_;
                         for (int a = 0; a < 3; ++a) { guf[a] += e3[a] * s; for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2]; }
                     }
@@ -2707,6 +2727,12 @@ struct upr_qp3 {
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
                     double t = ctv[q][r], lam = clv[q][r];
+                    if (C::SOFT && softp) {
+                        double sg = G[F::sfr + 5 * ic + r], ta = G[F::sfr + F::sfs + 5 * ic + r], ga = G[F::sfr + 2 * F::sfs + 5 * ic + r];
+                        sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
+                                       ccv[q][r], G[F::sfr + 3 * F::sfs + 5 * ic + r], acc, aux);
+                        if (what == 2) { G[F::sfr + 5 * ic + r] = sg; G[F::sfr + F::sfs + 5 * ic + r] = ta; G[F::sfr + 2 * F::sfs + 5 * ic + r] = ga; }
+                    } else
                     sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, ccv[q][r], acc, aux);
                     if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
                 }
@@ -2720,6 +2746,12 @@ struct upr_qp3 {
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
                     double t = G[F::ct + 5 * ic + r], lam = G[F::cl + 5 * ic + r];
+                    if (C::SOFT && softp) {
+                        double sg = G[F::sfr + 5 * ic + r], ta = G[F::sfr + F::sfs + 5 * ic + r], ga = G[F::sfr + 2 * F::sfs + 5 * ic + r];
+                        sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
+                                       G[F::cc + 5 * ic + r], G[F::sfr + 3 * F::sfs + 5 * ic + r], acc, aux);
+                        if (what == 2) { G[F::sfr + 5 * ic + r] = sg; G[F::sfr + F::sfs + 5 * ic + r] = ta; G[F::sfr + 2 * F::sfs + 5 * ic + r] = ga; }
+                    } else
                     sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam,
                               G[F::cc + 5 * ic + r], acc, aux);
                     if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
@@ -2746,6 +2778,11 @@ struct upr_qp3 {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
                 double t = otv[q], lam = olv[q];
+                if (C::SOFT && C::ROWS && softp) {
+                    double sg = G[F::sor + ei], ta = G[F::sor + F::sos + ei], ga = G[F::sor + 2 * F::sos + ei];
+                    sweep_row_soft(what, alpha, c, ds, t, lam, sg, ta, ga, ZL, zL, ocv[q], G[F::sor + 3 * F::sos + ei], acc, aux);
+                    if (what == 2) { G[F::sor + ei] = sg; G[F::sor + F::sos + ei] = ta; G[F::sor + 2 * F::sos + ei] = ga; }
+                } else
                 sweep_row(what, alpha, c, ds, t, lam, ocv[q], acc, aux);
                 if (what == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
             }
@@ -2925,7 +2962,7 @@ struct upr_qp3 {
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
-        softx = C::SOFT && P->soft_state_box != 0; softu = C::SOFT && P->soft_input_box != 0;
+        softx = C::SOFT && P->soft_state_box != 0; softu = C::SOFT && P->soft_input_box != 0; softp = C::SOFT && P->soft_poly != 0;
         ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
         rho_eq = upr_qp_rho_soft(P); rho_s = P->soft_eq ? rho_eq : UPR_QP_RHO_S;
         prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
@@ -2974,6 +3011,7 @@ struct upr_qp3 {
                 for (int i = 0; i < NQ; ++i) v -= g[i] * xs[k * NX + i];
                 const double t = d0 > UPR_QP_THR ? d0 : UPR_QP_THR;
                 G[F::od0 + ei] = v; G[F::ot + ei] = t; G[F::ol + ei] = UPR_QP_MU0 / t; G[F::oc + ei] = 0.0;
+                if (C::SOFT && C::ROWS && softp) { G[F::sor + ei] = 0.0; G[F::sor + F::sos + ei] = UPR_QP_THR; G[F::sor + 2 * F::sos + ei] = UPR_QP_MU0 / UPR_QP_THR; G[F::sor + 3 * F::sos + ei] = 0.0; }
             }
             UPR_FORT(e, C::NH) G[F::heew + e] = G[F::hee + e];   // knot 0 carries no such rows
         }
@@ -3013,11 +3051,12 @@ struct upr_qp3 {
                     const double c0 = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
                     const double t = c0 > UPR_QP_THR ? c0 : UPR_QP_THR;
                     G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = UPR_QP_MU0 / t; G[F::cc + 5 * ic + r] = 0.0;
+                    if (C::SOFT && softp) { G[F::sfr + 5 * ic + r] = 0.0; G[F::sfr + F::sfs + 5 * ic + r] = UPR_QP_THR; G[F::sfr + 2 * F::sfs + 5 * ic + r] = UPR_QP_MU0 / UPR_QP_THR; G[F::sfr + 3 * F::sfs + 5 * ic + r] = 0.0; }
                 }
             }
         }
         UPR_SYNC();
-        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no + (softx ? N * 2 * NX : 0) + (softu ? N * 2 * NU : 0);   // each softened row adds the pair (tau, gam)
+        const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no + (softx ? N * 2 * NX : 0) + (softu ? N * 2 * NU : 0) + (softp ? N * C::NP + (N - 1) * no : 0);   // each softened row adds the pair (tau, gam)
         double res[4] = {0, 0, 0, 0};
         int it = 0, status = 1;
         const double tol = P->qp_tol;
