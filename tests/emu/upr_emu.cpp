@@ -108,12 +108,12 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
              const double* Df, double* ws, long ws_stride, double* stats) {
     upr_qp_args A;
     A.P = P; A.d = upr_make_dims(P); A.xs = xs; A.us = us; A.x0 = x0; A.lin = lin; A.Df = Df; A.ws = ws; A.stats = stats; A.prof = nullptr;
-    if (P->N != 20) return -1;
     const bool softb = P->soft_state_box || P->soft_input_box || (P->soft_poly && (A.d.np > 0 || A.d.no > 0));   // upr_api.hip needs_soft
     // the instantiations libupright_mi launches (upr_api.hip: headline, UPR_QP3_EXTRA), one thread per workgroup
-#define EMU_QP3(a, b, c, e, sf, cond) EMU_QP3D(a, b, c, e, sf, false, cond)
-#define EMU_QP3D(a, b, c, e, sf, dense, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && (cond)) { \
-        typedef upr_qp3_cfg<a, b, c, e, 20, 1, true, sf, dense> C; \
+#define EMU_QP3(a, b, c, e, sf, cond) EMU_QP3N(a, b, c, e, 20, sf, false, cond)
+#define EMU_QP3D(a, b, c, e, sf, dense, cond) EMU_QP3N(a, b, c, e, 20, sf, dense, cond)
+#define EMU_QP3N(a, b, c, e, n, sf, dense, cond) if (P->nq == a && P->nb == b && P->nc == c && P->nf == e && P->N == n && (cond)) { \
+        typedef upr_qp3_cfg<a, b, c, e, n, 1, true, sf, dense> C; \
         if (!ws) return (long)upr_qp3_ws<C>::total; \
         A.d.ws_stride = (int)ws_stride; \
         upr_ctx ctx; ctx.tid = 0; ctx.nt = 1; \
@@ -125,8 +125,11 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
     EMU_QP3(9, 1, 4, 1, true, true)
     EMU_QP3(9, 8, 32, 1, true, true)
     EMU_QP3D(9, 3, 16, 3, false, true, !softb)
+    EMU_QP3N(6, 1, 4, 1, 20, true, false, true)
+    EMU_QP3N(6, 1, 4, 1, 10, true, false, true)
 #undef EMU_QP3
 #undef EMU_QP3D
+#undef EMU_QP3N
     return -1;
 }
 long emu_qp3_lds_doubles() { return (long)upr_qp3_lds<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total; }

@@ -447,3 +447,52 @@ def test_end_effector_orientation_cost_kernel_source(arrangements):
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert rc == 0 and np.abs(xs1[b] - xo).max() < 2e-5 and np.abs(us1[b] - uo).max() < 2e-4
     e.E.emu_set_way_q(None)
+
+
+@pytest.mark.parametrize("horizon", [2.0, 1.0])
+def test_ur10_shape_production_kernel_source(arrangements, horizon):
+    """BASELINE configs[0] (ur10_demo.yaml: fixed-base UR10, nq 6, one body, four frictionless contacts: nx 18, nu 10) on the
+    production QP kernel's source: the (6, 1, 4, 1) instantiations at horizon N = 20 (time_horizon 2.0, as shipped) and
+    N = 10 (time_horizon 1.0, the horizon BASELINE.json names).  The four normal forces cannot span the six object-dynamics
+    rows, so the hard equality gets the proximal treatment of upr_qp.h inside the kernel (until round 3 such problems ran the
+    second-structure kernel).  Against the generic kernel's source and the oracle on the same linearisation records."""
+    import copy
+    import json
+    from pathlib import Path
+
+    from upright_amd import control
+
+    cfg = copy.deepcopy(json.load(open(Path(__file__).parent / "golden" / "configs.json"))["ur10_demo"]["controller"])
+    cfg["mpc"]["time_horizon"] = horizon
+    bodies, contacts = control.objects_from_fixture(arrangements["pink_bottle"])
+    settings = control.ControllerSettings(cfg, bodies=bodies, contacts=contacts)
+    from upright_amd import control_bindings as cb
+
+    P = cb.problem_from_settings(settings)
+    assert (P.nq, P.nb, P.nc, P.nf, P.N) == (6, 1, 4, 1, int(round(horizon / 0.1)))
+    x0 = np.array(settings.initial_state)
+    # (frictionless contacts hold no tangential load: the fixed first knot is feasible only on an exactly level tray)
+    _, Cm = P.chain.forward(x0[:P.nq])
+    ez = np.array([0.0, 0.0, 1.0]); v = Cm.T @ ez; ax = np.cross(ez, v); s_, c_ = np.linalg.norm(ax), ez @ v
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    P.chain.tool_R = P.chain.tool_R @ (np.eye(3) + K + K @ K * ((1 - c_) / (s_ * s_)))
+    P.qp_tol, P.qp_iter_max = 1e-9, 60
+    p0, _ = P.chain.forward(x0[:P.nq])
+    B = 2
+    x0b = np.tile(x0, (B, 1))
+    way = np.stack([(p0 + np.array(off))[None] for off in ([0.3, 0.2, 0.1], [-0.2, 0.3, 0.0])])
+    P.way_t, P.way_p = np.zeros(1), way[0]
+    xs, us = stationary_guess(x0b, P.N, P.nu)
+    xs, us = np.ascontiguousarray(xs), np.ascontiguousarray(us)
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx1, du1, st1, _ = e.qp(1, xs, us, x0b, lin)
+    dx3, du3, st3, _ = e.qp(3, xs, us, x0b, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0b[b], xs[b], us[b])
+        assert rc == 0 and so.qp_status_last == 0 and st1[b, 2] == 0 and st3[b, 2] == 0
+        assert abs(st3[b, 1] - so.qp_iters_last) <= 1
+        for dx, du in ((dx1, du1), (dx3, du3)):
+            assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1.0, np.abs(dxo).max())
+            assert np.abs(du[b][:, :P.nq] - duo[:, :P.nq]).max() < 2e-4 * max(1.0, np.abs(duo).max())

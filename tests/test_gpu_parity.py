@@ -452,6 +452,9 @@ def _level_tool(chain, q_home):
 
 @pytest.mark.parametrize("name,override,level", [
     ("ur10_demo", {}, True),                                       # BASELINE configs[0]: fixed-base UR10, frictionless (nx 18, nu 10)
+    # ... at the horizon BASELINE.json names (N = 10); the shipped waypoint cannot be reached in one second under the terminal
+    # equality (both solvers stop at the iteration cap), so a nearer one:
+    ("ur10_demo", {"mpc.time_horizon": 1.0, "waypoints": [{"time": 0, "position": [0.15, 0.1, 0.05], "orientation": [0, 0, 0, 1]}]}, True),
     ("thing_demo", {"sqp.hpipm.slacks.enabled": False}, True),    # configs 2': Thing, frictionless (nx 27, nu 13), hard rows
     ("thing_demo", {}, True),                                      # as configured: HPIPM slacks on every inequality class (thing_demo.yaml)
     ("thing_demo", {}, False),                                     # ... and the tray 1 degree off level, as shipped: the general rows' slacks absorb the infeasible first knot
@@ -479,6 +482,8 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
         assert P.slacks["poly_ineq"]    # thing_demo.yaml: the general constraints (= the object-dynamics rows, nf = 1) carry slacks
     xo, uo, so, rc = Oracle(P).solve(0.0, x0, xs0[0], us0[0])
     st = m.mpc._mpc.stats()
+    if name == "ur10_demo":   # the production kernel's (6, 1, 4, 1) instantiations, horizon as a template axis (N = 20 | 10)
+        assert "upr_qp3_cfg<6, 1, 4, 1, %d, 256" % P.N in m.mpc._mpc.kernel_times()["qp_kernel"], m.mpc._mpc.kernel_times()["qp_kernel"]
     if P.nf == 1 and not level and P.slacks is None:
         # hard object-dynamics rows that the fixed first knot violates: both solvers stop at the iteration cap (as HPIPM
         # does in the reference), the plans agree to the accuracy an unconverged QP allows and stay usable

@@ -400,31 +400,33 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 // thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
 // (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
 #if defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_CONFIG3)
-#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, true, false, true) X(9, 8, 32, 1, false, true, false)
+#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, 20, true, false, true) X(9, 8, 32, 1, 20, false, true, false)
 #elif defined(UPR_HEADLINE_ONLY)
-#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false) X(9, 1, 4, 3, true, true, false)
+#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, 20, false, true, false) X(9, 1, 4, 3, 20, true, true, false)
 #else
-#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, false, true, false) X(9, 1, 4, 3, true, true, false) X(9, 1, 4, 1, false, true, false) X(9, 8, 32, 1, false, true, false) X(9, 3, 16, 3, true, false, true)
+#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, 20, false, true, false) X(9, 1, 4, 3, 20, true, true, false) X(9, 1, 4, 1, 20, false, true, false) X(9, 8, 32, 1, 20, false, true, false) \
+    X(9, 3, 16, 3, 20, true, false, true) X(6, 1, 4, 1, 20, false, true, false) X(6, 1, 4, 1, 10, false, true, false)
 #endif
 bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }
 // does the problem need a SOFT instantiation?  Slacks on its boxes, or slacks.poly_ineq with friction / state-polytopic rows
 bool needs_soft(const upr_problem& P, const upr_dims& d) { return soft_boxes(P) || (P.soft_poly && (d.np > 0 || d.no > 0)); }
-// does instantiation (a, b, c, e, rows, sf, dense) of UPR_QP3_EXTRA take this problem?  (The first match in list order is the one
+// does instantiation (a, b, c, e, horizon n, rows, sf, dense) of UPR_QP3_EXTRA take this problem?  (The first match in list order is the one
 // every site below uses: a SOFT problem without state-polytopic rows takes the instantiation without them.)
-bool qp3_match(const upr_problem& P, const upr_dims& d, int a, int b, int c, int e, bool rows, bool sf, bool dense) {
+bool qp3_match(const upr_problem& P, const upr_dims& d, int a, int b, int c, int e, int n, bool rows, bool sf, bool dense) {
     bool star = true;                                         // no two bodies share a contact point
     for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) star = false;
-    return P.nq == a && P.nb == b && P.nc == c && P.nf == e && (rows || d.no == 0) && (sf || !needs_soft(P, d)) && (dense || star);
+    return P.nq == a && P.nb == b && P.nc == c && P.nf == e && P.N == n && (rows || d.no == 0) && (sf || !needs_soft(P, d)) && (dense || star);
 }
 // can the production kernel take this problem, and in which instantiation?  0: no; 1: headline (hard boxes); 2: one of
 // UPR_QP3_EXTRA
 int qp3_variant(const upr_problem& P, const upr_dims& d) {
-    if (P.N != 20 || P.nq != 9) return 0;
     if (d.no > UPR_QP3_NOMAX) return 0;
-    if (d.nfc < d.ne && !P.soft_eq) return 0;                 // rank-deficient hard equality (proximal treatment): other kernels
+    // (a hard equality the contact forces cannot span -- frictionless one-body arrangements: nf nc < 6 nb -- gets the proximal
+    // treatment of upr_qp.h inside the kernel; multi-body shapes of that kind need soft_eq)
+    if (d.nfc < d.ne && !P.soft_eq && P.nb > 1) return 0;
     if (qp3_is_headline(P) && !needs_soft(P, d)) return 1;
-#define X(a, b, c, e, rows, sf, dense) if (qp3_match(P, d, a, b, c, e, rows, sf, dense)) return 2;
+#define X(a, b, c, e, n, rows, sf, dense) if (qp3_match(P, d, a, b, c, e, n, rows, sf, dense)) return 2;
     UPR_QP3_EXTRA(X)
 #undef X
     return 0;
@@ -438,7 +440,7 @@ int launch_qp3(upr_batch* h, const upr_qp_args& A) {
 }
 size_t qp3_ws_doubles(const upr_problem& P, const upr_dims& d, int variant) {
     if (variant == 1) return upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 512>>::total;   // (the far arrays grow with the lanes: largest NT)
-#define X(a, b, c, e, rows, sf, dense) if (qp3_match(P, d, a, b, c, e, rows, sf, dense)) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>>::total;
+#define X(a, b, c, e, n, rows, sf, dense) if (qp3_match(P, d, a, b, c, e, n, rows, sf, dense)) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, n, 256, rows, sf, dense>>::total;
     UPR_QP3_EXTRA(X)
 #undef X
     return 0;
@@ -456,7 +458,7 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
         }
     }
     if (h->use_qp3 == 2) {
-#define X(a, b, c, e, rows, sf, dense) if (qp3_match(h->P, h->d, a, b, c, e, rows, sf, dense)) return launch_qp3_cfg<upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>>(h, A);
+#define X(a, b, c, e, n, rows, sf, dense) if (qp3_match(h->P, h->d, a, b, c, e, n, rows, sf, dense)) return launch_qp3_cfg<upr_qp3_cfg<a, b, c, e, n, 256, rows, sf, dense>>(h, A);
         UPR_QP3_EXTRA(X)
 #undef X
     }
@@ -525,7 +527,7 @@ upr_fb_src fb_source(const upr_batch* h) {
         };
         // (these offsets lie in front of everything that depends on the workgroup size or on ROWS / SOFT)
         if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
-#define X(a, b, c, e, rows, sf, dense) else if (qp3_match(h->P, h->d, a, b, c, e, rows, sf, dense)) fill(upr_qp3_cfg<a, b, c, e, 20, 256, rows, sf, dense>());
+#define X(a, b, c, e, n, rows, sf, dense) else if (qp3_match(h->P, h->d, a, b, c, e, n, rows, sf, dense)) fill(upr_qp3_cfg<a, b, c, e, n, 256, rows, sf, dense>());
         UPR_QP3_EXTRA(X)
 #undef X
         return s;
@@ -693,7 +695,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     {
         char buf[128];
         if (h->use_qp3 == 1) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<9, 1, 4, 3, 20, %d, %s, false, false>>", h->qp_nt, h->d.no > 0 ? "true" : "false");
-#define X(a, b, c, e, rows, sf, dense) else if (h->use_qp3 == 2 && qp3_match(*P, h->d, a, b, c, e, rows, sf, dense)) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, 20, 256, %s, %s, %s>>", a, b, c, e, #rows, #sf, #dense);
+#define X(a, b, c, e, n, rows, sf, dense) else if (h->use_qp3 == 2 && qp3_match(*P, h->d, a, b, c, e, n, rows, sf, dense)) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, 256, %s, %s, %s>>", a, b, c, e, n, #rows, #sf, #dense);
         UPR_QP3_EXTRA(X)
 #undef X
         else if (h->use_qp2) snprintf(buf, sizeof(buf), "upr_qp2_kernel<upr_qp2_dims<%d, %d, %d, %d>, %d>", P->nq, P->nb, P->nc, P->nf, h->qp_nt == 512 ? 128 : h->qp_nt);

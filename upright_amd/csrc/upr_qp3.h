@@ -124,7 +124,13 @@ struct upr_qp3_lds {
                          sw0 = C::VCPRE ? Pa + (C::N - 1 - KS) * VCN : Pa, sw_vcb = sw0 /* (!VCPRE: Vc of the knot in work and of the next one) */,
                          sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */,
                          sw_pq = sw_w + r2(C::NX) /* (!VCPRE: the shares of Vc'Vc of waves 2 and 3, [wave][entry][lane]) */, sw_end = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
-                         yN = (C::SW && sw_end > ck + r2(C::NE * C::NX)) ? sw_end : ck + r2(C::NE * C::NX), dyN = yN + r2(C::NEN),
+                         // the scratch region Pa .. yN serves, at different times: the four-wave sweep's working set (Pa .. ck), the
+                         // one- / two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
+                         // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
+                         scr_sweep = ck + r2(C::NE * C::NX), scr_sw = C::SW ? (sw_end > sw0 + C::NKB * (C::SB * (C::SB + 1) / 2) ? sw_end : sw0 + r2(C::NKB * (C::SB * (C::SB + 1) / 2))) : 0,
+                         scr_prep = hux + r2((C::MULTI || C::COUPLED) ? 0 : C::N * C::NE * C::NE), scr_rows = hux + (C::ROWS ? 2 * (C::N - 1) * UPR_QP3_NOMAX : 0),
+                         scr_a = scr_sweep > scr_sw ? scr_sweep : scr_sw, scr_b = scr_prep > scr_rows ? scr_prep : scr_rows,
+                         yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
                          prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
@@ -277,6 +283,7 @@ struct upr_qp3 {
     double ZL, ZU, zL, zU;  // L2 / L1 penalties of lower / upper rows
     double rho_s;           // regularisation of the Schur complement: UPR_QP_RHO_S, or 1 / Z for a softened equality
     double rho_eq;          // 1 / Z for a softened equality (the row's residual is C dz + e - rho_eq nu), else 0
+    double rho_px;          // proximal treatment of a hard equality the forces cannot span (upr_qp.h UPR_QP_RHO_S_PROX): C dz + e = rho_px (nu+ - nu)
     double soft_stat;       // running max of the slack stationarity |Z sigma + z - lam - gam| (residuals)
     static constexpr int NCT0 = 2 * C::QX + 2 * C::QU;                // corrector targets of the rows per lane (F::cxr)
     static constexpr int NCT = (C::SOFT ? 2 : 1) * NCT0;             // SOFT: + the targets of the slack pairs, behind them
@@ -765,7 +772,7 @@ struct upr_qp3 {
                 L[O::ek + e] = v;
             }
             if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
-            L[O::ys + e] = v - v2;
+            L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #else
         UPR_FORT(e, N * NE) {
@@ -779,7 +786,7 @@ struct upr_qp3 {
                 L[O::ek + e] = v;
             } else v = L[O::ek + e];
             if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
-            L[O::ys + e] = v - v2;
+            L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #endif
         if (factor && !C::MULTI && !C::COUPLED) {
@@ -911,7 +918,7 @@ struct upr_qp3 {
                 // triangle, in the sweep's staging area).  That area overlaps the S blocks of the last knots, which other
                 // lanes of THIS wave read at the top of their factorisation: all Schur blocks sit on one wave (lockstep),
                 // so every read precedes every write.
-                static_assert(!C::VCPRE || (C::NKB <= 64 && C::NKB * (SB * (SB + 1) / 2) <= O::sw_end - O::sw0), "Lsi staging of phase D");
+                static_assert(!C::VCPRE || (C::NKB <= 64 && O::sw0 + C::NKB * (SB * (SB + 1) / 2) <= O::yN), "Lsi staging of phase D");
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -1741,9 +1748,9 @@ struct upr_qp3 {
 #else
             constexpr int NPB = NX;
 #endif
-            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::hjj - O::hux), "prep stages Z and S in the sweeps' working set");
+            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::yN - O::hux), "prep stages Z and S in the scratch region");
             static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
-            static_assert(2 * (N - 1) * UPR_QP3_NOMAX <= O::hjj - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
+            static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
 #ifndef UPR_HOST_EMU
             // dense Schur complement (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x 27) as 18
             // v_mfma_f64_16x16x4_f64 on ONE wave -- as lane jobs it was 162 three-row dot products on a wave and a half,
@@ -2964,7 +2971,7 @@ struct upr_qp3 {
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
         softx = C::SOFT && P->soft_state_box != 0; softu = C::SOFT && P->soft_input_box != 0; softp = C::SOFT && P->soft_poly != 0;
         ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
-        rho_eq = upr_qp_rho_soft(P); rho_s = P->soft_eq ? rho_eq : UPR_QP_RHO_S;
+        rho_eq = upr_qp_rho_soft(P); rho_s = upr_qp_rho_s(P, NE, NFC); rho_px = upr_qp_rho_prox(P, NE, NFC);
         prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
         if (prof) UPR_FORT(i, 64) L[O::prf + i] = 0.0;
         tic();
