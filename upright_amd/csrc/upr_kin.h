@@ -179,6 +179,146 @@ static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int
     upr_rmul_const(E.C, P->tool_R);
 }
 
+// ---- analytic tangents (round 3) --------------------------------------------------------------------------------------------
+// The forward-mode form above walks the chain once per tangent direction on (value, tangent) pairs: 27 walks per knot, every
+// one recomputing the same VALUES.  The functions below walk the chain ONCE per knot on plain values, leave a snapshot per
+// joint, and every direction's tangent of the end-effector state follows in closed form from the snapshot of its joint:
+// everything behind joint j moves RIGIDLY with q_j.  With the base of that motion (the link in front of the joint: origin o,
+// its velocity v_o and acceleration a_o as a point of that link, angular velocity w_b, angular acceleration al_b, axis z) and
+// the motion of the end effector relative to it
+//     rho = p - o,   w_r = w - w_b,   rho' = v - v_o - w_b x rho,   al_r = al - al_b - w_b x w_r,
+//     rho'' = a - a_o - al_b x rho - w_b x (w_b x rho) - 2 w_b x rho'
+// (the end effector's a = a_o + al_b x rho + w_b x (w_b x rho) + 2 w_b x rho' + rho''), a revolute joint gives
+//     d/dq:    dC = S(z) C, dp = z x rho, dw = z x w_r, dal = w_b x (z x w_r) + z x al_r,
+//              da = al_b x (z x rho) + w_b x (w_b x (z x rho)) + 2 w_b x (z x rho') + z x rho''
+//     d/dq':   dw = z, dal = w_b x z + z x w_r, da = 2 w_b x (z x rho) + 2 z x rho'
+//     d/dq'':  dal = z, da = z x rho
+// and a prismatic one (everything behind it translates along z)
+//     d/dq:    dp = z, da = al_b x z + w_b x (w_b x z);     d/dq':  da = 2 w_b x z;     d/dq'':  da = z.
+// Checked against the forward-mode walk and the oracle's dual numbers by the linearisation tests (1e-10 .. 1e-13).
+#define UPR_SNAP_J 18   // per joint: o, v_o, a_o, w_b, al_b, z
+#define UPR_SNAP_E 24   // end effector: C (9), p, v, w, a, al
+template <int NQ>
+static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap) {
+    upr_ee<double> E;
+    for (int i = 0; i < 9; ++i) E.C[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) { E.p[i] = 0.0; E.v[i] = 0.0; E.w[i] = 0.0; E.a[i] = 0.0; E.al[i] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const double q = x[j], qd = x[NQ + j], qdd = x[2 * NQ + j];
+        double r[3];
+        upr_rot_const(E.C, P->joint_p[j], r);
+        upr_carry(E, r);
+        upr_rmul_const(E.C, P->joint_R[j]);
+        double z[3];
+        upr_rot_const(E.C, P->joint_axis[j], z);
+        double* S = snap + j * UPR_SNAP_J;
+        for (int i = 0; i < 3; ++i) { S[i] = E.p[i]; S[3 + i] = E.v[i]; S[6 + i] = E.a[i]; S[9 + i] = E.w[i]; S[12 + i] = E.al[i]; S[15 + i] = z[i]; }
+        if (P->joint_type[j] == 1) {
+            double wz[3];
+            upr_cross(E.w, z, wz);
+            for (int i = 0; i < 3; ++i) { E.al[i] = E.al[i] + z[i] * qdd + wz[i] * qd; E.w[i] = E.w[i] + z[i] * qd; }
+            const double* ax = P->joint_axis[j];
+            double s_, c_;
+            if (sc) { s_ = sc[2 * j]; c_ = sc[2 * j + 1]; } else upr_sincos(q, &s_, &c_);
+            const double omc = 1.0 - c_;
+            double M[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) M[3 * a + b] = (ax[a] * ax[b]) * omc + ((a == b) ? c_ : 0.0);
+            M[1] = M[1] - ax[2] * s_; M[2] = M[2] + ax[1] * s_;
+            M[3] = M[3] + ax[2] * s_; M[5] = M[5] - ax[0] * s_;
+            M[6] = M[6] - ax[1] * s_; M[7] = M[7] + ax[0] * s_;
+            upr_rmul(E.C, M);
+        } else {
+            double d[3], wz[3], t[3], wd[3];
+            for (int i = 0; i < 3; ++i) d[i] = z[i] * q;
+            upr_cross(E.w, z, wz);
+            upr_cross(E.w, d, wd);
+            upr_cross(E.al, d, t);
+            for (int i = 0; i < 3; ++i) E.a[i] = E.a[i] + t[i];
+            upr_cross(E.w, wd, t);
+            for (int i = 0; i < 3; ++i) {
+                E.a[i] = E.a[i] + t[i] + (2.0 * wz[i]) * qd + z[i] * qdd;
+                E.v[i] = E.v[i] + wd[i] + z[i] * qd;
+                E.p[i] = E.p[i] + d[i];
+            }
+        }
+    }
+    double r[3];
+    upr_rot_const(E.C, P->tool_p, r);
+    upr_carry(E, r);
+    upr_rmul_const(E.C, P->tool_R);
+    double* T = snap + NQ * UPR_SNAP_J;
+    for (int i = 0; i < 9; ++i) T[i] = E.C[i];
+    for (int i = 0; i < 3; ++i) { T[9 + i] = E.p[i]; T[12 + i] = E.v[i]; T[15 + i] = E.w[i]; T[18 + i] = E.a[i]; T[21 + i] = E.al[i]; }
+}
+// end-effector state with the tangent along state coordinate dir (dir < 0: values only) out of the snapshots
+template <int NQ>
+static UPR_HDI void upr_ee_from_snap(const upr_problem* P, const double* snap, int dir, upr_ee<upr_dd>& E) {
+    const double* T = snap + NQ * UPR_SNAP_J;
+    const int cls = (dir >= 0) ? dir / NQ : 3, j = (dir >= 0) ? dir % NQ : 0;
+    const double* S = snap + j * UPR_SNAP_J;
+    const bool rev = P->joint_type[j] == 1;
+    double C[9], p[3], v[3], w[3], a[3], al[3], o[3], vo[3], ao[3], wb[3], ab[3], z[3];
+    for (int i = 0; i < 9; ++i) C[i] = T[i];
+    for (int i = 0; i < 3; ++i) { p[i] = T[9 + i]; v[i] = T[12 + i]; w[i] = T[15 + i]; a[i] = T[18 + i]; al[i] = T[21 + i];
+                                  o[i] = S[i]; vo[i] = S[3 + i]; ao[i] = S[6 + i]; wb[i] = S[9 + i]; ab[i] = S[12 + i]; z[i] = S[15 + i]; }
+    double rho[3], wr[3], t1[3], t2[3], rd[3], alr[3], rdd[3];
+    for (int i = 0; i < 3; ++i) { rho[i] = p[i] - o[i]; wr[i] = w[i] - wb[i]; }
+    upr_cross(wb, rho, t1);
+    for (int i = 0; i < 3; ++i) rd[i] = v[i] - vo[i] - t1[i];                       // rho'
+    upr_cross(wb, wr, t2);
+    for (int i = 0; i < 3; ++i) alr[i] = al[i] - ab[i] - t2[i];                      // al_r
+    upr_cross(wb, t1, t2);                                                           // w_b x (w_b x rho)
+    double t3[3], t4[3];
+    upr_cross(ab, rho, t3);
+    upr_cross(wb, rd, t4);
+    for (int i = 0; i < 3; ++i) rdd[i] = a[i] - ao[i] - t3[i] - t2[i] - 2.0 * t4[i];  // rho''
+    // u = d p / d q_j
+    double u[3], zr[3];
+    upr_cross(z, rho, zr);
+    for (int i = 0; i < 3; ++i) u[i] = rev ? zr[i] : z[i];
+    double dC[9], dp[3], dw[3], dal[3], da[3];
+    for (int i = 0; i < 9; ++i) dC[i] = 0.0;
+    for (int i = 0; i < 3; ++i) { dp[i] = 0.0; dw[i] = 0.0; dal[i] = 0.0; da[i] = 0.0; }
+    double wbu[3];
+    upr_cross(wb, u, wbu);
+    if (cls == 0) {
+        double abu[3], wwu[3];
+        upr_cross(ab, u, abu);
+        upr_cross(wb, wbu, wwu);
+        for (int i = 0; i < 3; ++i) { dp[i] = u[i]; da[i] = abu[i] + wwu[i]; }
+        if (rev) {
+            double zwr[3], wzwr[3], zalr[3], zrd[3], wzrd[3], zrdd[3];
+            upr_cross(z, wr, zwr);
+            upr_cross(wb, zwr, wzwr);
+            upr_cross(z, alr, zalr);
+            upr_cross(z, rd, zrd);
+            upr_cross(wb, zrd, wzrd);
+            upr_cross(z, rdd, zrdd);
+            for (int i = 0; i < 3; ++i) { dw[i] = zwr[i]; dal[i] = wzwr[i] + zalr[i]; da[i] = da[i] + 2.0 * wzrd[i] + zrdd[i]; }
+            // dC = S(z) C, column by column (C row-major)
+            for (int c = 0; c < 3; ++c) {
+                const double c0 = C[c], c1 = C[3 + c], c2 = C[6 + c];
+                dC[c] = z[1] * c2 - z[2] * c1; dC[3 + c] = z[2] * c0 - z[0] * c2; dC[6 + c] = z[0] * c1 - z[1] * c0;
+            }
+        }
+    } else if (cls == 1) {
+        for (int i = 0; i < 3; ++i) da[i] = 2.0 * wbu[i];
+        if (rev) {
+            double wbz[3], zwr[3], zrd[3];
+            upr_cross(wb, z, wbz);
+            upr_cross(z, wr, zwr);
+            upr_cross(z, rd, zrd);
+            for (int i = 0; i < 3; ++i) { dw[i] = z[i]; dal[i] = wbz[i] + zwr[i]; da[i] = da[i] + 2.0 * zrd[i]; }
+        }
+    } else if (cls == 2) {
+        for (int i = 0; i < 3; ++i) { da[i] = u[i]; dal[i] = rev ? z[i] : 0.0; }
+    }
+    for (int i = 0; i < 9; ++i) E.C[i] = {C[i], dC[i]};
+    for (int i = 0; i < 3; ++i) { E.p[i] = {p[i], dp[i]}; E.v[i] = {v[i], 0.0}; E.w[i] = {w[i], dw[i]}; E.a[i] = {a[i], da[i]}; E.al[i] = {al[i], dal[i]}; }
+}
+
 // Centres of the collision spheres (controller_interface.cpp:172-228: the spheres of
 // upright_assets/thing/xacro/collision_links.urdf.xacro ride on chain links, obstacle spheres are fixed in the
 // world): the same chain walk, positions only.  `put(s, c)` receives sphere s and its centre c[3].

@@ -23,7 +23,9 @@
 // (J / e: position rows, then the orientation rows used when the end-effector cost weighs orientation)
 static UPR_HDI int upr_lin_lds_sc(const upr_dims& d) { return d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6 + 9; }   // (sin q_j, cos q_j) [nq][2]
 static UPR_HDI int upr_lin_lds_base(const upr_dims& d) { return (upr_lin_lds_sc(d) + 2 * d.nq + 1 + 1) & ~1; }
-static UPR_HDI int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
+// [sphere centres ...] then the snapshots of the one value walk per knot (upr_kin.h: UPR_SNAP_J per joint + UPR_SNAP_E)
+static UPR_HDI int upr_lin_lds_snap(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
+static UPR_HDI int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return (upr_lin_lds_snap(d, n_sph) + d.nq * UPR_SNAP_J + UPR_SNAP_E + 1) & ~1; }
 
 struct upr_lin_args {
     const upr_problem* P;
@@ -112,6 +114,18 @@ static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q
         upr_target_rotation(A.P, A.way_q + (size_t)q.b * A.P->n_way * 4, q.t, sh + d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6);
 }
 
+// phase 1a (UPR_LIN_ANALYTIC): ONE walk of the chain per knot on plain values, by the knot's first lane; the tangent lanes
+// of phase 1 read the snapshot of their joint (upr_kin.h, "analytic tangents")
+#ifndef UPR_LIN_ANALYTIC
+#define UPR_LIN_ANALYTIC 1   // 0: every tangent lane walks the chain itself on (value, tangent) pairs (rounds 1 - 2; A/B runs)
+#endif
+template <int NQ>
+static UPR_HDI void upr_lin_phase1a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+#if UPR_LIN_ANALYTIC
+    if (lane == 0) upr_ee_walk_snap<NQ>(A.P, sh, sh + upr_lin_lds_sc(A.d), sh + upr_lin_lds_snap(A.d, A.P->n_sph));
+#endif
+}
+
 // phase 1: the tangent lanes.  ORI: the end-effector cost weighs orientation (compile-time: the error-row loops keep
 // constant trip counts)
 template <int NQ, bool ORI = false>
@@ -125,7 +139,11 @@ static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q
     constexpr bool ori = ORI;
     const int dir = (lane < d.nx) ? lane : -1;
     upr_ee<upr_dd> E;
+#if UPR_LIN_ANALYTIC
+    upr_ee_from_snap<NQ>(P, sh + upr_lin_lds_snap(d, P->n_sph), dir, E);
+#else
     upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E, sh + upr_lin_lds_sc(d));
+#endif
     if (!q.terminal) {
         const double scale = 1.0 / sqrt(6.0 * d.nb);
         const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
@@ -254,6 +272,11 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     if (live) { q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, sh); }
     __syncthreads();
     UPR_LIN_STAMP(0);
+#if UPR_LIN_ANALYTIC
+    if (live) upr_lin_phase1a<NQ>(A, q, lane, sh);
+    UPR_WSYNC();   // (the 32 lanes of a knot sit in one wave: LDS operations of a wave execute in order)
+    UPR_LIN_STAMP(1);
+#endif
     if (live) upr_lin_phase1<NQ, ORI>(A, q, lane, sh);
     UPR_LIN_STAMP(2);
     if (A.d.no > 0) {
