@@ -16,7 +16,7 @@ for _ in range(3):
     mpc.reset(); mpc.advance()
 mpc.sync()
 lib.upr_debug_lin_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 0)
-names = ["phase 0: stage x, u", "phase 0b: wrenches (lane 0)", "phase 1: chain walk, residual, stores", "barrier after phase 1", "phase 2: MFMA Hessian, gradient"]
+names = ["phase 0: stage x, u, sin/cos, Df f", "phase 1a: the value walk (one lane per knot)", "phase 1: tangents from the snapshots, residual, stores", "collision rows + barrier", "phase 2: MFMA Hessian, gradient"]
 n = out[7]
 for i, l in enumerate(names):
     print("%-42s %9.0f cycles / workgroup" % (l, out[i] / n))

@@ -300,7 +300,9 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     const int blocks = (A.npoints + 7) / 8;
     const size_t lds = (size_t)8 * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double);
     if (lds > 64 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
-    static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 2;   // (measured: 2 -> 0.130 ms, 3 -> 0.142 ms, 4 -> 0.32 ms with spills)
+    // (rounds 1 - 2, one forward-mode walk per tangent lane: 2 -> 0.130 ms, 3 -> 0.142 ms, 4 -> 0.32 ms with spills; round 3, one value
+    // walk per knot + closed-form tangents: 2 -> 0.091 ms, 3 -> 0.085 ms)
+    static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 3;
     if (A.way_q) {   // end-effector cost with orientation weights
         if (h->use_mfma) hipLaunchKernelGGL((upr_linearize_kernel<NQ, true, 2, true>), dim3(blocks), dim3(256), lds, h->stream, A);
         else hipLaunchKernelGGL((upr_linearize_kernel<NQ, false, 2, true>), dim3(blocks), dim3(256), lds, h->stream, A);
