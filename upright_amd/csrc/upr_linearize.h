@@ -254,38 +254,68 @@ __device__ unsigned long long upr_lin_prof[8];
 #else
 #define UPR_LIN_STAMP(i) ((void)0)
 #endif
-// 256 threads = 8 knots x 32 lanes.  USE_MFMA: Gauss-Newton Hessian through v_mfma_f64_16x16x4_f64.
+// 256 threads = 8 knots x 32 lanes per pass, UPR_LIN_PASSES passes per workgroup.  USE_MFMA: Gauss-Newton Hessian through
+// v_mfma_f64_16x16x4_f64.  The one value walk per knot (phase 1a) is a serial chain of ~1.3 k instructions whatever the
+// number of active lanes: the workgroup's 8 x PASSES walks run side by side on the first lanes of wave 0, ONCE, and the
+// other phases loop over the passes.
 // OCC: waves per SIMD the register allocation is held to (the kernel is latency bound: more resident knots hide more of it)
+#ifndef UPR_LIN_PASSES
+#define UPR_LIN_PASSES 3   // (measured, headline: 1 pass 0.085 ms, 2: 0.079, 3: 0.073, 4: 0.102 -- LDS then allows one workgroup less per CU)
+#endif
 template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false>
 __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NP = UPR_LIN_ANALYTIC ? UPR_LIN_PASSES : 1;
     const int per = upr_lin_lds_doubles(A.d, A.P->n_sph);
     const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const int p = blockIdx.x * 8 + sub;
-    const bool live = p < A.npoints;
-    double* sh = smem + sub * per;
-    upr_lin_point q;
+    const int base = blockIdx.x * 8 * NP;
 #ifdef UPR_LIN_PROF
     long long t_prof = __builtin_readcyclecounter();
     if (threadIdx.x == 0) atomicAdd(&upr_lin_prof[7], 1ull);
 #endif
-    if (live) { q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, sh); }
+#pragma unroll 1
+    for (int pp = 0; pp < NP; ++pp) {
+        const int slot = pp * 8 + sub, p = base + slot;
+        if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, smem + slot * per); }
+    }
     __syncthreads();
     UPR_LIN_STAMP(0);
 #if UPR_LIN_ANALYTIC
-    if (live) upr_lin_phase1a<NQ>(A, q, lane, sh);
-    UPR_WSYNC();   // (the 32 lanes of a knot sit in one wave: LDS operations of a wave execute in order)
+    if (threadIdx.x < 8 * NP) {
+        const int p = base + threadIdx.x;
+        if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase1a<NQ>(A, q, 0, smem + threadIdx.x * per); }
+    }
+    __syncthreads();
     UPR_LIN_STAMP(1);
 #endif
-    if (live) upr_lin_phase1<NQ, ORI>(A, q, lane, sh);
+#pragma unroll 1
+    for (int pp = 0; pp < NP; ++pp) {
+        const int slot = pp * 8 + sub, p = base + slot;
+        if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase1<NQ, ORI>(A, q, lane, smem + slot * per); }
+    }
     UPR_LIN_STAMP(2);
     if (A.d.no > 0) {
-        if (live) upr_lin_phase_obs_a<NQ>(A, q, lane, sh);
+#pragma unroll 1
+        for (int pp = 0; pp < NP; ++pp) {
+            const int slot = pp * 8 + sub, p = base + slot;
+            if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase_obs_a<NQ>(A, q, lane, smem + slot * per); }
+        }
         __syncthreads();
-        if (live) upr_lin_phase_obs_b<NQ>(A, q, lane, sh);
+#pragma unroll 1
+        for (int pp = 0; pp < NP; ++pp) {
+            const int slot = pp * 8 + sub, p = base + slot;
+            if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase_obs_b<NQ>(A, q, lane, smem + slot * per); }
+        }
     }
     __syncthreads();
     UPR_LIN_STAMP(3);
+#pragma unroll 1
+    for (int pp = 0; pp < NP; ++pp) {
+        const int slot0 = pp * 8 + sub, p = base + slot0;
+        const bool live = p < A.npoints;
+        double* sh = smem + slot0 * per;
+        upr_lin_point q;
+        if (live) q = upr_lin_locate(A, p);
     if (!USE_MFMA) {
         if (live) upr_lin_phase2<NQ, ORI>(A, q, lane, sh);
     } else {
@@ -299,8 +329,8 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
         const int wsub0 = (threadIdx.x >> 6) * 2;  // first knot slot of this wave
         typedef double v4d __attribute__((ext_vector_type(4)));
         for (int h = 0; h < 2; ++h) {
-            const int slot = wsub0 + h;
-            const int ph = blockIdx.x * 8 + slot;
+            const int slot = pp * 8 + wsub0 + h;
+            const int ph = base + slot;
             const double* shh = smem + slot * per;
             const double* sJ = shh + A.d.nx + A.d.nu + 6 * A.d.nb;
             double a = 0.0;
@@ -340,6 +370,7 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
                 upr_lin_phase2<NQ, ORI>(A, q, lane, sh);
             }
         }
+    }
     }
     UPR_LIN_STAMP(4);
 }
