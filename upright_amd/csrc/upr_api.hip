@@ -297,14 +297,16 @@ int need_device() {
 
 template <int NQ>
 int launch_linearize(upr_batch* h, const upr_lin_args& A) {
-    constexpr int KPW = 8 * (UPR_LIN_ANALYTIC ? UPR_LIN_PASSES : 1);   // knots per workgroup
+    static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 2;
+    // knots per workgroup: several passes (their value walks side by side) for the plain instantiation without collision rows
+    const bool multi = UPR_LIN_ANALYTIC && !A.way_q && h->use_mfma && occ == 2 && A.d.no == 0;
+    const int KPW = 8 * (multi ? UPR_LIN_PASSES : 1);
     const int blocks = (A.npoints + KPW - 1) / KPW;
     const size_t lds = (size_t)KPW * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double);
     if (lds > 160 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
     // (rounds 1 - 2, one forward-mode walk per tangent lane: 2 -> 0.130 ms, 3 -> 0.142 ms, 4 -> 0.32 ms with spills; round 3, one value
     // walk per knot + closed-form tangents: 2 -> 0.091 ms, 3 -> 0.085 ms;
     // with the walks of three passes side by side: 2 -> 0.073 ms, 3 -> 0.095 ms)
-    static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 2;
     auto launch = [&](void (*kern)(upr_lin_args)) -> int {
         if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, h->stream, A);
@@ -315,6 +317,7 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     else if (!h->use_mfma) rc = launch(upr_linearize_kernel<NQ, false>);
     else if (occ == 3) rc = launch(upr_linearize_kernel<NQ, true, 3>);
     else if (occ == 4) rc = launch(upr_linearize_kernel<NQ, true, 4>);
+    else if (multi) rc = launch(upr_linearize_kernel<NQ, true, 2, false, UPR_LIN_PASSES>);
     else rc = launch(upr_linearize_kernel<NQ, true>);
     if (rc) return rc;
     UPR_HIP(hipGetLastError());

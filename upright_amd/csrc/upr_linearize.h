@@ -262,10 +262,12 @@ __device__ unsigned long long upr_lin_prof[8];
 #ifndef UPR_LIN_PASSES
 #define UPR_LIN_PASSES 3   // (measured, headline: 1 pass 0.085 ms, 2: 0.079, 3: 0.073, 4: 0.102 -- LDS then allows one workgroup less per CU)
 #endif
-template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false>
+// NPASS: passes per workgroup (UPR_LIN_PASSES for problems without collision rows; with them the per-knot LDS area is three
+// times larger and one pass per workgroup measured best: configs[2] 1.11 ms against 1.70 ms with three passes)
+template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false, int NPASS = 1>
 __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NP = UPR_LIN_ANALYTIC ? UPR_LIN_PASSES : 1;
+    constexpr int NP = UPR_LIN_ANALYTIC ? NPASS : 1;
     const int per = upr_lin_lds_doubles(A.d, A.P->n_sph);
     const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int base = blockIdx.x * 8 * NP;
