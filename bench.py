@@ -278,6 +278,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         elapsed, failed, broke[0] = float(tt[0].item()), int(tt[1].item()), int(tt[2].item())
         assert u0_all[0].shape == (world * B, P.nu)
     kt = mpc.kernel_times()
+    roof, lin = roofline_objects(P, B, kt, mpc.stats(), 1, headline=False)   # (kernel times: means over the ticks; IPM iterations: the last tick's)
     goal_err = np.linalg.norm(np.array([P.chain.forward(x[b, :9])[0] for b in range(0, B, max(1, B // 64))])
                               - w["way"][::max(1, B // 64), 0], axis=1)
     out = {
@@ -289,6 +290,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         "qp_factorisation_broke_down_fraction": broke[0] / (B * world * ticks),   # (status 2: no step, no feedback policy for that tick)
         "tray_to_goal_m_after_run": {"mean": float(goal_err.mean()), "max": float(goal_err.max())},
         "finite": bool(np.all(np.isfinite(x))),
+        "roofline": roof, "roofline_linearize": lin,
         "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
     }
     if u0_all[0] is not None:
