@@ -24,6 +24,7 @@ static void lin_all_o(const upr_lin_args& A) {
     for (int p = 0; p < A.npoints; ++p) {
         upr_lin_point q = upr_lin_locate(A, p);
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase0(A, q, l, sh.data());
+        if (UPR_LIN_SC_ONCE) for (int j = 0; j < NQ; ++j) upr_lin_phase0_sc(A, q, j, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1a<NQ>(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ, ORI>(A, q, l, sh.data());
         if (A.d.no > 0) {

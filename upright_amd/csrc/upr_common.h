@@ -101,6 +101,7 @@ struct upr_dims {
     int ws_dx, ws_du, ws_sx, ws_su, ws_pi, ws_nu, ws_yN, ws_pin, ws_nun, ws_dyN, ws_t, ws_lam, ws_rc, ws_store, ws_stride;
     int soft;                               // any soft row class (slack arrays below are empty otherwise)
     int ws_sig, ws_tau, ws_gam, ws_rcs;     // per slot: slack sigma, its own slack tau and multiplier gam, its complementarity target
+    double eq_scale;                        // 1 / sqrt(6 nb): the scaling of the object-dynamics rows (balancing constraint's 1/sqrt(n))
 };
 
 static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
@@ -108,6 +109,7 @@ static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
     d.nq = P->nq; d.nb = P->nb; d.nc = P->nc; d.nf = P->nf; d.N = P->N;
     d.nx = 3 * P->nq; d.nfc = P->nf * P->nc; d.nu = P->nq + d.nfc;
     d.ne = 6 * P->nb; d.np = (P->nf == 3) ? 5 * P->nc : 0;
+    d.eq_scale = 1.0 / sqrt(6.0 * P->nb);
     d.neN = P->terminal_constraint ? 3 + 2 * P->nq : 0;
     d.lin_g = 0; d.lin_gx = d.ne; d.lin_cost = d.lin_gx + d.ne * d.nx; d.lin_grad = d.lin_cost + 1;
     d.no = P->n_pairs + P->n_proj;

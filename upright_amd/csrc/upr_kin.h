@@ -437,8 +437,8 @@ template <class T>
 static UPR_HDI void upr_body_residual(const upr_ee<T>& E, const double* bp, const double* g0, const double* F,
                                             const double* Tq, T* out) {
     T* tag = nullptr;
-    const double m = bp[0];
-    const double c[3] = {bp[1] / m, bp[2] / m, bp[3] / m};
+    const double m = bp[0], im = 1.0 / m;   // (one division: the centre of mass by the reciprocal)
+    const double c[3] = {bp[1] * im, bp[2] * im, bp[3] * im};
     const double I[9] = {bp[4], bp[5], bp[6], bp[5], bp[7], bp[8], bp[6], bp[8], bp[9]};
     // ddC c = (S(al) + S(w) S(w)) (C c) = al x r + w x (w x r), r = C c      util.h:39-44
     T r[3], t1[3], t2[3], acc[3];
@@ -460,7 +460,6 @@ static UPR_HDI void upr_body_residual(const upr_ee<T>& E, const double* bp, cons
         Ia[i] = I[3 * i] * ae[0] + I[3 * i + 1] * ae[1] + I[3 * i + 2] * ae[2];
     }
     upr_cross(we, Iw, tau);
-    const double im = 1.0 / m;
     for (int i = 0; i < 3; ++i) {
         out[i] = im * (gif[i] - upr_lift(F[i], tag));
         out[3 + i] = im * (tau[i] + Ia[i] - upr_lift(Tq[i], tag));

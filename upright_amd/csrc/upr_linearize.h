@@ -81,13 +81,26 @@ static UPR_HDI upr_lin_point upr_lin_locate(const upr_lin_args& A, int p) {
 // phase 0: stage x, u into LDS (coalesced: lane l loads element l) -- lanes 0..LPK-1 of the knot.  Two of the lanes that
 // carry no tangent work from global memory at the same time: the summed contact wrench per body (its forces straight from
 // the input vector, so it does not wait for the staging) and the desired orientation of the knot (SLERP of the waypoints)
+// sin / cos of joint angle j of the knot, straight from the input (no wait for the staging).  The f64 sincos is a few hundred
+// instructions whichever lanes run it: UPR_LIN_SC_ONCE = 1 runs it ONCE per workgroup, a lane per (knot, joint) over all the
+// passes' knots (rounds 1 - 3a: once per pass, on nq of the knot's 32 lanes)
+#ifndef UPR_LIN_SC_ONCE
+#define UPR_LIN_SC_ONCE 1
+#endif
+static UPR_HDI void upr_lin_phase0_sc(const upr_lin_args& A, const upr_lin_point& q, int j, double* sh) {
+    double s_, c_;
+    upr_sincos(q.x[j], &s_, &c_);
+    sh[upr_lin_lds_sc(A.d) + 2 * j] = s_; sh[upr_lin_lds_sc(A.d) + 2 * j + 1] = c_;
+}
 static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_dims& d = A.d;
     double* sx = sh; double* su = sh + d.nx;
     for (int i = lane; i < d.nx; i += UPR_LPK) sx[i] = q.x[i];
     for (int i = lane; i < d.nu; i += UPR_LPK) su[i] = q.terminal ? 0.0 : q.u[i];
+#if !UPR_LIN_SC_ONCE
     // sin / cos of the joint angles once per knot (lanes nq .. 2 nq - 1, straight from the input: no wait for the staging)
-    if (lane >= d.nq && lane < 2 * d.nq) { const int j = lane - d.nq; double s_, c_; upr_sincos(q.x[j], &s_, &c_); sh[upr_lin_lds_sc(d) + 2 * j] = s_; sh[upr_lin_lds_sc(d) + 2 * j + 1] = c_; }
+    if (lane >= d.nq && lane < 2 * d.nq) upr_lin_phase0_sc(A, q, lane - d.nq, sh);
+#endif
     if (A.Df != nullptr) {
         if (!q.terminal) {
             double* gf = sh + d.nx + d.nu;   // Df f of this knot, in the slot of the wrenches (6 nb doubles)
@@ -113,6 +126,84 @@ static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q
     if (lane == UPR_LPK - 2 && A.way_q != nullptr)
         upr_target_rotation(A.P, A.way_q + (size_t)q.b * A.P->n_way * 4, q.t, sh + d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6);
 }
+
+#ifndef UPR_HOST_EMU
+// Device form of phase 0 over ALL the passes' knots of the workgroup at once (the per-lane form above, pass by pass, keeps one
+// or two requests in flight per lane and pays a memory round trip per pass and per dependent step): every lane first REQUESTS
+// its elements of x and u of all passes, then the rows of Df f are spread a lane per (knot, row) with the row of Df and the
+// forces of the knot requested together, then everything is stored.  Same arithmetic, same order of the sums.
+#ifndef UPR_LIN_P0_BATCH
+#define UPR_LIN_P0_BATCH 1
+#endif
+template <int NQ, int NP>
+static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args& A, int base, int per, double* smem) {
+    const upr_dims& d = A.d;
+    constexpr int NX = 3 * NQ;
+    static_assert(NX <= UPR_LPK, "one state element per lane");
+    const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    double xv[NP], uv[NP][2];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int p = base + pp * 8 + sub;
+        xv[pp] = 0.0; uv[pp][0] = 0.0; uv[pp][1] = 0.0;
+        if (p < A.npoints) {
+            const upr_lin_point q = upr_lin_locate(A, p);
+            if (lane < NX) xv[pp] = q.x[lane];
+            if (!q.terminal) {
+                if (lane < d.nu) uv[pp][0] = q.u[lane];
+                if (lane + UPR_LPK < d.nu) uv[pp][1] = q.u[lane + UPR_LPK];
+            }
+        }
+    }
+    if (A.Df != nullptr) {
+        const int tot = 8 * NP * d.ne;
+        for (int idx = threadIdx.x; idx < tot; idx += 256) {
+            const int sp = idx / d.ne, r = idx - sp * d.ne, p = base + sp;
+            if (p >= A.npoints) continue;
+            const upr_lin_point q = upr_lin_locate(A, p);
+            if (q.terminal) continue;
+            const double* f = q.u + d.nq;
+            const double* D = A.Df + ((size_t)q.b * d.ne + r) * d.nfc;
+            double v = 0.0;
+            if (d.nfc == 12) {
+                double dv[12], fv[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { dv[j] = D[j]; fv[j] = f[j]; }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) v += dv[j] * fv[j];
+            } else {
+                int j = 0;
+                for (; j + 4 <= d.nfc; j += 4) {
+                    const double d0 = D[j], d1 = D[j + 1], d2 = D[j + 2], d3 = D[j + 3], f0 = f[j], f1 = f[j + 1], f2 = f[j + 2], f3 = f[j + 3];
+                    v += d0 * f0; v += d1 * f1; v += d2 * f2; v += d3 * f3;
+                }
+                for (; j < d.nfc; ++j) v += D[j] * f[j];
+            }
+            smem[sp * per + d.nx + d.nu + r] = v;
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int slot = pp * 8 + sub, p = base + slot;
+        if (p < A.npoints) {
+            double* sh = smem + slot * per;
+            if (lane < NX) sh[lane] = xv[pp];
+            if (lane < d.nu) sh[NX + lane] = uv[pp][0];
+            if (lane + UPR_LPK < d.nu) sh[NX + lane + UPR_LPK] = uv[pp][1];
+            const upr_lin_point q = upr_lin_locate(A, p);
+            for (int i = lane + 2 * UPR_LPK; i < d.nu; i += UPR_LPK) sh[NX + i] = q.terminal ? 0.0 : q.u[i];
+            if (A.Df == nullptr && lane == UPR_LPK - 1 && !q.terminal) {
+                double* Fw = sh + d.nx + d.nu;
+                const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
+                if (d.nc <= 4) upr_object_wrenches_small<4>(A.P, bp, q.u + d.nq, Fw);
+                else upr_object_wrenches(A.P, bp, q.u + d.nq, Fw);
+            }
+            if (lane == UPR_LPK - 2 && A.way_q != nullptr)
+                upr_target_rotation(A.P, A.way_q + (size_t)q.b * A.P->n_way * 4, q.t, sh + d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6);
+        }
+    }
+}
+#endif
 
 // phase 1a (UPR_LIN_ANALYTIC): ONE walk of the chain per knot on plain values, by the knot's first lane; the tangent lanes
 // of phase 1 read the snapshot of their joint (upr_kin.h, "analytic tangents")
@@ -145,7 +236,7 @@ static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q
     upr_ee_kinematics<upr_dd, NQ>(P, sx, dir, E, sh + upr_lin_lds_sc(d));
 #endif
     if (!q.terminal) {
-        const double scale = 1.0 / sqrt(6.0 * d.nb);
+        const double scale = d.eq_scale;   // (1 / sqrt(6 nb), from the host: an f64 sqrt and a division per lane and pass otherwise)
         const double* bp = A.body_params + (size_t)q.b * d.nb * 10;
         const double zero3[3] = {0.0, 0.0, 0.0};
         for (int b = 0; b < d.nb; ++b) {
@@ -275,11 +366,22 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     long long t_prof = __builtin_readcyclecounter();
     if (threadIdx.x == 0) atomicAdd(&upr_lin_prof[7], 1ull);
 #endif
+#if UPR_LIN_SC_ONCE
+    {
+        static_assert(8 * NP * NQ <= 256, "sincos lanes");
+        const int sp = threadIdx.x / NQ, sj = threadIdx.x % NQ;
+        if (sp < 8 * NP && base + sp < A.npoints) { const upr_lin_point q = upr_lin_locate(A, base + sp); upr_lin_phase0_sc(A, q, sj, smem + sp * per); }
+    }
+#endif
+#if UPR_LIN_P0_BATCH && UPR_LIN_SC_ONCE
+    upr_lin_phase0_batched<NQ, NP>(A, base, per, smem);
+#else
 #pragma unroll 1
     for (int pp = 0; pp < NP; ++pp) {
         const int slot = pp * 8 + sub, p = base + slot;
         if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase0(A, q, lane, smem + slot * per); }
     }
+#endif
     __syncthreads();
     UPR_LIN_STAMP(0);
 #if UPR_LIN_ANALYTIC

@@ -117,7 +117,7 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
         const double* bp = A.body_params + (size_t)b * nb * 10;
         if (EXACT && NBM == 1) upr_object_wrench_single<NFM / 3>(P, bp, U + nq, Fw);
         else upr_object_wrenches(P, bp, U + nq, Fw);
-        const double sc = 1.0 / sqrt(6.0 * nb);
+        const double sc = A.d.eq_scale;
 #pragma unroll
         for (int bb = 0; bb < (EXACT ? NBM : nb); ++bb) {
             double g[6];

@@ -2745,24 +2745,32 @@ struct upr_qp3 {
                 }
             }
         } else
-        if (NF == 3) for (int q = 0; q < C::QC; ++q) {
-            const int ic = tid_ + q * NT;
-            if (ic < C::NCI) {
-                const int k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
+        if (NF == 3) {
+            // one ROW per lane item (rounds 1 - 2: a contact, five rows, per lane -- all of them on the first NCI lanes, whose waves
+            // then ran fifteen rows per sweep against ten on the others); the rows of a lane requested together
+            constexpr int NR5 = 5 * C::NCI, QR5 = (NR5 + NT - 1) / NT;
+            double tv[QR5], lv[QR5], cv5[QR5];
+#pragma unroll
+            for (int q = 0; q < QR5; ++q) {
+                const int e = tid_ + q * NT, ec = (e < NR5) ? e : 0;
+                tv[q] = G[F::ct + ec]; lv[q] = G[F::cl + ec]; cv5[q] = G[F::cc + ec];
+            }
+#pragma unroll
+            for (int q = 0; q < QR5; ++q) {
+                const int e = tid_ + q * NT;
+                if (e >= NR5) continue;
+                const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
                 const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
-                for (int r = 0; r < 5; ++r) {
-                    const double* e3 = L + O::erow + 3 * (5 * ci + r);
-                    double t = G[F::ct + 5 * ic + r], lam = G[F::cl + 5 * ic + r];
-                    if (C::SOFT && softp) {
-                        double sg = G[F::sfr + 5 * ic + r], ta = G[F::sfr + F::sfs + 5 * ic + r], ga = G[F::sfr + 2 * F::sfs + 5 * ic + r];
-                        sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
-                                       G[F::cc + 5 * ic + r], G[F::sfr + 3 * F::sfs + 5 * ic + r], acc, aux);
-                        if (what == 2) { G[F::sfr + 5 * ic + r] = sg; G[F::sfr + F::sfs + 5 * ic + r] = ta; G[F::sfr + 2 * F::sfs + 5 * ic + r] = ga; }
-                    } else
-                    sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam,
-                              G[F::cc + 5 * ic + r], acc, aux);
-                    if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
-                }
+                const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                double t = tv[q], lam = lv[q];
+                if (C::SOFT && softp) {
+                    double sg = G[F::sfr + e], ta = G[F::sfr + F::sfs + e], ga = G[F::sfr + 2 * F::sfs + e];
+                    sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
+                                   cv5[q], G[F::sfr + 3 * F::sfs + e], acc, aux);
+                    if (what == 2) { G[F::sfr + e] = sg; G[F::sfr + F::sfs + e] = ta; G[F::sfr + 2 * F::sfs + e] = ga; }
+                } else
+                sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, cv5[q], acc, aux);
+                if (what == 2) { G[F::ct + e] = t; G[F::cl + e] = lam; }
             }
         }
         if (no > 0) {
@@ -2940,7 +2948,21 @@ struct upr_qp3 {
         (void)id;
 #endif
     }
+    // -DUPR_QP3_PROF_FLAT (experiment builds): slots 6 .. 9 time the parts of the update instead of the matrix sweep
+    UPR_HDI void ftoc(int id) {
+#ifdef UPR_QP3_PROF_FLAT
+        toc_raw(id);
+#else
+        (void)id;
+#endif
+    }
     UPR_HDI void toc(int id) {
+#ifdef UPR_QP3_PROF_FLAT
+        if (id >= 6 && id <= 9) return;
+#endif
+        toc_raw(id);
+    }
+    UPR_HDI void toc_raw(int id) {
 #ifndef UPR_HOST_EMU
 #ifdef UPR_QP3_PROF_MAT
         id = (id >= 100) ? id - 100 : ((id == 6) ? 1 : ((id == 8) ? 3 : ((id == 9) ? 5 : ((id == 7) ? 7 : 15))));
@@ -2966,6 +2988,12 @@ struct upr_qp3 {
 #endif
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
         lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
+#ifdef UPR_QP3_EXP_SHARELIN   // experiment only: every instance reads instance 0's record (what would the kernel gain if that traffic hit L2?)
+        lin = A.lin;
+#endif
+#ifdef UPR_QP3_EXP_SHAREG
+        G = A.ws + W::far;
+#endif
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
@@ -3114,20 +3142,43 @@ struct upr_qp3 {
             double ctm[NCT];
             forward<true>(ctm); toc(13);
             load_targets(ctm);
-            double a = reduce(ineq_sweep(0, 0.0, nullptr, ctm), 2);
+            const double a_loc = ineq_sweep(0, 0.0, nullptr, ctm);
+            ftoc(6);
+            double a = reduce(a_loc, 2);
+            ftoc(7);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
             ineq_sweep(2, a, nullptr, ctm);
             store_rows();
+            // (the multipliers' old values are requested in front of the barrier: their round trip overlaps it)
+            constexpr int QPI = (N1 * NX + NT - 1) / NT, QNU = (N * NE + NT - 1) / NT;
+            double pio[QPI], nuo[QNU], nun_[QNU];
+            {
+                const int tid_ = tid();
+#pragma unroll
+                for (int q = 0; q < QPI; ++q) { const int e = tid_ + q * NT; pio[q] = ws[W::pi + ((e < N1 * NX) ? e : 0)]; }
+#pragma unroll
+                for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT, ec = (e < N * NE) ? e : 0; nuo[q] = ws[W::nu + ec]; nun_[q] = G[F::nun + ec]; }
+            }
             UPR_SYNC();
-            UPR_FORT(e, N1 * NX) {
-                if (e >= NX) L[O::Z + e] += a * L[O::S + e];
-                ws[W::pi + e] += a * (L[O::Pa + e] - ws[W::pi + e]);
+            ftoc(8);
+            {
+                const int tid_ = tid();
+#pragma unroll
+                for (int q = 0; q < QPI; ++q) {
+                    const int e = tid_ + q * NT;
+                    if (e < N1 * NX) {
+                        if (e >= NX) L[O::Z + e] += a * L[O::S + e];
+                        ws[W::pi + e] = pio[q] + a * (L[O::Pa + e] - pio[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT; if (e < N * NE) ws[W::nu + e] = nuo[q] + a * (nun_[q] - nuo[q]); }
             }
             UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
-            UPR_FORT(e, N * NE) ws[W::nu + e] += a * (G[F::nun + e] - ws[W::nu + e]);
             UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
+            ftoc(9);
             toc(15);
         }
         // ---- result: step from the linearisation point
