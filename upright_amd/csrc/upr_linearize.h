@@ -135,18 +135,22 @@ static UPR_HDI void upr_lin_phase0(const upr_lin_args& A, const upr_lin_point& q
 #ifndef UPR_LIN_P0_BATCH
 #define UPR_LIN_P0_BATCH 1
 #endif
-template <int NQ, int NP>
+#ifndef UPR_LIN_OVERLAP
+#define UPR_LIN_OVERLAP 1   // the value walks (wave 0) run beside the staging (waves 1 - 3)
+#endif
+// G0: the first of the eight 32-lane groups that takes part (G0 = 2: wave 0 walks the chains meanwhile, see the kernel)
+template <int NQ, int NP, int G0 = 0>
 static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args& A, int base, int per, double* smem) {
     const upr_dims& d = A.d;
-    constexpr int NX = 3 * NQ;
+    constexpr int NX = 3 * NQ, NG = 8 - G0, NR = (8 * NP + NG - 1) / NG;
     static_assert(NX <= UPR_LPK, "one state element per lane");
-    const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    double xv[NP], uv[NP][2];
+    const int sub = (threadIdx.x >> 5) - G0, lane = threadIdx.x & 31;
+    double xv[NR], uv[NR][2];
 #pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-        const int p = base + pp * 8 + sub;
+    for (int pp = 0; pp < NR; ++pp) {
+        const int p = base + pp * NG + sub;
         xv[pp] = 0.0; uv[pp][0] = 0.0; uv[pp][1] = 0.0;
-        if (p < A.npoints) {
+        if (pp * NG + sub < 8 * NP && p < A.npoints) {
             const upr_lin_point q = upr_lin_locate(A, p);
             if (lane < NX) xv[pp] = q.x[lane];
             if (!q.terminal) {
@@ -157,7 +161,7 @@ static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args
     }
     if (A.Df != nullptr) {
         const int tot = 8 * NP * d.ne;
-        for (int idx = threadIdx.x; idx < tot; idx += 256) {
+        for (int idx = threadIdx.x - 32 * G0; idx < tot; idx += 32 * NG) {
             const int sp = idx / d.ne, r = idx - sp * d.ne, p = base + sp;
             if (p >= A.npoints) continue;
             const upr_lin_point q = upr_lin_locate(A, p);
@@ -183,9 +187,9 @@ static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args
         }
     }
 #pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-        const int slot = pp * 8 + sub, p = base + slot;
-        if (p < A.npoints) {
+    for (int pp = 0; pp < NR; ++pp) {
+        const int slot = pp * NG + sub, p = base + slot;
+        if (slot < 8 * NP && p < A.npoints) {
             double* sh = smem + slot * per;
             if (lane < NX) sh[lane] = xv[pp];
             if (lane < d.nu) sh[NX + lane] = uv[pp][0];
@@ -211,9 +215,10 @@ static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args
 #define UPR_LIN_ANALYTIC 1   // 0: every tangent lane walks the chain itself on (value, tangent) pairs (rounds 1 - 2; A/B runs)
 #endif
 template <int NQ>
-static UPR_HDI void upr_lin_phase1a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+static UPR_HDI void upr_lin_phase1a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh, const double* x = nullptr) {
 #if UPR_LIN_ANALYTIC
-    if (lane == 0) upr_ee_walk_snap<NQ>(A.P, sh, sh + upr_lin_lds_sc(A.d), sh + upr_lin_lds_snap(A.d, A.P->n_sph));
+    // (x: the state straight from the input when the staging into LDS runs at the same time on other waves)
+    if (lane == 0) upr_ee_walk_snap<NQ>(A.P, x ? x : sh, sh + upr_lin_lds_sc(A.d), sh + upr_lin_lds_snap(A.d, A.P->n_sph));
 #endif
 }
 
@@ -373,6 +378,19 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
         if (sp < 8 * NP && base + sp < A.npoints) { const upr_lin_point q = upr_lin_locate(A, base + sp); upr_lin_phase0_sc(A, q, sj, smem + sp * per); }
     }
 #endif
+#if UPR_LIN_P0_BATCH && UPR_LIN_SC_ONCE && UPR_LIN_ANALYTIC && UPR_LIN_OVERLAP
+    // The value walks (a serial chain on 8 NP lanes of wave 0, ~20 k cycles) need sin / cos and the state only: wave 0 walks with
+    // the state straight from the input while waves 1 - 3 do the staging and the rows of Df f.
+    static_assert(8 * NP <= 64, "walk lanes in wave 0");
+    __syncthreads();   // sin / cos
+    if (threadIdx.x < 64) {
+        const int p = base + threadIdx.x;
+        if (threadIdx.x < 8 * NP && p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase1a<NQ>(A, q, 0, smem + threadIdx.x * per, q.x); }
+    } else upr_lin_phase0_batched<NQ, NP, 2>(A, base, per, smem);
+    __syncthreads();
+    UPR_LIN_STAMP(0);
+    UPR_LIN_STAMP(1);
+#else
 #if UPR_LIN_P0_BATCH && UPR_LIN_SC_ONCE
     upr_lin_phase0_batched<NQ, NP>(A, base, per, smem);
 #else
@@ -391,6 +409,7 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     }
     __syncthreads();
     UPR_LIN_STAMP(1);
+#endif
 #endif
 #pragma unroll 1
     for (int pp = 0; pp < NP; ++pp) {

@@ -538,6 +538,7 @@ struct upr_qp3 {
                 L[O::hux + ei] = sr; L[O::hux + (N - 1) * UPR_QP3_NOMAX + ei] = wr;
             }
         }
+        ftoc(6, 2);
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -562,6 +563,7 @@ struct upr_qp3 {
                 L[O::wx + zo] = w0 + w1;
             }
         }
+        ftoc(7, 2);
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid_ + q * NT;
@@ -584,6 +586,7 @@ struct upr_qp3 {
                 L[O::wu + iu] = w0 + w1;
             }
         }
+        ftoc(8, 2);
         // dynamics residual of every knot in absolute variables (multiple-shooting defect of the iterate)
         if (fresh) UPR_FORT(e, N * NQ) {
             const int k = e / NQ, j = e % NQ;
@@ -593,6 +596,7 @@ struct upr_qp3 {
             L[O::bks + k * NX + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
             L[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
         }
+        ftoc(9, 2);
         UPR_SYNC(); toc(1);
         // end-effector part of the state gradient (knots 1 .. N-1), kept in gee for the corrector's pass
 #pragma unroll
@@ -2948,12 +2952,13 @@ struct upr_qp3 {
         (void)id;
 #endif
     }
-    // -DUPR_QP3_PROF_FLAT (experiment builds): slots 6 .. 9 time the parts of the update instead of the matrix sweep
-    UPR_HDI void ftoc(int id) {
+    // -DUPR_QP3_PROF_FLAT (experiment builds): slots 6 .. 9 time the parts of a flat phase instead of the matrix sweep
+    // (-DUPR_QP3_PROF_FLAT=1: the update, = 2: prep A)
+    UPR_HDI void ftoc(int id, int set = 1) {
 #ifdef UPR_QP3_PROF_FLAT
-        toc_raw(id);
+        if (set == UPR_QP3_PROF_FLAT) toc_raw(id);
 #else
-        (void)id;
+        (void)id; (void)set;
 #endif
     }
     UPR_HDI void toc(int id) {
