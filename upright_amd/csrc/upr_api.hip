@@ -80,7 +80,7 @@ __global__ void core_friction_rows_kernel(const upr_problem* P, int n, const dou
 
 // initial guess of every instance: previous solution re-sampled on the new grid (warm start), or the
 // stationary guess x_k = x0, u = 0 (DefaultInitializer); the first node is always the observation.
-__global__ void prepare_kernel(const upr_problem* P, upr_dims d, int B, const int* has_prev, const double* tprev,
+__global__ void prepare_kernel(const upr_problem* P, upr_dims d, int B, int has_prev /* a previous solution exists (every instance or none) */, const double* tprev,
                                const double* xs_prev, const double* us_prev, const double* t0, const double* x0,
                                double* xs, double* us, double* stats, int* done) {
     int b = blockIdx.x;
@@ -89,7 +89,7 @@ __global__ void prepare_kernel(const upr_problem* P, upr_dims d, int B, const in
     const double* up = us_prev + (size_t)b * N * nu;
     double* xo = xs + (size_t)b * (N + 1) * nx;
     double* uo = us + (size_t)b * N * nu;
-    const bool warm = has_prev[b] != 0;
+    const bool warm = has_prev != 0;
     for (int e = threadIdx.x; e < (N + 1) * nx; e += blockDim.x) {
         int k = e / nx, i = e % nx;
         double v;
@@ -226,7 +226,8 @@ struct upr_batch {
     double *body_params = nullptr, *way_p = nullptr, *way_q = nullptr, *t0 = nullptr, *x0 = nullptr;
     double *xs = nullptr, *us = nullptr, *xs_prev = nullptr, *us_prev = nullptr, *tprev = nullptr;
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
-    int *done = nullptr, *has_prev = nullptr;
+    int *done = nullptr;
+    bool has_prev = false;   // a solution of a previous advance exists (warm start, policy evaluation)
     int* order = nullptr;       // dispatch order of the QP launch: instances by the iteration count of their last QP, longest first
     bool order_on = true, order_valid = false;
     double* prof = nullptr;
@@ -560,32 +561,12 @@ upr_fb_src fb_source(const upr_batch* h) {
 // the headline's 10..13 iterations per instance, arrival order gives 25 on some slot against a mean of 22.7.  The
 // iteration count of an instance's previous QP predicts the next one well (same problem in a cold-start sweep, the
 // neighbouring problem in closed loop), so the launch hands the instances out sorted by it, longest first (LPT rule):
-// the short ones fill the gaps at the end.  Counting sort by one workgroup; the order within a bucket is whatever the
-// atomics give (it only permutes which workgroup solves which instance).
-__global__ void order_kernel(int B, const double* stats, int* order) {
-    __shared__ int cnt[256];
-    cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int key = (int)stats[(size_t)b * UPR_NSTATS + 1];
-        atomicAdd(&cnt[key < 0 ? 0 : (key > 255 ? 255 : key)], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int k = 255; k >= 0; --k) { const int c = cnt[k]; cnt[k] = acc; acc += c; }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int key = (int)stats[(size_t)b * UPR_NSTATS + 1];
-        order[atomicAdd(&cnt[key < 0 ? 0 : (key > 255 ? 255 : key)], 1)] = b;
-    }
-}
-
+// the short ones fill the gaps at the end.  The rank of an instance (ties by index) is computed by its own workgroup of the
+// line-search launch that follows the QP (upr_linesearch.h, order_out): it only permutes which workgroup solves which instance.
 int advance_impl(upr_batch* h) {
     const upr_dims& d = h->d;
     if (!h->guess_set) {
-        hipLaunchKernelGGL(prepare_kernel, dim3(h->B), dim3(256), 0, h->stream, h->dP, d, h->B, h->has_prev, h->tprev,
+        hipLaunchKernelGGL(prepare_kernel, dim3(h->B), dim3(256), 0, h->stream, h->dP, d, h->B, h->has_prev ? 1 : 0, h->tprev,
                            h->xs_prev, h->us_prev, h->t0, h->x0, h->xs, h->us, h->stats, h->done);
         UPR_HIP(hipGetLastError());
     } else {
@@ -603,16 +584,16 @@ int advance_impl(upr_batch* h) {
             if (h->fb && h->fb_fused && it == sqp_iters - 1) Q.fb = h->fb;
             if (h->order_on && h->order_valid) Q.order = h->order;
             KernelTimer T(h, 1); if (launch_qp(h, Q)) return 1; T.stop();
-            if (h->order_on) {
-                hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->stats, h->order);
-                UPR_HIP(hipGetLastError());
-                h->order_valid = true;
-            }
         }
         upr_ls_args L;
         L.P = h->dP; L.d = d; L.xs = h->xs; L.us = h->us; L.x0 = h->x0; L.t0 = h->t0; L.body_params = h->body_params;
         L.way_p = h->way_p; L.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
+        // folded into the line search's launch: the dispatch order of the next QP (rounds 2 - 3a: a one-workgroup counting sort
+        // of its own) and, behind the advance's last line search, the copy of the solution the next warm start reads
+        if (h->order_on) L.order_out = h->order;
+        if (it == sqp_iters - 1) { L.xs_prev = h->xs_prev; L.us_prev = h->us_prev; L.tprev = h->tprev; }
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
+        if (h->order_on) h->order_valid = true;
     }
     if (h->fb && !(h->fb_fused && sqp_iters > 0)) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
         if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
@@ -620,11 +601,13 @@ int advance_impl(upr_batch* h) {
         UPR_HIP(hipGetLastError());
     }
     h->hdyn_prev = h->hdyn0;
-    // remember the solution for the next warm start / policy evaluation
-    UPR_HIP(hipMemcpyAsync(h->xs_prev, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
-    UPR_HIP(hipMemcpyAsync(h->us_prev, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
-    UPR_HIP(hipMemcpyAsync(h->tprev, h->t0, sizeof(double) * h->B, hipMemcpyDeviceToDevice, h->stream));
-    UPR_HIP(hipMemsetAsync(h->has_prev, 1, sizeof(int) * h->B, h->stream));  // any non-zero pattern
+    // remember the solution for the next warm start / policy evaluation (the last line search did, unless there was none)
+    if (sqp_iters <= 0) {
+        UPR_HIP(hipMemcpyAsync(h->xs_prev, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
+        UPR_HIP(hipMemcpyAsync(h->us_prev, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
+        UPR_HIP(hipMemcpyAsync(h->tprev, h->t0, sizeof(double) * h->B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->has_prev = true;
     return 0;
 }
 
@@ -725,7 +708,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
         dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) || dev_alloc(&h->order, B) ||
-        dev_alloc(&h->has_prev, B) || (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
+        (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
         (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9) || dev_alloc(&h->pflag, B))))
         return bad();
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
@@ -762,7 +745,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->order); hipFree(h->has_prev); hipFree(h->prof); hipFree(h->kkt);
+    hipFree(h->done); hipFree(h->order); hipFree(h->prof); hipFree(h->kkt);
     hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -772,7 +755,7 @@ void upr_batch_destroy(upr_batch* h) {
 int upr_batch_reset(upr_batch* h, const double* way_p) {
     if (!h) return fail("null batch");
     if (way_p) UPR_HIP(hipMemcpyAsync(h->way_p, way_p, sizeof(double) * h->B * h->P.n_way * 3, hipMemcpyHostToDevice, h->stream));
-    UPR_HIP(hipMemsetAsync(h->has_prev, 0, sizeof(int) * h->B, h->stream));
+    h->has_prev = false;
     UPR_HIP(hipStreamSynchronize(h->stream));
     h->guess_set = false;
     return 0;
@@ -1117,7 +1100,7 @@ void* upr_batch_stream(upr_batch* h) { return h ? (void*)h->stream : nullptr; }
 /* forget the previous solution without a host synchronisation (cold start for the next advance) */
 int upr_batch_reset_async(upr_batch* h) {
     if (!h) return fail("null batch");
-    UPR_HIP(hipMemsetAsync(h->has_prev, 0, sizeof(int) * h->B, h->stream));
+    h->has_prev = false;
     h->guess_set = false;
     return 0;
 }

@@ -27,6 +27,12 @@ struct upr_ls_args {
     const double* dyn = nullptr;    // [B][9] observed dynamic-obstacle state (NULL: none)
     const double* pflag = nullptr;  // [B] projectile activation flag
     const double* way_q = nullptr;  // [B][n_way][4] target orientations; NULL unless Wee[3..5] != 0
+    // Engine bookkeeping folded into this launch (device kernel only; each was a stream operation of its own):
+    //   order_out: the dispatch order of the NEXT QP launch, longest first by the iteration count the QP that just ran left in
+    //              stats[.][1] -- every workgroup ranks its own instance (ties by index);
+    //   xs_prev ..: the solution remembered for the next warm start / policy evaluation (the advance's last line search)
+    int* order_out = nullptr;
+    double* xs_prev = nullptr; double* us_prev = nullptr; double* tprev = nullptr;
 };
 
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
@@ -348,7 +354,27 @@ template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODI
 __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
+    static_assert(NT == 64, "one wave per instance (the rank below is a wave reduction)");
+    if (A.order_out) {
+        const int B = gridDim.x, me = blockIdx.x;
+        auto key = [&](int o) { const int k = (int)A.stats[(size_t)o * UPR_NSTATS + 1]; return k < 0 ? 0 : (k > 255 ? 255 : k); };
+        const int mk = key(me);
+        int cnt = 0;
+        for (int o = threadIdx.x; o < B; o += NT) { const int k = key(o); cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (threadIdx.x == 0) A.order_out[cnt] = me;
+    }
     upr_ls_instance<NQ, NFM, NBM, EXACT>(ctx, A, blockIdx.x, smem);
+    if (A.xs_prev) {
+        __syncthreads();
+        const int b = blockIdx.x, nxs = (A.d.N + 1) * A.d.nx, nus = A.d.N * A.d.nu;
+        const double* xs = A.xs + (size_t)b * nxs; const double* us = A.us + (size_t)b * nus;
+        double* xp = A.xs_prev + (size_t)b * nxs; double* up = A.us_prev + (size_t)b * nus;
+        for (int e = threadIdx.x; e < nxs; e += NT) xp[e] = xs[e];
+        for (int e = threadIdx.x; e < nus; e += NT) up[e] = us[e];
+        if (threadIdx.x == 0) A.tprev[b] = A.t0[b];
+    }
 }
 #endif
 
