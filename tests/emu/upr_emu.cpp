@@ -159,7 +159,7 @@ void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const d
     A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter; A.way_q = upr_has_orientation_cost(P) ? g_way_q : nullptr;
     if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
     upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
-    std::vector<double> L(64);
+    std::vector<double> L(upr_ls_lds_doubles(A.d, 1) + 16);
     for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data()); else upr_ls_instance<9>(ctx, A, b, L.data()); }
 }
 }

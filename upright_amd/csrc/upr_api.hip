@@ -30,7 +30,7 @@ int fail(const std::string& msg) {
 #define UPR_HIP(call)                                                                                 \
     do {                                                                                              \
         hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));       \
+        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_) + " (upr_api.hip:" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
 // device scratch of one call: freed on every exit path (the early returns of UPR_HIP included)
@@ -303,7 +303,7 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     const bool multi = UPR_LIN_ANALYTIC && !A.way_q && h->use_mfma && occ == 2 && A.d.no == 0;
     const int KPW = 8 * (multi ? UPR_LIN_PASSES : 1);
     const int blocks = (A.npoints + KPW - 1) / KPW;
-    const size_t lds = (size_t)KPW * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double);
+    const size_t lds = (size_t)KPW * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
     if (lds > 160 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
     // (rounds 1 - 2, one forward-mode walk per tangent lane: 2 -> 0.130 ms, 3 -> 0.142 ms, 4 -> 0.32 ms with spills; round 3, one value
     // walk per knot + closed-form tangents: 2 -> 0.091 ms, 3 -> 0.085 ms;
@@ -483,13 +483,23 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
 }
 
 template <int NQ>
-int launch_linesearch(upr_batch* h, const upr_ls_args& A) {
-    const size_t lds = (size_t)(4 * 64 + 8) * sizeof(double);
+int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
+    upr_ls_args A = A0;
+    size_t lds = (size_t)upr_ls_lds_doubles(h->d, 64) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
+    if (lds > 64 * 1024) {   // long horizons of the large shapes: the trial trajectory only
+        A.stage_full = 0;
+        lds = (size_t)upr_ls_lds_doubles(h->d, 64, false) * sizeof(double) + sizeof(upr_problem) + 16;
+        if (lds > 160 * 1024) return fail("horizon too long for the line-search kernel's LDS");
+    }
+    auto launch = [&](void (*kern)(upr_ls_args)) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(h->B), dim3(64), lds, h->stream, A);
+    };
     // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
     // exactly the headline's contact structure (one body on the tray, four frictional contacts): every bound a constant
-    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1, true>), dim3(h->B), dim3(64), lds, h->stream, A);
-    else if (h->d.nfc <= 12 && h->d.nb == 1) hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64, 12, 1>), dim3(h->B), dim3(64), lds, h->stream, A);
-    else hipLaunchKernelGGL((upr_linesearch_kernel<NQ, 64>), dim3(h->B), dim3(64), lds, h->stream, A);
+    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(upr_linesearch_kernel<NQ, 64, 12, 1, true>);
+    else if (h->d.nfc <= 12 && h->d.nb == 1) launch(upr_linesearch_kernel<NQ, 64, 12, 1>);
+    else launch(upr_linesearch_kernel<NQ, 64>);
     UPR_HIP(hipGetLastError());
     return 0;
 }

@@ -362,7 +362,16 @@ __device__ unsigned long long upr_lin_prof[8];
 // times larger and one pass per workgroup measured best: configs[2] 1.11 ms against 1.70 ms with three passes)
 template <int NQ, bool USE_MFMA, int OCC = 2, bool ORI = false, int NPASS = 1>
 __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem_all[];
+    // the problem record in LDS (upr_linesearch.h: its elements are read all over the phases, the joint frames on the serial
+    // chain walk -- out of global memory each is a vector load with its own wait); visible behind the first barrier below
+    static_assert(sizeof(upr_problem) % sizeof(double) == 0, "copied as doubles");
+    constexpr int NPD = (int)(sizeof(upr_problem) / sizeof(double));
+    double* smem = smem_all + ((NPD + 1) & ~1);
+    {
+        const double* src = reinterpret_cast<const double*>(A.P);
+        for (int i = threadIdx.x; i < NPD; i += 256) smem_all[i] = src[i];
+    }
     constexpr int NP = UPR_LIN_ANALYTIC ? NPASS : 1;
     const int per = upr_lin_lds_doubles(A.d, A.P->n_sph);
     const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
@@ -382,7 +391,8 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     // The value walks (a serial chain on 8 NP lanes of wave 0, ~20 k cycles) need sin / cos and the state only: wave 0 walks with
     // the state straight from the input while waves 1 - 3 do the staging and the rows of Df f.
     static_assert(8 * NP <= 64, "walk lanes in wave 0");
-    __syncthreads();   // sin / cos
+    __syncthreads();   // sin / cos, the copy of the problem record
+    A.P = reinterpret_cast<const upr_problem*>(smem_all);
     if (threadIdx.x < 64) {
         const int p = base + threadIdx.x;
         if (threadIdx.x < 8 * NP && p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase1a<NQ>(A, q, 0, smem + threadIdx.x * per, q.x); }
@@ -401,6 +411,7 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     }
 #endif
     __syncthreads();
+    A.P = reinterpret_cast<const upr_problem*>(smem_all);
     UPR_LIN_STAMP(0);
 #if UPR_LIN_ANALYTIC
     if (threadIdx.x < 8 * NP) {

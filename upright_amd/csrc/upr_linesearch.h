@@ -33,6 +33,7 @@ struct upr_ls_args {
     //   xs_prev ..: the solution remembered for the next warm start / policy evaluation (the advance's last line search)
     int* order_out = nullptr;
     double* xs_prev = nullptr; double* us_prev = nullptr; double* tprev = nullptr;
+    int stage_full = 1;    // the instance's trajectory and step staged in LDS (upr_ls_lds_doubles)
 };
 
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
@@ -56,18 +57,17 @@ static UPR_HDI void upr_object_wrench_single(const upr_problem* P, const double*
     }
 }
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
-static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha, double* out) {
+// Xt / Ut: the trial trajectory xs + alpha dx, us + alpha du of the instance (staged by the workgroup, LDS on the device);
+// sc: (sin, cos) of the trial joint angles of every knot, [N + 1][NQ][2]
+static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double* Xt, const double* Ut, const double* sc, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N;
     constexpr int nq = NQ, nx = 3 * NQ;
     const int nu = EXACT ? NQ + NFM : d.nu;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
-    const double* xs = A.xs + (size_t)b * (N + 1) * nx; const double* us = A.us + (size_t)b * N * nu;
-    const double* ws = A.ws + (size_t)b * d.ws_stride;
-    const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
     double X[3 * NQ], U[NQ + NFM];
 #pragma unroll
-    for (int i = 0; i < nx; ++i) X[i] = xs[k * nx + i] + alpha * dx[k * nx + i];
+    for (int i = 0; i < nx; ++i) X[i] = Xt[k * nx + i];
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
     const double wt = (k < N) ? h : 1.0;
     if (k == 0) {
@@ -88,12 +88,12 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
         for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, dd[r]); iq += h * v * v; }
     }
     upr_ee<double> E;
-    upr_ee_kinematics<double, NQ>(P, X, -1, E);
+    upr_ee_kinematics<double, NQ>(P, X, -1, E, sc + k * 2 * NQ);
     double pd[3];
     upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * h, pd);
     if (k < N) {
 #pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) U[i] = us[k * nu + i] + alpha * du[k * nu + i];
+        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) U[i] = Ut[k * nu + i];
         double c = 0.0;
 #pragma unroll
         for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
@@ -111,10 +111,10 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
 #pragma unroll
         for (int j = 0; j < nq; ++j) {
             double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
-            const double* xn = xs + (k + 1) * nx; const double* dn = dx + (k + 1) * nx;
-            double e0 = q + h * v + h2 * a + h3 * u - (xn[j] + alpha * dn[j]);
-            double e1 = v + h * a + h2 * u - (xn[nq + j] + alpha * dn[nq + j]);
-            double e2 = a + h * u - (xn[2 * nq + j] + alpha * dn[2 * nq + j]);
+            const double* xn = Xt + (k + 1) * nx;
+            double e0 = q + h * v + h2 * a + h3 * u - xn[j];
+            double e1 = v + h * a + h2 * u - xn[nq + j];
+            double e2 = a + h * u - xn[2 * nq + j];
             dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
         }
         // object-dynamics equality
@@ -156,13 +156,13 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, double alpha
 // object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
 // of walking the chain again
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, bool EXACT = false>
-static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double* out) {
+static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, const double* xs_l, const double* us_l, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N;
     constexpr int nq = NQ, nx = 3 * NQ;
     const int nu = EXACT ? NQ + NFM : d.nu;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
-    const double* X = A.xs + ((size_t)b * (N + 1) + k) * nx;
+    const double* X = xs_l + k * nx;   // (the instance's trajectory, staged)
     const double* rec = A.lin + ((size_t)b * (N + 1) + k) * d.lin_stride;
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
     const double wt = (k < N) ? h : 1.0;
@@ -183,7 +183,7 @@ static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, double*
     }
     if (!EXACT && d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
     if (k < N) {
-        const double* U = A.us + ((size_t)b * N + k) * nu;
+        const double* U = us_l + k * nu;
         const double* xn = X + nx;
         double c = rec[d.lin_cost];
 #pragma unroll
@@ -251,7 +251,14 @@ static __device__ __forceinline__ void upr_ls_reduce4_wave(const double* part, d
 #define UPR_LS_REDUCE4(part, res) upr_ls_reduce4(ctx, L, part, res)
 #endif
 
-// L: 4*nt + 8 doubles of workgroup scratch
+// Workgroup scratch (doubles): the reduction area, then the instance's trajectory and step staged with coalesced requests
+// (a lane per knot reading its knot's 27 + 21 doubles straight from global memory touches a cache line of its own per
+// request: the address unit then serialises 21 lines per instruction -- the baseline pass alone took 24 k cycles), the
+// trial trajectory xs + alpha dx, us + alpha du of the step length in work, and (sin, cos) of its joint angles (computed
+// a lane per (knot, joint): inside the chain walk they were nine f64 sincos in series per lane)
+// (stage_full = 0 -- long horizons of the large shapes, where three copies do not fit: only the trial trajectory and the
+// sines / cosines live in LDS, the trajectory and the step are read where they lie)
+static UPR_HDI int upr_ls_lds_doubles(const upr_dims& d, int nt, bool full = true) { return 4 * nt + 8 + (full ? 3 : 1) * ((d.N + 1) * d.nx + d.N * d.nu) + 2 * (d.N + 1) * d.nq + 8; }
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
 static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
@@ -272,16 +279,25 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     const double* ws = A.ws + (size_t)b * d.ws_stride;
     const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
     const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
+    const int nxs = (N + 1) * nx, nus = N * nu;
+    double* Xt = L + ((4 * ctx.nt + 8 + 1) & ~1); double* Ut = Xt + nxs; double* sc = Ut + nus;
+    const double* xs_l = xs; const double* us_l = us; const double* dx_l = dx; const double* du_l = du;
+    if (A.stage_full) {
+        double* sx_ = sc + 2 * (N + 1) * nq; double* su_ = sx_ + nxs; double* sdx_ = su_ + nus; double* sdu_ = sdx_ + nxs;
+        UPR_FOR(i, nxs) { sx_[i] = xs[i]; sdx_[i] = dx[i]; }
+        UPR_FOR(i, nus) { su_[i] = us[i]; sdu_[i] = du[i]; }
+        UPR_SYNC();
+        xs_l = sx_; us_l = su_; dx_l = sdx_; du_l = sdu_;
+    }
     // baseline, step norms and Armijo descent metric (cost gradient . step)
     double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
-    UPR_FOR(k, N + 1) upr_ls_knot_base<NQ, NFM, EXACT>(A, b, k, part);
-    UPR_LS_REDUCE4(part, base);
-    UPR_LS_STAMP();
+    // (one pass over the knots for both sets of sums: the requests of the second set are in flight beside the first's)
     UPR_FOR(k, N + 1) {
+        upr_ls_knot_base<NQ, NFM, EXACT>(A, b, k, xs_l, us_l, part);
         constexpr int nxc = 3 * NQ;
         double sx[nxc], xv[nxc], gq[NQ];
 #pragma unroll
-        for (int i = 0; i < nxc; ++i) { sx[i] = dx[k * nxc + i]; xv[i] = (k < N) ? xs[k * nxc + i] : 0.0; }
+        for (int i = 0; i < nxc; ++i) { sx[i] = dx_l[k * nxc + i]; xv[i] = (k < N) ? xs_l[k * nxc + i] : 0.0; }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) gq[i] = (k < N) ? lin[(size_t)k * d.lin_stride + d.lin_grad + i] : 0.0;
 #pragma unroll
@@ -299,16 +315,18 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
                 constexpr int nuc = NQ + NFM;
                 double su[nuc], uv[nuc];
 #pragma unroll
-                for (int i = 0; i < nuc; ++i) { su[i] = du[k * nuc + i]; uv[i] = us[k * nuc + i]; }
+                for (int i = 0; i < nuc; ++i) { su[i] = du_l[k * nuc + i]; uv[i] = us_l[k * nuc + i]; }
 #pragma unroll
                 for (int i = 0; i < nuc; ++i) { aux[2] += su[i] * su[i]; aux[0] += P->dt * P->Rdiag[i] * uv[i] * su[i]; }
             } else for (int i = 0; i < nu; ++i) {
-                double s = du[k * nu + i];
+                double s = du_l[k * nu + i];
                 aux[2] += s * s;
-                aux[0] += P->dt * P->Rdiag[i] * us[k * nu + i] * s;
+                aux[0] += P->dt * P->Rdiag[i] * us_l[k * nu + i] * s;
             }
         }
     }
+    UPR_LS_REDUCE4(part, base);
+    UPR_LS_STAMP();
     UPR_LS_REDUCE4(aux, auxr);
     UPR_LS_STAMP();
     const double descent = auxr[0], dxn = sqrt(auxr[1]), dun = sqrt(auxr[2]);
@@ -318,7 +336,16 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     if (qp_status != 2.0) {
         do {
             double p2[4] = {0, 0, 0, 0};
-            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT>(A, b, k, alpha, p2);
+            UPR_FOR(i, nxs) Xt[i] = xs_l[i] + alpha * dx_l[i];
+            UPR_FOR(i, nus) Ut[i] = us_l[i] + alpha * du_l[i];
+            UPR_FOR(e, (N + 1) * NQ) {
+                const int k = e / NQ, j = e % NQ;
+                double s_ = 0.0, c_ = 1.0;
+                if (P->joint_type[j] == 1) upr_sincos(xs_l[k * nx + j] + alpha * dx_l[k * nx + j], &s_, &c_);
+                sc[2 * e] = s_; sc[2 * e + 1] = c_;
+            }
+            UPR_SYNC();
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT>(A, b, k, Xt, Ut, sc, p2);
             UPR_LS_REDUCE4(p2, perf);
             double viol = sqrt(perf[1] + perf[2] + perf[3]);
             if (viol > g_max) accepted = false;
@@ -331,8 +358,8 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     UPR_LS_STAMP();
     double cost = base[0], viol = base_viol;
     if (accepted) {
-        UPR_FOR(i, (N + 1) * nx) xs[i] += alpha * dx[i];
-        UPR_FOR(i, N * nu) us[i] += alpha * du[i];
+        UPR_FOR(i, nxs) xs[i] = Xt[i];   // (the trial trajectory of the accepted step length: xs + alpha dx, as staged)
+        UPR_FOR(i, nus) us[i] = Ut[i];
         cost = perf[0]; viol = sqrt(perf[1] + perf[2] + perf[3]);
     }
     bool conv = !accepted;                                                           // STEPSIZE
@@ -365,7 +392,20 @@ __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (threadIdx.x == 0) A.order_out[cnt] = me;
     }
-    upr_ls_instance<NQ, NFM, NBM, EXACT>(ctx, A, blockIdx.x, smem);
+    // The problem record (joint frames, bounds, weights, contacts: 11 KB) is read all over the evaluation, element by element
+    // and mostly on the serial chain walk -- out of global memory every one of those reads is a vector load with a wait of
+    // its own (the record may alias the kernel's stores, so they are not scalar loads): a copy in LDS, made with coalesced
+    // requests, serves them instead.
+    static_assert(sizeof(upr_problem) % sizeof(double) == 0, "copied as doubles");
+    constexpr int NPD = (int)(sizeof(upr_problem) / sizeof(double));
+    {
+        const double* src = reinterpret_cast<const double*>(A.P);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < NPD; i += NT) smem[i] = src[i];
+        __syncthreads();
+        A.P = reinterpret_cast<const upr_problem*>(smem);
+    }
+    upr_ls_instance<NQ, NFM, NBM, EXACT>(ctx, A, blockIdx.x, smem + ((NPD + 1) & ~1));
     if (A.xs_prev) {
         __syncthreads();
         const int b = blockIdx.x, nxs = (A.d.N + 1) * A.d.nx, nus = A.d.N * A.d.nu;
