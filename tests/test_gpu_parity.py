@@ -1473,7 +1473,7 @@ def test_headline_batch_iteration_counts_equal_the_oracles():
 
 def test_longest_first_dispatch_only_permutes_the_workgroups(arrangements, monkeypatch):
     """From the second QP launch of a handle on, workgroup i solves the instance with the i-th largest iteration count of
-    the previous launch (upr_api.hip order_kernel).  That is scheduling only: trajectories, gains and statistics are
+    the previous launch (ranked by the line-search launch, upr_linesearch.h order_out).  That is scheduling only: trajectories, gains and statistics are
     bitwise those of the plain launch order."""
     B = 192
     P, x0, way = _setup(arrangements, B, seed=71, use_feedback_policy=True)

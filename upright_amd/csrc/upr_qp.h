@@ -66,7 +66,7 @@ struct upr_qp_args {
     // it on the last QP of an advance only (upr_api.hip)
     double* fb = nullptr;
     // optional dispatch order: workgroup i solves instance order[i] (a permutation of 0..B-1).  The host passes the
-    // instances sorted by the IPM iteration count of their previous QP, longest first (upr_api.hip, order_kernel)
+    // instances sorted by the IPM iteration count of their previous QP, longest first (ranked inside the line-search launch, upr_linesearch.h order_out)
     const int* order = nullptr;
 };
 static UPR_HDI int upr_qp_instance(const upr_qp_args& A, int wg) { return A.order ? A.order[wg] : wg; }
