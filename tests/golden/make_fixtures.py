@@ -291,6 +291,9 @@ def main():
         # BASELINE config 4: the upright_robust planning demo (slacks, init_sqp_iteration 3, T = 10 s); its arrangement
         # is assembled at run time by planning_sim_loop.py:454-534 (robust_8corner above carries the same values)
         "robust_sim": "upright_robust/config/demos/sim.yaml",
+        # the sudden-obstacle experiments of the paper (not a BASELINE config; the same path): static obstacles of simple.yaml + ONE
+        # dynamic obstacle whose position jumps at t = 1 s (two `modes`; the simulator / Vicon re-sets the observed state)
+        "sudden_t1.0": "upright_cmd/config/ral23/experiments/sudden_obstacle/sudden_t1.0.yaml",
     }.items():
         d = core.parsing.load_config((REF / rel).as_posix())
         c = d["controller"]

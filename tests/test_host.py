@@ -43,7 +43,8 @@ def test_include_resolution(tmp_path):
         config.load_config(tmp_path / "pkg" / "loop.yaml")
 
 
-@pytest.mark.parametrize("name,arr", [("full_bottle_point1", "pink_bottle"), ("thing_demo", "pink_bottle"), ("ur10_demo", "pink_bottle")])
+@pytest.mark.parametrize("name,arr", [("full_bottle_point1", "pink_bottle"), ("thing_demo", "pink_bottle"), ("ur10_demo", "pink_bottle"),
+                                      ("sudden_t1.0", "pink_bottle"), ("projectile_head_on", "pink_bottle")])
 def test_controller_settings_match_reference_parse(arrangements, name, arr):
     """Row P of SURVEY.md section 8a: the merged controller dict of the reference (golden) through our
     ControllerSettings gives field-for-field the numbers the reference's wrappers.py computes."""
@@ -51,15 +52,24 @@ def test_controller_settings_match_reference_parse(arrangements, name, arr):
     c, par = g["controller"], g["parsed"]
     bodies, contacts = control.objects_from_fixture(arrangements[arr])
     s = control.ControllerSettings(c, bodies=bodies, contacts=contacts)
-    assert np.array_equal(s.initial_state, np.array(par["x0"]))
+    assert np.array_equal(s.initial_state[:len(par["x0"])], np.array(par["x0"]))   # (the robot part: obstacle states follow, below)
     for k in ("input_weight", "state_weight", "end_effector_weight", "input_limit_lower", "input_limit_upper",
               "state_limit_lower", "state_limit_upper"):
         assert np.array_equal(getattr(s, k), np.array(par[k])), k
     assert s.mpc.time_horizon == par["time_horizon"] and s.sqp.dt == par["dt"]
     assert s.dims.c == par["n_contacts"] and len(s.balancing_settings.bodies) == par["n_bodies"]
     assert s.dims.nf == (1 if c["balancing"]["frictionless"] else 3)
-    assert s.dims.x() == c["robot"]["dims"]["x"] and s.dims.u() == c["robot"]["dims"]["u"] + s.dims.nf * s.dims.c
+    assert s.dims.x() == c["robot"]["dims"]["x"] + 9 * s.dims.o and s.dims.u() == c["robot"]["dims"]["u"] + s.dims.nf * s.dims.c   # dimensions.h:32-45
     assert s.sqp.hpipm.iter_max == 30 and s.sqp.sqp_iteration == 1 and s.tracking.min_policy_update_time == 0.01
+    # dynamic obstacles (wrappers.py:360-396): modes parsed in order, the interface state seeded with modes[0] at rest
+    dyn = (c.get("obstacles") or {}).get("dynamic") or []
+    if c.get("obstacles", {}).get("enabled") and dyn:
+        obs = list(s.obstacle_settings.dynamic_obstacles)
+        assert len(obs) == len(dyn) and s.dims.o == len(dyn) and len(s.initial_state) == s.dims.robot.x + 9 * len(dyn)
+        for o, oc in zip(obs, dyn):
+            assert o.name == oc["name"] and o.radius == oc["radius"] and len(o.modes) == len(oc["modes"])
+            for mo, mc in zip(o.modes, oc["modes"]):
+                assert mo.time == mc["time"] and np.array_equal(mo.position, mc["position"]) and np.array_equal(mo.velocity, mc["velocity"])
 
 
 def test_problem_from_settings_and_unsupported_terms(arrangements):
