@@ -231,7 +231,8 @@ def contract_workload(B):
 def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     """configs[4]: `ticks` control periods of 10 ms for the whole batch: observation in (host -> device), one warm-started
     SQP iteration, policy out (device -> host), exact triple-integrator plant and ballistic ball on the host.  The
-    plant's states come from outside the engine every tick, so this rate includes both PCIe hops by construction."""
+    plant's states come from outside the engine every tick, so this rate includes both PCIe hops by construction.  One
+    `upr_batch_tick` per period (= setObservation + advanceMpc + evaluateMpcSolution of manager.py:156-176, one synchronisation)."""
     mpc = engine if engine is not None else make_engine(w)
     P, B = w["P"], mpc.B
     world = dist.get_world_size() if dist is not None else 1
@@ -241,12 +242,12 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     broke = [0]
     lat = []
     u0_all = [None]
+    stq_ = [None]
 
     def tick(x, t):
         tc = time.perf_counter()
-        mpc.set_observation(t, x)
-        mpc.advance()
-        _, u = mpc.evaluate(t, x_obs=x)
+        _, u, st_ = mpc.tick(t, x, want_stats=True)    # observation in, one SQP iteration, policy at the observation + statistics out: one call
+        stq_[0] = st_["qp_status_last"]
         if world > 1:   # exchange step of the closed loop: only u_0 of every instance, [B, nu] per rank
             import torch
 
@@ -266,7 +267,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     t0 = time.perf_counter()
     for _ in range(ticks):
         x = tick(x, t); t += dt
-        stq = mpc.stats()["qp_status_last"]
+        stq = stq_[0]
         failed += int(np.sum(stq != 0)); broke[0] += int(np.sum(stq == 2))
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -201,6 +201,14 @@ int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_ou
  * K_j are the Riccati gains of the last QP (sign convention of ocs2: u = bias + K x).  x_obs[B][nx], outputs as
  * upr_batch_evaluate.  Needs use_feedback_policy != 0 at creation. */
 int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out);
+/* One control period of the reference's loop in ONE call and one synchronisation: what ControllerManager.step does with three
+ * (manager.py:156-176: setObservation(t, x) -> advanceMpc() -> evaluateMpcSolution(t, x, x_opt, u_opt)), for callers that replan
+ * every period.  The observation is uploaded once (the policy is evaluated at the state that was just observed, at its own time),
+ * transfers go through the engine's pinned staging buffer, and the statistics of the solve come back with the result.
+ * x[B][nx_full] observed states, x_out[B][nx_full], u_out[B][nu] as upr_batch_evaluate[_policy]; stats_out[B][UPR_NSTATS] or NULL.
+ * Results are bit-identical to the three calls. */
+int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x, double* x_out, double* u_out, double* stats_out);
+
 /* ControllerInterface.getLinearFeedbackGain (pybindings.cpp:382-384) at the knots: K[B][N][nu][nx]; jerk rows from the
  * Riccati recursion, contact-force rows from the elimination of the object-dynamics equality
  * (f = f* - Hff^-1 Df' S^-1 C dx). */

@@ -1768,3 +1768,39 @@ def test_closed_loop_thrown_ball_with_soft_rows(arrangements):
     assert not np.any(failed == 2), np.argwhere(failed == 2)            # no broken factorisation: every tick has a policy
     assert np.mean(failed != 0) < 0.01, np.argwhere(failed != 0)        # (a stray tick at the iteration cap is not a failure of the loop)
     assert mind.min() > 0.28
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["headline", "thrown_ball"])
+def test_tick_equals_the_three_calls(arrangements, case):
+    """upr_batch_tick = set_observation + advance + evaluate at the observation (manager.py:156-176) in one call: bit-identical
+    plan, policy output and statistics over a short closed loop, for the plain state and for interface states with a dynamic
+    obstacle."""
+    B = 8
+    if case == "headline":
+        P = thing_problem(arrangements["pink_bottle"], use_feedback_policy=True)
+        x = level_tray_states(B, seed=5); way = waypoints_for(P, x)
+    else:
+        from test_emu import _projectile_case
+        P, x0r, way, _, _, dyn = _projectile_case(arrangements, B, use_feedback_policy=True)
+        x = np.concatenate([x0r, dyn], axis=1)
+    a, b = BatchMPC(P, B, way_p=way), BatchMPC(P, B, way_p=way)
+    if case != "headline":
+        a.set_projectile_flag(1.0); b.set_projectile_flag(1.0)
+    t, dt = 0.0, 0.01
+    for tick in range(5):
+        a.set_observation(t, x); a.advance(); xa, ua = a.evaluate(t, x_obs=x)
+        xb, ub, sb = b.tick(t, x, want_stats=True)
+        sa = a.stats()
+        assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+        assert np.array_equal(a.solution()[1], b.solution()[1])
+        j = ua[:, :9]
+        q, v, acc = x[:, :9], x[:, 9:18], x[:, 18:27]
+        xn = np.concatenate([q + dt * v + dt ** 2 / 2 * acc + dt ** 3 / 6 * j, v + dt * acc + dt ** 2 / 2 * j, acc + dt * j], axis=1)
+        if x.shape[1] > 27:
+            ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
+            xn = np.concatenate([xn, ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
+        x = xn; t += dt
+    a.close(); b.close()

@@ -336,15 +336,20 @@ class BatchControllerManager:
         settings = ControllerSettings(config, x0=x0[0], bodies=bodies, contacts=contacts)
         return cls(settings, config, x0, targets=targets, body_params=body_params)
 
-    def _solve(self, t, x):
+    def _solve(self, t, x, tick=False):
         cold = bool(self.settings.mpc.cold_start)
         if cold and not self._fresh:
             self.mpc.reset()
         if self._fresh or cold:
             self.mpc.set_sqp_iterations(int(self.settings.sqp.init_sqp_iteration))
-        self.mpc.set_observation(t, x)
-        self.mpc.advance()
+        out = None
+        if tick:    # observation in, solve, policy at the observation out: one call, one synchronisation (upr_batch_tick)
+            out = self.mpc.tick(t, x)
+        else:
+            self.mpc.set_observation(t, x)
+            self.mpc.advance()
         self._fresh = False
+        return out
 
     def warmstart(self):
         self._solve(0.0, self.x0)
@@ -353,8 +358,11 @@ class BatchControllerManager:
     def step(self, t, x):
         x = np.asarray(x, dtype=np.float64).reshape(self.B, self.problem.nx_full)
         if self.schedule.due(t):
-            self.schedule.timed(t, lambda: self._solve(t, x))
-        xo, uo = self.mpc.evaluate(t, x if self.problem.use_feedback_policy else None)
+            res = []
+            self.schedule.timed(t, lambda: res.append(self._solve(t, x, tick=True)))
+            xo, uo = res[0]
+        else:
+            xo, uo = self.mpc.evaluate(t, x if self.problem.use_feedback_policy else None)
         self.x_opt[:], self.u_opt[:] = xo, uo
         return self.x_opt, self.u_opt
 

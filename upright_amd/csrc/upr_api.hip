@@ -238,6 +238,7 @@ struct upr_batch {
     // solution belongs to), activation flag of the projectile rows
     double *dyn0 = nullptr, *pflag = nullptr;
     std::vector<double> hdyn0, hdyn_prev, htprev;
+    double* pin = nullptr;   // pinned host staging of upr_batch_tick
     int nxf = 0;   // interface state dimension 3 nq + 9 n_dyn
     bool guess_set = false;
     int sqp_iters_next = 0;   // > 0: SQP iterations of the next advance only (init_sqp_iteration of the first solve)
@@ -755,7 +756,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->order); hipFree(h->prof); hipFree(h->kkt);
+    hipFree(h->done); hipFree(h->order); if (h->pin) (void)hipHostFree(h->pin); hipFree(h->prof); hipFree(h->kkt);
     hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1186,6 +1187,48 @@ int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const
     narrow_states(h, x_obs, h->B, xo);
     if (evaluate_policy_core(h, t, t_stride, xo.data(), xr.data(), u_out)) return 1;
     widen_eval(h, t, t_stride, xr.data(), x_out);
+    return 0;
+}
+
+int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x, double* x_out, double* u_out, double* stats_out) {
+    if (!h) return fail("null batch");
+    if (!t || !x || !x_out || !u_out) return fail("upr_batch_tick: null argument");
+    const upr_dims& d = h->d;
+    const size_t B = (size_t)h->B, nx = (size_t)d.nx, nu = (size_t)d.nu, ndyn = h->P.n_dyn ? 9 : 0;
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, B * nx) || dev_alloc(&h->ev_x, B * nx) || dev_alloc(&h->ev_u, B * nu))) return 1;
+    // pinned staging: [t B][x B nx][dyn B 9] in, [x B nx][u B nu][stats B NSTATS] out
+    const size_t n_in = B + B * nx + B * ndyn, n_out = B * nx + B * nu + B * UPR_NSTATS;
+    if (!h->pin) {
+        UPR_HIP(hipHostMalloc((void**)&h->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
+    }
+    double* pt = h->pin; double* px = pt + B; double* pd = px + B * nx;
+    double* ox = h->pin + n_in; double* ou = ox + B * nx; double* os = ou + B * nu;
+    for (size_t b = 0; b < B; ++b) {
+        pt[b] = t[b * (t_stride ? 1 : 0)];
+        std::memcpy(px + b * nx, x + b * (size_t)h->nxf, sizeof(double) * nx);
+        if (ndyn) { std::memcpy(pd + b * 9, x + b * (size_t)h->nxf + nx, sizeof(double) * 9); std::memcpy(h->hdyn0.data() + b * 9, pd + b * 9, sizeof(double) * 9); }
+    }
+    UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    UPR_HIP(hipMemcpyAsync(h->x0, px, sizeof(double) * B * nx, hipMemcpyHostToDevice, h->stream));
+    if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * 9, hipMemcpyHostToDevice, h->stream));
+    auto t0c = std::chrono::steady_clock::now();
+    if (advance_impl(h)) return 1;
+    // the policy at the observation: time t0, state x0 (both already on the device)
+    if (h->fb) hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, h->t0, h->x0, h->ev_x, h->ev_u);
+    else hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->t0, 1, h->ev_x, h->ev_u);
+    UPR_HIP(hipGetLastError());
+    UPR_HIP(hipMemcpyAsync(ox, h->ev_x, sizeof(double) * B * nx, hipMemcpyDeviceToHost, h->stream));
+    UPR_HIP(hipMemcpyAsync(ou, h->ev_u, sizeof(double) * B * nu, hipMemcpyDeviceToHost, h->stream));
+    if (stats_out) UPR_HIP(hipMemcpyAsync(os, h->stats, sizeof(double) * B * UPR_NSTATS, hipMemcpyDeviceToHost, h->stream));
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
+    for (size_t b = 0; b < B; ++b) {
+        double* o = x_out + b * (size_t)h->nxf;
+        std::memcpy(o, ox + b * nx, sizeof(double) * nx);
+        if (ndyn) std::memcpy(o + nx, pd + b * 9, sizeof(double) * 9);   // (evaluated at the observation's own time: the obstacle where it was observed)
+    }
+    std::memcpy(u_out, ou, sizeof(double) * B * nu);
+    if (stats_out) std::memcpy(stats_out, os, sizeof(double) * B * UPR_NSTATS);
     return 0;
 }
 

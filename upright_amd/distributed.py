@@ -101,6 +101,12 @@ class StandInEngine:
         u = -(ids[:, None] + float(np.max(t))) + np.zeros((self.B, self.nu))
         return np.zeros((self.B, self.nxf)), u
 
+    def tick(self, t, x, want_stats=False):
+        """One control period (BatchMPC.tick): observation, solve, policy at the observation."""
+        self.set_observation(t, x); self.advance()
+        xo, u = self.evaluate(t, x_obs=x)
+        return (xo, u, self.stats()) if want_stats else (xo, u)
+
     def stats(self):
         return dict(qp_status_last=np.zeros(self.B), qp_iters_last=np.full(self.B, 10.0), constraint_violation=np.zeros(self.B))
 

@@ -87,6 +87,18 @@ class BatchMPC:
         check(self._lib.upr_batch_get_solution(self._h, ptr(ts), ptr(xs), ptr(us)))
         return ts, xs, us
 
+    def tick(self, t, x, want_stats=False):
+        """One control period: set_observation(t, x), advance(), evaluate(t, x_obs=x) in one call and one synchronisation
+        (upr_batch_tick).  Returns (x_opt, u_opt) or (x_opt, u_opt, stats)."""
+        t = cont(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        xo = cont(x).reshape(self.B, self.nxf)
+        xr = np.zeros((self.B, self.nxf)); u = np.zeros((self.B, self.nu))
+        s = np.zeros((self.B, _capi.NSTATS)) if want_stats else None
+        check(self._lib.upr_batch_tick(self._h, ptr(t), 1, ptr(xo), ptr(xr), ptr(u), ptr(s) if want_stats else None))
+        if want_stats:
+            return xr, u, {name: s[:, i] for i, name in enumerate(_capi.STAT_NAMES)}
+        return xr, u
+
     def evaluate(self, t, x_obs=None):
         """Plan state and input at time t.  With x_obs (B, nx) and use_feedback_policy the input is the linear
         policy u*(t) + K(t) (x_obs - x*(t)) of the last solve (ocs2::LinearController), else the feed-forward input."""
