@@ -58,6 +58,14 @@ class ControllerInterface {
         if (P_.use_feedback_policy) check(upr_batch_evaluate_policy(h_, t.data(), stride, x.data(), x_opt.data(), u_opt.data()));
         else check(upr_batch_evaluate(h_, t.data(), stride, x_opt.data(), u_opt.data()));
     }
+    // one control period of mpc_node / mrt_node in one call: setCurrentObservation + advanceMpc + evaluatePolicy at the observed
+    // state (upr_batch_tick: one upload, one synchronisation; bit-identical to the three calls above)
+    void tick(const std::vector<double>& t, const std::vector<double>& x, std::vector<double>& x_opt, std::vector<double>& u_opt) {
+        if ((int)x.size() != B_ * nx_) throw std::runtime_error("x must hold B * nx values");
+        if ((int)t.size() != B_ && t.size() != 1) throw std::runtime_error("t must hold B values or one");
+        x_opt.assign((size_t)B_ * nx_, 0.0); u_opt.assign((size_t)B_ * nu_, 0.0);
+        check(upr_batch_tick(h_, t.data(), t.size() == 1 ? 0 : 1, x.data(), x_opt.data(), u_opt.data(), nullptr));
+    }
     Solution solution() {
         Solution s;
         s.ts.assign((size_t)B_ * (P_.N + 1), 0.0); s.xs.assign((size_t)B_ * (P_.N + 1) * nx_, 0.0); s.us.assign((size_t)B_ * P_.N * nu_, 0.0);

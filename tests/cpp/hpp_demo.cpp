@@ -41,6 +41,10 @@ int main(int argc, char** argv) {
         std::printf("us"); for (double v : s.us) std::printf(" %.17g", v); std::printf("\n");
         std::printf("upol"); for (double v : uo) std::printf(" %.17g", v); std::printf("\n");
         if (P.use_feedback_policy) { std::vector<double> K = ctrl.feedback_gains(); double a = 0; for (double v : K) a += v * v; std::printf("Knorm2 %.17g\n", a); }
+        // a second control period through tick(): observation (the same state, 10 ms later), warm-started solve, policy at it
+        std::vector<double> xt, ut;
+        ctrl.tick({0.01}, x0, xt, ut);
+        std::printf("utick"); for (double v : ut) std::printf(" %.17g", v); std::printf("\n");
     } catch (const std::runtime_error& e) {
         std::printf("runtime_error: %s\n", e.what());
         return 1;

@@ -637,6 +637,8 @@ def test_cpp_header_twin_matches_python_path(arrangements, tmp_path):
     assert np.array_equal(out["xs"], xs.ravel()) and np.array_equal(out["us"], us.ravel())
     assert np.array_equal(out["upol"], up.ravel())
     assert abs(out["Knorm2"][0] - np.sum(mpc.feedback_gains() ** 2)) < 1e-9 * out["Knorm2"][0]
+    _, ut = mpc.tick(0.01, x0)                    # the C++ face's tick() against the shim's
+    assert np.array_equal(out["utick"], ut.ravel())
     mpc.close()
 
 
