@@ -24,6 +24,7 @@ extern "C" {
 #define UPR_MAX_NU 108 /* UPR_MAX_JOINTS + 3 * UPR_MAX_CONTACTS */
 #define UPR_MAX_SPHERES 16
 #define UPR_MAX_PAIRS 32
+#define UPR_MAX_DYN 4     /* dynamic obstacles (dimensions.h:32-45: the state carries 9 entries per obstacle) */
 
 /* Problem family shared by all instances of a batch: what ControllerInterface's constructor reads
  * from ControllerSettings (upright_control/src/controller_interface.cpp:103-393;
@@ -93,10 +94,11 @@ typedef struct upr_problem {
     int pair_a[UPR_MAX_PAIRS], pair_b[UPR_MAX_PAIRS];
     double obs_min_dist; /* controller.yaml:108 */
     /* pair_b == -1: the ground half-space z >= 0 (controller_interface.cpp:93-101).
-     * n_dyn (0 or 1) dynamic obstacles (system_dynamics.h:29-39; obstacles/dynamic.yaml): the state handed to
-     * set_observation / returned by get_solution / evaluate is [robot x (3 nq), obstacle r, v, a (9)]; the obstacle is
-     * uncontrolled, so inside the solve it is the ballistic function of time of its observed state.  Spheres with
-     * sph_frame == -2 ride on it. */
+     * n_dyn (0 .. UPR_MAX_DYN) dynamic obstacles (system_dynamics.h:29-39, dimensions.h:32-45; obstacles/dynamic.yaml): the
+     * state handed to set_observation / returned by get_solution / evaluate is [robot x (3 nq), then r, v, a (9) of every
+     * obstacle in turn]; an obstacle is uncontrolled, so inside the solve it is the ballistic function of time of its
+     * observed state.  Spheres with sph_frame == -2 - i ride on obstacle i (-2: the first).  The projectile-path rows below
+     * follow the LAST obstacle (projectile_path_constraint.h:82,114 read state.tail(9)). */
     int n_dyn;
     /* projectile_path_constraint.h:12-167 ("projectile_constraint"): rows w s (|c_i - r_closest| - dist_i),
      * w = proj_scale / dist_i, c_i the centre of sphere proj_sph[i], r_closest the closest future point of the

@@ -11,6 +11,7 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "_build" / "libupright_oracle.so"
 
 MAXJ, MAXC, MAXB, MAXW, MAXNX, MAXNU, MAXS, MAXP = 16, 64, 16, 8, 64, 208, 32, 64
+MAX_DYN = 4
 d = C.c_double
 
 
@@ -29,7 +30,7 @@ class OrcProblem(C.Structure):
         ("terminal_constraint", C.c_int),
         ("n_sph", C.c_int), ("sph_frame", C.c_int * MAXS), ("sph_off", d * 3 * MAXS), ("sph_r", d * MAXS),
         ("n_pairs", C.c_int), ("pair_a", C.c_int * MAXP), ("pair_b", C.c_int * MAXP), ("obs_min_dist", d),
-        ("n_dyn", C.c_int), ("dyn_x0", d * 9), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", d * 8),
+        ("n_dyn", C.c_int), ("dyn_x0", d * (9 * MAX_DYN)), ("n_proj", C.c_int), ("proj_sph", C.c_int * 8), ("proj_dist", d * 8),
         ("proj_scale", d), ("proj_s", d),
         ("soft_state_box", C.c_int), ("soft_input_box", C.c_int), ("soft_poly", C.c_int),
         ("soft_L2_lower", d), ("soft_L2_upper", d), ("soft_L1_lower", d), ("soft_L1_upper", d),
@@ -200,9 +201,11 @@ class Oracle:
         return c
 
     def set_dynamic_obstacle(self, x_obs, flag=1.0):
-        """Observed state [r, v, a] of the dynamic obstacle at the start of the horizon and the target's activation
-        flag of the projectile constraint."""
-        _fill(self.o.dyn_x0, x_obs)
+        """Observed states [r, v, a] of the dynamic obstacles (one after the other, 9 n_dyn values) at the start of the horizon
+        and the target's activation flag of the projectile constraint."""
+        x_obs = np.asarray(x_obs, dtype=np.float64).ravel()
+        for i in range(9 * MAX_DYN):
+            self.o.dyn_x0[i] = float(x_obs[i]) if i < len(x_obs) else 0.0
         self.o.proj_s = float(flag)
 
     def obstacle_rows(self, x, jac=True, tau=0.0):

@@ -164,8 +164,10 @@ template <class T>
 void sphere_centers(const orc_problem* P, const T* x, double tau, std::vector<V3<T>>& c) {
     const int nq = P->nq;
     c.assign(P->n_sph, V3<T>{{T(0.0), T(0.0), T(0.0)}});
-    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2)   // dynamic obstacle: ballistic, independent of the robot
-        for (int i = 0; i < 3; ++i) c[s][i] = T(P->dyn_x0[i] + tau * P->dyn_x0[3 + i] + 0.5 * tau * tau * P->dyn_x0[6 + i] + P->sph_off[s][i]);
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] <= -2) {   // rides on dynamic obstacle -2 - frame: ballistic, independent of the robot
+        const double* xo = P->dyn_x0 + 9 * (-2 - P->sph_frame[s]);
+        for (int i = 0; i < 3; ++i) c[s][i] = T(xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * xo[6 + i] + P->sph_off[s][i]);
+    }
     M3<T> R; for (int i = 0; i < 9; ++i) R.m[i] = T((i % 4 == 0) ? 1.0 : 0.0);
     V3<T> o{{T(0.0), T(0.0), T(0.0)}};
     auto place = [&](int frame) {
@@ -206,7 +208,8 @@ void obstacle_rows(const orc_problem* P, const T* x, double tau, T* d) {
     }
     // projectile path rows (the closest time is held fixed in the derivative, projectile_path_constraint.h:118-145)
     double ro[3], vo[3], ao[3];
-    for (int i = 0; i < 3; ++i) { ao[i] = P->dyn_x0[6 + i]; vo[i] = P->dyn_x0[3 + i] + tau * ao[i]; ro[i] = P->dyn_x0[i] + tau * P->dyn_x0[3 + i] + 0.5 * tau * tau * ao[i]; }
+    const double* xl = P->dyn_x0 + 9 * (P->n_dyn > 0 ? P->n_dyn - 1 : 0);   // projectile_path_constraint.h:82: state.tail(9), the last obstacle
+    for (int i = 0; i < 3; ++i) { ao[i] = xl[6 + i]; vo[i] = xl[3 + i] + tau * ao[i]; ro[i] = xl[i] + tau * xl[3 + i] + 0.5 * tau * tau * ao[i]; }
     for (int i = 0; i < P->n_proj; ++i) {
         const V3<T>& cl = c[P->proj_sph[i]];
         double dt = 0.0;

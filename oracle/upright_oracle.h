@@ -31,6 +31,7 @@ extern "C" {
 #define ORC_MAX_NU 208
 #define ORC_MAX_SPHERES 32
 #define ORC_MAX_PAIRS 64
+#define ORC_MAX_DYN 4
 
 typedef struct {
     /* ---- dimensions (upright_control/include/upright_control/dimensions.h:18-46) ---- */
@@ -100,11 +101,13 @@ typedef struct {
     int pair_a[ORC_MAX_PAIRS], pair_b[ORC_MAX_PAIRS];
     double obs_min_dist;
     /* pair_b == -1: the ground half-space z >= 0 (controller_interface.cpp:93-101): d = c_a.z - r_a - obs_min_dist.
-     * sph_frame == -2: the dynamic obstacle (system_dynamics.h:29-39: [r, v, a] with rdot = v, vdot = a, adot = 0),
-     * whose OBSERVED state at the start of the horizon is dyn_x0; it is uncontrolled, so over the horizon it is the
-     * known ballistic function of time r(tau) = r0 + tau v0 + tau^2/2 a0. */
-    int n_dyn;          /* 0 or 1 */
-    double dyn_x0[9];
+     * sph_frame == -2 - i: dynamic obstacle i (system_dynamics.h:29-39: [r, v, a] with rdot = v, vdot = a, adot = 0; the
+     * state carries 9 entries per obstacle, dimensions.h:32-45), whose OBSERVED state at the start of the horizon is
+     * dyn_x0[9 i ..]; it is uncontrolled, so over the horizon it is the known ballistic function of time
+     * r(tau) = r0 + tau v0 + tau^2/2 a0.  The projectile-path rows follow the LAST obstacle
+     * (projectile_path_constraint.h:82,114: state.tail(9)). */
+    int n_dyn;          /* 0 .. ORC_MAX_DYN */
+    double dyn_x0[9 * ORC_MAX_DYN];
     /* projectile_path_constraint.h:12-167: rows w s (|c - r_closest| - dist_i), w = proj_scale / dist_i, c the centre of
      * sphere proj_sph[i], r_closest the closest FUTURE point of the obstacle's path (cubic by Newton, 10 steps, 1e-4) */
     int n_proj;

@@ -280,6 +280,42 @@ def test_projectile_rows_kernel_source(arrangements):
     e.E.emu_set_dynamic(None, None)
 
 
+def test_two_dynamic_obstacles_kernel_source(arrangements):
+    """More than one dynamic obstacle (dimensions.h:32-45; system_pinocchio_mapping.h:84-97): spheres with sph_frame -2 - i ride
+    on obstacle i, every obstacle is propagated ballistically to every knot, and the projectile-path row follows the LAST
+    obstacle (projectile_path_constraint.h:82: state.tail(9)).  Linearisation kernel source against the oracle."""
+    from upright_amd import robots
+
+    B = 2
+    P, x0, way, xs, us, ball = _projectile_case(arrangements, B)
+    pairs = [("wrist3_collision_link_0", "ground"), ("base_collision_link_0", "chair1"), ("forearm_collision_sphere_link2_0", "projectile1"),
+             ("balanced_object_collision_link_0", "chair1")]
+    for k, v in robots.collision_model(P.chain, pairs, dynamic={"chair1": 0.25, "projectile1": 0.2}).items():
+        setattr(P, k, v)
+    P.n_dyn = 2
+    P.proj_sph = np.zeros(0, dtype=np.int32); P.proj_dist = np.zeros(0)
+    robots.add_projectile_rows(P, ["balanced_object_collision_link"], [0.35], 0.2)
+    assert sorted(f for f in P.sph_frame if f <= -2) == [-3, -2]
+    chair = np.tile(np.array([0.3, 0.4, 0.25, 0.0, 0.2, 0.0, 0.05, 0.0, 0.0]), (B, 1)); chair[1, :3] += 0.2
+    dyn = np.ascontiguousarray(np.concatenate([chair, ball], axis=1))       # [B][2][9]: chair first, the ball last
+    e = Emu(P, B)
+    flags = np.ones(B)                       # (kept alive: the emulation holds the pointer)
+    e.E.emu_set_dynamic(p(dyn), p(flags))
+    rng = np.random.default_rng(5)
+    xr = xs + rng.uniform(-0.2, 0.2, xs.shape)
+    lin = e.linearize(way, np.zeros(B), xr, us)
+    nrow = 5
+    assert e.lin_stride == 223 + nrow * 10
+    for b in range(B):
+        O = Oracle(P); O.set_dynamic_obstacle(dyn[b], 1.0)
+        for k in range(P.N):
+            d, dq = O.obstacle_rows(xr[b, k], tau=k * P.dt)
+            r = lin[b, k, 223:]
+            assert np.abs(r[:4] - d[:4]).max() < 1e-12 and np.abs(r[nrow:].reshape(nrow, 9)[:4] - dq[:4]).max() < 1e-11
+            assert abs(r[4] - d[4]) < 1e-9 and np.abs(r[nrow:].reshape(nrow, 9)[4] - dq[4]).max() < 1e-8
+    e.E.emu_set_dynamic(None, None)
+
+
 def test_soft_rows_kernel_source(arrangements):
     """HPIPM slack variables (hpipm_interface SlackSettings, wrappers.py:121-143): the generic QP kernel with
     softened state-box / input-box / polytopic rows follows the oracle's iterate path, on a feasible instance and on

@@ -197,9 +197,19 @@ def test_dynamic_obstacle_and_projectile_settings(arrangements):
     with pytest.raises(RuntimeError, match="second object"):
         control_bindings.problem_from_settings(s)
     g["obstacles"]["collision_pairs"].pop()
-    g["obstacles"]["dynamic"].append(dict(g["obstacles"]["dynamic"][0], name="projectile2"))
+    # a second dynamic obstacle (dimensions.h:32-45: 9 more state entries; system_pinocchio_mapping.h:84-97 loops over dims.o):
+    # its sphere rides on the second 9-block, the projectile rows follow the LAST obstacle (projectile_path_constraint.h:82)
+    g["obstacles"]["dynamic"].append({"name": "chair1", "radius": 0.25, "modes": [{"time": 0, "position": [1.5, 1, 0.25], "velocity": [0, 0, 0], "acceleration": [0, 0, 0]}]})
+    g["obstacles"]["collision_pairs"].append(["base_collision_link_0", "chair1"])
     s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
-    with pytest.raises(RuntimeError, match="one dynamic obstacle"):
+    assert s.dims.o == 2 and s.dims.x() == 45 and np.array_equal(s.initial_state[36:39], [1.5, 1, 0.25])
+    P2 = control_bindings.problem_from_settings(s)
+    assert (P2.nx_full, P2.n_dyn) == (45, 2) and sorted(f for f in P2.sph_frame if f <= -2) == [-3, -2]
+    assert P2.sph_frame[list(P2.sphere_names).index("chair1")] == -3 and P2.sph_frame[list(P2.sphere_names).index("projectile1")] == -2
+    for k in range(control_bindings.MAX_DYNAMIC_OBSTACLES - 1):
+        g["obstacles"]["dynamic"].append(dict(g["obstacles"]["dynamic"][1], name="chair%d" % (k + 2)))
+    s = control.ControllerSettings(g, bodies=bodies, contacts=contacts)
+    with pytest.raises(RuntimeError, match="dynamic obstacles"):
         control_bindings.problem_from_settings(s)
 
 

@@ -283,11 +283,14 @@ class SystemPinocchioMapping:
         return np.concatenate([o[6:9] for o in obs] + [xr[d.q + d.v: d.q + 2 * d.v]])
 
 
+MAX_DYNAMIC_OBSTACLES = 4   # UPR_MAX_DYN (include/upright_mi.h)
+
+
 def problem_from_settings(s):
     """ControllerSettings -> Problem (what ControllerInterface's constructor assembles,
     controller_interface.cpp:103-393).  Raises RuntimeError for OCP terms outside the accelerated path."""
-    if len(s.obstacle_settings.dynamic_obstacles) > 1:
-        raise RuntimeError("the MI355X engine supports one dynamic obstacle")
+    if len(s.obstacle_settings.dynamic_obstacles) > MAX_DYNAMIC_OBSTACLES:
+        raise RuntimeError("the MI355X engine supports %d dynamic obstacles" % MAX_DYNAMIC_OBSTACLES)
     if s.inertial_alignment_settings.cost_enabled or s.inertial_alignment_settings.constraint_enabled:
         raise RuntimeError("inertial alignment is outside the accelerated path (SURVEY.md section 2, row 12)")
     if s.end_effector_box_constraint_enabled:
@@ -300,8 +303,8 @@ def problem_from_settings(s):
     if sl.enabled and (sl.upper_low_bound != 0 or sl.lower_low_bound != 0):
         raise RuntimeError("slack lower bounds other than 0 are not supported by the MI355X engine")
     d = s.dims
-    if d.o != len(s.obstacle_settings.dynamic_obstacles) or d.o > 1:
-        raise RuntimeError("dims.o must equal the number of dynamic obstacles (at most one)")
+    if d.o != len(s.obstacle_settings.dynamic_obstacles):
+        raise RuntimeError("dims.o must equal the number of dynamic obstacles")
     base = robot_base_type_to_string(s.robot_base_type)
     chain = robots.from_config({"base_type": base, "dims": {"q": d.robot.q}, "base_pose": list(s.base_pose)})
     from .core_bindings import contact_tables
@@ -359,9 +362,9 @@ def problem_from_settings(s):
                 setattr(P, k, v)
             P.obs_min_dist = float(s.obstacle_settings.minimum_distance)
         if s.projectile_path_constraint_enabled:
-            # controller_interface.cpp:272-294; the constraint reads the LAST 9 entries of the state
-            if d.o != 1:
-                raise RuntimeError("projectile_path_constraint needs one dynamic obstacle")
+            # controller_interface.cpp:272-294; the constraint reads the LAST 9 entries of the state: the last dynamic obstacle
+            if d.o < 1:
+                raise RuntimeError("projectile_path_constraint needs a dynamic obstacle")
             robots.add_projectile_rows(P, s.projectile_path_collision_links, s.projectile_path_distances, s.projectile_path_scale)
     except ValueError as e:
         raise RuntimeError(str(e))

@@ -271,8 +271,8 @@ int check_problem(const upr_problem* P) {
     for (int i = 0; i < 6; ++i) if (!(P->Wee[i] >= 0)) return fail("end-effector weights must be non-negative");
     if (P->n_sph < 0 || P->n_sph > UPR_MAX_SPHERES) return fail("n_sph out of range");
     if (P->n_pairs < 0 || P->n_pairs > UPR_MAX_PAIRS) return fail("n_pairs out of range");
-    if (P->n_dyn < 0 || P->n_dyn > 1) return fail("n_dyn must be 0 or 1");
-    if (P->n_proj < 0 || P->n_proj > 8 || (P->n_proj > 0 && P->n_dyn != 1)) return fail("projectile rows need one dynamic obstacle (n_proj <= 8)");
+    if (P->n_dyn < 0 || P->n_dyn > UPR_MAX_DYN) return fail("n_dyn must be in 0 .. UPR_MAX_DYN");
+    if (P->n_proj < 0 || P->n_proj > 8 || (P->n_proj > 0 && P->n_dyn < 1)) return fail("projectile rows need a dynamic obstacle (n_proj <= 8; they follow the last one)");
     if (P->soft_state_box || P->soft_input_box || P->soft_poly) {
         if (!(P->soft_L2_lower >= 0) || !(P->soft_L2_upper >= 0) || !(P->soft_L1_lower >= 0) || !(P->soft_L1_upper >= 0)) return fail("slack penalties must be non-negative");
         if (!(P->soft_L2_lower + P->soft_L1_lower > 0) || !(P->soft_L2_upper + P->soft_L1_upper > 0)) return fail("softened rows need a positive L1 or L2 penalty");
@@ -280,7 +280,7 @@ int check_problem(const upr_problem* P) {
     if (P->soft_eq && (!(P->soft_L2_lower > 0) || P->soft_L2_lower != P->soft_L2_upper || P->soft_L1_lower != 0 || P->soft_L1_upper != 0))
         return fail("a softened object-dynamics equality needs equal positive L2 penalties and zero L1 penalties (the slack pair is eliminated to a quadratic penalty)");
     for (int i = 0; i < P->n_proj; ++i) if (P->proj_sph[i] < 0 || P->proj_sph[i] >= P->n_sph || !(P->proj_dist[i] > 0)) return fail("projectile row out of range");
-    for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] < -2 || P->sph_frame[i] > P->nq || (P->sph_frame[i] == -2 && P->n_dyn != 1)) return fail("sph_frame out of range");
+    for (int i = 0; i < P->n_sph; ++i) if (P->sph_frame[i] > P->nq || (P->sph_frame[i] <= -2 && -2 - P->sph_frame[i] >= P->n_dyn)) return fail("sph_frame out of range");
     for (int i = 0; i < P->n_pairs; ++i)
         if (P->pair_a[i] < 0 || P->pair_a[i] >= P->n_sph || P->pair_b[i] < -1 || P->pair_b[i] >= P->n_sph || P->pair_a[i] == P->pair_b[i]) return fail("collision pair out of range");
     for (int i = 0; i < P->nc; ++i) {
@@ -720,7 +720,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
         dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) || dev_alloc(&h->order, B) ||
         (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
-        (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9) || dev_alloc(&h->pflag, B))))
+        (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9 * P->n_dyn) || dev_alloc(&h->pflag, B))))
         return bad();
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
     hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
@@ -916,8 +916,8 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
     A.P = h->dP; A.d = d; A.body_params = h->body_params; A.way_p = h->way_p; A.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; A.t0 = dt_; A.xs = dx; A.us = du; A.inst = dinst;
     A.lin = dlin; A.ee_out = dee; A.npoints = n; A.Df = h->Df;
     if (h->P.n_dyn) {   // points mode: the obstacle state of every point as given
-        if (ddyn.alloc((size_t)n * 9)) return 1;
-        if (dyn_pts) UPR_HIP(hipMemcpy(ddyn, dyn_pts, sizeof(double) * n * 9, hipMemcpyHostToDevice));
+        if (ddyn.alloc((size_t)n * 9 * h->P.n_dyn)) return 1;
+        if (dyn_pts) UPR_HIP(hipMemcpy(ddyn, dyn_pts, sizeof(double) * n * 9 * h->P.n_dyn, hipMemcpyHostToDevice));
         A.dyn = ddyn; A.pflag = h->pflag;
     }
     if (do_linearize(h, A)) return 1;
@@ -935,10 +935,11 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
     const upr_dims& d = h->d;
     std::vector<double> rec, xr, dyn;
     if (h->P.n_dyn) {   // interface states [robot x, obstacle]; Jacobian outputs keep the 3 nq robot columns
-        xr.resize((size_t)n * d.nx); dyn.resize((size_t)n * 9);
+        const size_t nd9 = 9 * (size_t)h->P.n_dyn;
+        xr.resize((size_t)n * d.nx); dyn.resize((size_t)n * nd9);
         for (int i = 0; i < n; ++i) {
             std::memcpy(xr.data() + (size_t)i * d.nx, x + (size_t)i * h->nxf, sizeof(double) * d.nx);
-            std::memcpy(dyn.data() + (size_t)i * 9, x + (size_t)i * h->nxf + d.nx, sizeof(double) * 9);
+            std::memcpy(dyn.data() + (size_t)i * nd9, x + (size_t)i * h->nxf + d.nx, sizeof(double) * nd9);
         }
         x = xr.data();
     }
@@ -963,7 +964,7 @@ int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* dd, do
     std::vector<double> t(n, 0.0), u((size_t)n * d.nu, 0.0), rec, xr((size_t)n * d.nx), dyn((size_t)n * 9 * h->P.n_dyn);
     for (int i = 0; i < n; ++i) {   // interface states: [robot x, obstacle r v a]
         std::memcpy(xr.data() + (size_t)i * d.nx, x + (size_t)i * h->nxf, sizeof(double) * d.nx);
-        if (h->P.n_dyn) std::memcpy(dyn.data() + (size_t)i * 9, x + (size_t)i * h->nxf + d.nx, sizeof(double) * 9);
+        if (h->P.n_dyn) std::memcpy(dyn.data() + (size_t)i * 9 * h->P.n_dyn, x + (size_t)i * h->nxf + d.nx, sizeof(double) * 9 * h->P.n_dyn);
     }
     if (linearize_points_impl(h, n, inst.data(), t.data(), xr.data(), u.data(), rec, nullptr, h->P.n_dyn ? dyn.data() : nullptr)) return 1;
     for (int i = 0; i < n; ++i) {
@@ -1124,8 +1125,9 @@ static void narrow_states(const upr_batch* h, const double* xf, size_t n, std::v
     xr.resize(n * h->d.nx);
     for (size_t i = 0; i < n; ++i) std::memcpy(xr.data() + i * h->d.nx, xf + i * h->nxf, sizeof(double) * h->d.nx);
 }
-static void obstacle_after(const double* xo, double tau, double* out) {
-    for (int i = 0; i < 3; ++i) { out[6 + i] = xo[6 + i]; out[3 + i] = xo[3 + i] + tau * xo[6 + i]; out[i] = xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * xo[6 + i]; }
+static void obstacle_after(const double* xo, double tau, double* out, int n_dyn = 1) {   // every obstacle of an instance: [n_dyn][9]
+    for (int o = 0; o < n_dyn; ++o, xo += 9, out += 9)
+        for (int i = 0; i < 3; ++i) { out[6 + i] = xo[6 + i]; out[3 + i] = xo[3 + i] + tau * xo[6 + i]; out[i] = xo[i] + tau * xo[3 + i] + 0.5 * tau * tau * xo[6 + i]; }
 }
 
 int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x) {
@@ -1133,8 +1135,9 @@ int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const
     if (!h->P.n_dyn) return set_observation_core(h, t, t_stride, x);
     std::vector<double> xr;
     narrow_states(h, x, h->B, xr);
-    for (int b = 0; b < h->B; ++b) std::memcpy(h->hdyn0.data() + (size_t)b * 9, x + (size_t)b * h->nxf + h->d.nx, sizeof(double) * 9);
-    UPR_HIP(hipMemcpy(h->dyn0, h->hdyn0.data(), sizeof(double) * h->B * 9, hipMemcpyHostToDevice));
+    const size_t nd9 = 9 * (size_t)h->P.n_dyn;
+    for (int b = 0; b < h->B; ++b) std::memcpy(h->hdyn0.data() + (size_t)b * nd9, x + (size_t)b * h->nxf + h->d.nx, sizeof(double) * nd9);
+    UPR_HIP(hipMemcpy(h->dyn0, h->hdyn0.data(), sizeof(double) * h->B * nd9, hipMemcpyHostToDevice));
     return set_observation_core(h, t, t_stride, xr.data());
 }
 
@@ -1155,7 +1158,7 @@ int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
     for (int b = 0; b < h->B; ++b) for (int k = 0; k <= d.N; ++k) {
         double* o = xs + ((size_t)b * (d.N + 1) + k) * h->nxf;
         std::memcpy(o, xr.data() + ((size_t)b * (d.N + 1) + k) * d.nx, sizeof(double) * d.nx);
-        obstacle_after(h->hdyn0.data() + (size_t)b * 9, k * h->P.dt, o + d.nx);
+        obstacle_after(h->hdyn0.data() + (size_t)b * 9 * h->P.n_dyn, k * h->P.dt, o + d.nx, h->P.n_dyn);
     }
     return 0;
 }
@@ -1167,7 +1170,7 @@ static void widen_eval(upr_batch* h, const double* t, int t_stride, const double
         double* o = x_out + (size_t)b * h->nxf;
         std::memcpy(o, xr + (size_t)b * h->d.nx, sizeof(double) * h->d.nx);
         double tau = t[(size_t)b * (t_stride ? 1 : 0)] - tp[b];
-        obstacle_after(h->hdyn_prev.data() + (size_t)b * 9, tau > 0.0 ? tau : 0.0, o + h->d.nx);
+        obstacle_after(h->hdyn_prev.data() + (size_t)b * 9 * h->P.n_dyn, tau > 0.0 ? tau : 0.0, o + h->d.nx, h->P.n_dyn);
     }
 }
 
@@ -1194,9 +1197,9 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     if (!h) return fail("null batch");
     if (!t || !x || !x_out || !u_out) return fail("upr_batch_tick: null argument");
     const upr_dims& d = h->d;
-    const size_t B = (size_t)h->B, nx = (size_t)d.nx, nu = (size_t)d.nu, ndyn = h->P.n_dyn ? 9 : 0;
+    const size_t B = (size_t)h->B, nx = (size_t)d.nx, nu = (size_t)d.nu, ndyn = 9 * (size_t)h->P.n_dyn;
     if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, B * nx) || dev_alloc(&h->ev_x, B * nx) || dev_alloc(&h->ev_u, B * nu))) return 1;
-    // pinned staging: [t B][x B nx][dyn B 9] in, [x B nx][u B nu][stats B NSTATS] out
+    // pinned staging: [t B][x B nx][dyn B 9 n_dyn] in, [x B nx][u B nu][stats B NSTATS] out
     const size_t n_in = B + B * nx + B * ndyn, n_out = B * nx + B * nu + B * UPR_NSTATS;
     if (!h->pin) {
         UPR_HIP(hipHostMalloc((void**)&h->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
@@ -1206,11 +1209,11 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     for (size_t b = 0; b < B; ++b) {
         pt[b] = t[b * (t_stride ? 1 : 0)];
         std::memcpy(px + b * nx, x + b * (size_t)h->nxf, sizeof(double) * nx);
-        if (ndyn) { std::memcpy(pd + b * 9, x + b * (size_t)h->nxf + nx, sizeof(double) * 9); std::memcpy(h->hdyn0.data() + b * 9, pd + b * 9, sizeof(double) * 9); }
+        if (ndyn) { std::memcpy(pd + b * ndyn, x + b * (size_t)h->nxf + nx, sizeof(double) * ndyn); std::memcpy(h->hdyn0.data() + b * ndyn, pd + b * ndyn, sizeof(double) * ndyn); }
     }
     UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     UPR_HIP(hipMemcpyAsync(h->x0, px, sizeof(double) * B * nx, hipMemcpyHostToDevice, h->stream));
-    if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * 9, hipMemcpyHostToDevice, h->stream));
+    if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * ndyn, hipMemcpyHostToDevice, h->stream));
     auto t0c = std::chrono::steady_clock::now();
     if (advance_impl(h)) return 1;
     // the policy at the observation: time t0, state x0 (both already on the device)
@@ -1225,7 +1228,7 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     for (size_t b = 0; b < B; ++b) {
         double* o = x_out + b * (size_t)h->nxf;
         std::memcpy(o, ox + b * nx, sizeof(double) * nx);
-        if (ndyn) std::memcpy(o + nx, pd + b * 9, sizeof(double) * 9);   // (evaluated at the observation's own time: the obstacle where it was observed)
+        if (ndyn) std::memcpy(o + nx, pd + b * ndyn, sizeof(double) * ndyn);   // (evaluated at the observation's own time: the obstacle where it was observed)
     }
     std::memcpy(u_out, ou, sizeof(double) * B * nu);
     if (stats_out) std::memcpy(stats_out, os, sizeof(double) * B * UPR_NSTATS);

@@ -416,13 +416,14 @@ static UPR_HDI double upr_state_row(const upr_problem* P, int r, CEN cen, const 
     *wgt = flag * P->proj_scale / P->proj_dist[i];
     return *wgt * (dist - P->proj_dist[i]);
 }
-// values of the state rows at a configuration (line search): d[n_pairs + n_proj]; xo: obstacle state at this knot
+// values of the state rows at a configuration (line search): d[n_pairs + n_proj]; xo: the obstacles' states at this knot,
+// [n_dyn][9] (the projectile rows follow the last one: projectile_path_constraint.h:82 reads state.tail(9))
 template <int NQ>
 static UPR_HDI void upr_obstacle_values(const upr_problem* P, const double* x, const double* xo, double flag, double* d) {
     double c[UPR_MAX_SPHERES][3];
     double ro[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
-    if (xo) upr_obstacle_at(xo, 0.0, ro, vo, ao);
-    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2) for (int i = 0; i < 3; ++i) c[s][i] = ro[i] + P->sph_off[s][i];
+    if (xo && P->n_dyn > 0) upr_obstacle_at(xo + 9 * (P->n_dyn - 1), 0.0, ro, vo, ao);
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] <= -2) for (int i = 0; i < 3; ++i) c[s][i] = (xo ? xo[9 * (-2 - P->sph_frame[s]) + i] : 0.0) + P->sph_off[s][i];
     upr_sphere_walk<double, NQ>(P, x, -1, [&](int s, const double* cs) { c[s][0] = cs[0]; c[s][1] = cs[1]; c[s][2] = cs[2]; });
     for (int r = 0; r < P->n_pairs + P->n_proj; ++r) {
         int sa, sb; double n[3], w;

@@ -274,21 +274,24 @@ static UPR_HDI void upr_lin_phase1(const upr_lin_args& A, const upr_lin_point& q
 //   a: lane l < nq walks the chain with the tangent along q_l and leaves every sphere centre's tangent in LDS
 //      (lane 0 also the values);  b: lane r owns pair r: distance and its gradient n . (dc_a/dq - dc_b/dq)
 // obstacle state at this point (trajectory mode: k dt after the observation)
-static UPR_HDI void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point& q, double* ro, double* vo, double* ao) {
+// (obstacle oi of the point's instance; A.dyn is [instance | point][n_dyn][9])
+static UPR_HDI void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point& q, int oi, double* ro, double* vo, double* ao) {
     for (int i = 0; i < 3; ++i) { ro[i] = 0.0; vo[i] = 0.0; ao[i] = 0.0; }
     if (!A.dyn) return;
-    if (A.inst) upr_obstacle_at(A.dyn + (size_t)q.p * 9, 0.0, ro, vo, ao);
-    else upr_obstacle_at(A.dyn + (size_t)q.b * 9, q.k * A.P->dt, ro, vo, ao);
+    const int nd = A.P->n_dyn;
+    if (A.inst) upr_obstacle_at(A.dyn + ((size_t)q.p * nd + oi) * 9, 0.0, ro, vo, ao);
+    else upr_obstacle_at(A.dyn + ((size_t)q.b * nd + oi) * 9, q.k * A.P->dt, ro, vo, ao);
 }
 template <int NQ>
 static UPR_HDI void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_problem* P = A.P;
     double* sc = sh + upr_lin_lds_base(A.d);
     if (q.terminal || lane >= NQ) return;
-    double ro[3], vo[3], ao[3];
-    upr_lin_obstacle(A, q, ro, vo, ao);
-    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] == -2)   // rides on the obstacle: no dependence on q
+    for (int s = 0; s < P->n_sph; ++s) if (P->sph_frame[s] <= -2) {   // rides on an obstacle: no dependence on q
+        double ro[3], vo[3], ao[3];
+        upr_lin_obstacle(A, q, -2 - P->sph_frame[s], ro, vo, ao);
         for (int i = 0; i < 3; ++i) { sc[(s * 3 + i) * (1 + NQ) + 1 + lane] = 0.0; if (lane == 0) sc[(s * 3 + i) * (1 + NQ)] = ro[i] + P->sph_off[s][i]; }
+    }
     upr_sphere_walk<upr_dd, NQ>(P, sh, lane, [&](int s, const upr_dd* c) {
         for (int i = 0; i < 3; ++i) {
             sc[(s * 3 + i) * (1 + NQ) + 1 + lane] = c[i].d;
@@ -302,7 +305,7 @@ static UPR_HDI void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_poi
     const double* sc = sh + upr_lin_lds_base(d);
     if (q.terminal) return;
     double ro[3], vo[3], ao[3];
-    upr_lin_obstacle(A, q, ro, vo, ao);
+    upr_lin_obstacle(A, q, A.P->n_dyn > 0 ? A.P->n_dyn - 1 : 0, ro, vo, ao);   // (the projectile rows follow the last obstacle: state.tail(9))
     const double flag = A.pflag ? A.pflag[q.b] : 0.0;
     for (int r = lane; r < d.no; r += UPR_LPK) {
         int sa, sb; double n[3], w;

@@ -24,7 +24,7 @@ struct upr_ls_args {
     double* stats;         // [B][UPR_NSTATS]
     int* done;             // [B] convergence flag
     int iter;              // SQP iteration index (0-based)
-    const double* dyn = nullptr;    // [B][9] observed dynamic-obstacle state (NULL: none)
+    const double* dyn = nullptr;    // [B][n_dyn][9] observed dynamic-obstacle states (NULL: none)
     const double* pflag = nullptr;  // [B] projectile activation flag
     const double* way_q = nullptr;  // [B][n_way][4] target orientations; NULL unless Wee[3..5] != 0
     // Engine bookkeeping folded into this launch (device kernel only; each was a stream operation of its own):
@@ -82,8 +82,8 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
         }
     }
     if (!EXACT && d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1); EXACT: the problem has none
-        double dd[UPR_MAX_PAIRS + 8], xo[9];
-        if (A.dyn) { upr_obstacle_at(A.dyn + (size_t)b * 9, k * h, xo, xo + 3, xo + 6); }
+        double dd[UPR_MAX_PAIRS + 8], xo[9 * UPR_MAX_DYN];
+        if (A.dyn) for (int oi = 0; oi < P->n_dyn; ++oi) upr_obstacle_at(A.dyn + ((size_t)b * P->n_dyn + oi) * 9, k * h, xo + 9 * oi, xo + 9 * oi + 3, xo + 9 * oi + 6);
         upr_obstacle_values<NQ>(P, X, A.dyn ? xo : nullptr, A.pflag ? A.pflag[b] : 0.0, dd);
         for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, dd[r]); iq += h * v * v; }
     }

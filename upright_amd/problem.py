@@ -57,8 +57,8 @@ class Problem:
     pair_a: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
     pair_b: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))
     obs_min_dist: float = 0.1  # controller.yaml:108
-    # pair_b == -1: ground half-space; sph_frame == -2: the dynamic obstacle (state [r, v, a] appended to x,
-    # system_dynamics.h:29-39); projectile path rows (projectile_path_constraint.h): spheres whose centres are the
+    # pair_b == -1: ground half-space; sph_frame == -2 - i: dynamic obstacle i (its state [r, v, a] is the i-th 9-block appended
+    # to x, system_dynamics.h:29-39, dimensions.h:32-45); projectile path rows (projectile_path_constraint.h): spheres whose centres are the
     # checked link positions, their distances and the scale
     n_dyn: int = 0
     proj_sph: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))

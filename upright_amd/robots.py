@@ -237,15 +237,16 @@ def link_frame(chain, link):
 def collision_model(chain, pairs, spheres=None, dynamic=None):
     """Sphere table and pair index lists for the named collision pairs of `obstacles.collision_pairs`
     (obstacles/simple.yaml:11-41, obstacles/dynamic.yaml:19-37; pinocchio appends `_0` to geometry names).
-    `dynamic`: {name: radius} of the dynamic obstacles (controller_interface.cpp:55-82: a sphere on a translating
-    joint); "ground" is the half-space z >= 0 (controller_interface.cpp:93-101).  Returns a dict with the Problem
+    `dynamic`: {name: radius} of the dynamic obstacles IN THE ORDER of `obstacles.dynamic` (controller_interface.cpp:55-82: a
+    sphere on a translating joint each; the i-th owns the i-th 9-block of obstacle state); "ground" is the half-space z >= 0 (controller_interface.cpp:93-101).  Returns a dict with the Problem
     fields sph_frame, sph_off, sph_r, pair_a, pair_b (pair_b = -1: ground)."""
     table = dict(COLLISION_SPHERES)
     table.update(SIMPLE_OBSTACLES)
     if spheres:
         table.update(spheres)
-    for n, r in (dynamic or {}).items():
-        table[n] = ("dynamic", (0.0, 0.0, 0.0), float(r))
+    dyn_index = {}
+    for i, (n, r) in enumerate((dynamic or {}).items()):   # (in the order of obstacles.dynamic: obstacle i owns state entries 9 i .. 9 i + 8)
+        table[n] = ("dynamic", (0.0, 0.0, 0.0), float(r)); dyn_index[n] = i
     strip = lambda n: n[:-2] if n.endswith("_0") else n
     names = []
     for a, b in pairs:
@@ -266,7 +267,7 @@ def collision_model(chain, pairs, spheres=None, dynamic=None):
         link, off, _ = table[n]
         off = np.asarray(off, dtype=np.float64)
         if link == "dynamic":
-            f = -2
+            f = -2 - dyn_index[n]   # rides on dynamic obstacle dyn_index[n] (include/upright_mi.h: sph_frame)
         else:
             f = link_frame(chain, link)
             if link == "base_link" and f == -1 and chain.base_pose is not None:
