@@ -2,7 +2,7 @@
 
 Same class and attribute names; `ControllerInterface` drives one instance (B = 1) of the batched HIP
 engine through the C-ABI of libupright_mi.so.  Covered: the balancing OCP (object-dynamics equality, friction
-rows), obstacle avoidance over sphere pairs, one dynamic obstacle with the projectile-path constraint, HPIPM
+rows), obstacle avoidance over sphere pairs, up to four dynamic obstacles, the projectile-path constraint on the last, HPIPM
 slack settings, the linear feedback policy.  What the engine does not cover raises RuntimeError -- at
 construction for OCP terms (inertial alignment, end-effector box, operating points), at the call for the
 solver-internal getters (value function, Lagrangian, visualisation) -- the way the reference throws
