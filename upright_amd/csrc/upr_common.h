@@ -78,6 +78,9 @@ static inline UPR_HD double upr_rsqrt(double x) {
 
 // 1/x the same way: hardware estimate + one second-order step y (1 + e + e^2), e = 1 - x y (the IEEE division
 // sequence costs ~100 dependent cycles; the flat phases of the QP kernel are bound by two or three of them per row)
+// z + a s as ONE fused operation, wherever the iterate takes a step: the rows' sweep forms the same new value ahead of the update
+// of the iterate (upr_qp3.h, ineq_sweep what == 4) and both must round alike
+static inline UPR_HD double upr_step(double z, double a, double s) { return __builtin_fma(a, s, z); }
 static inline UPR_HD double upr_rcp(double x) {
 #ifdef UPR_HOST_EMU
     return 1.0 / x;

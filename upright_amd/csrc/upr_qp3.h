@@ -202,6 +202,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_SW2
 #define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
 #endif
+#ifndef UPR_QP3_FUSERES
+#define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
+#endif
 #ifndef UPR_QP3_PRIO_MAT
 #define UPR_QP3_PRIO_MAT 0   // every wave during the matrix sweep: 2 measured no different from 0 (3.235 vs 3.230 ms)
 #endif
@@ -2688,18 +2691,37 @@ struct upr_qp3 {
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
         double acc = 0.0;
         const int tid_ = tid();
+        // what == 4: the step of what == 2 and then, with the row's value cn at the NEW iterate, the residual terms of what == 3
+        // (|cn - t| into acc, lam t into aux) -- what the next iteration's first residual pass would compute from the updated
+        // iterate.  cn is formed exactly as that pass forms it: the new primal value z + alpha dz first (upr_step, the same
+        // operation as the update of the iterate in solve()), then the row.
+        const bool w4 = what == 4;
+        const int wstep = w4 ? 2 : what;
+        auto hard = [&](double c, double ds, double cn, double& t, double& lam, double ct) {
+            if (!w4) { sweep_row(what, alpha, c, ds, t, lam, ct, acc, aux); return; }
+            double unused = 0.0;
+            sweep_row(2, alpha, c, ds, t, lam, ct, unused, nullptr);
+            sweep_row(3, 0.0, cn, 0.0, t, lam, 0.0, acc, aux);
+        };
+        auto soft = [&](double c, double ds, double cn, double& t, double& lam, double& sg, double& ta, double& ga, double Zp, double zp, double ct, double cts) {
+            if (!w4) { sweep_row_soft(what, alpha, c, ds, t, lam, sg, ta, ga, Zp, zp, ct, cts, acc, aux); return; }
+            double unused = 0.0;
+            sweep_row_soft(2, alpha, c, ds, t, lam, sg, ta, ga, Zp, zp, ct, cts, unused, nullptr);
+            sweep_row_soft(3, 0.0, cn, 0.0, t, lam, sg, ta, ga, Zp, zp, 0.0, 0.0, acc, aux);
+        };
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
                 const double X = L[O::Z + zo], dS = L[O::S + zo];
+                const double Xn = w4 ? upr_step(X, alpha, dS) : X;
                 if (C::SOFT && softx) {
-                    sweep_row_soft(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, ctm[2 * q], ctm[(NCT0 + 2 * q) % NCT], acc, aux);
-                    sweep_row_soft(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, ctm[2 * q + 1], ctm[(NCT0 + 2 * q + 1) % NCT], acc, aux);
+                    soft(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, ctm[2 * q], ctm[(NCT0 + 2 * q) % NCT]);
+                    soft(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, ctm[2 * q + 1], ctm[(NCT0 + 2 * q + 1) % NCT]);
                 } else {
-                    sweep_row(what, alpha, X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], acc, aux);
-                    sweep_row(what, alpha, L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], acc, aux);
+                    hard(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q][0], lx[q][0], ctm[2 * q]);
+                    hard(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q][1], lx[q][1], ctm[2 * q + 1]);
                 }
             }
         }
@@ -2709,12 +2731,13 @@ struct upr_qp3 {
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                const double Un = w4 ? upr_step(U, alpha, dS) : U;
                 if (C::SOFT && softu) {
-                    sweep_row_soft(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, ctm[2 * C::QX + 2 * q], ctm[(NCT0 + 2 * C::QX + 2 * q) % NCT], acc, aux);
-                    sweep_row_soft(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, ctm[2 * C::QX + 2 * q + 1], ctm[(NCT0 + 2 * C::QX + 2 * q + 1) % NCT], acc, aux);
+                    soft(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, ctm[2 * C::QX + 2 * q], ctm[(NCT0 + 2 * C::QX + 2 * q) % NCT]);
+                    soft(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, ctm[2 * C::QX + 2 * q + 1], ctm[(NCT0 + 2 * C::QX + 2 * q + 1) % NCT]);
                 } else {
-                    sweep_row(what, alpha, U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q], acc, aux);
-                    sweep_row(what, alpha, L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1], acc, aux);
+                    hard(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q]);
+                    hard(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1]);
                 }
             }
         }
@@ -2738,14 +2761,15 @@ struct upr_qp3 {
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
                     double t = ctv[q][r], lam = clv[q][r];
+                    const double fn0 = w4 ? upr_step(f[0], alpha, sf[0]) : f[0], fn1 = w4 ? upr_step(f[1], alpha, sf[1]) : f[1], fn2 = w4 ? upr_step(f[2], alpha, sf[2]) : f[2];
                     if (C::SOFT && softp) {
                         double sg = G[F::sfr + 5 * ic + r], ta = G[F::sfr + F::sfs + 5 * ic + r], ga = G[F::sfr + 2 * F::sfs + 5 * ic + r];
-                        sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
-                                       ccv[q][r], G[F::sfr + 3 * F::sfs + 5 * ic + r], acc, aux);
-                        if (what == 2) { G[F::sfr + 5 * ic + r] = sg; G[F::sfr + F::sfs + 5 * ic + r] = ta; G[F::sfr + 2 * F::sfs + 5 * ic + r] = ga; }
+                        soft(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, sg, ta, ga, ZL, zL,
+                             ccv[q][r], G[F::sfr + 3 * F::sfs + 5 * ic + r]);
+                        if (wstep == 2) { G[F::sfr + 5 * ic + r] = sg; G[F::sfr + F::sfs + 5 * ic + r] = ta; G[F::sfr + 2 * F::sfs + 5 * ic + r] = ga; }
                     } else
-                    sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, ccv[q][r], acc, aux);
-                    if (what == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
+                    hard(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, ccv[q][r]);
+                    if (wstep == 2) { G[F::ct + 5 * ic + r] = t; G[F::cl + 5 * ic + r] = lam; }
                 }
             }
         } else
@@ -2767,14 +2791,15 @@ struct upr_qp3 {
                 const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
                 const double* e3 = L + O::erow + 3 * (5 * ci + r);
                 double t = tv[q], lam = lv[q];
+                const double fn0 = w4 ? upr_step(f[0], alpha, sf[0]) : f[0], fn1 = w4 ? upr_step(f[1], alpha, sf[1]) : f[1], fn2 = w4 ? upr_step(f[2], alpha, sf[2]) : f[2];
                 if (C::SOFT && softp) {
                     double sg = G[F::sfr + e], ta = G[F::sfr + F::sfs + e], ga = G[F::sfr + 2 * F::sfs + e];
-                    sweep_row_soft(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, sg, ta, ga, ZL, zL,
-                                   cv5[q], G[F::sfr + 3 * F::sfs + e], acc, aux);
-                    if (what == 2) { G[F::sfr + e] = sg; G[F::sfr + F::sfs + e] = ta; G[F::sfr + 2 * F::sfs + e] = ga; }
+                    soft(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, sg, ta, ga, ZL, zL,
+                         cv5[q], G[F::sfr + 3 * F::sfs + e]);
+                    if (wstep == 2) { G[F::sfr + e] = sg; G[F::sfr + F::sfs + e] = ta; G[F::sfr + 2 * F::sfs + e] = ga; }
                 } else
-                sweep_row(what, alpha, e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], t, lam, cv5[q], acc, aux);
-                if (what == 2) { G[F::ct + e] = t; G[F::cl + e] = lam; }
+                hard(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, cv5[q]);
+                if (wstep == 2) { G[F::ct + e] = t; G[F::cl + e] = lam; }
             }
         }
         if (no > 0) {
@@ -2793,17 +2818,21 @@ struct upr_qp3 {
                 const int e = tid_ + q * NT;
                 if (e >= (N - 1) * no) continue;
                 const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
-                double c = od[q], ds = 0.0;
+                double c = od[q], ds = 0.0, cn = od[q];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
+                for (int i = 0; i < NQ; ++i) {
+                    const double z = L[O::Z + k * NX + i], sz = L[O::S + k * NX + i];
+                    c += gq[q][i] * z; ds += gq[q][i] * sz;
+                    if (w4) cn += gq[q][i] * upr_step(z, alpha, sz);
+                }
                 double t = otv[q], lam = olv[q];
                 if (C::SOFT && C::ROWS && softp) {
                     double sg = G[F::sor + ei], ta = G[F::sor + F::sos + ei], ga = G[F::sor + 2 * F::sos + ei];
-                    sweep_row_soft(what, alpha, c, ds, t, lam, sg, ta, ga, ZL, zL, ocv[q], G[F::sor + 3 * F::sos + ei], acc, aux);
-                    if (what == 2) { G[F::sor + ei] = sg; G[F::sor + F::sos + ei] = ta; G[F::sor + 2 * F::sos + ei] = ga; }
+                    soft(c, ds, cn, t, lam, sg, ta, ga, ZL, zL, ocv[q], G[F::sor + 3 * F::sos + ei]);
+                    if (wstep == 2) { G[F::sor + ei] = sg; G[F::sor + F::sos + ei] = ta; G[F::sor + 2 * F::sos + ei] = ga; }
                 } else
-                sweep_row(what, alpha, c, ds, t, lam, ocv[q], acc, aux);
-                if (what == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
+                hard(c, ds, cn, t, lam, ocv[q]);
+                if (wstep == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
             }
         }
         if (what == 0) acc = acc > 1e-30 ? 1.0 / acc : 1e30;
@@ -3097,7 +3126,8 @@ struct upr_qp3 {
         }
         UPR_SYNC();
         const int ntot = N * (2 * NU + C::NP) + N * 2 * NX + (N - 1) * no + (softx ? N * 2 * NX : 0) + (softu ? N * 2 * NU : 0) + (softp ? N * C::NP + (N - 1) * no : 0);   // each softened row adds the pair (tau, gam)
-        double res[4] = {0, 0, 0, 0};
+        double res[4] = {0, 0, 0, 0}, res_next[4] = {0, 0, 0, 0};
+        bool have_next = false;
         int it = 0, status = 1;
         const double tol = P->qp_tol;
         const double tol_stat = P->qp_tol_stat > 0.0 ? P->qp_tol_stat : tol;   // HPIPM tol_stat (upright_mi.h)
@@ -3107,7 +3137,9 @@ struct upr_qp3 {
             // tolerance: until then the stationarity / equality residuals are not evaluated
 #pragma nounroll
             for (int pass = 0; pass < 2; ++pass) {
-                residuals(ntot, res, pass == 1);
+                if (pass == 0 && have_next) {   // left by the rows' step of the previous iteration (ineq_sweep what == 4)
+                    res[0] = 1e300; res[1] = 1e300; res[2] = res_next[2]; res[3] = res_next[3] / (ntot > 0 ? ntot : 1);
+                } else residuals(ntot, res, pass == 1);
                 if (!((it > 0 && res[2] < tol && res[3] < tol) || it >= P->qp_iter_max)) break;
             }
             toc(0);
@@ -3153,7 +3185,13 @@ struct upr_qp3 {
             ftoc(7);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
+#if UPR_QP3_FUSERES
+            // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass
+            res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
+            res_next[2] = ineq_sweep(4, a, &res_next[3], ctm);
+#else
             ineq_sweep(2, a, nullptr, ctm);
+#endif
             store_rows();
             // (the multipliers' old values are requested in front of the barrier: their round trip overlaps it)
             constexpr int QPI = (N1 * NX + NT - 1) / NT, QNU = (N * NE + NT - 1) / NT;
@@ -3165,7 +3203,12 @@ struct upr_qp3 {
 #pragma unroll
                 for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT, ec = (e < N * NE) ? e : 0; nuo[q] = ws[W::nu + ec]; nun_[q] = G[F::nun + ec]; }
             }
+#if UPR_QP3_FUSERES
+            reduce4(res_next);   // (its barriers are the one the update of the iterate needs: every lane is through with Z and S)
+            have_next = true;
+#else
             UPR_SYNC();
+#endif
             ftoc(8);
             {
                 const int tid_ = tid();
@@ -3173,14 +3216,14 @@ struct upr_qp3 {
                 for (int q = 0; q < QPI; ++q) {
                     const int e = tid_ + q * NT;
                     if (e < N1 * NX) {
-                        if (e >= NX) L[O::Z + e] += a * L[O::S + e];
+                        if (e >= NX) L[O::Z + e] = upr_step(L[O::Z + e], a, L[O::S + e]);
                         ws[W::pi + e] = pio[q] + a * (L[O::Pa + e] - pio[q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT; if (e < N * NE) ws[W::nu + e] = nuo[q] + a * (nun_[q] - nuo[q]); }
             }
-            UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] += a * L[O::S + N1 * NX + e];
+            UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] = upr_step(L[O::Z + N1 * NX + e], a, L[O::S + N1 * NX + e]);
             UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
             ftoc(9);
