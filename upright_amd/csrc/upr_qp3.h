@@ -136,7 +136,10 @@ struct upr_qp3_lds {
                          prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
                          // multi-body shapes: the contacts that load each body (indices as doubles) and their number
-                         clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0), total = ccnt + r2(C::NB > 1 ? C::NB : 0);
+                         clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
+                         // stacked bodies (COUPLED): the dense Schur complement of every knot, packed lower triangle, assembled block by block
+                         // by a lane per (knot, body pair) and factored by the knot's lane (prep D)
+                         sdn = ccnt + r2(C::NB > 1 ? C::NB : 0), total = sdn + r2(C::COUPLED ? C::N * (C::SB * (C::SB + 1) / 2) : 0);
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -827,6 +830,63 @@ struct upr_qp3 {
         // D: one lane per Schur block (a knot; a (knot, body) pair of the multi-body shapes): factor (LDS staging -> global),
         // ys = Lsi ee, zt = Lsi' ys
         constexpr int SB = C::SB;
+        if (C::COUPLED && factor) {
+            // dense S of every knot straight from the inverse contact factors (G[lfi], written in phase B) and Df:
+            // S = rho I + sum_c (Lf_c^-1 Df_c')' (Lf_c^-1 Df_c').  A contact loads the rows of at most two bodies, so S is assembled
+            // in 6 x 6 blocks, a lane per (knot, body pair): 36 accumulators a lane (rounds 2 - 3e: the knot's lane assembled all
+            // 171 entries itself in front of the factorisation, out of a scratch frame).  Every entry sums its contacts in the
+            // same order as before.  (Also tried: the factorisation on the knot's lane in place, the inverse a lane per column and
+            // the two products a lane per row -- bit-identical and slower: phase D 142 k cycles against 91 k.)
+            constexpr int NBL = C::NB * (C::NB + 1) / 2, NPK = SB * (SB + 1) / 2;
+            UPR_FORT(e, N * NBL) {
+                const int k = e / NBL, bl = e % NBL;
+                int bi = 0, b0 = 0;
+#pragma unroll
+                for (int i = 1; i < C::NB; ++i) if (bl >= i * (i + 1) / 2) { bi = i; b0 = i * (i + 1) / 2; }
+                const int bj = bl - b0;
+                double acc[6][6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) acc[r][c] = (bi == bj && r == c) ? rho_s : 0.0;
+                for (int ci = 0; ci < NC; ++ci) {
+                    const int b1 = P->contact_body1[ci], b2 = P->contact_body2[ci];
+                    if ((bi != b1 && bi != b2) || (bj != b1 && bj != b2)) continue;
+                    double Bk[NF == 3 ? 9 : 1];
+                    if (NF == 3) {
+#pragma unroll
+                        for (int a = 0; a < 9; ++a) Bk[a] = G[F::lfi + k * C::NLF + 9 * ci + a];
+                    } else Bk[0] = G[F::lfi + k * C::NLF + ci];
+                    double zi[6][NF], zj[6][NF];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        const double* di = L + O::df + (6 * bi + r) * NFC + NF * ci;
+                        const double* dj = L + O::df + (6 * bj + r) * NFC + NF * ci;
+                        if (NF == 3) {
+                            { const double d0 = di[0], d1 = di[1], d2 = di[2]; zi[r][0] = Bk[0] * d0; zi[r][1 % NF] = Bk[3 % (NF == 3 ? 9 : 1)] * d0 + Bk[4 % (NF == 3 ? 9 : 1)] * d1; zi[r][2 % NF] = Bk[6 % (NF == 3 ? 9 : 1)] * d0 + Bk[7 % (NF == 3 ? 9 : 1)] * d1 + Bk[8 % (NF == 3 ? 9 : 1)] * d2; }
+                            { const double d0 = dj[0], d1 = dj[1], d2 = dj[2]; zj[r][0] = Bk[0] * d0; zj[r][1 % NF] = Bk[3 % (NF == 3 ? 9 : 1)] * d0 + Bk[4 % (NF == 3 ? 9 : 1)] * d1; zj[r][2 % NF] = Bk[6 % (NF == 3 ? 9 : 1)] * d0 + Bk[7 % (NF == 3 ? 9 : 1)] * d1 + Bk[8 % (NF == 3 ? 9 : 1)] * d2; }
+                        } else { zi[r][0] = Bk[0] * di[0]; zj[r][0] = Bk[0] * dj[0]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int a = 0; a < NF; ++a) v += zi[r][a] * zj[c][a];
+                            acc[r][c] += v;
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const int R = 6 * bi + r, Cc = 6 * bj + c;
+                        if (Cc <= R) L[O::sdn + k * NPK + R * (R + 1) / 2 + Cc] = acc[r][c];
+                    }
+            }
+            UPR_SYNC();
+        }
         UPR_FORT(kb, C::NKB) {
             double* Ls = G + F::lsi + kb * SB * SB;
             double Lr[SB * SB];                                   // the inverse factor stays in registers for the two products
@@ -855,52 +915,13 @@ struct upr_qp3 {
                     }
                     ok = upr_chol_inv_serial<SB>(Sm, Lr);
                 } else if (C::COUPLED) {
-                    // dense S of the knot straight from the inverse contact factors (G[lfi], written in phase B) and Df:
-                    // S = rho I + sum_c (Lf_c^-1 Df_c')' (Lf_c^-1 Df_c'); a contact loads the rows of at most two bodies, every
-                    // lane walks the same contact at the same time, so the body tests below do not diverge
+                    // dense S of the knot, assembled above (LDS, packed lower triangle)
                     const int k = kb;
                     double Sm[SB * SB];
 #pragma unroll
                     for (int r = 0; r < SB; ++r)
 #pragma unroll
-                        for (int c = 0; c <= r; ++c) Sm[r * SB + c] = (r == c) ? rho_s : 0.0;
-                    for (int ci = 0; ci < NC; ++ci) {
-                        const int b1 = P->contact_body1[ci], b2 = P->contact_body2[ci];
-                        double Bk[NF == 3 ? 9 : 1];
-                        if (NF == 3) {
-#pragma unroll
-                            for (int a = 0; a < 9; ++a) Bk[a] = G[F::lfi + k * C::NLF + 9 * ci + a];
-                        } else Bk[0] = G[F::lfi + k * C::NLF + ci];
-                        double zb[C::NB][6][NF];
-#pragma unroll
-                        for (int bi = 0; bi < C::NB; ++bi) {
-                            if (bi != b1 && bi != b2) continue;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                const double* dr = L + O::df + (6 * bi + r) * NFC + NF * ci;
-                                if (NF == 3) { const double d0 = dr[0], d1 = dr[1], d2 = dr[2]; zb[bi][r][0] = Bk[0] * d0; zb[bi][r][1 % NF] = Bk[3 % (NF == 3 ? 9 : 1)] * d0 + Bk[4 % (NF == 3 ? 9 : 1)] * d1; zb[bi][r][2 % NF] = Bk[6 % (NF == 3 ? 9 : 1)] * d0 + Bk[7 % (NF == 3 ? 9 : 1)] * d1 + Bk[8 % (NF == 3 ? 9 : 1)] * d2; }
-                                else zb[bi][r][0] = Bk[0] * dr[0];
-                            }
-                        }
-#pragma unroll
-                        for (int bi = 0; bi < C::NB; ++bi) {
-                            if (bi != b1 && bi != b2) continue;
-#pragma unroll
-                            for (int bj = 0; bj <= bi; ++bj) {
-                                if (bj != b1 && bj != b2) continue;
-#pragma unroll
-                                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                                    for (int c = 0; c < 6; ++c) {
-                                        if (bi == bj && c > r) continue;
-                                        double v = 0.0;
-#pragma unroll
-                                        for (int a = 0; a < NF; ++a) v += zb[bi][r][a] * zb[bj][c][a];
-                                        Sm[(6 * bi + r) * SB + 6 * bj + c] += v;
-                                    }
-                            }
-                        }
-                    }
+                        for (int c = 0; c <= r; ++c) Sm[r * SB + c] = L[O::sdn + k * (SB * (SB + 1) / 2) + r * (r + 1) / 2 + c];
                     ok = upr_chol_inv_serial<SB>(Sm, Ls);       // (the inverse goes to memory: factor and inverse together exceed the registers)
                 } else ok = upr_chol_inv_serial<SB>(L + O::hux + kb * SB * SB, Lr);
                 if (!ok) L[O::misc] = 1.0;
