@@ -1773,21 +1773,21 @@ def test_closed_loop_thrown_ball_with_soft_rows(arrangements):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["headline", "thrown_ball"])
+@pytest.mark.parametrize("case", ["headline", "headline_feedforward", "thrown_ball"])
 def test_tick_equals_the_three_calls(arrangements, case):
     """upr_batch_tick = set_observation + advance + evaluate at the observation (manager.py:156-176) in one call: bit-identical
     plan, policy output and statistics over a short closed loop, for the plain state and for interface states with a dynamic
     obstacle."""
     B = 8
-    if case == "headline":
-        P = thing_problem(arrangements["pink_bottle"], use_feedback_policy=True)
+    if case.startswith("headline"):   # (feedforward: sqp.use_feedback_policy off, the plan's input at the observation time)
+        P = thing_problem(arrangements["pink_bottle"], use_feedback_policy=(case == "headline"))
         x = level_tray_states(B, seed=5); way = waypoints_for(P, x)
     else:
         from test_emu import _projectile_case
         P, x0r, way, _, _, dyn = _projectile_case(arrangements, B, use_feedback_policy=True)
         x = np.concatenate([x0r, dyn], axis=1)
     a, b = BatchMPC(P, B, way_p=way), BatchMPC(P, B, way_p=way)
-    if case != "headline":
+    if case == "thrown_ball":
         a.set_projectile_flag(1.0); b.set_projectile_flag(1.0)
     t, dt = 0.0, 0.01
     for tick in range(5):
