@@ -14,6 +14,9 @@ Outputs (tests/golden/):
   configs.json        merged controller dicts (numeric fields the ControllerSettings mirror reads)
                       for the BASELINE.json configs, via the reference's include resolver
   parse_dsl.json      parse_number / parse_array known answers
+  inertial.json       upright_robust.modelling.UncertainObject.M (spatial mass matrix about the EE origin) of every body of three
+                      arrangements and upright_robust.utils.body_gravity6 at three orientations: the reference's own numpy
+                      statement of the inertial half of the object-dynamics residual (third reference-held answer for a1 / a3)
   grasp.json          upright_robust.modelling.compute_grasp_matrix (contact forces -> body wrenches) for three arrangements:
                       a statement of the wrench map that is independent of the C++ (second reference-held answer for a1 / a2)
 
@@ -191,7 +194,7 @@ def arrangement_input(cfg, name):
     `dump_arrangement`'s output without reading the reference tree."""
     arr = copy.deepcopy(cfg["arrangements"][name])
     types = {"ee"} | {o["type"] for o in arr["objects"]}
-    return {"arrangement": arr, "objects": {t: copy.deepcopy(cfg["objects"][t]) for t in types}}
+    return {"arrangement": arr, "objects": {t: copy.deepcopy(cfg["objects"][t]) for t in sorted(types)}}
 
 
 def jsonable(x):
@@ -277,6 +280,23 @@ def main():
     with open(OUT / "grasp.json", "w") as f:
         json.dump(grasp, f, indent=1)
 
+    # --- spatial mass matrices and the gravity twist (upright_robust/modelling.py:47-77, utils.py:5-13) -----------------------
+    import upright_robust.utils as rutils
+
+    inertial = {"arrangements": {}, "gravity": []}
+    for name, c in (("pink_bottle", cfg), ("box_arch", cfg), ("robust_8corner", rcfg)):
+        c2 = copy.deepcopy(c)
+        c2.setdefault("balancing", {})["arrangement"] = name
+        bodies, _ = core.parsing.parse_control_objects(c2)
+        inertial["arrangements"][name] = {
+            "names": sorted(bodies),
+            "M": [mdl.UncertainObject(bodies[n]).M.tolist() for n in sorted(bodies)],
+        }
+    for C_ew in (np.eye(3), _rotx(0.3) @ _roty(-0.2), _rotz(1.1) @ _roty(0.4) @ _rotx(-0.7)):
+        inertial["gravity"].append({"C_ew": C_ew.tolist(), "G": np.asarray(rutils.body_gravity6(C_ew)).tolist()})
+    with open(OUT / "inertial.json", "w") as f:
+        json.dump(inertial, f, indent=1)
+
     # --- merged configs for the BASELINE configs ------------------------------------------------
     configs = {}
     for key, rel in {
@@ -294,6 +314,11 @@ def main():
         # the sudden-obstacle experiments of the paper (not a BASELINE config; the same path): static obstacles of simple.yaml + ONE
         # dynamic obstacle whose position jumps at t = 1 s (two `modes`; the simulator / Vicon re-sets the observed state)
         "sudden_t1.0": "upright_cmd/config/ral23/experiments/sudden_obstacle/sudden_t1.0.yaml",
+        # the paper's other free-space arrangements (VERDICT r03 missing 1): seven cups (star, with friction), two stacked dice,
+        # and the bottle on the arm alone (base joints locked)
+        "full_cups_point1": "upright_cmd/config/ral23/experiments/freespace/full/full_cups_point1.yaml",
+        "full_dice_point1": "upright_cmd/config/ral23/experiments/freespace/full/full_dice_point1.yaml",
+        "full_bottle_arm_only": "upright_cmd/config/ral23/experiments/freespace/full/full_bottle_arm_only.yaml",
     }.items():
         d = core.parsing.load_config((REF / rel).as_posix())
         c = d["controller"]

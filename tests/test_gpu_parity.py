@@ -47,6 +47,32 @@ def test_core_functions(arrangements, name):
     assert np.abs(got - ref).max() < 1e-13
 
 
+@pytest.mark.parametrize("name", ["pink_bottle", "box_arch", "robust_8corner"])
+def test_inertial_half_against_reference_spatial_mass_matrix(arrangements, name):
+    """The engine's upr_core_object_dynamics against the reference's own numpy statement of the inertial wrench
+    (upright_robust/modelling.py:47-77 UncertainObject.M, utils.py:5-13 body_gravity6; tests/golden/inertial.json): zero
+    contact forces, omega = 0, random a, alpha at the fixture's orientations: m [force rows; torque rows + c x force rows] =
+    M (A - G) to 1e-12.  (omega != 0 is unpinned: the bias term needs rigeo.skew6, absent.)"""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle import inertial_wrench_about_ee_origin
+    fx = json.load(open(Path(__file__).resolve().parent / "golden" / "inertial.json"))
+    arr = arrangements[name]
+    Ms = np.asarray(fx["arrangements"][name]["M"])
+    P = thing_problem(arr)
+    rng = np.random.default_rng(5)
+    n = 8
+    for gcase in fx["gravity"]:
+        C_ew = np.asarray(gcase["C_ew"]); G = np.asarray(gcase["G"])
+        a, al = rng.normal(size=(2, n, 3)) * 3.0
+        rows = core_object_dynamics(P, P.body_params, np.zeros((n, 3 * P.nc)), np.broadcast_to(C_ew.T, (n, 3, 3)).copy(), np.zeros((n, 3)), al, a)
+        for i in range(n):
+            A = np.concatenate([C_ew @ a[i], C_ew @ al[i]])
+            got = inertial_wrench_about_ee_origin(P, arr, rows[i])
+            ref = np.stack([Ms[b] @ (A - G) for b in range(P.nb)])
+            assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("name,mfma", [("pink_bottle", "1"), ("pink_bottle", "0"), ("box_arch", "1"), ("foam_die2", "1")])
 def test_linearize_points(arrangements, name, mfma, monkeypatch):
     """Per-knot linearisation kernel (both Gauss-Newton Hessian paths) against the oracle's terms."""

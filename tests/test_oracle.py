@@ -331,3 +331,46 @@ def test_wrench_map_against_reference_grasp_matrix(arrangements, name, nf):
     u2 = u.copy(); u2[9:] += df
     g0 = O.eq_constraint(x, u, jac=False); g1 = O.eq_constraint(x, u2, jac=False)
     assert np.abs((g1 - g0) - D_ref @ df).max() < 1e-12 * max(1.0, np.abs(D_ref).max())
+
+
+def _inertial_fixture():
+    return json.load(open(Path(__file__).resolve().parent / "golden" / "inertial.json"))
+
+
+def inertial_wrench_about_ee_origin(P, arr, rows):
+    """m [force rows; torque rows + c x force rows] per body: the inertial wrench about the EE origin out of the per-body
+    residual of contact_constraints.h:79-101 (which is divided by m and takes its torque about the centre of mass)."""
+    out = []
+    for b, body in enumerate(arr["bodies"]):
+        m, c = body["mass"], np.asarray(body["com"])
+        F = m * rows[6 * b:6 * b + 3]
+        T = m * rows[6 * b + 3:6 * b + 6] + np.cross(c, F)
+        out.append(np.concatenate([F, T]))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "box_arch", "robust_8corner"])
+def test_inertial_half_against_reference_spatial_mass_matrix(arrangements, name):
+    """Third reference-held answer (a1 / a3): the inertial half of the object-dynamics residual as upright_robust states it in
+    numpy, independent of the C++ headers -- UncertainObject.M (modelling.py:47-77: spatial mass matrix about the EE origin,
+    parallel-axis inertia) and body_gravity6 (utils.py:5-13), both dumped by tests/golden/make_fixtures.py.  With zero contact
+    forces and omega = 0 the residual of body b is the wrench M_b (A - G) with A = [C_ew a; C_ew alpha].
+    omega != 0 stays unpinned: the bias term needs rigeo.skew6, which is absent here."""
+    fx = _inertial_fixture()
+    arr = arrangements[name]
+    Ms = np.asarray(fx["arrangements"][name]["M"])
+    assert fx["arrangements"][name]["names"] == [b["name"] for b in arr["bodies"]]
+    P = thing_problem(arr)
+    O = Oracle(P)
+    rng = np.random.default_rng(5)
+    z = np.zeros(3)
+    for gcase in fx["gravity"]:
+        C_ew = np.asarray(gcase["C_ew"]); G = np.asarray(gcase["G"])
+        assert np.abs(G[:3] - C_ew @ np.asarray(P.gravity)).max() < 1e-14 and np.abs(G[3:]).max() == 0.0
+        for _ in range(3):
+            a, al = rng.normal(size=(2, 3)) * 3.0
+            A = np.concatenate([C_ew @ a, C_ew @ al])
+            rows = O.object_dynamics(np.zeros(3 * P.nc), C_ew.T, z, al, a)
+            got = inertial_wrench_about_ee_origin(P, arr, rows)
+            ref = np.stack([Ms[b] @ (A - G) for b in range(P.nb)])
+            assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
