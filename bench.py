@@ -241,20 +241,41 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     failed = 0
     broke = [0]
     lat = []
+    lat_x = []
     u0_all = [None]
     stq_ = [None]
+    u_dev = u_out = ext = None
+    if world > 1:
+        # exchange buffers of the closed loop: u_0 stays on the device (engine buffer -> u_dev on the engine's stream -> RCCL)
+        import torch
+
+        from upright_amd.distributed import all_gather_first_inputs
+
+        u_dev = torch.empty((B, P.nu), dtype=torch.float64, device=device)
+        u_out = torch.empty((world * B, P.nu), dtype=torch.float64, device=device)
+        if device != "cpu" and hasattr(mpc, "stream_ptr") and mpc.stream_ptr():
+            ext = torch.cuda.ExternalStream(mpc.stream_ptr())
 
     def tick(x, t):
         tc = time.perf_counter()
         _, u, st_ = mpc.tick(t, x, want_stats=True)    # observation in, one SQP iteration, policy at the observation + statistics out: one call
         stq_[0] = st_["qp_status_last"]
-        if world > 1:   # exchange step of the closed loop: only u_0 of every instance, [B, nu] per rank
-            import torch
-
-            from upright_amd.distributed import all_gather_first_inputs
-
-            u0_all[0] = all_gather_first_inputs(torch.as_tensor(np.ascontiguousarray(u), device=device))
         lat.append(time.perf_counter() - tc)
+        if world > 1:   # exchange step of the closed loop: only u_0 of every instance, [B, nu] per rank,
+            # gathered from the engine's DEVICE buffer (no second trip over PCIe); the tick's latency with the exchange is
+            # stamped only when the collective has completed
+            mpc.copy_policy_device(u_dev.data_ptr())
+            if ext is not None:
+                torch.cuda.current_stream().wait_stream(ext)
+            else:
+                mpc.sync()
+            u0_all[0], hd = all_gather_first_inputs(u_dev, out=u_out, async_op=True)
+            hd.wait()
+            if device != "cpu":
+                torch.cuda.current_stream().synchronize()
+            if ext is not None:
+                ext.wait_stream(torch.cuda.current_stream())      # u_dev is free for the next tick's copy
+            lat_x.append(time.perf_counter() - tc)
         j = u[:, :9]
         q, v, a = x[:, :9], x[:, 9:18], x[:, 18:27]
         ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
@@ -262,7 +283,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
                                ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
 
     x = tick(x, t); t += dt          # first solve: cold start + allocation effects, untimed
-    lat.clear()
+    lat.clear(); lat_x.clear()
     mpc.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(ticks):
@@ -284,7 +305,9 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
                               - w["way"][::max(1, B // 64), 0], axis=1)
     out = {
         "workload": w["name"], "value": B * world * ticks / elapsed, "unit": "solves/s", "n_gpus": world, "ms_per_tick": 1e3 * elapsed / ticks,
-        "ms_per_tick_p99_engine": 1e3 * float(np.quantile(lat, 0.99)), "control_period_ms": 10.0, "ticks": ticks,
+        "ms_per_tick_p99_engine": 1e3 * float(np.quantile(lat, 0.99)),
+        "ms_per_tick_p99_with_exchange": 1e3 * float(np.quantile(lat_x, 0.99)) if lat_x else None,
+        "control_period_ms": 10.0, "ticks": ticks,
         "real_time_factor": 0.01 * ticks / elapsed,
         "exchange": "all-gather of u_0 per tick" if world > 1 else None,
         "qp_not_converged_fraction": failed / (B * world * ticks),
@@ -300,10 +323,11 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     return out
 
 
-def make_engine(w):
+def make_engine(w, device_index=None):
+    """The engine of one rank, on HIP device `device_index` (the launcher's LOCAL_RANK; None: the current device)."""
     from upright_amd.engine import BatchMPC
 
-    mpc = BatchMPC(w["P"], len(w["x0"]), way_p=w["way"], body_params=w["body_params"])
+    mpc = BatchMPC(w["P"], len(w["x0"]), way_p=w["way"], body_params=w["body_params"], device=device_index)
     mpc.set_observation(0.0, w["x0"])
     return mpc
 
@@ -410,7 +434,12 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
         # HIP-event duration: an algorithmic-model rate (the contract's definition), not executed flops -- those are
         # `achieved_issued`.  `bound` names the roofline the kernel sits closer to (fp64 "mfma" = vector = matrix peak, or
         # "hbm" by the counter traffic); it reaches neither: `bound_detail`.
-        "bound": "hbm" if (frac_hbm is not None and frac_hbm > frac) else "mfma",
+        # neither roofline is approached (executed flops <= 14 % of the fp64 peak, counter traffic mostly L2 /
+        # Infinity-Cache hits on dependent chains) -- the kernel is LATENCY bound and the label says so; `nearest_roofline`
+        # names the roofline it sits closer to, judged by the EXECUTED flops when the instruction-mix counters exist
+        # (the model count overstates them) and by the model count otherwise.
+        "bound": "latency",
+        "nearest_roofline": None,
         "bound_detail": "latency / issue bound: dependent fp64 chains of the Riccati recursion (one or two waves per instance carry "
                         "the serial sweeps), far from both the fp64 and the HBM roofline",
         "achieved": qp_tflops,
@@ -431,6 +460,10 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
         roof["achieved_issued"] = issued / (kt["qp_ms"] * 1e-3) / 1e12
         roof["frac_issued"] = roof["achieved_issued"] / PEAK_FP64_TFLOPS
         roof["issued_source"] = issued_src
+    f_exec = roof.get("frac_issued", frac)
+    roof["nearest_roofline"] = "hbm" if (frac_hbm is not None and frac_hbm > f_exec) else "mfma"
+    if max(f_exec, frac_hbm or 0.0) >= 0.5:
+        roof["bound"] = roof["nearest_roofline"]
     lin = {
         "kernel": "upr_linearize_kernel",
         "bound": "hbm",
@@ -646,13 +679,21 @@ def main():
     if not dry and not g.LIB.exists():
         g.build()
 
-    def engine_for(w):
-        if not dry:
-            return make_engine(w)
-        from upright_amd.distributed import StandInEngine
+    engine_devices = []
 
-        Pw = w["P"]
-        return StandInEngine(len(w["x0"]), rank * len(w["x0"]), Pw.N, Pw.nx, Pw.nu, nxf=w["x0"].shape[1])
+    def engine_for(w):
+        # rank r of a node drives GPU LOCAL_RANK: the engine is created on that device explicitly (upr_set_device), not on
+        # whatever torch left current
+        if not dry:
+            e = make_engine(w, device_index=local_rank)
+            assert e.device_index() == local_rank, (e.device_index(), local_rank)
+        else:
+            from upright_amd.distributed import StandInEngine
+
+            Pw = w["P"]
+            e = StandInEngine(len(w["x0"]), rank * len(w["x0"]), Pw.N, Pw.nx, Pw.nu, nxf=w["x0"].shape[1], device=local_rank)
+        engine_devices.append(e.device_index())
+        return e
 
     w = headline_workload(args.batch, rank, world)
     P, B = w["P"], args.batch
@@ -682,6 +723,10 @@ def main():
             extra.append(contract_entry(contract_workload(1024), args.extra_steps, 1))
         extra = [_strip(e) for e in extra]
 
+    rank_devices = [sorted(set(engine_devices))]
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, sorted(set(engine_devices)))
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         roof, lin = roofline_objects(P, B, kt, st, P.sqp_iters, headline=True)
@@ -709,6 +754,7 @@ def main():
             "roofline": roof,
             "roofline_linearize": lin,
             "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
+            "rank_devices": rank_devices,      # HIP device index of every engine each rank created (rank r: [LOCAL_RANK r])
         }
         if dry:
             out["dry_run"] = True

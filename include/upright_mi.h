@@ -132,6 +132,10 @@ typedef struct upr_problem {
 const char* upr_last_error(void);
 /* 1 if a HIP device is usable, else 0 (never initialises anything else) */
 int upr_device_available(void);
+/* One process per GPU (torch.distributed launchers hand every rank its LOCAL_RANK): select the HIP device the NEXT
+ * upr_batch_create of this thread uses.  A handle remembers its device (upr_batch_device) and every call on it makes that device
+ * current first.  The reference has no counterpart (one CPU solver per process). */
+int upr_set_device(int device);
 
 /* ------------------------------------------------------------------------------------------------
  * upright_core.bindings twins (upright_core/src/pybindings.cpp:53-56).  Batched: n states at once.
@@ -269,11 +273,16 @@ int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches);
 int upr_batch_enable_timing(upr_batch* h, int on);
 /* name of the QP kernel instantiation this handle launches (as rocprofv3 prints it): bench.py's roofline.kernel */
 const char* upr_batch_qp_kernel_name(const upr_batch* h);
+int upr_batch_device(const upr_batch* h);   /* the HIP device the handle lives on; -1 for a null handle */
 
 /* copy the current solution into caller-owned DEVICE buffers (torch tensors handed to the RCCL
  * all-gather of solved trajectories): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the
  * engine's stream, follow with upr_batch_sync. */
 int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst);
+/* copy the inputs the last upr_batch_tick evaluated, u[B][nu] (the u_0 of every instance: what the closed loop's exchange
+ * step gathers), from the engine's device buffer into a caller-owned DEVICE buffer; asynchronous on the engine's
+ * stream.  Fails before the first tick. */
+int upr_batch_copy_policy_device(upr_batch* h, void* u_dst);
 /* the engine's HIP stream (a hipStream_t): for callers that order their own streams against it with events instead of
  * upr_batch_sync -- the RCCL exchange step of bench.py makes the collective's stream wait for the copy-out, no host sync */
 void* upr_batch_stream(upr_batch* h);

@@ -43,7 +43,34 @@ static void qp2_all(const upr_qp_args& A, int B) {
 }
 
 
+template <int NQ>
+static void ee_tangents(const upr_problem* P, const double* x, double* snap_form, double* walk_form) {
+    double sc[2 * NQ], snap[NQ * UPR_SNAP_J + UPR_SNAP_E];
+    for (int j = 0; j < NQ; ++j) upr_sincos(x[j], &sc[2 * j], &sc[2 * j + 1]);
+    upr_ee_walk_snap<NQ>(P, x, sc, snap);
+    auto dump = [](const upr_ee<upr_dd>& E, double* o) {
+        int n = 0;
+        for (int i = 0; i < 3; ++i) { o[n] = E.p[i].v; o[30 + n++] = E.p[i].d; }
+        for (int i = 0; i < 9; ++i) { o[n] = E.C[i].v; o[30 + n++] = E.C[i].d; }
+        for (int i = 0; i < 3; ++i) { o[n] = E.v[i].v; o[30 + n++] = E.v[i].d; }
+        for (int i = 0; i < 3; ++i) { o[n] = E.w[i].v; o[30 + n++] = E.w[i].d; }
+        for (int i = 0; i < 3; ++i) { o[n] = E.a[i].v; o[30 + n++] = E.a[i].d; }
+        for (int i = 0; i < 3; ++i) { o[n] = E.al[i].v; o[30 + n++] = E.al[i].d; }
+    };
+    for (int dir = 0; dir < 3 * NQ; ++dir) {
+        upr_ee<upr_dd> E;
+        upr_ee_from_snap<NQ>(P, snap, dir, E); dump(E, snap_form + 60 * dir);
+        upr_ee_kinematics<upr_dd, NQ>(P, x, dir, E, sc); dump(E, walk_form + 60 * dir);
+    }
+}
+
 extern "C" {
+
+// end-effector state [p 3, C 9, v 3, w 3, a 3, al 3] and its tangent along every state coordinate, [3 nq][2][30]: the closed
+// form out of the per-joint snapshots (upr_ee_from_snap, what the linearisation kernel runs) and the forward-mode walk
+void emu_ee_tangents(const upr_problem* P, const double* x, double* snap_form, double* walk_form) {
+    if (P->nq == 6) ee_tangents<6>(P, x, snap_form, walk_form); else ee_tangents<9>(P, x, snap_form, walk_form);
+}
 
 void emu_dims(const upr_problem* P, int* out) {
     upr_dims d = upr_make_dims(P);

@@ -183,5 +183,7 @@ def test_bench_dry_run_two_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["value"] == 0.0
+    # rank 1 ran with LOCAL_RANK = 1 and created every one of its engines for device 1 (the path the 8-GPU run takes)
+    assert out["rank_devices"] == [[0], [1]]
     names = [e["workload"][:10] for e in out["extra_workloads"]]
     assert names == ["configs[3]", "configs[4]"] and all(e["n_gpus"] == 2 for e in out["extra_workloads"])

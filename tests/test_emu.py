@@ -532,3 +532,24 @@ def test_ur10_shape_production_kernel_source(arrangements, horizon):
         for dx, du in ((dx1, du1), (dx3, du3)):
             assert np.abs(dx[b] - dxo).max() < 2e-5 * max(1.0, np.abs(dxo).max())
             assert np.abs(du[b][:, :P.nq] - duo[:, :P.nq]).max() < 2e-4 * max(1.0, np.abs(duo).max())
+
+
+def test_closed_form_ee_tangents_equal_the_forward_mode_walk(arrangements):
+    """upr_ee_from_snap (what the linearisation kernel runs: every tangent of the end-effector state as a closed form of its
+    joint's snapshot) against the forward-mode walk on (value, tangent) pairs, for all 30 entries of the state -- the
+    VELOCITY included, which no term of the path consumes yet (it carried a zero tangent) -- along all 3 nq
+    state coordinates (the Thing chain: two prismatic and seven revolute joints), at random states with non-zero joint rates
+    and accelerations."""
+    P = thing_problem(arrangements["pink_bottle"])
+    E = C.CDLL(str(EMU))
+    cp = _capi.problem_to_c(P)
+    rng = np.random.default_rng(17)
+    nx = 3 * P.nq
+    for _ in range(5):
+        x = rng.uniform(-1.0, 1.0, nx)
+        a = np.zeros((nx, 2, 30)); b = np.zeros((nx, 2, 30))
+        E.emu_ee_tangents(C.byref(cp), p(x), p(a), p(b))
+        scale = max(1.0, np.abs(b).max())
+        assert np.abs(a[:, 0] - b[:, 0]).max() < 1e-13 * scale
+        assert np.abs(a[:, 1] - b[:, 1]).max() < 1e-12 * scale, np.unravel_index(np.abs(a[:, 1] - b[:, 1]).argmax(), (nx, 30))
+        assert np.abs(b[:, 1, 12:15]).max() > 0.1      # the velocity tangent is not trivially zero

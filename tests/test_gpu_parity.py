@@ -1538,7 +1538,8 @@ def test_config3_full_size_properties():
     mpc.advance()
     _, xs, us = mpc.solution()
     st = mpc.stats()
-    assert "DENSE" not in mpc.kernel_times()["qp_kernel"] and "9, 3, 16, 3" in mpc.kernel_times()["qp_kernel"]   # the production instantiation ran
+    # the production instantiation ran: (nq, nb, nc, nf, N, NT, ROWS, SOFT, DENSE) = (9, 3, 16, 3, 20, 256, true, false, true)
+    assert "upr_qp3_cfg<9, 3, 16, 3, 20, 256, true, false, true>" in mpc.kernel_times()["qp_kernel"].replace("  ", " ")
     assert np.all(st["qp_status_last"] == 0) and np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
     assert st["constraint_violation"].max() < 1e-4
     h = P.dt

@@ -217,10 +217,16 @@ __global__ void evaluate_policy_kernel(const upr_problem* P, upr_dims d, int B, 
 }  // namespace
 
 // ========================================================================================================
+// every entry point that takes a handle: the handle's own device is made current for the calling thread (the HIP "current
+// device" is per thread; a stream may only be used with its device current), so that one process can hold engines on several
+// GPUs and a launcher's rank r runs on the GPU its engine was created on whatever another library selected in between
+#define UPR_ENTER(h) do { if (!(h)) return fail("null batch"); if ((h)->device >= 0) UPR_HIP(hipSetDevice((h)->device)); } while (0)
+
 struct upr_batch {
     upr_problem P;
     upr_dims d;
     int B = 0;
+    int device = -1;            // HIP device the handle's buffers and stream live on (the current device at upr_batch_create)
     hipStream_t stream = nullptr;
     upr_problem* dP = nullptr;
     double *body_params = nullptr, *way_p = nullptr, *way_q = nullptr, *t0 = nullptr, *x0 = nullptr;
@@ -228,6 +234,7 @@ struct upr_batch {
     double *lin = nullptr, *Df = nullptr, *ws = nullptr, *stats = nullptr;
     int *done = nullptr;
     bool has_prev = false;   // a solution of a previous advance exists (warm start, policy evaluation)
+    unsigned char* iter_key = nullptr;   // [B] IPM iteration count of the last QP, one byte per instance (what `order` is ranked by)
     int* order = nullptr;       // dispatch order of the QP launch: instances by the iteration count of their last QP, longest first
     bool order_on = true, order_valid = false;
     double* prof = nullptr;
@@ -515,7 +522,7 @@ upr_lin_args traj_lin_args(upr_batch* h) {
 }
 upr_qp_args make_qp_args(upr_batch* h) {
     upr_qp_args A;
-    A.P = h->dP; A.d = h->d; A.xs = h->xs; A.us = h->us; A.x0 = h->x0; A.lin = h->lin; A.Df = h->Df; A.ws = h->ws; A.stats = h->stats; A.prof = h->prof;
+    A.P = h->dP; A.d = h->d; A.xs = h->xs; A.us = h->us; A.x0 = h->x0; A.lin = h->lin; A.Df = h->Df; A.ws = h->ws; A.stats = h->stats; A.prof = h->prof; A.iter_key = h->iter_key;
     return A;
 }
 
@@ -601,7 +608,7 @@ int advance_impl(upr_batch* h) {
         L.way_p = h->way_p; L.way_q = upr_has_orientation_cost(&h->P) ? h->way_q : nullptr; L.lin = h->lin; L.ws = h->ws; L.stats = h->stats; L.done = h->done; L.iter = it; L.dyn = h->dyn0; L.pflag = h->pflag;
         // folded into the line search's launch: the dispatch order of the next QP (rounds 2 - 3a: a one-workgroup counting sort
         // of its own) and, behind the advance's last line search, the copy of the solution the next warm start reads
-        if (h->order_on) L.order_out = h->order;
+        if (h->order_on) { L.order_out = h->order; L.iter_key = h->iter_key; }
         if (it == sqp_iters - 1) { L.xs_prev = h->xs_prev; L.us_prev = h->us_prev; L.tprev = h->tprev; }
         { KernelTimer T(h, 2); int rc = (h->P.nq == 6) ? launch_linesearch<6>(h, L) : launch_linesearch<9>(h, L); if (rc) return 1; T.stop(); }
         if (h->order_on) h->order_valid = true;
@@ -674,6 +681,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (B < 1) { fail("B must be >= 1"); return nullptr; }
     if (need_device()) return nullptr;
     upr_batch* h = new upr_batch();
+    if (hipGetDevice(&h->device) != hipSuccess) { fail("hipGetDevice failed"); delete h; return nullptr; }
     h->P = *P; h->d = upr_make_dims(P); h->B = B;
     h->nxf = h->d.nx + 9 * P->n_dyn;
     h->hdyn0.assign((size_t)B * 9 * P->n_dyn, 0.0); h->hdyn_prev = h->hdyn0; h->htprev.assign(B, 0.0);
@@ -718,7 +726,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         dev_alloc(&h->x0, (size_t)B * d.nx) || dev_alloc(&h->xs, (size_t)B * n1 * d.nx) || dev_alloc(&h->us, (size_t)B * d.N * d.nu) ||
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
-        dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) || dev_alloc(&h->order, B) ||
+        dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) || dev_alloc(&h->order, B) || dev_alloc(&h->iter_key, ((size_t)B + 3) & ~(size_t)3) ||
         (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
         (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9 * P->n_dyn) || dev_alloc(&h->pflag, B))))
         return bad();
@@ -756,7 +764,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->order); if (h->pin) (void)hipHostFree(h->pin); hipFree(h->prof); hipFree(h->kkt);
+    hipFree(h->done); hipFree(h->order); hipFree(h->iter_key); if (h->pin) (void)hipHostFree(h->pin); hipFree(h->prof); hipFree(h->kkt);
     hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -764,7 +772,7 @@ void upr_batch_destroy(upr_batch* h) {
 }
 
 int upr_batch_reset(upr_batch* h, const double* way_p) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (way_p) UPR_HIP(hipMemcpyAsync(h->way_p, way_p, sizeof(double) * h->B * h->P.n_way * 3, hipMemcpyHostToDevice, h->stream));
     h->has_prev = false;
     UPR_HIP(hipStreamSynchronize(h->stream));
@@ -773,7 +781,7 @@ int upr_batch_reset(upr_batch* h, const double* way_p) {
 }
 
 int upr_batch_set_target_orientations(upr_batch* h, const double* way_q) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!way_q) return fail("upr_batch_set_target_orientations: way_q is NULL");
     std::vector<double> q(way_q, way_q + (size_t)h->B * h->P.n_way * 4);
     for (size_t i = 0; i < q.size(); i += 4) {   // unit quaternions (the reference builds Quatd from the target's coefficients)
@@ -787,7 +795,7 @@ int upr_batch_set_target_orientations(upr_batch* h, const double* way_q) {
 }
 
 static int set_observation_core(upr_batch* h, const double* t, int t_stride, const double* x) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
     UPR_HIP(hipMemcpyAsync(h->t0, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
@@ -797,7 +805,7 @@ static int set_observation_core(upr_batch* h, const double* t, int t_stride, con
 }
 
 static int set_guess_core(upr_batch* h, const double* xs, const double* us) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     UPR_HIP(hipMemcpyAsync(h->xs, xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyHostToDevice, h->stream));
     UPR_HIP(hipMemcpyAsync(h->us, us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyHostToDevice, h->stream));
@@ -807,25 +815,25 @@ static int set_guess_core(upr_batch* h, const double* xs, const double* us) {
 }
 
 int upr_batch_set_sqp_iterations(upr_batch* h, int n) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (n < 0 || n > 1000) return fail("upr_batch_set_sqp_iterations: n out of range");
     h->sqp_iters_next = n;
     return 0;
 }
 
 int upr_batch_advance_async(upr_batch* h) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     return advance_impl(h);
 }
 
 int upr_batch_sync(upr_batch* h) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     UPR_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int upr_batch_advance(upr_batch* h) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     auto t0 = std::chrono::steady_clock::now();
     if (advance_impl(h)) return 1;
     UPR_HIP(hipStreamSynchronize(h->stream));
@@ -834,7 +842,7 @@ int upr_batch_advance(upr_batch* h) {
 }
 
 static int get_solution_core(upr_batch* h, double* ts, double* xs, double* us) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     UPR_HIP(hipStreamSynchronize(h->stream));
     if (ts) {
@@ -848,7 +856,7 @@ static int get_solution_core(upr_batch* h, double* ts, double* xs, double* us) {
 }
 
 static int evaluate_core(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     // (per-tick path of the closed loop: scratch preallocated in the handle on first use)
     if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
@@ -864,7 +872,7 @@ static int evaluate_core(upr_batch* h, const double* t, int t_stride, double* x_
 }
 
 static int evaluate_policy_core(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->fb) return fail("upr_batch_evaluate_policy: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
     if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
@@ -881,7 +889,7 @@ static int evaluate_policy_core(upr_batch* h, const double* t, int t_stride, con
 }
 
 static int get_feedback_core(upr_batch* h, double* K) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->fb) return fail("upr_batch_get_feedback: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
     UPR_HIP(hipStreamSynchronize(h->stream));
@@ -894,7 +902,7 @@ double upr_batch_last_solve_ms(const upr_batch* h) { return h ? h->last_ms : 0.0
 const char* upr_batch_qp_kernel_name(const upr_batch* h) { return h ? h->qp_name.c_str() : ""; }
 
 int upr_batch_get_stats(upr_batch* h, double* stats) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     UPR_HIP(hipStreamSynchronize(h->stream));
     UPR_HIP(hipMemcpy(stats, h->stats, sizeof(double) * h->B * UPR_NSTATS, hipMemcpyDeviceToHost));
     return 0;
@@ -930,7 +938,7 @@ static int linearize_points_impl(upr_batch* h, int n, const int* inst, const dou
 
 int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const double* t, const double* x, const double* u,
                                double* g, double* gx, double* cost, double* grad, double* hess, double* ee) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (n <= 0) return 0;
     const upr_dims& d = h->d;
     std::vector<double> rec, xr, dyn;
@@ -956,7 +964,7 @@ int upr_batch_linearize_points(upr_batch* h, int n, const int* inst, const doubl
 }
 
 int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* dd, double* dq) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     if (d.no == 0) return fail("upr_batch_obstacle_rows: the problem has no collision pairs / projectile rows");
     if (n <= 0) return 0;
@@ -976,7 +984,7 @@ int upr_batch_obstacle_rows(upr_batch* h, int n, const double* x, double* dd, do
 }
 
 int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (inst < 0 || inst >= h->B) return fail("instance index out of range");
     const upr_dims& d = h->d;
     for (int r = 0; r < d.ne; ++r) {
@@ -987,7 +995,7 @@ int upr_batch_eq_input_jacobian(upr_batch* h, int inst, double* gu) {
 }
 
 static int qp_step_core(upr_batch* h, double* dxs, double* dus) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     if (do_linearize(h, traj_lin_args(h))) return 1;
     if (launch_qp(h, make_qp_args(h))) return 1;
@@ -1007,7 +1015,7 @@ static int qp_step_core(upr_batch* h, double* dxs, double* dus) {
  * terminal-equality multipliers, lam[B][N+1][ni] inequality multipliers, ni = 2 nx + 2 nu + np + no in the slot order
  * [x lower][x upper][u lower][u upper][friction rows][collision / projectile rows]; *ni_out = ni.  Any pointer may be NULL. */
 int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double* nu, double* yN, double* lam, int* ni_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (h->P.n_dyn) return fail("upr_batch_qp_kkt: not available with a dynamic obstacle (interface states)");
     const upr_dims& d = h->d;
     if (ni_out) *ni_out = d.ni_stage;
@@ -1049,7 +1057,7 @@ int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double*
 }
 
 int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (xs) *xs = h->xs;
     if (us) *us = h->us;
     return 0;
@@ -1057,7 +1065,7 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
 
 /* debug: per-phase cycle counters of the production QP kernel, prof[B][4 waves][16]; allocate on first use */
 int upr_batch_qp_profile(upr_batch* h, double* out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->prof) { if (dev_alloc(&h->prof, (size_t)h->B * 64)) return 1; return 0; }
     UPR_HIP(hipStreamSynchronize(h->stream));
     if (out) UPR_HIP(hipMemcpy(out, h->prof, sizeof(double) * h->B * 64, hipMemcpyDeviceToHost));
@@ -1067,7 +1075,7 @@ int upr_batch_qp_profile(upr_batch* h, double* out) {
 
 /* debug / test accessor: the per-knot linearisation records of the current trajectory, lin[B][N+1][stride] */
 int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     UPR_HIP(hipStreamSynchronize(h->stream));
     if (stride) *stride = h->d.lin_stride;
     if (lin) UPR_HIP(hipMemcpy(lin, h->lin, sizeof(double) * h->B * (h->d.N + 1) * h->d.lin_stride, hipMemcpyDeviceToHost));
@@ -1075,14 +1083,14 @@ int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
 }
 
 int upr_batch_enable_timing(upr_batch* h, int on) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     h->timing = on != 0;
     for (int i = 0; i < 3; ++i) { h->k_ms[i] = 0; h->k_launches[i] = 0; }
     return 0;
 }
 
 int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     UPR_HIP(hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < h->ev_slot.size(); ++i) {
         float t = 0;
@@ -1100,18 +1108,36 @@ int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches) {
 /* copy the current solution into caller-owned DEVICE buffers (e.g. torch tensors handed to an RCCL
  * all-gather): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the engine's stream. */
 int upr_batch_copy_solution_device(upr_batch* h, void* xs_dst, void* us_dst) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     const upr_dims& d = h->d;
     if (xs_dst) UPR_HIP(hipMemcpyAsync(xs_dst, h->xs, sizeof(double) * h->B * (d.N + 1) * d.nx, hipMemcpyDeviceToDevice, h->stream));
     if (us_dst) UPR_HIP(hipMemcpyAsync(us_dst, h->us, sizeof(double) * h->B * d.N * d.nu, hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
+int upr_batch_copy_policy_device(upr_batch* h, void* u_dst) {
+    UPR_ENTER(h);
+    if (!h->ev_u) return fail("upr_batch_copy_policy_device: no tick has run on this handle");
+    if (!u_dst) return fail("upr_batch_copy_policy_device: null destination");
+    UPR_HIP(hipMemcpyAsync(u_dst, h->ev_u, sizeof(double) * h->B * h->d.nu, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
 void* upr_batch_stream(upr_batch* h) { return h ? (void*)h->stream : nullptr; }
+
+int upr_set_device(int device) {
+    if (need_device()) return 1;
+    int n = 0;
+    UPR_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("upr_set_device: no such device");
+    UPR_HIP(hipSetDevice(device));
+    return 0;
+}
+int upr_batch_device(const upr_batch* h) { return h ? h->device : -1; }
 
 /* forget the previous solution without a host synchronisation (cold start for the next advance) */
 int upr_batch_reset_async(upr_batch* h) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     h->has_prev = false;
     h->guess_set = false;
     return 0;
@@ -1131,7 +1157,7 @@ static void obstacle_after(const double* xo, double tau, double* out, int n_dyn 
 }
 
 int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const double* x) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn) return set_observation_core(h, t, t_stride, x);
     std::vector<double> xr;
     narrow_states(h, x, h->B, xr);
@@ -1142,7 +1168,7 @@ int upr_batch_set_observation(upr_batch* h, const double* t, int t_stride, const
 }
 
 int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn) return set_guess_core(h, xs, us);
     std::vector<double> xr;
     narrow_states(h, xs, (size_t)h->B * (h->d.N + 1), xr);
@@ -1150,7 +1176,7 @@ int upr_batch_set_guess(upr_batch* h, const double* xs, const double* us) {
 }
 
 int upr_batch_get_solution(upr_batch* h, double* ts, double* xs, double* us) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn || !xs) return get_solution_core(h, ts, xs, us);
     const upr_dims& d = h->d;
     std::vector<double> xr((size_t)h->B * (d.N + 1) * d.nx);
@@ -1175,7 +1201,7 @@ static void widen_eval(upr_batch* h, const double* t, int t_stride, const double
 }
 
 int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_out, double* u_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn) return evaluate_core(h, t, t_stride, x_out, u_out);
     std::vector<double> xr((size_t)h->B * h->d.nx);
     if (evaluate_core(h, t, t_stride, xr.data(), u_out)) return 1;
@@ -1184,7 +1210,7 @@ int upr_batch_evaluate(upr_batch* h, const double* t, int t_stride, double* x_ou
 }
 
 int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const double* x_obs, double* x_out, double* u_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn) return evaluate_policy_core(h, t, t_stride, x_obs, x_out, u_out);
     std::vector<double> xo, xr((size_t)h->B * h->d.nx);
     narrow_states(h, x_obs, h->B, xo);
@@ -1194,7 +1220,7 @@ int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const
 }
 
 int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x, double* x_out, double* u_out, double* stats_out) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!t || !x || !x_out || !u_out) return fail("upr_batch_tick: null argument");
     const upr_dims& d = h->d;
     const size_t B = (size_t)h->B, nx = (size_t)d.nx, nu = (size_t)d.nu, ndyn = 9 * (size_t)h->P.n_dyn;
@@ -1236,7 +1262,7 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
 }
 
 int upr_batch_get_feedback(upr_batch* h, double* K) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn) return get_feedback_core(h, K);
     const upr_dims& d = h->d;
     std::vector<double> Kr((size_t)h->B * d.N * d.nu * d.nx);
@@ -1250,7 +1276,7 @@ int upr_batch_get_feedback(upr_batch* h, double* K) {
 }
 
 int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->P.n_dyn || !dxs) return qp_step_core(h, dxs, dus);
     const upr_dims& d = h->d;
     std::vector<double> xr((size_t)h->B * (d.N + 1) * d.nx);
@@ -1264,7 +1290,7 @@ int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus) {
 }
 
 int upr_batch_set_projectile_flag(upr_batch* h, const double* sflag) {
-    if (!h) return fail("null batch");
+    UPR_ENTER(h);
     if (!h->pflag) return fail("upr_batch_set_projectile_flag: the problem has no dynamic obstacle");
     UPR_HIP(hipMemcpy(h->pflag, sflag, sizeof(double) * h->B, hipMemcpyHostToDevice));
     return 0;

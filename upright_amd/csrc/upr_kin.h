@@ -278,16 +278,17 @@ static UPR_HDI void upr_ee_from_snap(const upr_problem* P, const double* snap, i
     double u[3], zr[3];
     upr_cross(z, rho, zr);
     for (int i = 0; i < 3; ++i) u[i] = rev ? zr[i] : z[i];
-    double dC[9], dp[3], dw[3], dal[3], da[3];
+    double dC[9], dp[3], dv[3], dw[3], dal[3], da[3];
     for (int i = 0; i < 9; ++i) dC[i] = 0.0;
-    for (int i = 0; i < 3; ++i) { dp[i] = 0.0; dw[i] = 0.0; dal[i] = 0.0; da[i] = 0.0; }
+    for (int i = 0; i < 3; ++i) { dp[i] = 0.0; dv[i] = 0.0; dw[i] = 0.0; dal[i] = 0.0; da[i] = 0.0; }
     double wbu[3];
     upr_cross(wb, u, wbu);
     if (cls == 0) {
         double abu[3], wwu[3];
         upr_cross(ab, u, abu);
         upr_cross(wb, wbu, wwu);
-        for (int i = 0; i < 3; ++i) { dp[i] = u[i]; da[i] = abu[i] + wwu[i]; }
+        // v = v_o + w_b x rho + rho': d/dq = w_b x u (+ z x rho' for a revolute joint: rho' turns with the link)
+        for (int i = 0; i < 3; ++i) { dp[i] = u[i]; dv[i] = wbu[i]; da[i] = abu[i] + wwu[i]; }
         if (rev) {
             double zwr[3], wzwr[3], zalr[3], zrd[3], wzrd[3], zrdd[3];
             upr_cross(z, wr, zwr);
@@ -296,7 +297,7 @@ static UPR_HDI void upr_ee_from_snap(const upr_problem* P, const double* snap, i
             upr_cross(z, rd, zrd);
             upr_cross(wb, zrd, wzrd);
             upr_cross(z, rdd, zrdd);
-            for (int i = 0; i < 3; ++i) { dw[i] = zwr[i]; dal[i] = wzwr[i] + zalr[i]; da[i] = da[i] + 2.0 * wzrd[i] + zrdd[i]; }
+            for (int i = 0; i < 3; ++i) { dv[i] = dv[i] + zrd[i]; dw[i] = zwr[i]; dal[i] = wzwr[i] + zalr[i]; da[i] = da[i] + 2.0 * wzrd[i] + zrdd[i]; }
             // dC = S(z) C, column by column (C row-major)
             for (int c = 0; c < 3; ++c) {
                 const double c0 = C[c], c1 = C[3 + c], c2 = C[6 + c];
@@ -304,7 +305,7 @@ static UPR_HDI void upr_ee_from_snap(const upr_problem* P, const double* snap, i
             }
         }
     } else if (cls == 1) {
-        for (int i = 0; i < 3; ++i) da[i] = 2.0 * wbu[i];
+        for (int i = 0; i < 3; ++i) { dv[i] = u[i]; da[i] = 2.0 * wbu[i]; }
         if (rev) {
             double wbz[3], zwr[3], zrd[3];
             upr_cross(wb, z, wbz);
@@ -316,7 +317,7 @@ static UPR_HDI void upr_ee_from_snap(const upr_problem* P, const double* snap, i
         for (int i = 0; i < 3; ++i) { da[i] = u[i]; dal[i] = rev ? z[i] : 0.0; }
     }
     for (int i = 0; i < 9; ++i) E.C[i] = {C[i], dC[i]};
-    for (int i = 0; i < 3; ++i) { E.p[i] = {p[i], dp[i]}; E.v[i] = {v[i], 0.0}; E.w[i] = {w[i], dw[i]}; E.a[i] = {a[i], da[i]}; E.al[i] = {al[i], dal[i]}; }
+    for (int i = 0; i < 3; ++i) { E.p[i] = {p[i], dp[i]}; E.v[i] = {v[i], dv[i]}; E.w[i] = {w[i], dw[i]}; E.a[i] = {a[i], da[i]}; E.al[i] = {al[i], dal[i]}; }
 }
 
 // Centres of the collision spheres (controller_interface.cpp:172-228: the spheres of

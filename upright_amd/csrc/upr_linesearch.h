@@ -29,9 +29,10 @@ struct upr_ls_args {
     const double* way_q = nullptr;  // [B][n_way][4] target orientations; NULL unless Wee[3..5] != 0
     // Engine bookkeeping folded into this launch (device kernel only; each was a stream operation of its own):
     //   order_out: the dispatch order of the NEXT QP launch, longest first by the iteration count the QP that just ran left in
-    //              stats[.][1] -- every workgroup ranks its own instance (ties by index);
+    //              iter_key[.] (one byte per instance, upr_qp_args::iter_key) -- every workgroup ranks its own instance (ties by index);
     //   xs_prev ..: the solution remembered for the next warm start / policy evaluation (the advance's last line search)
     int* order_out = nullptr;
+    const unsigned char* iter_key = nullptr;
     double* xs_prev = nullptr; double* us_prev = nullptr; double* tprev = nullptr;
     int stage_full = 1;    // the instance's trajectory and step staged in LDS (upr_ls_lds_doubles)
 };
@@ -383,11 +384,18 @@ __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
     static_assert(NT == 64, "one wave per instance (the rank below is a wave reduction)");
     if (A.order_out) {
+        // B one-byte keys, read four at a time by consecutive lanes (B bytes per workgroup out of the L2: 16 MB per launch at
+        // B = 4096 where ranking on stats[.][1], one 96-byte stride per instance, moved 1 GB)
         const int B = gridDim.x, me = blockIdx.x;
-        auto key = [&](int o) { const int k = (int)A.stats[(size_t)o * UPR_NSTATS + 1]; return k < 0 ? 0 : (k > 255 ? 255 : k); };
-        const int mk = key(me);
+        const int mk = A.iter_key[me];
         int cnt = 0;
-        for (int o = threadIdx.x; o < B; o += NT) { const int k = key(o); cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
+        const unsigned int* k4 = reinterpret_cast<const unsigned int*>(A.iter_key);
+        for (int o4 = threadIdx.x; o4 < (B >> 2); o4 += NT) {
+            const unsigned int w = k4[o4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int k = (int)((w >> (8 * j)) & 255u), o = 4 * o4 + j; cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
+        }
+        for (int o = (B & ~3) + threadIdx.x; o < B; o += NT) { const int k = A.iter_key[o]; cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (threadIdx.x == 0) A.order_out[cnt] = me;

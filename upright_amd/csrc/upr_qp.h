@@ -68,7 +68,12 @@ struct upr_qp_args {
     // optional dispatch order: workgroup i solves instance order[i] (a permutation of 0..B-1).  The host passes the
     // instances sorted by the IPM iteration count of their previous QP, longest first (ranked inside the line-search launch, upr_linesearch.h order_out)
     const int* order = nullptr;
+    // optional: the IPM iteration count of every instance as one byte, iter_key[B] (clamped to 255): what the ranking inside the
+    // line-search launch sorts by.  A compact array so that every workgroup of that launch reads all B keys with coalesced
+    // requests (B bytes; ranking on stats[.][1] touched one cache line per instance and workgroup: O(B^2) lines)
+    unsigned char* iter_key = nullptr;
 };
+static UPR_HDI void upr_qp_store_key(const upr_qp_args& A, int b, int it) { if (A.iter_key) A.iter_key[b] = (unsigned char)(it < 0 ? 0 : (it > 255 ? 255 : it)); }
 static UPR_HDI int upr_qp_instance(const upr_qp_args& A, int wg) { return A.order ? A.order[wg] : wg; }
 static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + (d.N + 1) * d.ni_stage; }
 
@@ -1045,6 +1050,7 @@ static inline UPR_HD void upr_qp_solve(const upr_ctx& ctx, const upr_qp_args& A,
     if (ctx.tid == 0) {
         double* st = A.stats + (size_t)b * UPR_NSTATS;
         st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];
+        upr_qp_store_key(A, b, it);
     }
     UPR_SYNC();
 }

@@ -795,6 +795,7 @@ static inline UPR_HD void upr_qp2_solve(const upr_ctx& ctx, const upr_qp_args& A
     upr_qp2<D> S(ctx, A, b, L);
     S.prof = A.prof ? A.prof + (size_t)b * 16 : nullptr;
     S.solve(A.stats + (size_t)b * UPR_NSTATS);
+    if (ctx.tid == 0) upr_qp_store_key(A, b, (int)A.stats[(size_t)b * UPR_NSTATS + 1]);
 }
 
 template <class D>

@@ -947,6 +947,7 @@ struct upr_qp3 {
                 // lanes of THIS wave read at the top of their factorisation: all Schur blocks sit on one wave (lockstep),
                 // so every read precedes every write.
                 static_assert(!C::VCPRE || (C::NKB <= 64 && O::sw0 + C::NKB * (SB * (SB + 1) / 2) <= O::yN), "Lsi staging of phase D");
+                UPR_WSYNC();   // (compiler-level: no lane's store below may be hoisted above another lane's reads of S; free at run time)
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -3277,6 +3278,7 @@ struct upr_qp3 {
         if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;
             st[1] = it; st[2] = status; st[6] = res[0]; st[7] = res[1]; st[8] = res[2]; st[9] = res[3];
+            upr_qp_store_key(A, b, it);
         }
         UPR_SYNC();
     }

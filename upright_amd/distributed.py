@@ -59,17 +59,18 @@ def all_gather_solutions(xs_local, us_local, counts=None, group=None, async_op=F
     return gather(xs_local), gather(us_local), counts
 
 
-def all_gather_first_inputs(u0_local, group=None):
+def all_gather_first_inputs(u0_local, group=None, out=None, async_op=False):
     """Closed loop (BASELINE configs[4]): per control tick only the first input u_0 of every instance
     is exchanged, [B, nu] per rank -> [world B, nu] on every rank (equal shards).  u0_local: torch tensor (CPU for gloo,
-    CUDA for nccl)."""
+    CUDA for nccl).  out: a preallocated [world B, nu] tensor (no allocation per tick); async_op: returns (out, handle)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    out = torch.empty((world * u0_local.shape[0],) + tuple(u0_local.shape[1:]), dtype=u0_local.dtype, device=u0_local.device)
-    dist.all_gather_into_tensor(out, u0_local.contiguous(), group=group)
-    return out
+    if out is None:
+        out = torch.empty((world * u0_local.shape[0],) + tuple(u0_local.shape[1:]), dtype=u0_local.dtype, device=u0_local.device)
+    h = dist.all_gather_into_tensor(out, u0_local.contiguous(), group=group, async_op=async_op)
+    return (out, h) if async_op else out
 
 
 class StandInEngine:
@@ -77,8 +78,9 @@ class StandInEngine:
     filled with +-b) -- the solve itself needs a GPU.  Used by the gloo world-size-2 tests and by `bench.py --dry-run`;
     never by a measurement."""
 
-    def __init__(self, B, lo, N, nx, nu, nxf=None):
+    def __init__(self, B, lo, N, nx, nu, nxf=None, device=0):
         self.B, self.N, self.nx, self.nu, self.lo = B, N, nx, nu, lo
+        self.device = int(device)
         self.nxf = nxf or nx
         ids = np.arange(lo, lo + B, dtype=np.float64)
         self.xs = np.ascontiguousarray(ids[:, None, None] + np.zeros((B, N + 1, nx)))
@@ -86,6 +88,7 @@ class StandInEngine:
         self.calls = []
         self.t = 0.0
 
+    def device_index(self): return self.device
     def reset_async(self): self.calls.append("reset")
     def advance_async(self): self.calls.append("advance")
     def advance(self): self.calls.append("advance")
@@ -112,6 +115,13 @@ class StandInEngine:
 
     def kernel_times(self):
         return dict(linearize_ms=0.0, qp_ms=0.0, linesearch_ms=0.0, launches=[0, 0, 0], qp_kernel="stand-in")
+
+    def copy_policy_device(self, up):
+        import ctypes
+
+        _, u = self.evaluate(self.t)
+        u = np.ascontiguousarray(u)
+        ctypes.memmove(up, u.ctypes.data, u.nbytes)
 
     def copy_solution_device(self, xp, up):
         import ctypes

@@ -13,7 +13,7 @@ from ._capi import check, cont, iptr, ptr
 
 
 class BatchMPC:
-    def __init__(self, problem, B=1, body_params=None, way_p=None, way_q=None):
+    def __init__(self, problem, B=1, body_params=None, way_p=None, way_q=None, device=None):
         self.problem = problem.validate()
         self.B = int(B)
         self.nx, self.nu, self.N = problem.nx, problem.nu, problem.N
@@ -27,6 +27,8 @@ class BatchMPC:
         self.way_p = cont(way_p).reshape(self.B, len(problem.way_t), 3)
         self._c = _capi.problem_to_c(problem)
         self._lib = _capi.lib()
+        if device is not None:     # one process per GPU: the launcher's LOCAL_RANK (None: the thread's current device)
+            check(self._lib.upr_set_device(int(device)))
         self._h = self._lib.upr_batch_create(C.byref(self._c), self.B, ptr(self.body_params), ptr(self.way_p))
         if not self._h:
             raise RuntimeError(self._lib.upr_last_error().decode())
@@ -187,6 +189,13 @@ class BatchMPC:
 
     def copy_solution_device(self, xs_ptr, us_ptr):
         check(self._lib.upr_batch_copy_solution_device(self._h, C.c_void_p(xs_ptr), C.c_void_p(us_ptr)))
+
+    def copy_policy_device(self, u_ptr):
+        """u_0 of every instance as the last tick() evaluated it, device -> device on the engine's stream (asynchronous)."""
+        check(self._lib.upr_batch_copy_policy_device(self._h, C.c_void_p(u_ptr)))
+
+    def device_index(self):
+        return int(self._lib.upr_batch_device(self._h))
 
     def stream_ptr(self):
         """The engine's HIP stream (hipStream_t) as an integer, e.g. for torch.cuda.ExternalStream."""
