@@ -20,6 +20,9 @@ def arrangements():
 @pytest.fixture(scope="session", autouse=True)
 def _build_native():
     """Build the oracle, the engine library and the test-only host emulation once per session."""
+    import os
+
     import __graft_entry__ as g
 
-    g.build()
+    if os.environ.get("UPR_SKIP_BUILD") != "1":     # (development loops only: the libraries are already built)
+        g.build()

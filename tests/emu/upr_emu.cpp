@@ -28,6 +28,9 @@ static void lin_all_o(const upr_lin_args& A) {
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1a<NQ>(A, q, l, sh.data());
         for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase1<NQ, ORI>(A, q, l, sh.data());
         if (A.d.no > 0) {
+#if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
+            if (A.dyn) for (int oi = 0; oi < A.P->n_dyn; ++oi) upr_lin_stage_obstacle(A, q, oi, sh.data());
+#endif
             for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_a<NQ>(A, q, l, sh.data());
             for (int l = 0; l < UPR_LPK; ++l) upr_lin_phase_obs_b<NQ>(A, q, l, sh.data());
         }

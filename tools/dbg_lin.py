@@ -5,8 +5,11 @@ sys.path.insert(0, '.')
 import numpy as np
 import bench
 from upright_amd import _capi
-w = bench.headline_workload(1024)
+name = sys.argv[1] if len(sys.argv) > 1 else "headline"
+w = {"config3": lambda: bench.config3_workload(4096), "config4": lambda: bench.config4_workload(1024), "config5": lambda: bench.config5_workload(1024),
+     "headline": lambda: bench.headline_workload(1024)}[name]()
 mpc = bench.make_engine(w)
+if name == "config5": mpc.set_projectile_flag(1.0)
 lib = _capi.lib()
 out = np.zeros(8)
 mpc.reset(); mpc.advance()
@@ -16,7 +19,7 @@ for _ in range(3):
     mpc.reset(); mpc.advance()
 mpc.sync()
 lib.upr_debug_lin_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 0)
-names = ["phase 0: stage x, u, sin/cos, Df f", "phase 1a: the value walk (one lane per knot)", "phase 1: tangents from the snapshots, residual, stores", "collision rows + barrier", "phase 2: MFMA Hessian, gradient"]
+names = ["phase 0: stage x, u, sin/cos, Df f", "phase 1a: the value walk (one lane per knot)", "phase 1: tangents from the snapshots, residual, stores", "collision rows + barrier", "phase 2: MFMA Hessian, gradient", "collision rows a: sphere centres"]
 n = out[7]
 for i, l in enumerate(names):
     print("%-42s %9.0f cycles / workgroup" % (l, out[i] / n))

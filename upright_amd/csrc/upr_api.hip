@@ -304,12 +304,19 @@ int need_device() {
     return 0;
 }
 
+#ifndef UPR_LIN_ROW_PASSES_DEFAULT
+#define UPR_LIN_ROW_PASSES_DEFAULT 2
+#endif
 template <int NQ>
 int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     static const int occ = getenv("UPR_LIN_OCC") ? atoi(getenv("UPR_LIN_OCC")) : 2;
     // knots per workgroup: several passes (their value walks side by side) for the plain instantiation without collision rows
     const bool multi = UPR_LIN_ANALYTIC && !A.way_q && h->use_mfma && occ == 2 && A.d.no == 0;
-    const int KPW = 8 * (multi ? UPR_LIN_PASSES : 1);
+    // with collision rows (snapshot form, round 4: 156 instead of 480 doubles of LDS per knot for 16 spheres): UPR_LIN_ROW_PASSES
+    // passes per workgroup (1, 2 or 3)
+    static const int row_passes = getenv("UPR_LIN_ROW_PASSES") ? atoi(getenv("UPR_LIN_ROW_PASSES")) : UPR_LIN_ROW_PASSES_DEFAULT;
+    const bool multi_rows = UPR_LIN_ANALYTIC && UPR_LIN_OBS_SNAP && !A.way_q && h->use_mfma && occ == 2 && A.d.no > 0 && (row_passes == 2 || row_passes == 3);
+    const int KPW = 8 * (multi ? UPR_LIN_PASSES : (multi_rows ? row_passes : 1));
     const int blocks = (A.npoints + KPW - 1) / KPW;
     const size_t lds = (size_t)KPW * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
     if (lds > 160 * 1024) return fail("collision model too large for the linearisation kernel's LDS");
@@ -327,6 +334,8 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     else if (occ == 3) rc = launch(upr_linearize_kernel<NQ, true, 3>);
     else if (occ == 4) rc = launch(upr_linearize_kernel<NQ, true, 4>);
     else if (multi) rc = launch(upr_linearize_kernel<NQ, true, 2, false, UPR_LIN_PASSES>);
+    else if (multi_rows && row_passes == 3) rc = launch(upr_linearize_kernel<NQ, true, 2, false, 3>);
+    else if (multi_rows) rc = launch(upr_linearize_kernel<NQ, true, 2, false, 2>);
     else rc = launch(upr_linearize_kernel<NQ, true>);
     if (rc) return rc;
     UPR_HIP(hipGetLastError());
@@ -494,7 +503,13 @@ template <int NQ>
 int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     upr_ls_args A = A0;
     size_t lds = (size_t)upr_ls_lds_doubles(h->d, 64) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
-    if (lds > 64 * 1024) {   // long horizons of the large shapes: the trial trajectory only
+    // Three staged copies (trajectory, step, trial trajectory) pay for the small shapes only: with one wave per workgroup the LDS
+    // footprint IS the occupancy, and for the large input vectors it costs more than the uncoalesced reads it replaces
+    // (r04, tools/r4_lin.sh: configs[2] 1.58 ms staged / 1.01 ms not, configs[3] 0.249 / 0.171; the headline shape, 40 KB
+    // staged, stays).  UPR_LS_STAGE_FULL = 0 / 1 forces either form (A/B runs).
+    static const int stage_env = getenv("UPR_LS_STAGE_FULL") ? atoi(getenv("UPR_LS_STAGE_FULL")) : -1;
+    const bool stage_off = stage_env == 0 || (stage_env < 0 && lds > 41 * 1024);
+    if (lds > 64 * 1024 || stage_off) {   // (also: long horizons of the large shapes, where three copies do not fit)
         A.stage_full = 0;
         lds = (size_t)upr_ls_lds_doubles(h->d, 64, false) * sizeof(double) + sizeof(upr_problem) + 16;
         if (lds > 160 * 1024) return fail("horizon too long for the line-search kernel's LDS");

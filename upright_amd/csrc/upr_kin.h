@@ -198,8 +198,11 @@ static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int
 // Checked against the forward-mode walk and the oracle's dual numbers by the linearisation tests (1e-10 .. 1e-13).
 #define UPR_SNAP_J 18   // per joint: o, v_o, a_o, w_b, al_b, z
 #define UPR_SNAP_E 24   // end effector: C (9), p, v, w, a, al
+// frames (optional, problems with collision spheres): the link frame BEHIND joint j after its motion, [j][C 9, p 3] -- the
+// spheres that ride on link j are placed from it (UPR_SNAP_F doubles per joint)
+#define UPR_SNAP_F 12
 template <int NQ>
-static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap) {
+static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap, double* frames = nullptr) {
     upr_ee<double> E;
     for (int i = 0; i < 9; ++i) E.C[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 3; ++i) { E.p[i] = 0.0; E.v[i] = 0.0; E.w[i] = 0.0; E.a[i] = 0.0; E.al[i] = 0.0; }
@@ -242,6 +245,11 @@ static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, cons
                 E.v[i] = E.v[i] + wd[i] + z[i] * qd;
                 E.p[i] = E.p[i] + d[i];
             }
+        }
+        if (frames) {
+            double* Fj = frames + j * UPR_SNAP_F;
+            for (int i = 0; i < 9; ++i) Fj[i] = E.C[i];
+            for (int i = 0; i < 3; ++i) Fj[9 + i] = E.p[i];
         }
     }
     double r[3];
@@ -381,7 +389,7 @@ static UPR_HDI double upr_projectile_closest_time(const double* c, const double*
     double x = 0.0;
     for (int i = 0; i < 10; ++i) {
         const double f = ((a * x + b) * x + cc) * x + dd, df = (3.0 * a * x + 2.0 * b) * x + cc;
-        const double upd = f / df;
+        const double upd = f * upr_rcp(df);   // (hardware reciprocal + one second-order step: the IEEE sequence is ~100 dependent cycles per trip)
         x -= upd;
         if (fabs(upd) < 1e-4) break;
     }
@@ -402,8 +410,9 @@ static UPR_HDI double upr_state_row(const upr_problem* P, int r, CEN cen, const 
         *sa = a; *sb = b; *wgt = 1.0;
         if (b < 0) { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; return cen(a, 2) - (P->sph_r[a] + P->obs_min_dist); }
         double e[3] = {cen(a, 0) - cen(b, 0), cen(a, 1) - cen(b, 1), cen(a, 2) - cen(b, 2)};
-        const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-        for (int i = 0; i < 3; ++i) n[i] = e[i] / dist;
+        // |e| and e / |e| from one reciprocal square root (relative error < 3e-16) instead of a square root and three divisions
+        const double ss = e[0] * e[0] + e[1] * e[1] + e[2] * e[2], ri = upr_rsqrt(ss), dist = ss * ri;
+        for (int i = 0; i < 3; ++i) n[i] = e[i] * ri;
         return dist - (P->sph_r[a] + P->sph_r[b] + P->obs_min_dist);
     }
     const int i = r - P->n_pairs, a = P->proj_sph[i];
@@ -412,8 +421,8 @@ static UPR_HDI double upr_state_row(const upr_problem* P, int r, CEN cen, const 
     const double dt = (flag > 0.5) ? upr_projectile_closest_time(c, ro, vo, ao) : 0.0;
     double e[3];
     for (int j = 0; j < 3; ++j) e[j] = c[j] - (ro[j] + dt * vo[j] + 0.5 * dt * dt * ao[j]);
-    const double dist = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-    for (int j = 0; j < 3; ++j) n[j] = e[j] / dist;
+    const double ss = e[0] * e[0] + e[1] * e[1] + e[2] * e[2], ri = upr_rsqrt(ss), dist = ss * ri;
+    for (int j = 0; j < 3; ++j) n[j] = e[j] * ri;
     *wgt = flag * P->proj_scale / P->proj_dist[i];
     return *wgt * (dist - P->proj_dist[i]);
 }

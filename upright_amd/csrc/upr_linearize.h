@@ -18,13 +18,32 @@
 #include "upr_kin.h"
 
 #define UPR_LPK 32
+#ifndef UPR_LIN_ANALYTIC
+#define UPR_LIN_ANALYTIC 1   // 0: every tangent lane walks the chain itself on (value, tangent) pairs (rounds 1 - 2; A/B runs)
+#endif
 
 // LDS per knot (doubles): x[nx] u[nu] Fw[6 nb] J[6 nq] e[6] Rref[9] sincos[2 nq] | sphere centres and their q-tangents [ns][3][1 + nq]
 // (J / e: position rows, then the orientation rows used when the end-effector cost weighs orientation)
 static UPR_HDI int upr_lin_lds_sc(const upr_dims& d) { return d.nx + d.nu + 6 * d.nb + 6 * d.nq + 6 + 9; }   // (sin q_j, cos q_j) [nq][2]
 static UPR_HDI int upr_lin_lds_base(const upr_dims& d) { return (upr_lin_lds_sc(d) + 2 * d.nq + 1 + 1) & ~1; }
 // [sphere centres ...] then the snapshots of the one value walk per knot (upr_kin.h: UPR_SNAP_J per joint + UPR_SNAP_E)
-static UPR_HDI int upr_lin_lds_snap(const upr_dims& d, int n_sph = 0) { return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0); }
+// UPR_LIN_OBS_SNAP = 1 (round 4): the collision rows out of the value walk's snapshots -- the area holds the sphere centres
+// [ns][3] and the link frames [nq][UPR_SNAP_F] the walk leaves for placing them; 0: rounds 2 - 3, nq forward-mode walks of the
+// spheres per knot, centres and their q-tangents [ns][3][1 + nq] (A/B builds)
+#ifndef UPR_LIN_OBS_SNAP
+#define UPR_LIN_OBS_SNAP 1
+#endif
+static UPR_HDI int upr_lin_lds_frames(const upr_dims& d, int n_sph) { return upr_lin_lds_base(d) + ((n_sph * 3 + 1) & ~1); }
+// (+ the dynamic obstacles' states at the knot, [UPR_MAX_DYN][r 3, v 3, a 3]: staged at the top of the kernel, so that no row
+// waits for a global load of its own)
+static UPR_HDI int upr_lin_lds_dyn(const upr_dims& d, int n_sph) { return upr_lin_lds_frames(d, n_sph) + d.nq * UPR_SNAP_F; }
+static UPR_HDI int upr_lin_lds_snap(const upr_dims& d, int n_sph = 0) {
+#if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
+    return d.no > 0 ? upr_lin_lds_dyn(d, n_sph) + 9 * UPR_MAX_DYN + 1 : upr_lin_lds_base(d);
+#else
+    return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0);
+#endif
+}
 static UPR_HDI int upr_lin_lds_doubles(const upr_dims& d, int n_sph = 0) { return (upr_lin_lds_snap(d, n_sph) + d.nq * UPR_SNAP_J + UPR_SNAP_E + 1) & ~1; }
 
 struct upr_lin_args {
@@ -211,14 +230,12 @@ static __device__ __forceinline__ void upr_lin_phase0_batched(const upr_lin_args
 
 // phase 1a (UPR_LIN_ANALYTIC): ONE walk of the chain per knot on plain values, by the knot's first lane; the tangent lanes
 // of phase 1 read the snapshot of their joint (upr_kin.h, "analytic tangents")
-#ifndef UPR_LIN_ANALYTIC
-#define UPR_LIN_ANALYTIC 1   // 0: every tangent lane walks the chain itself on (value, tangent) pairs (rounds 1 - 2; A/B runs)
-#endif
 template <int NQ>
 static UPR_HDI void upr_lin_phase1a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh, const double* x = nullptr) {
 #if UPR_LIN_ANALYTIC
     // (x: the state straight from the input when the staging into LDS runs at the same time on other waves)
-    if (lane == 0) upr_ee_walk_snap<NQ>(A.P, x ? x : sh, sh + upr_lin_lds_sc(A.d), sh + upr_lin_lds_snap(A.d, A.P->n_sph));
+    if (lane == 0) upr_ee_walk_snap<NQ>(A.P, x ? x : sh, sh + upr_lin_lds_sc(A.d), sh + upr_lin_lds_snap(A.d, A.P->n_sph),
+                                        (UPR_LIN_OBS_SNAP && A.d.no > 0) ? sh + upr_lin_lds_frames(A.d, A.P->n_sph) : nullptr);
 #endif
 }
 
@@ -282,6 +299,92 @@ static UPR_HDI void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point&
     if (A.inst) upr_obstacle_at(A.dyn + ((size_t)q.p * nd + oi) * 9, 0.0, ro, vo, ao);
     else upr_obstacle_at(A.dyn + ((size_t)q.b * nd + oi) * 9, q.k * A.P->dt, ro, vo, ao);
 }
+#if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
+// Snapshot form (round 4).  The value walk of phase 1a left, per joint j, the origin o_j and the axis z_j (snapshots) and the
+// link frame behind the joint (frames).  a: lane s owns sphere s and places its centre from the frame it rides on (world,
+// link j, tool, or obstacle i) -- no walk;  b: lane r owns row r: value and unit direction n as before, and the gradient in
+// closed form: a sphere on link f moves rigidly with every joint j <= f, so
+//     d c / d q_j = z_j x (c - o_j)   (revolute),   z_j   (prismatic),   0   (j > f, world and obstacle spheres),
+// i.e. (d row / d q_j) = w n . (t_a,j - t_b,j).  The lanes of a knot sit in one wave: a wave-local ordering point separates
+// the two (no workgroup barrier), and the per-knot LDS area shrinks from [ns][3][1 + nq] to [ns][3] + [nq][12].
+// state of obstacle oi at the knot into the knot's LDS area (any lane; before the barrier in front of the rows)
+static UPR_HDI void upr_lin_stage_obstacle(const upr_lin_args& A, const upr_lin_point& q, int oi, double* sh) {
+    double* D = sh + upr_lin_lds_dyn(A.d, A.P->n_sph) + 9 * oi;
+    upr_lin_obstacle(A, q, oi, D, D + 3, D + 6);
+    if (oi == 0) sh[upr_lin_lds_dyn(A.d, A.P->n_sph) + 9 * UPR_MAX_DYN] = A.pflag ? A.pflag[q.b] : 0.0;   // activation flag of the projectile rows
+}
+// one sphere of one knot
+template <int NQ>
+static UPR_HDI void upr_lin_obs_sphere(const upr_lin_args& A, const upr_lin_point& q, int s, double* sh) {
+    const upr_problem* P = A.P;
+    double* sc = sh + upr_lin_lds_base(A.d);
+    const double* fr = sh + upr_lin_lds_frames(A.d, P->n_sph);
+    const double* T = sh + upr_lin_lds_snap(A.d, P->n_sph) + NQ * UPR_SNAP_J;
+    if (q.terminal) return;
+    {
+        const int f = P->sph_frame[s];
+        const double* off = P->sph_off[s];
+        double c[3];
+        if (f <= -2) {
+            const double* ro = sh + upr_lin_lds_dyn(A.d, P->n_sph) + 9 * (-2 - f);
+            for (int i = 0; i < 3; ++i) c[i] = ro[i] + off[i];
+        } else if (f < 0) {
+            for (int i = 0; i < 3; ++i) c[i] = off[i];
+        } else {
+            const double* Cf = (f >= NQ) ? T : fr + f * UPR_SNAP_F;
+            const double* pf = (f >= NQ) ? T + 9 : Cf + 9;
+            for (int i = 0; i < 3; ++i) c[i] = pf[i] + Cf[3 * i] * off[0] + Cf[3 * i + 1] * off[1] + Cf[3 * i + 2] * off[2];
+        }
+        for (int i = 0; i < 3; ++i) sc[3 * s + i] = c[i];
+    }
+}
+template <int NQ>
+static UPR_HDI void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
+    for (int s = lane; s < A.P->n_sph; s += UPR_LPK) upr_lin_obs_sphere<NQ>(A, q, s, sh);
+}
+// one row of one knot
+template <int NQ>
+static UPR_HDI void upr_lin_obs_row(const upr_lin_args& A, const upr_lin_point& q, int r, const double* sh) {
+    const upr_problem* P = A.P; const upr_dims& d = A.d;
+    const double* sc = sh + upr_lin_lds_base(d);
+    const double* snap = sh + upr_lin_lds_snap(d, P->n_sph);
+    if (q.terminal) return;
+    // (the projectile rows follow the last obstacle: state.tail(9); its state at the knot was staged at the top of the kernel)
+    const double* ro = sh + upr_lin_lds_dyn(d, P->n_sph) + 9 * (P->n_dyn > 0 ? P->n_dyn - 1 : 0);
+    const double* vo = ro + 3; const double* ao = ro + 6;
+    const double flag = (A.dyn && r >= P->n_pairs) ? sh[upr_lin_lds_dyn(d, P->n_sph) + 9 * UPR_MAX_DYN] : 0.0;
+    {
+        int sa, sb; double n[3], w;
+        q.out[d.lin_obs + r] = upr_state_row(P, r, [&](int s, int i) { return sc[3 * s + i]; }, ro, vo, ao, flag, &sa, &sb, n, &w);
+        const int fa = P->sph_frame[sa], fb = (sb >= 0) ? P->sph_frame[sb] : -1;
+        double ca[3], cb[3];
+        for (int i = 0; i < 3; ++i) { ca[i] = sc[3 * sa + i]; cb[i] = (sb >= 0) ? sc[3 * sb + i] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const double* S = snap + j * UPR_SNAP_J;
+            const double o[3] = {S[0], S[1], S[2]}, z[3] = {S[15], S[16], S[17]};
+            const bool rev = P->joint_type[j] == 1;
+            // n . (z x (c - o)) = (c - o) . (n x z): the two spheres differ only in c
+            double nz[3];
+            upr_cross(n, z, nz);
+            double v = 0.0;
+            if (rev) {
+                if (fa >= j) v += (ca[0] - o[0]) * nz[0] + (ca[1] - o[1]) * nz[1] + (ca[2] - o[2]) * nz[2];
+                if (fb >= j) v -= (cb[0] - o[0]) * nz[0] + (cb[1] - o[1]) * nz[1] + (cb[2] - o[2]) * nz[2];
+            } else {
+                const double nd = n[0] * z[0] + n[1] * z[1] + n[2] * z[2];
+                if (fa >= j) v += nd;
+                if (fb >= j) v -= nd;
+            }
+            q.out[d.lin_obs + d.no + r * NQ + j] = w * v;
+        }
+    }
+}
+template <int NQ>
+static UPR_HDI void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_point& q, int lane, const double* sh) {
+    for (int r = lane; r < A.d.no; r += UPR_LPK) upr_lin_obs_row<NQ>(A, q, r, sh);
+}
+#else
 template <int NQ>
 static UPR_HDI void upr_lin_phase_obs_a(const upr_lin_args& A, const upr_lin_point& q, int lane, double* sh) {
     const upr_problem* P = A.P;
@@ -317,6 +420,7 @@ static UPR_HDI void upr_lin_phase_obs_b(const upr_lin_args& A, const upr_lin_poi
         }
     }
 }
+#endif
 
 // phase 2 (VALU path): gradient, Gauss-Newton Hessian, cost from the LDS-staged position Jacobian
 template <int NQ, bool ORI = false>
@@ -390,6 +494,15 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
         if (sp < 8 * NP && base + sp < A.npoints) { const upr_lin_point q = upr_lin_locate(A, base + sp); upr_lin_phase0_sc(A, q, sj, smem + sp * per); }
     }
 #endif
+#if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
+    if (A.d.no > 0 && A.dyn) {   // the obstacles' states at every knot of the workgroup (read by the rows behind three barriers)
+        const int nd = A.P->n_dyn;   // (A.P is still the global record here)
+        for (int idx = threadIdx.x; idx < 8 * NP * nd; idx += 256) {
+            const int sp = idx / nd, oi = idx - sp * nd;
+            if (base + sp < A.npoints) { const upr_lin_point q = upr_lin_locate(A, base + sp); upr_lin_stage_obstacle(A, q, oi, smem + sp * per); }
+        }
+    }
+#endif
 #if UPR_LIN_P0_BATCH && UPR_LIN_SC_ONCE && UPR_LIN_ANALYTIC && UPR_LIN_OVERLAP
     // The value walks (a serial chain on 8 NP lanes of wave 0, ~20 k cycles) need sin / cos and the state only: wave 0 walks with
     // the state straight from the input while waves 1 - 3 do the staging and the rows of Df f.
@@ -432,6 +545,24 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
     }
     UPR_LIN_STAMP(2);
     if (A.d.no > 0) {
+#if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
+        // (snapshot form: the 32 lanes of a knot group sit in one wave, so a wave-local ordering point separates placing the
+        // spheres from the rows that read them; the group's lanes take (pass, sphere) and (pass, row) jobs of ALL its passes at
+        // once -- a problem with five rows per knot keeps ten lanes busy for one trip instead of five lanes for two)
+        const int ns = A.P->n_sph, no = A.d.no;
+#pragma unroll 1
+        for (int idx = lane; idx < NP * ns; idx += UPR_LPK) {
+            const int pp = idx / ns, s = idx - pp * ns, slot = pp * 8 + sub, p = base + slot;
+            if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_obs_sphere<NQ>(A, q, s, smem + slot * per); }
+        }
+        UPR_LIN_STAMP(5);
+        UPR_WSYNC();
+#pragma unroll 1
+        for (int idx = lane; idx < NP * no; idx += UPR_LPK) {
+            const int pp = idx / no, r = idx - pp * no, slot = pp * 8 + sub, p = base + slot;
+            if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_obs_row<NQ>(A, q, r, smem + slot * per); }
+        }
+#else
 #pragma unroll 1
         for (int pp = 0; pp < NP; ++pp) {
             const int slot = pp * 8 + sub, p = base + slot;
@@ -443,6 +574,7 @@ __global__ void __launch_bounds__(256, OCC) upr_linearize_kernel(upr_lin_args A)
             const int slot = pp * 8 + sub, p = base + slot;
             if (p < A.npoints) { const upr_lin_point q = upr_lin_locate(A, p); upr_lin_phase_obs_b<NQ>(A, q, lane, smem + slot * per); }
         }
+#endif
     }
     __syncthreads();
     UPR_LIN_STAMP(3);
