@@ -528,6 +528,106 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
     assert np.all(np.isfinite(u))
 
 
+# the dice (two stacked 20 g foam dice) from the shipped first pose to the shipped waypoint (2.2 m away): the first QP drives
+# several friction rows of the light bodies to their bounds.  The ORACLE's dense-stage Riccati then sits on a floor of the
+# stationarity residual (1e-4 .. 5e-3 while its equality, inequality and complementarity residuals pass 1e-8) and stops at the
+# iteration cap; the production kernel converges -- test_dice_as_shipped checks its point against the independent numpy assembly
+# of the optimality conditions instead.  The oracle-parity / speed tests use half the distance, where both converge (8 iterations).
+DICE_NEAR = {"waypoints": [{"time": 0, "position": [-1.0, 0.5, 0], "orientation": [0, 0, 0, 1]}]}
+PAPER_CONFIGS = [
+    # (golden merged config, arrangement, instantiation of the production kernel it must select, overrides)
+    ("full_dice_point1", "foam_die2", "upr_qp3_cfg<9, 2, 8, 3, 20, 256, false, false, true>", DICE_NEAR),   # two stacked dice: dense 12 x 12 Schur complement
+    ("full_bottle_arm_only", "pink_bottle", "upr_qp3_cfg<6, 1, 4, 3, 20, 256, false, false, false>", {}),  # the bottle on the arm alone (base locked), with friction
+    ("full_cups_point1", "blue_cups", "upr_qp3_cfg<9, 7, 28, 3, 20, 256, false, false, false>", {}),       # seven cups: star arrangement with friction, nu = 93
+]
+
+
+def test_dice_as_shipped(arrangements):
+    """full_dice_point1.yaml exactly as shipped (see DICE_NEAR above): the production kernel's first QP converges; its primal-dual
+    point satisfies the optimality conditions assembled independently in numpy (tests/kkt_check.py) to 1e-6; the oracle, which
+    stops at its iteration cap on a stationarity floor with the other three residuals below 1e-8, hands over a plan that agrees
+    to 1e-3."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from kkt_check import kkt_residuals
+    m = _manager_from_golden("full_dice_point1", arrangements, arr="foam_die2")
+    P = m.mpc.problem
+    x0 = np.array(m.settings.initial_state)[None]
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, 1, way_p=np.asarray(P.way_p)[None])
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    sol = mpc.qp_kkt()
+    lin = mpc.lin_records()
+    st = mpc.stats()
+    assert "upr_qp3_cfg<9, 2, 8, 3, 20, 256, false, false, true>" in mpc.kernel_times()["qp_kernel"]
+    assert st["qp_status_last"][0] == 0 and st["qp_iters_last"][0] < P.qp_iter_max
+    res = kkt_residuals(P, P.body_params, x0[0], xs0[0], us0[0], lin[0], {k: v[0] for k, v in sol.items()})
+    assert res.max() < 1e-6, res
+    mpc.close()
+    m.warmstart()
+    _, xs, us = m.get_mpc_trajectory()
+    xo, uo, so, rc = Oracle(P).solve(0.0, x0[0], xs0[0], us0[0])
+    assert so.qp_status_last == 1 and max(so.qp_res[1:]) < 1e-8 and so.qp_res[0] > 1e-6     # the oracle's floor (if this changes, tighten the test)
+    assert np.abs(xs - xo).max() < 1e-3 and abs(np.linalg.norm(xs) - np.linalg.norm(xo)) < 1e-3
+
+
+@pytest.mark.parametrize("name,arr,kernel,override", PAPER_CONFIGS)
+def test_paper_arrangements_through_the_manager(arrangements, name, arr, kernel, override):
+    """The paper's other free-space experiments (upright_cmd/config/ral23/experiments/freespace/full/{full_dice_point1,
+    full_bottle_arm_only,full_cups_point1}.yaml; a third of the reference's experiment files use these arrangements) from
+    their golden merged configs through the reference's call sequence (ControllerManager.from_config -> warmstart ->
+    get_mpc_trajectory): the production kernel structure takes them (an upr_qp3_cfg< instantiation, not the generic or
+    the second structure), and the plan matches the oracle to north_star's 1e-4 on the norms."""
+    m = _manager_from_golden(name, arrangements, arr=arr, **override)
+    P = m.mpc.problem
+    x0 = np.array(m.settings.initial_state)
+    m.warmstart()
+    ts, xs, us = m.get_mpc_trajectory()
+    assert xs.shape == (P.N + 1, P.nx) and us.shape == (P.N + 1, P.nu)
+    kn = m.mpc._mpc.kernel_times()["qp_kernel"]
+    assert kernel in kn, kn
+    xs0, us0 = stationary_guess(x0[None], P.N, P.nu)
+    xo, uo, so, rc = Oracle(P).solve(0.0, x0, xs0[0], us0[0])
+    st = m.mpc._mpc.stats()
+    assert rc == 0 and so.qp_status_last == 0 and st["qp_status_last"][0] == 0
+    assert st["qp_iters_last"][0] == so.qp_iters_last
+    assert np.abs(xs - xo).max() < 1e-4 and np.abs(us[:-1] - uo).max() < 1e-3
+    assert abs(np.linalg.norm(xs) - np.linalg.norm(xo)) < 1e-4 and abs(np.linalg.norm(us[:-1]) - np.linalg.norm(uo)) < 1e-4
+
+
+@pytest.mark.parametrize("name,arr,kernel,override", PAPER_CONFIGS)
+def test_paper_arrangements_production_kernel_speed(arrangements, name, arr, kernel, override, monkeypatch):
+    """The same problems as a batch of 256: the production instantiation against the generic (runtime-dimension) kernel of
+    the same build on the same inputs -- at least ten times faster per QP launch, same plans."""
+    m = _manager_from_golden(name, arrangements, arr=arr, **override)
+    P = m.mpc.problem
+    B = 256
+    x0 = np.tile(np.array(m.settings.initial_state), (B, 1))
+    rng = np.random.default_rng(8)
+    x0[:, P.nq:2 * P.nq] += rng.uniform(-0.05, 0.05, (B, P.nq))    # different joint rates: different QPs
+    way = np.tile(np.asarray(P.way_p), (B, 1, 1))
+    out = {}
+    for tag, env in (("production", None), ("generic", "1")):
+        if env is None:
+            monkeypatch.delenv("UPR_QP_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("UPR_QP_KERNEL", env)
+        mpc = BatchMPC(P, B, way_p=way)
+        mpc.set_observation(0.0, x0)
+        mpc.advance()
+        mpc.enable_timing(True)
+        mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
+        kt = mpc.kernel_times()
+        _, xs, us = mpc.solution()
+        out[tag] = (kt["qp_ms"], kt["qp_kernel"], xs, us, mpc.stats()["qp_status_last"].copy())
+        mpc.close()
+    assert kernel in out["production"][1] and "upr_qp3" not in out["generic"][1]
+    assert np.all(out["production"][4] == 0) and np.all(out["generic"][4] == 0)
+    assert np.abs(out["production"][2] - out["generic"][2]).max() < 2e-5
+    assert out["generic"][0] >= 10.0 * out["production"][0], (out["generic"][0], out["production"][0])
+
+
 def test_robust_arrangement_per_instance_parameters(arrangements):
     """BASELINE config 4 (upright_robust, planning_sim_loop.py:454-534): eight copies of one cuboid, one per vertex of
     the CoM box, 32 frictionless contact points (nx 27, nu 41, 48 equality rows / knot), and a DIFFERENT inertial

@@ -128,7 +128,10 @@ struct upr_qp3_lds {
                          // one- / two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
                          // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
                          scr_sweep = ck + r2(C::NE * C::NX), scr_sw = C::SW ? (sw_end > sw0 + C::NKB * (C::SB * (C::SB + 1) / 2) ? sw_end : sw0 + r2(C::NKB * (C::SB * (C::SB + 1) / 2))) : 0,
-                         scr_prep = hux + r2((C::MULTI || C::COUPLED) ? 0 : C::N * C::NE * C::NE), scr_rows = hux + (C::ROWS ? 2 * (C::N - 1) * UPR_QP3_NOMAX : 0),
+                         // prep's staging of the one-body shapes: Z = Lf^-1 Df' of all knots from Pa, the Schur complements behind it -- at
+                         // hux where Z ends before it (nine joints), right behind Z otherwise (six joints with friction: P is 18 x 18)
+                         sst = (C::MULTI || C::COUPLED) ? hux : (Pa + r2(C::N * C::NE * C::NFC) > hux ? Pa + r2(C::N * C::NE * C::NFC) : hux),
+                         scr_prep = sst + r2((C::MULTI || C::COUPLED) ? 0 : C::N * C::NE * C::NE), scr_rows = hux + (C::ROWS ? 2 * (C::N - 1) * UPR_QP3_NOMAX : 0),
                          scr_a = scr_sweep > scr_sw ? scr_sweep : scr_sw, scr_b = scr_prep > scr_rows ? scr_prep : scr_rows,
                          yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
@@ -650,7 +653,7 @@ struct upr_qp3 {
             G[F::heew + k * C::NH + t] = hee_kt + v / h;
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
-        if (C::MULTI && no > 0) UPR_SYNC();   // (Z of the multi-body shapes extends over the LDS the row multipliers above were staged in)
+        if ((C::MULTI || O::sst > O::hux) && no > 0) UPR_SYNC();   // (Z of these shapes extends over the LDS the row multipliers above were staged in)
 #pragma unroll
         for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
@@ -807,7 +810,7 @@ struct upr_qp3 {
                 const double* zr = L + O::Pa + (k * NE + r) * NFC; const double* zc = L + O::Pa + (k * NE + c) * NFC;
 #pragma unroll
                 for (int i = 0; i < NFC; ++i) acc += zr[i] * zc[i];
-                L[O::hux + k * NE * NE + r * NE + c] = acc;
+                L[O::sst + k * NE * NE + r * NE + c] = acc;
             }
         }
         UPR_SYNC(); toc(3);
@@ -923,7 +926,7 @@ struct upr_qp3 {
 #pragma unroll
                         for (int c = 0; c <= r; ++c) Sm[r * SB + c] = L[O::sdn + k * (SB * (SB + 1) / 2) + r * (r + 1) / 2 + c];
                     ok = upr_chol_inv_serial<SB>(Sm, Ls);       // (the inverse goes to memory: factor and inverse together exceed the registers)
-                } else ok = upr_chol_inv_serial<SB>(L + O::hux + kb * SB * SB, Lr);
+                } else ok = upr_chol_inv_serial<SB>(L + O::sst + kb * SB * SB, Lr);
                 if (!ok) L[O::misc] = 1.0;
                 if (C::COUPLED) {
 #pragma unroll
@@ -1719,7 +1722,10 @@ struct upr_qp3 {
 #ifndef UPR_HOST_EMU
         if constexpr (SW2) { backward_mat_sw2(); return; }
         else if constexpr (C::VCPRE) { backward_mat_sw(); return; }
+        else
 #endif
+        {   // (the four-wave form: the host emulation, and instantiations without the one- / two-wave sweep -- discarded, with its
+            // shape-specific assertions, for every device instantiation that runs those)
         UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
@@ -1777,7 +1783,7 @@ struct upr_qp3 {
 #else
             constexpr int NPB = NX;
 #endif
-            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::hux - O::Pa && N * NE * NE <= O::yN - O::hux), "prep stages Z and S in the scratch region");
+            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::sst - O::Pa && N * NE * NE <= O::yN - O::sst), "prep stages Z and S in the scratch region");
             static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
 #ifndef UPR_HOST_EMU
@@ -2107,6 +2113,7 @@ struct upr_qp3 {
         UPR_FORT(e, C::NH) G[F::Ljis + e] = L[lkb(0) + e];
 #endif
         UPR_SYNC();
+        }
     }
 
     // ---- backward sweep, vector part, for the current right-hand side ----------------------------------------
