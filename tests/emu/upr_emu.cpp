@@ -159,6 +159,9 @@ long emu_qp3(const upr_problem* P, int B, const double* xs, const double* us, co
     EMU_QP3D(9, 3, 16, 3, false, true, !softb)
     EMU_QP3N(6, 1, 4, 1, 20, true, false, true)
     EMU_QP3N(6, 1, 4, 1, 10, true, false, true)
+    EMU_QP3D(9, 7, 28, 3, false, false, !softb)   // round 4: seven cups (star, friction: BIGF), two stacked dice, arm-only with friction
+    EMU_QP3D(9, 2, 8, 3, false, true, !softb)
+    EMU_QP3N(6, 1, 4, 3, 20, false, false, !softb)
 #undef EMU_QP3
 #undef EMU_QP3D
 #undef EMU_QP3N

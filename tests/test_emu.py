@@ -553,3 +553,25 @@ def test_closed_form_ee_tangents_equal_the_forward_mode_walk(arrangements):
         assert np.abs(a[:, 0] - b[:, 0]).max() < 1e-13 * scale
         assert np.abs(a[:, 1] - b[:, 1]).max() < 1e-12 * scale, np.unravel_index(np.abs(a[:, 1] - b[:, 1]).argmax(), (nx, 30))
         assert np.abs(b[:, 1, 12:15]).max() > 0.1      # the velocity tangent is not trivially zero
+
+
+@pytest.mark.parametrize("name", ["blue_cups", "foam_die2"])
+def test_paper_arrangement_shapes_production_kernel_source(arrangements, name):
+    """The production kernel's instantiations for the paper's other arrangements -- seven cups (star arrangement WITH friction,
+    nu = 93: compact Df, no staged Z, far hf / ek: upr_qp3_cfg::BIGF) and two stacked dice (dense 12 x 12 Schur complement) --
+    follow the oracle's iterate path: identical steps after a fixed number of interior-point iterations."""
+    B = 2
+    P = thing_problem(arrangements[name], qp_tol=0.0, qp_iter_max=6)
+    x0 = level_tray_states(B, seed=13)
+    way = waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0))
+    xs, us = stationary_guess(x0, P.N, P.nu)
+    xs, us = np.ascontiguousarray(xs), np.ascontiguousarray(us)
+    e = Emu(P, B)
+    lin = e.linearize(way, np.zeros(B), xs, us)
+    dx, du, stats, ws = e.qp(3, xs, us, x0, lin)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P).qp_step(0.0, x0[b], xs[b], us[b])
+        assert stats[b, 1] == 6 == so.qp_iters_last
+        assert np.abs(dx[b] - dxo).max() < 1e-7 * max(1, np.abs(dxo).max())
+        assert np.abs(du[b] - duo).max() < 1e-7 * max(1, np.abs(duo).max())

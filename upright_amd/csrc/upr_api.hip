@@ -429,7 +429,7 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 // thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
 // (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
 #if defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_SHAPES)
-#define UPR_QP3_EXTRA(X) X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false)
+#define UPR_QP3_EXTRA(X) X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false) X(9, 7, 28, 3, 20, false, false, false)
 #elif defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_CONFIG3)
 #define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, 20, true, false, true) X(9, 8, 32, 1, 20, false, true, false)
 #elif defined(UPR_HEADLINE_ONLY)
@@ -437,7 +437,7 @@ int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
 #else
 #define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, 20, false, true, false) X(9, 1, 4, 3, 20, true, true, false) X(9, 1, 4, 1, 20, false, true, false) X(9, 8, 32, 1, 20, false, true, false) \
     X(9, 3, 16, 3, 20, true, false, true) X(6, 1, 4, 1, 20, false, true, false) X(6, 1, 4, 1, 10, false, true, false) \
-    X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false)   /* round 4: the paper's dice (two stacked bodies, dense 12 x 12) and arm-only runs with friction */
+    X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false) X(9, 7, 28, 3, 20, false, false, false)   /* round 4: the paper's dice (two stacked bodies, dense 12 x 12), arm-only runs with friction, seven cups (star with friction: upr_qp3_cfg::BIGF) */
 #endif
 bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }

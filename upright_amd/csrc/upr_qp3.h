@@ -38,6 +38,12 @@ template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true
 struct upr_qp3_cfg {
     static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
     static constexpr bool ROWS = ROWS_, SOFT = SOFT_, COUPLED = DENSE_ && NB_ > 1, MULTI = NB_ > 1 && !DENSE_;
+    // BIGF: star arrangements WITH friction (the paper's seven cups: nu = 93).  Their force-indexed arrays do not fit the LDS next
+    // to the sweeps' working set: Df is kept compact ([force column][the six rows of the body its contact loads] instead of the
+    // dense 6 nb x nf nc), Z = Lf^-1 Df' is not staged (the lane of a (knot, body) block forms its twelve columns from the contact
+    // factors where it accumulates S_b), and the force part of the back-substitution hf and the equality residual ek -- touched
+    // by the flat phases only -- live in the far arrays
+    static constexpr bool BIGF = MULTI && NF_ == 3;
     static constexpr int SB = COUPLED ? 6 * NB_ : 6, NKB = COUPLED ? N_ : N_ * NB_;   // Schur block size; number of blocks
     static constexpr int NLS = COUPLED ? 36 * NB_ * NB_ : NB_ * 36;                   // doubles of the inverse Schur factor(s) of a knot
     static constexpr int N1 = N + 1;
@@ -105,13 +111,13 @@ template <class C>
 struct upr_qp3_lds {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
     static constexpr int Z = 0, S = Z + r2(C::NZ), gxs = S + r2(C::NZ), wx = gxs + r2(C::N1 * C::NX), gus = wx + r2(C::N1 * C::NX),
-                         wu = gus + r2(C::N * C::NU), cs = wu + r2(C::N * C::NU), hf = cs + r2(C::N * C::NX), ys = hf + r2(C::N * C::NFC),
+                         wu = gus + r2(C::N * C::NU), cs = wu + r2(C::N * C::NU), hf = cs + r2(C::N * C::NX), ys = hf + r2(C::BIGF ? 0 : C::N * C::NFC),
                          zt = ys + r2(C::N * C::NE), cv = zt, ek = zt + r2(C::N * C::NE),
                          // constants
-                         xlb = ek + r2(C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
+                         xlb = ek + r2(C::BIGF ? 0 : C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
                          rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
                          // working set of the sweeps
-                         Pa = df + r2(C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX),
+                         Pa = df + r2(C::BIGF ? 6 * C::NFC : C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX),
                          // V = Lj^-1 Hux and the packed factor Lj of the knot in work and of the previous one (double buffered:
                          // K = Lj^-T V of the previous knot is formed by an idle wave while wave 0 factors the next)
                          vm = hux + r2(C::NQ * C::NX), lk = vm + 2 * r2(C::NQ * C::NX),
@@ -356,6 +362,10 @@ struct upr_qp3 {
     // h, h2, h3 on a lane-dependent index would be turned into an indexed load and pin the whole object in scratch
     UPR_HDI double coefA(int a, int b) const { return ((a == b) ? 1.0 : 0.0) + (((a == 0 && b == 1) || (a == 1 && b == 2)) ? 1.0 : 0.0) * h + ((a == 0 && b == 2) ? 1.0 : 0.0) * h2; }
     UPR_HDI double coefB(int a) const { return ((a == 0) ? 1.0 : 0.0) * h3 + ((a == 1) ? 1.0 : 0.0) * h2 + ((a == 2) ? 1.0 : 0.0) * h; }
+    // entry (r, col) of Df (BIGF: compact, valid for the rows of the body the column's contact loads); hf and ek (BIGF: far arrays)
+    UPR_HDI double DF(int r, int col) const { return C::BIGF ? L[O::df + col * 6 + (r - 6 * (r / 6))] : L[O::df + r * NFC + col]; }
+    UPR_HDI double* hfp() const { return C::BIGF ? G + F::hf : L + O::hf; }
+    UPR_HDI double* ekp() const { return C::BIGF ? G + F::ek : L + O::ek; }
     // row r of Df times a force-indexed vector.  Multi-body shapes: the row of body r / 6 has entries at the contacts that
     // load that body only (O::clist), four of 32 columns for the robust arrangement
     UPR_HDI double df_dot(int r, const double* vf) const {
@@ -366,7 +376,7 @@ struct upr_qp3 {
             for (int j = 0; j < n; ++j) {
                 const int ci = (int)L[O::clist + bb * NC + j];
 #pragma unroll
-                for (int a = 0; a < NF; ++a) v += L[O::df + r * NFC + NF * ci + a] * vf[NF * ci + a];
+                for (int a = 0; a < NF; ++a) v += DF(r, NF * ci + a) * vf[NF * ci + a];
             }
         }
         return v;
@@ -685,7 +695,9 @@ struct upr_qp3 {
                         if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
                         for (int a = 0; a < 9; ++a) Bk[a] = Hc[a];
                         // Z = Lf^-1 Df' of this contact (S = Z'Z + rho I is assembled in phase C); staged where the sweeps keep P
-                        if (C::MULTI) {
+                        if (C::BIGF) {
+                            // (Z is formed by the block's lane in phase D out of the factor stored above)
+                        } else if (C::MULTI) {
                             // star arrangement: the contact loads one body only, Z keeps that body's six rows, [knot][force][6]
                             const int b2 = P->contact_body2[ci];
 #pragma unroll
@@ -708,7 +720,7 @@ struct upr_qp3 {
                     double yv[3], hv[3];
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * guf[b2]; yv[a] = v; }
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * yv[b2]; hv[a] = v; }
-                    for (int a = 0; a < 3; ++a) { G[F::yf + k * NFC + 3 * ci + a] = yv[a]; L[O::hf + k * NFC + 3 * ci + a] = hv[a]; }
+                    for (int a = 0; a < 3; ++a) { G[F::yf + k * NFC + 3 * ci + a] = yv[a]; hfp()[k * NFC + 3 * ci + a] = hv[a]; }
                 } else {
                     if (level == 0) continue;
                     const int uo = k * NU + NQ + ci;
@@ -720,7 +732,7 @@ struct upr_qp3 {
                     }
                     const double lf = G[F::lfi + k * C::NLF + ci];
                     const double yv = lf * L[O::gus + uo];
-                    G[F::yf + k * NFC + ci] = yv; L[O::hf + k * NFC + ci] = lf * yv;
+                    G[F::yf + k * NFC + ci] = yv; hfp()[k * NFC + ci] = lf * yv;
                 }
             }
         }
@@ -742,7 +754,7 @@ struct upr_qp3 {
                         for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q % (PRE_C ? QR : 1)][c] * zx[c];
                     }
                     v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                    if (act && part == 0) L[O::ek + e] = v + e0r[q % (PRE_C ? QR : 1)];
+                    if (act && part == 0) ekp()[e] = v + e0r[q % (PRE_C ? QR : 1)];
                 }
             } else {
                 // multi-body shapes: the rows of C come straight from the records, GQ rows of a lane requested together
@@ -771,20 +783,20 @@ struct upr_qp3 {
 #pragma unroll
                         for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? zx[c] : 0.0);
                         v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                        if (act && part == 0) L[O::ek + e] = v + e0b[g];
+                        if (act && part == 0) ekp()[e] = v + e0b[g];
                     }
                 }
             }
-            UPR_SYNC_LDS();
+            if (C::BIGF) UPR_SYNC(); else UPR_SYNC_LDS();   // (BIGF: ek is a far array -- its stores are global)
         }
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
-            double v = L[O::ek + e], v2 = 0.0;
+            double v = ekp()[e], v2 = 0.0;
             if (fresh) {
                 v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
-                L[O::ek + e] = v;
+                ekp()[e] = v;
             }
-            if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
+            if (level > 0) v2 = df_dot(r, hfp() + k * NFC);
             L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #else
@@ -796,9 +808,9 @@ struct upr_qp3 {
                 v = G[F::e0 + e];
                 for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
                 v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
-                L[O::ek + e] = v;
-            } else v = L[O::ek + e];
-            if (level > 0) v2 = df_dot(r, L + O::hf + k * NFC);
+                ekp()[e] = v;
+            } else v = ekp()[e];
+            if (level > 0) v2 = df_dot(r, hfp() + k * NFC);
             L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #endif
@@ -905,11 +917,26 @@ struct upr_qp3 {
                         for (int c = 0; c <= r; ++c) Sm[r * SB + c] = (r == c) ? rho_s : 0.0;
                     for (int ci = 0; ci < NC; ++ci) {
                         if (P->contact_body2[ci] != b) continue;
+                        double Bk[C::BIGF ? 9 : 1];
+                        if (C::BIGF) {
+#pragma unroll
+                            for (int a9 = 0; a9 < 9; ++a9) Bk[a9 % (C::BIGF ? 9 : 1)] = G[F::lfi + k * C::NLF + 9 * ci + a9];
+                        }
                         for (int a = 0; a < NF; ++a) {
                             const double* z = L + O::Pa + (k * NFC + NF * ci + a) * 6;
                             double zv[SB];
+                            if (C::BIGF) {
+                                // column a of Z = Lf^-1 Df' of this contact: row a of the inverse factor times the body's rows of Df
+#pragma unroll
+                                for (int r = 0; r < SB; ++r) {
+                                    double v = 0.0;
+                                    for (int b3 = 0; b3 <= a; ++b3) v += Bk[(3 * a + b3) % (C::BIGF ? 9 : 1)] * L[O::df + (NF * ci + b3) * 6 + r];
+                                    zv[r] = v;
+                                }
+                            } else {
 #pragma unroll
                             for (int r = 0; r < SB; ++r) zv[r] = z[r];
+                            }
 #pragma unroll
                             for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -1784,7 +1811,7 @@ struct upr_qp3 {
             constexpr int NPB = NX;
 #endif
             static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::sst - O::Pa && N * NE * NE <= O::yN - O::sst), "prep stages Z and S in the scratch region");
-            static_assert(!C::MULTI || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
+            static_assert(!C::MULTI || C::BIGF || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
 #ifndef UPR_HOST_EMU
             // dense Schur complement (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x 27) as 18
@@ -2512,7 +2539,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = 0.0;
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) v += L[O::df + (rb + r) * NFC + 3 * ci + a] * L[O::cv + k * NE + rb + r];
+                        for (int r = 0; r < 6; ++r) v += DF(rb + r, 3 * ci + a) * L[O::cv + k * NE + rb + r];
                         dfn[a] = v; }
                     if (C::COUPLED && P->contact_body1[ci] >= 0) {   // ... and of the body underneath
                         const int rb1 = 6 * P->contact_body1[ci];
@@ -2577,7 +2604,10 @@ struct upr_qp3 {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
                     double dfn[3], tf[3];
-                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * G[F::nun + k * NE + r]; dfn[a] = v; }
+                    for (int a = 0; a < 3; ++a) { double v = 0.0;
+                        if (C::BIGF) { const int rb = 6 * P->contact_body2[ci]; for (int r = 0; r < 6; ++r) v += DF(rb + r, 3 * ci + a) * G[F::nun + k * NE + rb + r]; }
+                        else for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + 3 * ci + a] * G[F::nun + k * NE + r];
+                        dfn[a] = v; }
                     const double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
                     for (int a = 0; a < 3; ++a) { double v = G[F::yf + k * NFC + 3 * ci + a]; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * dfn[b2]; tf[a] = v; }
                     for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * tf[b2]; Su(k)[NQ + 3 * ci + a] = -v; }
@@ -2907,7 +2937,7 @@ struct upr_qp3 {
             else if (C::NB == 1) { for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q]; }
             else {   // (the column of a force has entries in the rows of the bodies its contact loads only)
                 const int ci = (i - NQ) / NF, b2 = P->contact_body2[ci], b1 = P->contact_body1[ci];
-                for (int q = 0; q < 6; ++q) v += L[O::df + (6 * b2 + q) * NFC + (i - NQ)] * nu[k * NE + 6 * b2 + q];
+                for (int q = 0; q < 6; ++q) v += DF(6 * b2 + q, i - NQ) * nu[k * NE + 6 * b2 + q];
                 if (b1 >= 0) for (int q = 0; q < 6; ++q) v += L[O::df + (6 * b1 + q) * NFC + (i - NQ)] * nu[k * NE + 6 * b1 + q];
             }
             r_stat = fmax(r_stat, fabs(v));
@@ -2920,7 +2950,7 @@ struct upr_qp3 {
             r_eq = fmax(r_eq, fabs(v + h * a + h2 * u - Xn[NQ + j]));
             r_eq = fmax(r_eq, fabs(a + h * u - Xn[2 * NQ + j]));
         }
-        UPR_FORT(e, N * NE) r_eq = fmax(r_eq, fabs(L[O::ek + e] - rho_eq * nu[e]));
+        UPR_FORT(e, N * NE) r_eq = fmax(r_eq, fabs(ekp()[e] - rho_eq * nu[e]));
         terminal_residual();
         UPR_SYNC();
         if (neN > 0) UPR_FORT(q, C::NEN) r_eq = fmax(r_eq, fabs(L[O::eN + q]));
@@ -2968,8 +2998,13 @@ struct upr_qp3 {
                 double t3[NF];
 #pragma unroll
                 for (int a = 0; a < NF; ++a) { double v = 0.0;
+                    if (C::BIGF) {   // (compact Df: the six rows of the contact's body; t2 is indexed at run time here)
+                        const int rb = 6 * P->contact_body2[ci];
+                        for (int r = 0; r < 6; ++r) v += DF(rb + r, NF * ci + a) * t2[rb + r];
+                    } else {
 #pragma unroll
                     for (int r = 0; r < NE; ++r) v += L[O::df + r * NFC + NF * ci + a] * t2[r];
+                    }
                     t3[a] = v; }
                 double* o = out + ((size_t)k * NU + NQ + NF * ci) * NX + c;
                 if (NF == 3) {
@@ -3070,7 +3105,8 @@ struct upr_qp3 {
         UPR_FORT(i, NX) { L[O::xlb + i] = P->x_lb[i]; L[O::xub + i] = P->x_ub[i]; L[O::qd + i] = P->Qdiag[i]; L[O::xd + i] = P->xd[i]; }
         UPR_FORT(i, NU) { L[O::ulb + i] = P->u_lb[i]; L[O::uub + i] = P->u_ub[i]; L[O::rd + i] = P->Rdiag[i]; }
         if (NF == 3) UPR_FORT(e, C::NP) { double e3[3]; upr_friction_row_jac(P, e / 5, e % 5, e3); L[O::erow + 3 * e] = e3[0]; L[O::erow + 3 * e + 1] = e3[1]; L[O::erow + 3 * e + 2] = e3[2]; }
-        UPR_FORT(e, NE * NFC) L[O::df + e] = Dfg[e];
+        if (C::BIGF) UPR_FORT(e, 6 * NFC) { const int col = e / 6, r6 = e % 6; L[O::df + e] = Dfg[(6 * P->contact_body2[col / NF] + r6) * NFC + col]; }
+        else UPR_FORT(e, NE * NFC) L[O::df + e] = Dfg[e];
         if (C::NB > 1) UPR_FORT(bb, C::NB) {
             int n = 0;
             for (int ci = 0; ci < NC; ++ci) if (P->contact_body2[ci] == bb || P->contact_body1[ci] == bb) L[O::clist + bb * NC + n++] = (double)ci;
@@ -3097,7 +3133,8 @@ struct upr_qp3 {
             const double* Ck = rec(k) + lin_gx + r * NX;
             double v = rec(k)[lin_g + r];
             for (int j = 0; j < NX; ++j) v -= Ck[j] * xs[k * NX + j];
-            for (int i = 0; i < NFC; ++i) v -= L[O::df + r * NFC + i] * us[k * NU + NQ + i];
+            if (C::BIGF) v -= df_dot(r, us + k * NU + NQ);
+            else for (int i = 0; i < NFC; ++i) v -= L[O::df + r * NFC + i] * us[k * NU + NQ + i];
             G[F::e0 + e] = v;
         }
         if (no > 0) {
