@@ -142,7 +142,7 @@ def config3_workload(B):
         setattr(P, k, v)
     rng = np.random.default_rng(1)
     x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
-    x0[:, 1] = 0.2 + rng.uniform(-0.08, 0.08, B)   # clear of obstacle 3's margin (the stock home pose of this chain model is inside it)
+    x0[:, :2] += rng.uniform(-0.08, 0.08, (B, 2))   # around the stock home pose (round 4: the arm mount that clears every pair there, upright_amd/robots.py)
     return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(0.0, -2.0, 0.25)), body_params=None,
                 name=f"configs[2]: Thing + box_arch (3 bodies, 16 contacts: nx 27, nu 57, 18 eq + 80 friction + 20 collision rows/knot), "
                      f"N=20, batch={B}, cold start, sqp_iteration=1")

@@ -883,6 +883,58 @@ int ipm_solve(const QP& qp, int iter_max, double tol, double tol_stat, QPSol& so
             std::vector<vec> eprox = eres;
             if (rho_prox > 0.0) for (int k = 0; k < N; ++k) for (int r = 0; r < ne; ++r) eprox[k][r] += rho_prox * nu_[k][r];
             ric.solve(hxN, hu, bres, eprox, eNres, ddx, ddu, pi_new, nu_new, dyN);
+            // Iterative refinement of the Newton step (HPIPM: itref): the residual of the reduced KKT system at the computed
+            // step, solved for a correction with the factorisation at hand.  Only when the residual is far above rounding
+            // (> 1e-8): with barrier weights of 1e8 and more on several rows of one contact the dense factorisation of Huu
+            // loses the digits the stationarity test (1e-6) needs, and the iteration then sits on that floor until the cap --
+            // two stacked 20 g dice, a projectile row active at a converged plan.  Well-conditioned steps are left bit for bit.
+            for (int ref = 0; ref < 3; ++ref) {
+                std::vector<vec> r1(N + 1, vec(nx, 0.0)), r2(N, vec(nu, 0.0)), r3(N, vec(nx, 0.0)), r4(N, vec(ne, 0.0));
+                double rmax = 0.0;
+                for (int k = 1; k <= N; ++k) for (int i = 0; i < nx; ++i) {
+                    double v = hxN[k][i] - pi_new[k][i] + Hxx_add[k][i] * ddx[k][i];
+                    const vec& Q = (k < N ? qp.st[k].Q : qp.QN);
+                    for (int j = 0; j < nx; ++j) v += Q[i * nx + j] * ddx[k][j];
+                    if (k < N) {
+                        if (!Hxx_dense.empty() && !Hxx_dense[k].empty()) for (int j = 0; j < nx; ++j) v += Hxx_dense[k][i * nx + j] * ddx[k][j];
+                        for (int l = 0; l < nx; ++l) v += A[l * nx + i] * pi_new[k + 1][l];
+                        for (int r = 0; r < ne; ++r) v += qp.st[k].Ce[r * nx + i] * nu_new[k][r];
+                    } else for (int r = 0; r < neN; ++r) {
+                        double c = eNres[r]; for (int j = 0; j < nx; ++j) c += qp.CN[r * nx + j] * ddx[N][j];
+                        v += qp.CN[r * nx + i] * c / ric.rhoN;
+                    }
+                    r1[k][i] = v; rmax = std::max(rmax, std::fabs(v));
+                }
+                for (int k = 0; k < N; ++k) {
+                    const StageQP& s = qp.st[k];
+                    for (int i = 0; i < nu; ++i) {
+                        double v = hu[k][i] + s.Rd[i] * ddu[k][i];
+                        for (int j = 0; j < nu; ++j) v += Huu_add[k][i * nu + j] * ddu[k][j];
+                        for (int l = 0; l < nx; ++l) v += B[l * nu + i] * pi_new[k + 1][l];
+                        for (int r = 0; r < ne; ++r) v += s.De[r * nu + i] * nu_new[k][r];
+                        r2[k][i] = v; rmax = std::max(rmax, std::fabs(v));
+                    }
+                    for (int i = 0; i < nx; ++i) {
+                        double v = bres[k][i] - ddx[k + 1][i];
+                        for (int j = 0; j < nx; ++j) v += A[i * nx + j] * ddx[k][j];
+                        for (int j = 0; j < nu; ++j) v += B[i * nu + j] * ddu[k][j];
+                        r3[k][i] = v; rmax = std::max(rmax, std::fabs(v));
+                    }
+                    for (int r = 0; r < ne; ++r) {
+                        double v = eprox[k][r] - ric.rho_s * nu_new[k][r];
+                        for (int j = 0; j < nx; ++j) v += s.Ce[r * nx + j] * ddx[k][j];
+                        for (int j = 0; j < nu; ++j) v += s.De[r * nu + j] * ddu[k][j];
+                        r4[k][r] = v; rmax = std::max(rmax, std::fabs(v));
+                    }
+                }
+                if (!(rmax > 1e-8)) break;
+                std::vector<vec> cx(N + 1, vec(nx, 0.0)), cu(N, vec(nu, 0.0)), cpi(N + 1, vec(nx, 0.0)), cnu(N, vec(ne, 0.0));
+                vec cyN(neN, 0.0), zN(neN, 0.0);
+                ric.solve(r1, r2, r3, r4, zN, cx, cu, cpi, cnu, cyN);
+                for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i) { if (k >= 1) ddx[k][i] += cx[k][i]; pi_new[k][i] += cpi[k][i]; }
+                for (int k = 0; k < N; ++k) { for (int i = 0; i < nu; ++i) ddu[k][i] += cu[k][i]; for (int r = 0; r < ne; ++r) nu_new[k][r] += cnu[k][r]; }
+                for (int r = 0; r < neN; ++r) dyN[r] += cyN[r];
+            }
             for (int k = 0; k <= N; ++k) {
                 int o = 0;
                 if (k >= 1) {

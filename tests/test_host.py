@@ -368,3 +368,54 @@ def test_system_pinocchio_mapping_obstacle_coordinates_first():
         # a state of the wrong length is an error (Eigen would read out of bounds: the mirror refuses)
         with pytest.raises(ValueError):
             m.get_pinocchio_joint_position(x[:-1])
+
+
+def test_home_pose_and_the_arm_mount():
+    """What the chain model of upright_amd/robots.py does to the reference's own scene: at the stock home
+    configuration (thing.yaml:16) the signed distance d = |c_a - c_b| - r_a - r_b - minimum_distance of every collision pair of
+    obstacles/simple.yaml:11-41, for the four right-angle yaws of the arm mount.  The shipped one (-pi/2) clears all 20 pairs
+    and keeps home EE and the _point1 target within the arm's reach (_point1.yaml:1-2: "doable with either base or arm");
+    the mount of rounds 1 - 3 (yaw 0) starts 0.16 m inside obstacle 3's margin -- a recorded number now, not a comment."""
+    import json
+    from pathlib import Path
+
+    from upright_amd import robots
+    from upright_amd.problem import THING_HOME
+
+    cfg = json.load(open(Path(__file__).resolve().parent / "golden" / "configs.json"))["static_arch_point3"]["controller"]
+    dmin = float(cfg["obstacles"]["minimum_distance"])
+    assert len(cfg["obstacles"]["collision_pairs"]) == 20 == len(robots.SIMPLE_COLLISION_PAIRS)
+
+    def scene(yaw):
+        saved = robots.ARM_MOUNT_RPY.copy()
+        try:
+            robots.ARM_MOUNT_RPY[:] = (0.0, 0.0, yaw)
+            ch = robots.thing()
+        finally:
+            robots.ARM_MOUNT_RPY[:] = saved
+        cm = robots.collision_model(ch, robots.SIMPLE_COLLISION_PAIRS)
+        R, o, fr = np.eye(3), np.zeros(3), {-1: (np.eye(3), np.zeros(3))}
+        for i, (j, qi) in enumerate(zip(ch.joints, THING_HOME)):
+            o = o + R @ j.p
+            R = R @ j.R
+            if j.kind == robots.REVOLUTE:
+                R = R @ robots._axis_rot(j.axis, qi)
+            else:
+                o = o + R @ j.axis * qi
+            fr[i] = (R.copy(), o.copy())
+        fr[ch.nq] = (R @ ch.tool_R, o + R @ ch.tool_p)
+        c = np.array([fr[f][1] + fr[f][0] @ off for f, off in zip(cm["sph_frame"], cm["sph_off"])])
+        d = np.array([np.linalg.norm(c[a] - c[b]) - cm["sph_r"][a] - cm["sph_r"][b] - dmin for a, b in zip(cm["pair_a"], cm["pair_b"])])
+        ee = ch.forward(THING_HOME)[0]
+        shoulder = fr[2][1] + fr[2][0] @ ch.joints[3].p       # origin of shoulder_pan on the base at home
+        reach = [np.linalg.norm((ee - shoulder)[:2]), np.linalg.norm((ee + np.array([-2.0, 1.0, 0.0]) - shoulder)[:2])]
+        return d, reach
+
+    d, reach = scene(float(robots.ARM_MOUNT_RPY[2]))
+    assert robots.ARM_MOUNT_RPY[2] == -np.pi / 2
+    assert d.min() > 0.29, d.min()                            # every pair clears minimum_distance at home, by 0.30 m or more
+    assert max(reach) < 1.40, reach                           # home EE and the _point1 target within reach of the shoulder axis
+    table = {yaw: scene(yaw) for yaw in (0.0, np.pi / 2, np.pi)}
+    assert table[0.0][0].min() < -0.16 and int((table[0.0][0] < 0).sum()) == 3      # rounds 1 - 3: tray and wrist inside obstacle 3's margin
+    for yaw in (0.0, np.pi / 2, np.pi):
+        assert max(table[yaw][1]) > 1.8                       # ... and the other mounts put the _point1 target out of the arm's reach
