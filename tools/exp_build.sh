@@ -3,6 +3,6 @@
 # extra -D flags are passed through.  Run with UPR_LIB=libupright_mi_exp.so.  Never the production library.
 set -e
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DUPR_HEADLINE_ONLY "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DUPR_MONOLITHIC -DUPR_HEADLINE_ONLY "$@" \
     -o upright_amd/${OUT:-libupright_mi_exp.so} upright_amd/csrc/upr_api.hip 2>&1 | grep -E "error" || true
 ls -l upright_amd/${OUT:-libupright_mi_exp.so}

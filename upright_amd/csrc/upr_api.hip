@@ -17,6 +17,8 @@
 #include "upr_qp.h"
 #include "upr_qp2.h"
 #include "upr_qp3.h"
+#include "upr_qp3_list.h"
+#include "upr_qp3_launch.h"
 
 namespace {
 
@@ -416,29 +418,15 @@ size_t qp2_ws_doubles(const upr_problem& P, const upr_dims& d) {
 // third-structure ("production") kernel.  The headline shape (nq 9, nb 1, nc 4, nf 3, N 20) in three workgroup sizes, with
 // and without state-polytopic rows; further (shape, SOFT) instantiations at 256 lanes for the configurations the
 // reference ships with HPIPM slacks: thing_demo (one body, frictionless) and the upright_robust 8-corner arrangement.
+// (the kernels themselves are instantiated in upr_qp3_inst.hip, one translation unit per part of upr_qp3_list.h, compiled side
+// by side; this file only declares their launchers -- -DUPR_MONOLITHIC instantiates them here instead: experiment builds)
 template <class C>
 int launch_qp3_cfg(upr_batch* h, const upr_qp_args& A) {
-    const size_t lds = (size_t)upr_qp3_lds<C>::total * sizeof(double);
-    if (lds > 160 * 1024) return fail("QP working set exceeds 160 KiB of LDS");
-    if (lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)upr_qp3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((upr_qp3_kernel<C>), dim3(h->B), dim3(C::NT), lds, h->stream, A);
-    UPR_HIP(hipGetLastError());
+    const int rc = upr_qp3_launch<C>(h->stream, h->B, A);
+    if (rc == -1) return fail("QP working set exceeds 160 KiB of LDS");
+    if (rc != 0) return fail(std::string("upr_qp3_kernel launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
-// (nq, nb, nc, nf, ROWS, SOFT, DENSE) instantiations besides the headline's: the headline shape with slacks on its boxes,
-// thing_demo (one body, frictionless, slacks), the upright_robust 8-corner arrangement (star, slacks), and box_arch
-// (three stacked bodies that share contacts: dense Schur complement; with the collision rows of obstacles/simple.yaml)
-#if defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_SHAPES)
-#define UPR_QP3_EXTRA(X) X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false) X(9, 7, 28, 3, 20, false, false, false)
-#elif defined(UPR_HEADLINE_ONLY) && defined(UPR_EXP_CONFIG3)
-#define UPR_QP3_EXTRA(X) X(9, 3, 16, 3, 20, true, false, true) X(9, 8, 32, 1, 20, false, true, false)
-#elif defined(UPR_HEADLINE_ONLY)
-#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, 20, false, true, false) X(9, 1, 4, 3, 20, true, true, false)
-#else
-#define UPR_QP3_EXTRA(X) X(9, 1, 4, 3, 20, false, true, false) X(9, 1, 4, 3, 20, true, true, false) X(9, 1, 4, 1, 20, false, true, false) X(9, 8, 32, 1, 20, false, true, false) \
-    X(9, 3, 16, 3, 20, true, false, true) X(6, 1, 4, 1, 20, false, true, false) X(6, 1, 4, 1, 10, false, true, false) \
-    X(9, 2, 8, 3, 20, false, false, true) X(6, 1, 4, 3, 20, false, false, false) X(9, 7, 28, 3, 20, false, false, false)   /* round 4: the paper's dice (two stacked bodies, dense 12 x 12), arm-only runs with friction, seven cups (star with friction: upr_qp3_cfg::BIGF) */
-#endif
 bool qp3_is_headline(const upr_problem& P) { return P.nq == 9 && P.nb == 1 && P.nc == 4 && P.nf == 3 && P.N == 20; }
 bool soft_boxes(const upr_problem& P) { return P.soft_state_box || P.soft_input_box; }
 // does the problem need a SOFT instantiation?  Slacks on its boxes, or slacks.poly_ineq with friction / state-polytopic rows
