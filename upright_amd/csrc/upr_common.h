@@ -19,6 +19,7 @@
 #define UPR_SYNC() ((void)0)
 #define UPR_SYNC_LDS() ((void)0)
 #define UPR_WSYNC() ((void)0)
+#define UPR_WSYNC_LDS() ((void)0)
 struct upr_ctx { int tid; int nt; };
 #else
 #include <hip/hip_runtime.h>
@@ -32,6 +33,8 @@ struct upr_ctx { int tid; int nt; };
 // wave-level ordering point: LDS operations of one wave are executed in program order, so only the
 // compiler has to be kept from moving code across it
 #define UPR_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// the same for LDS traffic only: outstanding GLOBAL stores of the wave are not waited for (the fences above drain them)
+#define UPR_WSYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 struct upr_ctx { int tid; int nt; };
 #endif
 

@@ -148,7 +148,10 @@ struct upr_qp3_lds {
                          clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
                          // stacked bodies (COUPLED): the dense Schur complement of every knot, packed lower triangle, assembled block by block
                          // by a lane per (knot, body pair) and factored by the knot's lane (prep D)
-                         sdn = ccnt + r2(C::NB > 1 ? C::NB : 0), total = sdn + r2(C::COUPLED ? C::N * (C::SB * (C::SB + 1) / 2) : 0);
+                         sdn = ccnt + r2(C::NB > 1 ? C::NB : 0),
+                         // ... and, per body pair (bi >= bj), the contacts that load BOTH bodies (indices as doubles) and their number
+                         plist = sdn + r2(C::COUPLED ? C::N * (C::SB * (C::SB + 1) / 2) : 0), pcnt = plist + r2(C::COUPLED ? (C::NB * (C::NB + 1) / 2) * C::NC : 0),
+                         total = pcnt + r2(C::COUPLED ? C::NB * (C::NB + 1) / 2 : 0);
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -216,6 +219,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #endif
 #ifndef UPR_QP3_FUSERES
 #define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
+#endif
+#ifndef UPR_QP3_COOP_SCHUR
+#define UPR_QP3_COOP_SCHUR 1   // dense Schur complement (stacked bodies): cooperative factorisation, SB lanes per knot (0: a lane per knot, rounds 2 - 3; A/B runs)
 #endif
 #ifndef UPR_QP3_PRIO_MAT
 #define UPR_QP3_PRIO_MAT 0   // every wave during the matrix sweep: 2 measured no different from 0 (3.235 vs 3.230 ms)
@@ -864,9 +870,47 @@ struct upr_qp3 {
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
                     for (int c = 0; c < 6; ++c) acc[r][c] = (bi == bj && r == c) ? rho_s : 0.0;
-                for (int ci = 0; ci < NC; ++ci) {
-                    const int b1 = P->contact_body1[ci], b2 = P->contact_body2[ci];
-                    if ((bi != b1 && bi != b2) || (bj != b1 && bj != b2)) continue;
+                // The contacts of the pair come from its list (O::plist, built once per solve), the inverse contact factors of the
+                // first PF of them are requested TOGETHER and the products run without a branch (a factor beyond the list is zero:
+                // exact zeros are added).  Rounds 2 - 3 scanned all contacts with a test each: every matching contact then paid its
+                // own global round trip -- about 45 k of the 82 k cycles phase D cost per interior-point iteration of configs[2].
+                constexpr int PF = (NC < 8) ? NC : 8, NBK = (NF == 3) ? 9 : 1;
+                const int npl = (int)L[O::pcnt + bl];
+                double Bq[PF][NBK]; int cq[PF];
+#pragma unroll
+                for (int t = 0; t < PF; ++t) {
+                    cq[t] = (int)L[O::plist + bl * NC + t];
+#pragma unroll
+                    for (int a = 0; a < NBK; ++a) { const double v = G[F::lfi + k * C::NLF + NBK * cq[t] + a]; Bq[t][a] = (t < npl) ? v : 0.0; }
+                }
+#pragma unroll
+                for (int t = 0; t < PF; ++t) {
+                    const int ci = cq[t];
+                    double Bk[NBK];
+#pragma unroll
+                    for (int a = 0; a < NBK; ++a) Bk[a] = Bq[t][a];
+                    double zi[6][NF], zj[6][NF];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        const double* di = L + O::df + (6 * bi + r) * NFC + NF * ci;
+                        const double* dj = L + O::df + (6 * bj + r) * NFC + NF * ci;
+                        if (NF == 3) {
+                            { const double d0 = di[0], d1 = di[1], d2 = di[2]; zi[r][0] = Bk[0] * d0; zi[r][1 % NF] = Bk[3 % NBK] * d0 + Bk[4 % NBK] * d1; zi[r][2 % NF] = Bk[6 % NBK] * d0 + Bk[7 % NBK] * d1 + Bk[8 % NBK] * d2; }
+                            { const double d0 = dj[0], d1 = dj[1], d2 = dj[2]; zj[r][0] = Bk[0] * d0; zj[r][1 % NF] = Bk[3 % NBK] * d0 + Bk[4 % NBK] * d1; zj[r][2 % NF] = Bk[6 % NBK] * d0 + Bk[7 % NBK] * d1 + Bk[8 % NBK] * d2; }
+                        } else { zi[r][0] = Bk[0] * di[0]; zj[r][0] = Bk[0] * dj[0]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int a = 0; a < NF; ++a) v += zi[r][a] * zj[c][a];
+                            acc[r][c] += v;
+                        }
+                }
+                for (int t = PF; t < npl; ++t) {   // (longer lists: one contact at a time)
+                    const int ci = (int)L[O::plist + bl * NC + t];
                     double Bk[NF == 3 ? 9 : 1];
                     if (NF == 3) {
 #pragma unroll
@@ -901,7 +945,135 @@ struct upr_qp3 {
                     }
             }
             UPR_SYNC();
+            ftoc(6, 3);
         }
+#ifndef UPR_HOST_EMU
+        if constexpr (C::COUPLED && UPR_QP3_COOP_SCHUR) {
+            // Cooperative form of phase D for the dense Schur complement (round 4): SB lanes per knot, lane i owns ROW i of S through a
+            // right-looking Cholesky factorisation -- the pivot column crosses the group through a slot per wave, the reciprocal
+            // pivot by a lane shuffle -- then COLUMN i of the inverse factor by forward substitution out of the packed factor in
+            // LDS (in place over S), and the two products ys = Lsi ee (a row per lane, out of the packed inverse in LDS) and
+            // zt = Lsi' ys (the lane's own column).  Every sum runs in the order of the one-lane form (upr_chol_inv_serial, rounds
+            // 2 - 3: one lane per knot, 171 entries in a scratch frame: with the assembly 82 k of the 505 k cycles of an
+            // interior-point iteration of configs[2]); the groups of a wave run in lockstep, so wave-local ordering points are
+            // all it takes.  The packed inverse stays in LDS for the corrector's call (level 1), which then needs no global operand.
+            // (KQ: knots a lane carries side by side.  The chain of a pivot -- reciprocal square root, shuffle, LDS round trip: 640
+            // cycles -- is latency, and two independent chains would share it; measured with KQ = 2 the 72 extra registers go to
+            // scratch in this 512-register kernel and the phase takes 240 k cycles instead of 68 k: one knot per lane, two passes.)
+            constexpr int GP = 64 / SB, KW = GP * (NT / 64), KQ = 1, KPP = KW * KQ, NPS = (N + KPP - 1) / KPP, NPK = SB * (SB + 1) / 2;
+            static_assert(GP >= 1 && O::Pa + 64 * KQ * (NT / 64) <= O::yN, "a group per knot inside a wave; pivot-column slots in the sweeps' working set");
+            const int ln = lane(), g = ln / SB, i = ln - g * SB, wv = wb >> 6;
+            const int gc = (g < GP) ? g : 0, ri = i * (i + 1) / 2;
+            double* colb = L + O::Pa + wv * 64 * KQ;
+            bool ok = true;
+#pragma unroll 1
+            for (int pass = 0; pass < NPS; ++pass) {
+                int kq[KQ]; bool act[KQ]; double* Sk[KQ];
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    kq[q] = pass * KPP + q * KW + wv * GP + g;
+                    act[q] = g < GP && kq[q] < N;
+                    if (!act[q]) kq[q] = 0;
+                    Sk[q] = L + O::sdn + kq[q] * NPK;
+                }
+                double col[KQ][SB];
+                if (factor) {
+                    double row[KQ][SB];
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                        for (int c = 0; c < SB; ++c) row[q][c] = (c <= i) ? Sk[q][ri + c] : 0.0;
+#pragma unroll
+                    for (int p = 0; p < SB; ++p) {
+                        double lp[KQ];
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q) {
+                            double s = row[q][p];
+                            if (i == p && !(s > 0.0)) { if (act[q]) ok = false; s = 1.0; }
+                            const double idg = upr_rsqrt(i == p ? s : 1.0);
+                            const double d = __shfl(idg, gc * SB + p);
+                            lp[q] = (i > p) ? row[q][p] * d : ((i == p) ? d : row[q][p]);
+                            row[q][p] = lp[q];
+                        }
+                        if (p + 1 < SB) {
+#pragma unroll
+                            for (int q = 0; q < KQ; ++q) colb[64 * q + ln] = lp[q];
+                            UPR_WSYNC_LDS();
+                            // (no test on c <= i: the entries of a row beyond its diagonal are never used, and a test would put every
+                            //  one of these reads into a branch of its own with a full LDS round trip: measured 2.3 k cycles per pivot)
+#pragma unroll
+                            for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                                for (int c = p + 1; c < SB; ++c) row[q][c] -= lp[q] * colb[64 * q + gc * SB + c];
+                            UPR_WSYNC_LDS();
+                        }
+                    }
+                    ftoc(7, 3);
+                    // the factor (reciprocal pivots on the diagonal) in place over S, then column i of its inverse
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) if (act[q]) {
+#pragma unroll
+                        for (int c = 0; c < SB; ++c) if (c <= i) Sk[q][ri + c] = row[q][c];
+                    }
+                    UPR_WSYNC_LDS();
+                    // forward substitution in axpy form: once entry r of the column is known it goes into the running sums of all
+                    // later entries (seventeen independent operations) -- the dot-product form made every one of its 153 operations
+                    // wait for its own LDS read behind the previous one (19 k cycles for two passes); each sum still takes its terms
+                    // in the order of the one-lane form
+                    // (the running sums live in the column's own registers until their entry is due)
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                        for (int r = 0; r < SB; ++r) col[q][r] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < SB; ++r)
+#pragma unroll
+                        for (int q = 0; q < KQ; ++q) {
+                            const double rec = Sk[q][r * (r + 1) / 2 + r];
+                            col[q][r] = (r < i) ? 0.0 : ((r == i) ? rec : -col[q][r] * rec);
+#pragma unroll
+                            for (int s2 = r + 1; s2 < SB; ++s2) col[q][s2] += Sk[q][s2 * (s2 + 1) / 2 + r] * col[q][r];   // (col[r] = 0 above the lane's own column: exact zeros)
+                        }
+                    UPR_WSYNC_LDS();   // every lane is through with the factor: the packed inverse takes its place
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) if (act[q]) {
+                        double* Lsg = G + F::lsi + kq[q] * SB * SB;
+#pragma unroll
+                        for (int r = 0; r < SB; ++r) { Lsg[r * SB + i] = col[q][r]; if (r >= i) Sk[q][r * (r + 1) / 2 + i] = col[q][r]; }
+                    }
+                } else {
+                    // (level 1: the packed inverse of the predictor's call is still in LDS)
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                        for (int r = 0; r < SB; ++r) { const double v = Sk[q][r * (r + 1) / 2 + ((r >= i) ? i : 0)]; col[q][r] = (r >= i) ? v : 0.0; }
+                }
+                UPR_WSYNC_LDS();
+                ftoc(8, 3);
+                double yv[KQ], zv[KQ];
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    yv[q] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < SB; ++m) { const double e = L[O::ys + kq[q] * SB + m], a = Sk[q][ri + m]; yv[q] += ((m <= i) ? a : 0.0) * e; }
+                }
+                UPR_WSYNC_LDS();
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) if (act[q]) L[O::ys + kq[q] * SB + i] = yv[q];
+                UPR_WSYNC_LDS();
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    zv[q] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < SB; ++m) zv[q] += col[q][m] * L[O::ys + kq[q] * SB + m];
+                    if (act[q]) L[O::zt + kq[q] * SB + i] = zv[q];
+                }
+                UPR_WSYNC_LDS();
+                ftoc(9, 3);
+            }
+            if (!ok) L[O::misc] = 1.0;
+        } else
+#endif
         UPR_FORT(kb, C::NKB) {
             double* Ls = G + F::lsi + kb * SB * SB;
             double Lr[SB * SB];                                   // the inverse factor stays in registers for the two products
@@ -3111,6 +3283,19 @@ struct upr_qp3 {
             int n = 0;
             for (int ci = 0; ci < NC; ++ci) if (P->contact_body2[ci] == bb || P->contact_body1[ci] == bb) L[O::clist + bb * NC + n++] = (double)ci;
             L[O::ccnt + bb] = (double)n;
+        }
+        if (C::COUPLED) UPR_FORT(bl, C::NB * (C::NB + 1) / 2) {
+            int bi = 0, b0 = 0;
+            for (int i = 1; i < C::NB; ++i) if (bl >= i * (i + 1) / 2) { bi = i; b0 = i * (i + 1) / 2; }
+            const int bj = bl - b0;
+            int n = 0;
+            for (int ci = 0; ci < NC; ++ci) {
+                const int b1 = P->contact_body1[ci], b2 = P->contact_body2[ci];
+                if ((bi == b1 || bi == b2) && (bj == b1 || bj == b2)) L[O::plist + bl * NC + n++] = (double)ci;
+            }
+            for (int t = n; t < NC; ++t) L[O::plist + bl * NC + t] = L[O::plist + bl * NC];   // (padding: a valid index)
+            if (n == 0) for (int t = 0; t < NC; ++t) L[O::plist + bl * NC + t] = 0.0;
+            L[O::pcnt + bl] = (double)n;
         }
         UPR_FORT(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
         UPR_FORT(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
