@@ -95,6 +95,37 @@ def pmc_traffic(kernel=None):
     return {}, None
 
 
+def pmc_workload(key):
+    """Counters of ONE workload from the newest committed per-workload pass (profiles/r*_pmc_workloads.csv, tools/profile_all.sh:
+    `bench.py --only <key>` under rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE and the instruction mix; per-dispatch
+    means).  Returns ({"qp": {counter: mean}, "linearize": {...}, "batch": B of the pass}, file name) or ({}, None)."""
+    import csv
+
+    best = _latest_profile("r*_pmc_workloads.csv")
+    if best is None:
+        return {}, None
+    out = {"qp": {}, "linearize": {}}
+    for row in csv.reader(l for l in open(best) if not l.startswith("#")):
+        if len(row) == 6 and row[0] == key:
+            _, kernel, counter, _, mean, batch = row
+            tag = "linearize" if "upr_linearize_kernel" in kernel else ("qp" if "upr_qp" in kernel else None)
+            if tag:
+                out[tag][counter] = float(mean)
+                out["batch"] = int(batch)
+    return (out, best.name) if (out["qp"] or out["linearize"]) else ({}, None)
+
+
+def _hbm_bytes(c):
+    """gfx950 correction of MI355X_MICROARCH.md: (2 FETCH_SIZE + WRITE_SIZE) KB."""
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in c and "WRITE_SIZE" in c) else None
+
+
+def _issued_flops(c):
+    if "SQ_INSTS_VALU_FMA_F64" not in c:
+        return None
+    return 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)) + 2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+
+
 def pmc_issued_flops(kernel=None):
     """fp64 flops the QP kernel ISSUED per launch according to the newest committed instruction-mix pass
     (profiles/r*_pmc_mfma.csv, or r*_pmc_mfma_all.csv for a named kernel of the other workloads; wave instructions x 64
@@ -143,7 +174,7 @@ def config3_workload(B):
     rng = np.random.default_rng(1)
     x0 = np.tile(np.concatenate([THING_HOME, np.zeros(18)]), (B, 1))
     x0[:, :2] += rng.uniform(-0.08, 0.08, (B, 2))   # around the stock home pose (round 4: the arm mount that clears every pair there, upright_amd/robots.py)
-    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(0.0, -2.0, 0.25)), body_params=None,
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(0.0, -2.0, 0.25)), body_params=None, key="config3",
                 name=f"configs[2]: Thing + box_arch (3 bodies, 16 contacts: nx 27, nu 57, 18 eq + 80 friction + 20 collision rows/knot), "
                      f"N=20, batch={B}, cold start, sqp_iteration=1")
 
@@ -172,7 +203,7 @@ def config4_workload(B, rank=0, world=1):
     x0[:, :2] += rng.uniform(-0.25, 0.25, (Bg, 2))
     lo, hi = shard_range(Bg, rank, world)
     x0, bp = x0[lo:hi], bp[lo:hi]
-    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0)), body_params=bp,
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0, offset=(-2.0, 1.0, 0.0)), body_params=bp, key="config4",
                 name=f"configs[3]: upright_robust 8-corner arrangement (8 bodies, 32 frictionless contacts: nx 27, nu 41, 48 soft eq rows/knot), "
                      f"per-instance inertial parameters, N=20, batch={B} per GPU, cold start, init_sqp_iteration=3")
 
@@ -207,7 +238,7 @@ def config5_workload(B, rank=0, world=1, slacks=False):
         v0 = 2.5 * perp + np.array([0.0, 0.0, 0.5 * 9.81 * T])
         cross = p + 0.5 * goal[b] + np.array([0.0, 0.0, 0.25])
         dyn[b] = np.concatenate([cross - v0 * T - 0.5 * a0 * T * T, v0, a0])
-    return dict(P=P, x0=np.concatenate([x0, dyn], axis=1), way=(p + goal)[:, None, :], body_params=None,
+    return dict(P=P, x0=np.concatenate([x0, dyn], axis=1), way=(p + goal)[:, None, :], body_params=None, key="config5s" if slacks else "config5",
                 name=f"configs[4]: Thing + pink_bottle + thrown ball (5 collision / projectile rows per knot), N=20, closed loop at 100 Hz "
                      f"(one warm-started SQP iteration per tick, linear feedback policy at the observed state), goal sweep of {B} goals per GPU"
                      + (", sqp.hpipm.slacks.enabled (state_box, input_box, poly_ineq: the reference's remedy for rows one step cannot restore)" if slacks else ""))
@@ -223,7 +254,7 @@ def contract_workload(B):
 
     P = thing_problem(_arrangements()["pink_bottle"], use_feedback_policy=True)
     x0 = contract_states(B, seed=0)
-    return dict(P=P, x0=x0, way=waypoints_for(P, x0), body_params=None,
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0), body_params=None, key="contract",
                 name=f"configs[1] on SURVEY 8(d)'s start distribution as written (U(+-0.25) on all nine joints, U(+-0.2) velocities, seed 0), "
                      f"batch={B}, cold start, sqp_iteration=1: most starts are infeasible at the fixed first knot (tray tilted beyond the friction cone)")
 
@@ -300,7 +331,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         elapsed, failed, broke[0] = float(tt[0].item()), int(tt[1].item()), int(tt[2].item())
         assert u0_all[0].shape == (world * B, P.nu)
     kt = mpc.kernel_times()
-    roof, lin = roofline_objects(P, B, kt, mpc.stats(), 1, headline=False)   # (kernel times: means over the ticks; IPM iterations: the last tick's)
+    roof, lin = roofline_objects(P, B, kt, mpc.stats(), 1, headline=False, key=w.get("key"))   # (kernel times: means over the ticks; IPM iterations: the last tick's)
     goal_err = np.linalg.norm(np.array([P.chain.forward(x[b, :9])[0] for b in range(0, B, max(1, B // 64))])
                               - w["way"][::max(1, B // 64), 0], axis=1)
     out = {
@@ -412,8 +443,9 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
     return elapsed, gathered[0]
 
 
-def roofline_objects(P, B, kt, st, sqp_iters, headline):
-    """`roofline` (QP kernel: the dominant one) and `roofline_linearize` objects of one workload."""
+def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
+    """`roofline` (QP kernel: the dominant one) and `roofline_linearize` objects of one workload.  key: the workload's name in the
+    per-workload counter file (pmc_workload); counters are used only when the pass ran the same batch size."""
     knots = B * (P.N + 1)                                  # one linearise launch covers every knot of the batch once
     lin_bytes = bytes_per_knot(P) * knots
     lin_gbs = lin_bytes / (kt["linearize_ms"] * 1e-3) / 1e9 if kt["linearize_ms"] > 0 else 0.0
@@ -426,6 +458,12 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
     kkey = None if headline else kname.split("upr_qp3_kernel<")[-1].rstrip(">").strip() if "upr_qp3_kernel<" in kname else kname
     traffic, traffic_src = pmc_traffic(kkey) if (not headline or B == 1024) else ({}, None)
     issued, issued_src = pmc_issued_flops(kkey) if (not headline or B == 1024) else (None, None)
+    wl, wl_src = pmc_workload(key or ("headline" if headline else ""))
+    if wl and wl.get("batch") == B:          # round 4: counters of this very workload at this very batch size
+        traffic, traffic_src = {"qp": _hbm_bytes(wl["qp"]), "linearize": _hbm_bytes(wl["linearize"])}, wl_src
+        issued, issued_src = _issued_flops(wl["qp"]), wl_src
+    else:
+        wl = {}
     frac = qp_tflops / PEAK_FP64_TFLOPS
     frac_hbm = (traffic["qp"] / (kt["qp_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic.get("qp") and kt["qp_ms"] > 0) else None
     roof = {
@@ -471,11 +509,19 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline):
         "peak": PEAK_HBM_GBS,
         "unit": "GB/s",
         "frac": lin_gbs / PEAK_HBM_GBS,
-        "traffic": traffic.get("linearize") if headline else None,
+        "traffic": traffic.get("linearize") if (headline or wl) else None,
+        "traffic_source": traffic_src if (headline or wl) else None,
         "algorithmic_bytes": lin_bytes,
         "avg_launch_ms": kt["linearize_ms"],
         "bytes_per_knot": bytes_per_knot(P),
     }
+    lc = wl.get("linearize", {}) if wl else {}
+    if "SQ_BUSY_CYCLES" in lc:
+        # MFMA utilisation of the Gauss-Newton Hessian assembly (north_star): matrix-pipe busy cycles over the SQ-busy cycles of the
+        # launch (both summed over the chip), and the v_mfma_f64_16x16x4_f64 instructions behind it (one per knot and error-row block)
+        lin["mfma_util"] = lc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / lc["SQ_BUSY_CYCLES"] if lc["SQ_BUSY_CYCLES"] > 0 else None
+        lin["mfma_instructions"] = lc.get("SQ_INSTS_VALU_MFMA_F64")
+        lin["valu_instructions"] = lc.get("SQ_INSTS_VALU")
     return roof, lin
 
 
@@ -495,7 +541,7 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
     B = mpc.B
     if world > 1:
         assert gathered is not None and gathered[0].shape[0] == world * B
-    roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False)
+    roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False, key=w.get("key"))
     out = {
         "workload": w["name"], "value": B * world * steps / elapsed, "unit": "solves/s", "n_gpus": world,
         "exchange": "all-gather of solved trajectories" if world > 1 else None, "ms_per_step": 1e3 * elapsed / steps,
@@ -521,7 +567,7 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
         mpc.sync()
         el = time.perf_counter() - t0
         kw, sw = mpc.kernel_times(), mpc.stats()
-        roof_w, _ = roofline_objects(w["P"], B, kw, sw, w["P"].sqp_iters, headline=False)
+        roof_w, _ = roofline_objects(w["P"], B, kw, sw, w["P"].sqp_iters, headline=False, key=w.get("key"))
         out["warm"] = {
             "what": f"{n_timed} further SQP iterations after {steps + warmup} cold solves and {n_settle} settling iterations, no reset",
             "value": B * n_timed / el, "unit": "solves/s", "ms_per_step": 1e3 * el / n_timed,
@@ -645,6 +691,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3], configs[4])")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--closed-loop-ticks", type=int, default=150, help="control periods of the configs[4] closed-loop run")
+    ap.add_argument("--only", default=None, choices=["config3", "config4", "config5", "config5s", "contract"],
+                    help="run ONE of the other workloads alone and print its entry (the per-workload counter passes of tools/profile_all.sh)")
     ap.add_argument("--dry-run", action="store_true", help="control flow only: gloo on the CPU, stand-in engines with fake solutions; prints a line marked dry_run (never a measurement)")
     args = ap.parse_args()
 
@@ -695,6 +743,17 @@ def main():
         engine_devices.append(e.device_index())
         return e
 
+    if args.only:
+        if world != 1 or dry:
+            raise SystemExit("bench.py --only runs on one GPU")
+        wo = {"config3": lambda: config3_workload(4096), "config4": lambda: config4_workload(1024), "config5": lambda: config5_workload(1024),
+              "config5s": lambda: config5_workload(1024, slacks=True), "contract": lambda: contract_workload(1024)}[args.only]()
+        if args.only.startswith("config5"):
+            e = time_closed_loop(wo, args.closed_loop_ticks, device=device, engine=engine_for(wo))
+        else:
+            e = time_extra(wo, args.extra_steps, 1, warm=(9, 3) if args.only == "config3" else None, engine=engine_for(wo))
+        print(json.dumps(_strip(e)))
+        return
     w = headline_workload(args.batch, rank, world)
     P, B = w["P"], args.batch
     mpc = engine_for(w)

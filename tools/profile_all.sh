@@ -21,5 +21,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write_all -o ${TAG} -- python3 $XARGS > $OUT/prof_${TAG}_write_all.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $OUT/prof_${TAG}_mf_all -o ${TAG} -- python3 $XARGS > $OUT/prof_${TAG}_mf_all.log 2>&1
 python3 tools/summarize_profiles.py $TAG all
+#   7. (round 4) the same counters PER WORKLOAD, one short run of each workload alone                 -> <tag>_pmc_workloads.csv
+bash tools/pmc_workloads.sh $TAG > $OUT/prof_${TAG}_workloads.log 2>&1
 head -c 600 $OUT/${TAG}_bench.json; echo
 head -8 $OUT/${TAG}_kernel_stats_all.csv
