@@ -161,6 +161,20 @@ def headline_workload(B, rank=0, world=1):
                      f"batch={B} level-tray random start states per GPU, cold start, sqp_iteration=1, qp iter_max=30")
 
 
+def headline_r03_geometry_workload(B):
+    """The headline workload as rounds 1 - 3 measured it: the arm mounted at yaw 0 (round 4 fixed the mount at -pi/2 from the
+    reference's own scene, upright_amd/robots.py; the level-tray starts and the target offset are the same).  Kept so that the
+    kernels can be compared across rounds on equal work: the interior-point iteration counts of the two batches differ
+    (10.2 against 10.5 on average, longest 13 against 16), and a launch lasts as long as its slowest pair of instances."""
+    from upright_amd.problem import thing_problem
+    from upright_amd.sampling import level_tray_states, waypoints_for
+
+    P = thing_problem(_arrangements()["pink_bottle"], use_feedback_policy=True, mount_yaw=0.0)
+    x0 = level_tray_states(B, seed=0)
+    return dict(P=P, x0=x0, way=waypoints_for(P, x0), body_params=None, key="headline_r03",
+                name=f"configs[1] with the arm mount of rounds 1 - 3 (yaw 0; same starts and target offset): Thing + pink_bottle, N=20, batch={B}, cold start, sqp_iteration=1")
+
+
 def config3_workload(B):
     """configs[2]: box_arch (3 bodies, 16 contact points, arrangements.yaml:8-51) + the 20 sphere pairs of
     obstacles/simple.yaml:11-41, waypoint _point3 [0, -2, 0.25], seed 1."""
@@ -780,6 +794,7 @@ def main():
             extra.append(time_closed_loop(w5s, args.closed_loop_ticks, dist=dist, device=device, engine=engine_for(w5s)))
         if world == 1 and not dry:
             extra.append(contract_entry(contract_workload(1024), args.extra_steps, 1))
+            extra.append(time_extra(headline_r03_geometry_workload(1024), 10, 3))
         extra = [_strip(e) for e in extra]
 
     rank_devices = [sorted(set(engine_devices))]

@@ -136,11 +136,11 @@ def contacts_from_fixture(arr):
 THING_HOME = np.array([-1.0, 1.0, 0.0, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, -0.25 * np.pi, 0.5 * np.pi, 0.417 * np.pi])
 
 
-def thing_problem(arrangement, nf=3, N=20, dt=0.1, force_weight=0.001, waypoint_offset=(-2.0, 1.0, 0.0), x0=None, **kw):
+def thing_problem(arrangement, nf=3, N=20, dt=0.1, force_weight=0.001, waypoint_offset=(-2.0, 1.0, 0.0), x0=None, mount_yaw=None, **kw):
     """Headline configuration H: Thing + arrangement, weights/limits of
     `robots/thing.yaml:61-86`, `controller.yaml:54-79`, target = EE(x0) + offset
     (`wrappers.py:31-43`, `ral23/experiments/_point1.yaml:3-8`)."""
-    chain = robots.thing()
+    chain = robots.thing(mount_yaw=mount_yaw)
     c = contacts_from_fixture(arrangement)
     nq = 9
     nc = len(c["contact_mu"])

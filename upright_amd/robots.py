@@ -158,21 +158,23 @@ def _tool(calibration):
     return R, p
 
 
-def _arm_mount(calibration):
-    R, p = rpy_to_rot(ARM_MOUNT_RPY), ARM_MOUNT_XYZ.copy()
+def _arm_mount(calibration, mount_yaw=None):
+    rpy = ARM_MOUNT_RPY if mount_yaw is None else np.array([ARM_MOUNT_RPY[0], ARM_MOUNT_RPY[1], float(mount_yaw)])
+    R, p = rpy_to_rot(rpy), ARM_MOUNT_XYZ.copy()
     b = calibration["base_to_arm_transform"]
     return _compose(R, p, rpy_to_rot(b["rpy"]), np.array(b["xyz"], dtype=float))
 
 
-def thing(calibration=None):
-    """Omnidirectional base (PX, PY, RZ) + UR10: nq = 9 (`robots/thing.yaml:43-47`)."""
+def thing(calibration=None, mount_yaw=None):
+    """Omnidirectional base (PX, PY, RZ) + UR10: nq = 9 (`robots/thing.yaml:43-47`).  mount_yaw: another yaw of the arm mount than
+    ARM_MOUNT_RPY's (comparisons with rounds 1 - 3, which had it at 0)."""
     calibration = calibration or CALIBRATION_REAL
     base = [
         Joint(PRISMATIC, np.array([1.0, 0, 0]), name="x_to_world_joint"),
         Joint(PRISMATIC, np.array([0, 1.0, 0]), name="y_to_x_joint"),
         Joint(REVOLUTE, np.array([0, 0, 1.0]), name="base_to_y_joint"),
     ]
-    R0, p0 = _arm_mount(calibration)
+    R0, p0 = _arm_mount(calibration, mount_yaw)
     tR, tp = _tool(calibration)
     return Chain(base + _ur10_joints(R0, p0), tR, tp, "thing")
 
