@@ -108,6 +108,7 @@ struct upr_dims {
     int soft;                               // any soft row class (slack arrays below are empty otherwise)
     int ws_sig, ws_tau, ws_gam, ws_rcs;     // per slot: slack sigma, its own slack tau and multiplier gam, its complementarity target
     double eq_scale;                        // 1 / sqrt(6 nb): the scaling of the object-dynamics rows (balancing constraint's 1/sqrt(n))
+    int n_dyn;                              // dynamic obstacles (their states are staged per knot by the linearisation kernel)
 };
 
 static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
@@ -118,7 +119,7 @@ static inline UPR_HD upr_dims upr_make_dims(const upr_problem* P) {
     d.eq_scale = 1.0 / sqrt(6.0 * P->nb);
     d.neN = P->terminal_constraint ? 3 + 2 * P->nq : 0;
     d.lin_g = 0; d.lin_gx = d.ne; d.lin_cost = d.lin_gx + d.ne * d.nx; d.lin_grad = d.lin_cost + 1;
-    d.no = P->n_pairs + P->n_proj;
+    d.no = P->n_pairs + P->n_proj; d.n_dyn = P->n_dyn;
     d.lin_hess = d.lin_grad + d.nq; d.lin_obs = d.lin_hess + d.nq * (d.nq + 1) / 2; d.lin_stride = d.lin_obs + d.no * (1 + d.nq);
     d.ni_stage = 2 * d.nx + 2 * d.nu + d.np + d.no;
     d.ss_kx = 0; d.ss_hjj = d.ss_kx + d.nq * d.nx; d.ss_hff = d.ss_hjj + d.nq * d.nq;

@@ -39,7 +39,9 @@ static UPR_HDI int upr_lin_lds_frames(const upr_dims& d, int n_sph) { return upr
 static UPR_HDI int upr_lin_lds_dyn(const upr_dims& d, int n_sph) { return upr_lin_lds_frames(d, n_sph) + d.nq * UPR_SNAP_F; }
 static UPR_HDI int upr_lin_lds_snap(const upr_dims& d, int n_sph = 0) {
 #if UPR_LIN_OBS_SNAP && UPR_LIN_ANALYTIC
-    return d.no > 0 ? upr_lin_lds_dyn(d, n_sph) + 9 * UPR_MAX_DYN + 1 : upr_lin_lds_base(d);
+    // (the obstacle area only where there are obstacles: 37 doubles per knot put configs[2]'s sixteen knots beyond 80 KB, i.e. one
+    //  workgroup per CU instead of two: 0.39 -> 0.57 ms)
+    return d.no > 0 ? upr_lin_lds_dyn(d, n_sph) + (d.n_dyn > 0 ? ((9 * d.n_dyn + 1 + 1) & ~1) : 0) : upr_lin_lds_base(d);
 #else
     return upr_lin_lds_base(d) + (d.no > 0 ? n_sph * 3 * (1 + d.nq) : 0);
 #endif
@@ -311,7 +313,7 @@ static UPR_HDI void upr_lin_obstacle(const upr_lin_args& A, const upr_lin_point&
 static UPR_HDI void upr_lin_stage_obstacle(const upr_lin_args& A, const upr_lin_point& q, int oi, double* sh) {
     double* D = sh + upr_lin_lds_dyn(A.d, A.P->n_sph) + 9 * oi;
     upr_lin_obstacle(A, q, oi, D, D + 3, D + 6);
-    if (oi == 0) sh[upr_lin_lds_dyn(A.d, A.P->n_sph) + 9 * UPR_MAX_DYN] = A.pflag ? A.pflag[q.b] : 0.0;   // activation flag of the projectile rows
+    if (oi == 0) sh[upr_lin_lds_dyn(A.d, A.P->n_sph) + 9 * A.d.n_dyn] = A.pflag ? A.pflag[q.b] : 0.0;   // activation flag of the projectile rows
 }
 // one sphere of one knot
 template <int NQ>
@@ -352,7 +354,7 @@ static UPR_HDI void upr_lin_obs_row(const upr_lin_args& A, const upr_lin_point& 
     // (the projectile rows follow the last obstacle: state.tail(9); its state at the knot was staged at the top of the kernel)
     const double* ro = sh + upr_lin_lds_dyn(d, P->n_sph) + 9 * (P->n_dyn > 0 ? P->n_dyn - 1 : 0);
     const double* vo = ro + 3; const double* ao = ro + 6;
-    const double flag = (A.dyn && r >= P->n_pairs) ? sh[upr_lin_lds_dyn(d, P->n_sph) + 9 * UPR_MAX_DYN] : 0.0;
+    const double flag = (A.dyn && r >= P->n_pairs) ? sh[upr_lin_lds_dyn(d, P->n_sph) + 9 * d.n_dyn] : 0.0;
     {
         int sa, sb; double n[3], w;
         q.out[d.lin_obs + r] = upr_state_row(P, r, [&](int s, int i) { return sc[3 * s + i]; }, ro, vo, ao, flag, &sa, &sb, n, &w);
