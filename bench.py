@@ -273,7 +273,7 @@ def contract_workload(B):
                      f"batch={B}, cold start, sqp_iteration=1: most starts are infeasible at the fixed first knot (tray tilted beyond the friction cone)")
 
 
-def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
+def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None, force_exchange=False):
     """configs[4]: `ticks` control periods of 10 ms for the whole batch: observation in (host -> device), one warm-started
     SQP iteration, policy out (device -> host), exact triple-integrator plant and ballistic ball on the host.  The
     plant's states come from outside the engine every tick, so this rate includes both PCIe hops by construction.  One
@@ -281,6 +281,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     mpc = engine if engine is not None else make_engine(w)
     P, B = w["P"], mpc.B
     world = dist.get_world_size() if dist is not None else 1
+    exchange = world > 1 or (force_exchange and dist is not None)     # (force_exchange: the one-GPU test of the nccl branch)
     mpc.set_projectile_flag(1.0)
     x, t, dt = w["x0"].copy(), 0.0, 0.01
     failed = 0
@@ -290,7 +291,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
     u0_all = [None]
     stq_ = [None]
     u_dev = u_out = ext = None
-    if world > 1:
+    if exchange:
         # exchange buffers of the closed loop: u_0 stays on the device (engine buffer -> u_dev on the engine's stream -> RCCL)
         import torch
 
@@ -306,7 +307,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         _, u, st_ = mpc.tick(t, x, want_stats=True)    # observation in, one SQP iteration, policy at the observation + statistics out: one call
         stq_[0] = st_["qp_status_last"]
         lat.append(time.perf_counter() - tc)
-        if world > 1:   # exchange step of the closed loop: only u_0 of every instance, [B, nu] per rank,
+        if exchange:   # exchange step of the closed loop: only u_0 of every instance, [B, nu] per rank,
             # gathered from the engine's DEVICE buffer (no second trip over PCIe); the tick's latency with the exchange is
             # stamped only when the collective has completed
             mpc.copy_policy_device(u_dev.data_ptr())
@@ -354,7 +355,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None):
         "ms_per_tick_p99_with_exchange": 1e3 * float(np.quantile(lat_x, 0.99)) if lat_x else None,
         "control_period_ms": 10.0, "ticks": ticks,
         "real_time_factor": 0.01 * ticks / elapsed,
-        "exchange": "all-gather of u_0 per tick" if world > 1 else None,
+        "exchange": "all-gather of u_0 per tick" if exchange else None,
         "qp_not_converged_fraction": failed / (B * world * ticks),
         "qp_factorisation_broke_down_fraction": broke[0] / (B * world * ticks),   # (status 2: no step, no feedback policy for that tick)
         "tray_to_goal_m_after_run": {"mean": float(goal_err.mean()), "max": float(goal_err.max())},

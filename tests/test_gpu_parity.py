@@ -1300,6 +1300,14 @@ def test_nccl_gather_of_real_solutions(arrangements):
         torch.cuda.synchronize()
         assert g0.shape == (B, P.nu) and np.array_equal(g0.cpu().numpy(), u0)
         mpc.close()
+        # ... as bench.py's closed loop runs it (round 4): u_0 stays on the device -- upr_batch_copy_policy_device on the engine's
+        # stream, an event, the asynchronous collective, its handle awaited before the tick's latency is stamped
+        w5 = bench.config5_workload(8)
+        e5 = bench.make_engine(w5, device_index=0)
+        out5 = bench.time_closed_loop(w5, 5, dist=dist, device="cuda", engine=e5, force_exchange=True)
+        u0g = out5["u0_gathered"].cpu().numpy()
+        assert out5["exchange"] == "all-gather of u_0 per tick" and u0g.shape == (8, w5["P"].nu) and np.all(np.isfinite(u0g))
+        assert out5["ms_per_tick_p99_with_exchange"] is not None and out5["ms_per_tick_p99_with_exchange"] >= out5["ms_per_tick_p99_engine"]
     finally:
         dist.destroy_process_group()
 
