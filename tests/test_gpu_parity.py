@@ -1670,16 +1670,17 @@ def test_config3_full_size_properties():
 
 @pytest.mark.parametrize("B,N", [(1, 20), (3, 10), (2, 30), (5, 5)])
 def test_edge_sizes_single_instances_and_other_horizons(arrangements, B, N):
-    """Edges of the batch / horizon sizes: one instance, odd batches, horizons other than the production kernel's 20
-    (BASELINE config 1 names horizon 10; those run the run-time-dimension kernels).  One SQP iteration against the oracle at
-    north_star's tolerance; an empty batch is refused."""
+    """Edges of the batch / horizon sizes: one instance, odd batches, horizons other than the listed instantiations' 20
+    (BASELINE config 1 names horizon 10): since round 4 those are instantiated at run time (hiprtc) and run the production
+    structure too.  One SQP iteration against the oracle at north_star's tolerance; an empty batch is refused."""
     P = thing_problem(arrangements["pink_bottle"], N=N, use_feedback_policy=True)
     x0 = level_tray_states(B, seed=90 + N)
     # the terminal equality [p_d - p; v; a] = 0 must be reachable inside the horizon: 2.2 m for T >= 2 s, a short move otherwise
     # (with the default target both solvers stop at the iteration cap for N = 5 and 10, status 1 on either side)
     way = waypoints_for(P, x0) if N >= 20 else waypoints_for(P, x0, offset=(-0.004 * N * N, 0.002 * N * N, 0.0))
     mpc = BatchMPC(P, B, way_p=way)
-    assert ("cfg<" in mpc.kernel_times()["qp_kernel"]) == (N == 20)     # production kernel only at its compiled horizon
+    kn = mpc.kernel_times()["qp_kernel"]
+    assert kn.startswith("upr_qp3_kernel<") if N == 20 else kn == "upr_qp3_jit<upr_qp3_cfg<9, 1, 4, 3, %d, 256, false, false, false>>" % N
     mpc.set_observation(0.0, x0)
     mpc.advance()
     _, xs, us = mpc.solution()
@@ -2004,3 +2005,45 @@ def test_two_dynamic_obstacles(arrangements):
     xe, ue = mpc.tick(0.01, x)
     assert np.array_equal(xe[:, 27:], x[:, 27:]) and np.all(np.isfinite(ue))
     mpc.close()
+
+
+def test_unlisted_shape_is_instantiated_at_run_time(arrangements, monkeypatch, tmp_path):
+    """A shape outside upr_qp3_list.h -- the headline arrangement at horizon N = 12 -- no longer falls to the second-structure kernel:
+    upr_batch_create instantiates the production structure for it with hiprtc out of upr_qp3.h (upr_api.hip, "run-time
+    instantiation"), caches the code object on disk by shape key and source hash, and the solve matches the oracle like the listed
+    shapes do.  A second handle (a second 'process' as far as the disk cache goes: the in-memory cache is per shape and device, so
+    the file is what a new process would find) loads the cached code object."""
+    import time
+
+    monkeypatch.setenv("UPR_QP3_JIT", "1")
+    monkeypatch.setenv("UPR_JIT_CACHE", str(tmp_path / "jit"))
+    B, N = 3, 12
+    P = thing_problem(arrangements["pink_bottle"], N=N)
+    x0 = level_tray_states(B, seed=23)
+    way = waypoints_for(P, x0, offset=(-0.6, 0.3, 0.0))
+    t0 = time.time()
+    mpc = BatchMPC(P, B, way_p=way)
+    t_create = time.time() - t0
+    kn = mpc.kernel_times()["qp_kernel"]
+    assert kn == "upr_qp3_jit<upr_qp3_cfg<9, 1, 4, 3, 12, 256, false, false, false>>", kn
+    files = list((tmp_path / "jit").glob("qp3_9__1__4__3__12__256__false__false__false_*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 100000
+    mpc.set_observation(0.0, x0)
+    mpc.advance()
+    _, xs, us = mpc.solution()
+    st = mpc.stats()
+    xs0, us0 = stationary_guess(x0, N, P.nu)
+    xo, uo, so, _ = Oracle(P).solve_batch(0.0, x0, xs0, us0, way_p=way, nthreads=1)
+    for b in range(B):
+        assert st["qp_status_last"][b] == 0 == so[b].qp_status_last and st["qp_iters_last"][b] == so[b].qp_iters_last
+        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-3
+        assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo[b])) < 1e-4 and abs(np.linalg.norm(us[b]) - np.linalg.norm(uo[b])) < 1e-4
+    mpc.close()
+    # the same shape with the switch off: the second-structure kernel, same plan
+    monkeypatch.setenv("UPR_QP3_JIT", "0")
+    m2 = BatchMPC(P, B, way_p=way)
+    assert "upr_qp3" not in m2.kernel_times()["qp_kernel"]
+    m2.set_observation(0.0, x0); m2.advance()
+    assert np.abs(m2.solution()[1] - xs).max() < 2e-5
+    m2.close()
+    print("create with compile: %.1f s" % t_create)

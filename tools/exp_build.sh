@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DUPR_MONOLITHIC -DUPR_HEADLINE_ONLY "$@" \
-    -o upright_amd/${OUT:-libupright_mi_exp.so} upright_amd/csrc/upr_api.hip 2>&1 | grep -E "error" || true
+    -o upright_amd/${OUT:-libupright_mi_exp.so} upright_amd/csrc/upr_api.hip -lhiprtc -ldl 2>&1 | grep -E "error" || true
 ls -l upright_amd/${OUT:-libupright_mi_exp.so}

@@ -1,8 +1,18 @@
 // upr_api.hip -- C-ABI of libupright_mi.so (include/upright_mi.h): host orchestration of the HIP kernels.
 // No CPU compute path: every entry point that computes launches kernels on the current HIP device.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <chrono>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -224,6 +234,14 @@ __global__ void evaluate_policy_kernel(const upr_problem* P, upr_dims d, int B, 
 // GPUs and a launcher's rank r runs on the GPU its engine was created on whatever another library selected in between
 #define UPR_ENTER(h) do { if (!(h)) return fail("null batch"); if ((h)->device >= 0) UPR_HIP(hipSetDevice((h)->device)); } while (0)
 
+// an instantiation of the production QP kernel made at run time (hiprtc; "run-time instantiation" further down)
+struct upr_jit_kernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    size_t lds = 0, ws = 0;
+    std::string cfg;    // the template arguments, as rocprofv3 prints them
+};
+
 struct upr_batch {
     upr_problem P;
     upr_dims d;
@@ -254,7 +272,8 @@ struct upr_batch {
     double last_ms = 0.0;
     int qp_nt = 0;
     bool use_qp2 = false;
-    int use_qp3 = 0;   // 0: no; 1: headline instantiations; 2: one of UPR_QP3_EXTRA (qp3_variant)
+    int use_qp3 = 0;   // 0: no; 1: headline instantiations; 2: one of UPR_QP3_EXTRA (qp3_variant); 3: instantiated at run time (jit)
+    struct upr_jit_kernel* jit = nullptr;
     bool fb_fused = false;   // the selected QP kernel writes the feedback gains itself (upr_qp_args::fb)
     bool use_mfma = true;
     bool timing = false;
@@ -466,7 +485,135 @@ size_t qp3_ws_doubles(const upr_problem& P, const upr_dims& d, int variant) {
     return 0;
 }
 
+// ---- run-time instantiation of the production kernel (round 4) ---------------------------------------------------------------
+// The hand list of upr_qp3_list.h covers the shapes the reference's configs use.  Any other shape the structure can take (one
+// chain of 6 or 9 joints, star or stacked arrangement, nf 1 | 3, with or without rows / slacks, a horizon whose working set fits
+// the LDS) is instantiated at upr_batch_create with hiprtc out of the SAME header -- upr_qp3.h with its template arguments as a
+// macro -- instead of falling back to the second-structure or generic kernel (20 - 40x slower per QP).  The code object is cached
+// in memory per process and on disk ($UPR_JIT_CACHE or ~/.cache/upright_amd) under the shape key and a hash of the kernel
+// headers, so a shape costs its compile time once per machine -- measured: about TWO SECONDS (comgr in-process; the same
+// instantiation takes hipcc 45 s, most of it the host pass), and the code runs as fast as the ahead-of-time one (headline 2.237
+// against 2.224 ms per launch, upright_robust 6.31 against 6.35).  UPR_QP3_JIT = 0: never (the second-structure / generic kernels
+// take such shapes, as in rounds 1 - 3); = 2: also for the listed shapes (diagnostic); unset or 1: every capable shape.
+std::mutex g_jit_mutex;
+std::map<std::string, upr_jit_kernel> g_jit;
+
+extern "C" const char* upr_last_error(void);
+std::string jit_csrc_dir() {
+    if (const char* e = getenv("UPR_CSRC_DIR")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&upr_last_error, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t s = p.rfind('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/csrc";
+    }
+    return "upright_amd/csrc";
+}
+bool jit_read(const std::string& path, std::string* out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss; ss << f.rdbuf(); *out = ss.str();
+    return true;
+}
+// can the production structure take this problem at all?  (what upr_qp3.h asserts or assumes; the LDS is checked after the compile)
+bool jit_capable(const upr_problem& P, const upr_dims& d) {
+    if (P.nq != 6 && P.nq != 9) return false;
+    if (d.no > UPR_QP3_NOMAX || P.N < 2 || P.N > 64) return false;
+    if (d.nfc < d.ne && !P.soft_eq && P.nb > 1) return false;
+    return true;
+}
+bool jit_wanted(int B) {
+    (void)B;
+    if (const char* e = getenv("UPR_QP3_JIT")) return atoi(e) != 0;
+    return true;
+}
+int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
+    bool star = true;
+    for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) star = false;
+    const bool rows = d.no > 0, soft = needs_soft(P, d), dense = !star;
+    char cfg[128];
+    snprintf(cfg, sizeof(cfg), "%d, %d, %d, %d, %d, 256, %s, %s, %s", P.nq, P.nb, P.nc, P.nf, P.N, rows ? "true" : "false", soft ? "true" : "false", dense ? "true" : "false");
+    int dev = 0;
+    UPR_HIP(hipGetDevice(&dev));
+    const std::string key = std::string(cfg) + " @" + std::to_string(dev);
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    auto it = g_jit.find(key);
+    if (it != g_jit.end()) { *out = &it->second; return 0; }
+    const std::string dir = jit_csrc_dir();
+    // source version: FNV-1a over the headers the kernel is made of
+    unsigned long long hsh = 1469598103934665603ull;
+    for (const char* f : {"upr_common.h", "upr_kin.h", "upr_qp.h", "upr_qp2.h", "upr_qp3.h"}) {
+        std::string txt;
+        if (!jit_read(dir + "/" + f, &txt)) return fail("run-time instantiation: cannot read " + dir + "/" + f + " (set UPR_CSRC_DIR)");
+        for (unsigned char c : txt) { hsh ^= c; hsh *= 1099511628211ull; }
+    }
+    std::string cache = getenv("UPR_JIT_CACHE") ? getenv("UPR_JIT_CACHE") : (std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/upright_amd");
+    (void)mkdir((cache.substr(0, cache.rfind('/'))).c_str(), 0755);
+    (void)mkdir(cache.c_str(), 0755);
+    std::string fname = cfg;
+    for (char& c : fname) if (c == ',' || c == ' ') c = '_';
+    char hx[32]; snprintf(hx, sizeof(hx), "%016llx", hsh);
+    const std::string path = cache + "/qp3_" + fname + "_" + hx + ".hsaco";
+    std::string code;
+    if (!jit_read(path, &code)) {
+        const std::string src =
+            "#include \"upr_qp3.h\"\n"
+            "typedef upr_qp3_cfg<UPR_QP3_JIT_CFG> upr_jit_cfg;\n"
+            "extern \"C\" __global__ void __launch_bounds__(upr_jit_cfg::NT, (upr_jit_cfg::NT <= 256 && upr_jit_cfg::NB == 1) ? 2 : 1) upr_qp3_jit(upr_qp_args A) {\n"
+            "    extern __shared__ __attribute__((aligned(16))) double smem[];\n"
+            "    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = upr_jit_cfg::NT;\n"
+            "    upr_qp3_solve<upr_jit_cfg>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);\n"
+            "}\n"
+            "extern \"C\" __global__ void upr_qp3_jit_info(int* out) { out[0] = upr_qp3_lds<upr_jit_cfg>::total; out[1] = upr_qp3_ws<upr_jit_cfg>::total; }\n";
+        fprintf(stderr, "libupright_mi: instantiating the production QP kernel for upr_qp3_cfg<%s> (once per machine: %s)\n", cfg, path.c_str());
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "upr_qp3_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
+        const std::string inc = "-I" + dir, def = std::string("-DUPR_QP3_JIT_CFG=") + cfg;
+        std::string defc = def;
+        defc.erase(std::remove(defc.begin(), defc.end(), ' '), defc.end());
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), "-I/opt/rocm/include", defc.c_str()};
+        const hiprtcResult rc = hiprtcCompileProgram(prog, 8, opts);
+        if (rc != HIPRTC_SUCCESS) {
+            size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+            std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            return fail("run-time instantiation of upr_qp3_cfg<" + std::string(cfg) + "> failed: " + log.substr(0, 2000));
+        }
+        size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+        code.resize(cs); hiprtcGetCode(prog, &code[0]);
+        hiprtcDestroyProgram(&prog);
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        { std::ofstream f(tmp, std::ios::binary); f.write(code.data(), (std::streamsize)code.size()); }
+        (void)rename(tmp.c_str(), path.c_str());
+    }
+    upr_jit_kernel k;
+    k.cfg = cfg;
+    UPR_HIP(hipModuleLoadData(&k.mod, code.data()));
+    hipFunction_t info;
+    UPR_HIP(hipModuleGetFunction(&k.fn, k.mod, "upr_qp3_jit"));
+    UPR_HIP(hipModuleGetFunction(&info, k.mod, "upr_qp3_jit_info"));
+    DevBuf<int> di;
+    if (di.alloc(2)) return 1;
+    int* dp = di;
+    void* args[] = {&dp};
+    UPR_HIP(hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
+    int hi[2] = {0, 0};
+    UPR_HIP(hipMemcpy(hi, dp, sizeof(hi), hipMemcpyDeviceToHost));
+    k.lds = (size_t)hi[0] * sizeof(double); k.ws = (size_t)hi[1];
+    if (k.lds > 160 * 1024) { (void)hipModuleUnload(k.mod); return fail("run-time instantiation: the working set of upr_qp3_cfg<" + std::string(cfg) + "> exceeds 160 KiB of LDS"); }
+    if (k.lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds));
+    auto ins = g_jit.emplace(key, k);
+    *out = &ins.first->second;
+    return 0;
+}
+
 int launch_qp(upr_batch* h, const upr_qp_args& A) {
+    if (h->use_qp3 == 3) {
+        upr_qp_args Ac = A;
+        void* args[] = {&Ac};
+        UPR_HIP(hipModuleLaunchKernel(h->jit->fn, (unsigned)h->B, 1, 1, 256, 1, 1, (unsigned)h->jit->lds, h->stream, args, nullptr));
+        return 0;
+    }
     if (h->use_qp3 == 1) {
         switch (h->qp_nt) {
             case 256: return launch_qp3<256>(h, A);
@@ -698,6 +845,14 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     const bool plain = P->n_pairs + P->n_proj == 0 && !soft;   // rows only the generic kernel has
     h->use_qp3 = qp3_variant(*P, h->d);
     h->use_qp2 = qp2_has_shape(*P) && plain;
+    const bool forced_other = (getenv("UPR_QP_KERNEL") && atoi(getenv("UPR_QP_KERNEL")) < 3) || (getenv("UPR_QP_GENERIC") && atoi(getenv("UPR_QP_GENERIC")) != 0);
+    if (getenv("UPR_QP3_JIT") && atoi(getenv("UPR_QP3_JIT")) == 2) h->use_qp3 = 0;   // (diagnostic: the run-time instantiation also for the listed shapes)
+    if (h->use_qp3 == 0 && !forced_other && jit_wanted(B) && jit_capable(*P, h->d)) {
+        // a shape outside the list: instantiate the production structure for it now (falls back with a note if that fails)
+        upr_jit_kernel* k = nullptr;
+        if (jit_get(*P, h->d, &k) == 0) { h->use_qp3 = 3; h->jit = k; }
+        else fprintf(stderr, "libupright_mi: %s -- using the %s kernel instead\n", g_err.c_str(), h->use_qp2 ? "second-structure" : "generic");
+    }
     // UPR_QP_KERNEL = 1 (generic) | 2 | 3 selects an older structure for A/B measurements and tests
     if (const char* e = getenv("UPR_QP_KERNEL")) { int v = atoi(e); if (v < 3) h->use_qp3 = 0; if (v < 2) h->use_qp2 = false; }
     if (const char* e = getenv("UPR_QP_GENERIC")) { if (atoi(e) != 0) { h->use_qp2 = false; h->use_qp3 = 0; } }
@@ -709,7 +864,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     {   // every QP kernel indexes the instance workspace with the same stride: the largest any selectable one needs
         size_t need = qp2_ws_doubles(*P, h->d);
         if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need;
-        if (h->use_qp3) { need = qp3_ws_doubles(*P, h->d, h->use_qp3); if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
+        if (h->use_qp3) { need = (h->use_qp3 == 3) ? h->jit->ws : qp3_ws_doubles(*P, h->d, h->use_qp3); if ((size_t)h->d.ws_stride < need) h->d.ws_stride = (int)need; }
     }
     {
         char buf[128];
@@ -717,6 +872,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
 #define X(a, b, c, e, n, rows, sf, dense) else if (h->use_qp3 == 2 && qp3_match(*P, h->d, a, b, c, e, n, rows, sf, dense)) snprintf(buf, sizeof(buf), "upr_qp3_kernel<upr_qp3_cfg<%d, %d, %d, %d, %d, 256, %s, %s, %s>>", a, b, c, e, n, #rows, #sf, #dense);
         UPR_QP3_EXTRA(X)
 #undef X
+        else if (h->use_qp3 == 3) snprintf(buf, sizeof(buf), "upr_qp3_jit<upr_qp3_cfg<%s>>", h->jit->cfg.c_str());
         else if (h->use_qp2) snprintf(buf, sizeof(buf), "upr_qp2_kernel<upr_qp2_dims<%d, %d, %d, %d>, %d>", P->nq, P->nb, P->nc, P->nf, h->qp_nt == 512 ? 128 : h->qp_nt);
         else snprintf(buf, sizeof(buf), "upr_qp_kernel<%d>", generic_nt(h));
         h->qp_name = buf;
