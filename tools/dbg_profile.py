@@ -11,6 +11,8 @@ import bench
 bp=None
 if "config3" in sys.argv: w=bench.config3_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
 elif "config4" in sys.argv: w=bench.config4_workload(B); P,x0,way,bp=w["P"],w["x0"],w["way"],w["body_params"]; P.sqp_iters=1
+elif "config5s" in sys.argv: w=bench.config5_workload(B, slacks=True); P,x0,way=w["P"],w["x0"],w["way"]
+elif "config5" in sys.argv: w=bench.config5_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
 else:
     P=thing_problem(arr['pink_bottle'])
     x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
@@ -21,6 +23,7 @@ if MAT:
 for nt in [a for a in sys.argv[2:] if a.isdigit()] or ["256"]:
     os.environ["UPR_QP_NT"]=nt
     mpc=BatchMPC(P,B,way_p=way,body_params=bp); mpc.set_observation(0.0,x0)
+    if P.n_dyn: mpc.set_projectile_flag(1.0)
     mpc.advance()
     mpc.qp_profile()   # arm
     mpc.reset(); mpc.advance()

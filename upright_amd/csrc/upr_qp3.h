@@ -754,10 +754,13 @@ struct upr_qp3 {
                     const bool act = e4 < N * NE * 4;
                     const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
                     double v = 0.0;
-                    if (act) {
+                    {   // (branch-free, as the quads of the forward tail: see there)
                         const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+                        double zv[CH];
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckr[q % (PRE_C ? QR : 1)][c] * zx[c];
+                        for (int c = 0; c < CH; ++c) zv[c] = zx[c];
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) v += (act ? ckr[q % (PRE_C ? QR : 1)][c] : 0.0) * zv[c];
                     }
                     v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
                     if (act && part == 0) ekp()[e] = v + e0r[q % (PRE_C ? QR : 1)];
@@ -2632,10 +2635,16 @@ struct upr_qp3 {
                 const bool act = tl >= 0 && e4 < N * NE * 4;
                 const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
                 double v = 0.0;
-                if (act) {
+                {
+                    // (no test per column and none on `act`: a test puts each LDS read into a branch of its own with a full round
+                    //  trip -- seven in a row per job.  The coefficients beyond the row's end are zero, what is read there is the
+                    //  next knot's first entries: exact zeros are added; lanes without a job compute on knot 0 and store nothing)
                     const double* sx = Sx(e / NE) + part * CH;
+                    double sv[CH];
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) if (c < NX - 3 * CH || part < 3) v += ckq[q % (PRE_V ? QV : 1)][c] * sx[c];
+                    for (int c = 0; c < CH; ++c) sv[c] = sx[c];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) v += (act ? ckq[q % (PRE_V ? QV : 1)][c] : 0.0) * sv[c];
                 }
                 v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
                 if (act && part == 0) L[O::cv + e] = v;
