@@ -471,8 +471,11 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
     # counters: the headline workload's own pass; for the other workloads the all-workloads pass, looked up by kernel name
     # (template arguments as rocprofv3 prints them)
     kkey = None if headline else kname.split("upr_qp3_kernel<")[-1].rstrip(">").strip() if "upr_qp3_kernel<" in kname else kname
-    traffic, traffic_src = pmc_traffic(kkey) if (not headline or B == 1024) else ({}, None)
-    issued, issued_src = pmc_issued_flops(kkey) if (not headline or B == 1024) else (None, None)
+    # (the name-keyed files of rounds 2 - 3 only when the workload has no key of its own: a kernel name is shared by workloads
+    #  whose launches differ -- the per-workload file of round 4 is the one that says which launch the counters belong to)
+    legacy = key is None and (not headline or B == 1024)
+    traffic, traffic_src = pmc_traffic(kkey) if legacy else ({}, None)
+    issued, issued_src = pmc_issued_flops(kkey) if legacy else (None, None)
     wl, wl_src = pmc_workload(key or ("headline" if headline else ""))
     if wl and wl.get("batch") == B:          # round 4: counters of this very workload at this very batch size
         traffic, traffic_src = {"qp": _hbm_bytes(wl["qp"]), "linearize": _hbm_bytes(wl["linearize"])}, wl_src
@@ -706,7 +709,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3], configs[4])")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--closed-loop-ticks", type=int, default=150, help="control periods of the configs[4] closed-loop run")
-    ap.add_argument("--only", default=None, choices=["config3", "config4", "config5", "config5s", "contract"],
+    ap.add_argument("--only", default=None, choices=["config3", "config4", "config5", "config5s", "contract", "headline_r03"],
                     help="run ONE of the other workloads alone and print its entry (the per-workload counter passes of tools/profile_all.sh)")
     ap.add_argument("--dry-run", action="store_true", help="control flow only: gloo on the CPU, stand-in engines with fake solutions; prints a line marked dry_run (never a measurement)")
     args = ap.parse_args()
@@ -762,7 +765,8 @@ def main():
         if world != 1 or dry:
             raise SystemExit("bench.py --only runs on one GPU")
         wo = {"config3": lambda: config3_workload(4096), "config4": lambda: config4_workload(1024), "config5": lambda: config5_workload(1024),
-              "config5s": lambda: config5_workload(1024, slacks=True), "contract": lambda: contract_workload(1024)}[args.only]()
+              "config5s": lambda: config5_workload(1024, slacks=True), "contract": lambda: contract_workload(1024),
+              "headline_r03": lambda: headline_r03_geometry_workload(1024)}[args.only]()
         if args.only.startswith("config5"):
             e = time_closed_loop(wo, args.closed_loop_ticks, device=device, engine=engine_for(wo))
         else:
@@ -804,7 +808,7 @@ def main():
         dist.all_gather_object(rank_devices, sorted(set(engine_devices)))
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        roof, lin = roofline_objects(P, B, kt, st, P.sqp_iters, headline=True)
+        roof, lin = roofline_objects(P, B, kt, st, P.sqp_iters, headline=True, key="headline")
         out = {
             "metric": METRIC,
             "value": B * world * args.steps / elapsed,

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 MIX="SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU"
-for W in headline config3 config4 config5 config5s contract; do
+for W in headline config3 config4 config5 config5s contract headline_r03; do
   if [ $W = headline ]; then ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"; else ARGS="bench.py --only $W --extra-steps 2 --closed-loop-ticks 20 --no-cpu-baseline"; fi
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pw_${TAG}_${W}_fetch -o $W -- python3 $ARGS > $OUT/pw_${TAG}_${W}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw_${TAG}_${W}_write -o $W -- python3 $ARGS > $OUT/pw_${TAG}_${W}_write.log 2>&1
@@ -18,7 +18,7 @@ for W in headline config3 config4 config5 config5s contract; do
 done
 python3 - <<PY
 import csv, glob, collections
-batch = {"headline": 1024, "config3": 4096, "config4": 1024, "config5": 1024, "config5s": 1024, "contract": 1024}
+batch = {"headline": 1024, "config3": 4096, "config4": 1024, "config5": 1024, "config5s": 1024, "contract": 1024, "headline_r03": 1024}
 with open("$OUT/${TAG}_pmc_workloads.csv", "w") as fh:
     fh.write("# tools/pmc_workloads.sh: rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | instruction mix), one short run per workload\n")
     fh.write("# FETCH_SIZE / WRITE_SIZE in KB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction, MI355X_MICROARCH.md); the rest: per-dispatch means summed over the chip\n")
