@@ -547,6 +547,12 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
         if (!jit_read(dir + "/" + f, &txt)) return fail("run-time instantiation: cannot read " + dir + "/" + f + " (set UPR_CSRC_DIR)");
         for (unsigned char c : txt) { hsh ^= c; hsh *= 1099511628211ull; }
     }
+    // UPR_JIT_FLAGS: extra compiler options for experiments (e.g. "-DUPR_QP3_PROF_FLAT=3"), part of the cache key
+    std::vector<std::string> xflags;
+    if (const char* e = getenv("UPR_JIT_FLAGS")) {
+        std::stringstream ss(e); std::string w;
+        while (ss >> w) { xflags.push_back(w); for (unsigned char c : w) { hsh ^= c; hsh *= 1099511628211ull; } }
+    }
     std::string cache = getenv("UPR_JIT_CACHE") ? getenv("UPR_JIT_CACHE") : (std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/upright_amd");
     (void)mkdir((cache.substr(0, cache.rfind('/'))).c_str(), 0755);
     (void)mkdir(cache.c_str(), 0755);
@@ -571,8 +577,9 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
         const std::string inc = "-I" + dir, def = std::string("-DUPR_QP3_JIT_CFG=") + cfg;
         std::string defc = def;
         defc.erase(std::remove(defc.begin(), defc.end(), ' '), defc.end());
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), "-I/opt/rocm/include", defc.c_str()};
-        const hiprtcResult rc = hiprtcCompileProgram(prog, 8, opts);
+        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), "-I/opt/rocm/include", defc.c_str()};
+        for (const std::string& w : xflags) opts.push_back(w.c_str());
+        const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
         if (rc != HIPRTC_SUCCESS) {
             size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
             std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);

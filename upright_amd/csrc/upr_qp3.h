@@ -21,6 +21,12 @@
 #include "upr_qp.h"
 #include "upr_qp2.h"
 
+#ifndef UPR_QP3_OFFL_PRIO
+#define UPR_QP3_OFFL_PRIO 0
+#endif
+#ifndef UPR_QP3_OFFLOAD
+#define UPR_QP3_OFFLOAD 0   // 1: two-wave matrix sweep, one-body shapes: the side work of the factoring wave (feedback column, P+ b, fused predictor step) on waves 2 / 3 -- bit-identical and MEASURED SLOWER (round 4: 2.195 -> 2.235 .. 2.244 ms per headline launch), kept for A/B runs
+#endif
 // ROWS_: the instantiation takes state-polytopic rows (collision / projectile).  Problems without such rows run the
 // ROWS_ = false instantiation, in which every trace of them folds away (their runtime trip counts and the runtime
 // Hessian offset cost 1.8 % of the headline solve when they were compiled in unconditionally); layouts do not depend on it.
@@ -129,7 +135,11 @@ struct upr_qp3_lds {
                          VCN = VCS * C::NX, KS = (r2(C::NZ) / VCN < C::N - 1) ? r2(C::NZ) / VCN : C::N - 1, HXS = (C::NQ + 1) & ~1,
                          sw0 = C::VCPRE ? Pa + (C::N - 1 - KS) * VCN : Pa, sw_vcb = sw0 /* (!VCPRE: Vc of the knot in work and of the next one) */,
                          sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */,
-                         sw_pq = sw_w + r2(C::NX) /* (!VCPRE: the shares of Vc'Vc of waves 2 and 3, [wave][entry][lane]) */, sw_end = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
+                         sw_pq = sw_w + r2(C::NX) /* (!VCPRE: the shares of Vc'Vc of waves 2 and 3, [wave][entry][lane]) */,
+                         // OFFL (one-body shapes at 256 lanes and more, UPR_QP3_OFFLOAD): V = Lj^-1 Hux in an area of its own, [column][nq] -- Hux
+                         // then has one writer (wave 1, before barrier A) and readers only between A and B (wave 0 and the wave that repeats
+                         // the factorisation for the side work)
+                         sw_v = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64), sw_end = sw_v + ((C::VCPRE && C::NT >= 256 && UPR_QP3_OFFLOAD) ? r2(C::NX * C::NQ) : 0),
                          // the scratch region Pa .. yN serves, at different times: the four-wave sweep's working set (Pa .. ck), the
                          // one- / two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
                          // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
@@ -1470,12 +1480,108 @@ struct upr_qp3 {
     // third of them the factorisation).  Here wave 1 keeps the blocks of P (A'P+A, Hux, Hjj, P+ b partial sums; the Vc'Vc part of
     // the update while wave 0 factors; then the V'V part) and wave 0 the columns (factorisation, V, K).  Two LDS-only workgroup
     // barriers per knot hand Hjj / Hux over (A) and V back (B); the remaining waves only take part in the barriers.
+    // pieces of the two-wave matrix sweep that either wave 0 or (OFFL) waves 2 / 3 run -----------------------------------------
+    // start value of the fused predictor recursion, lane c < nx
+    UPR_HDI double wt_terminal(int l) const {
+        const double irho = 1.0 / UPR_QP_RHO_N;
+        double v = L[O::gxs + N * NX + l];
+        if (neN > 0) {
+            if (l < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + l] * (L[O::yN + q] + irho * L[O::eN + q]); }
+            else v += L[O::yN + 3 + (l - NQ)] + irho * L[O::eN + 3 + (l - NQ)];
+        }
+        return v;
+    }
+    // every lane factors Hjj for itself and carries its column (vcl) of Hux / of the identity through the eliminations
+    UPR_HDI void sw2_factor(double (&a)[NQ][NQ], double (&hx)[NQ], int vcl, bool& ok) const {
+        constexpr int HXS = O::HXS;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
+#pragma unroll
+        for (int p2 = 0; p2 < NQ; ++p2) {
+            const double piv = a[p2][p2];
+            ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
+            const double idg = upr_rsqrt(piv);
+#pragma unroll
+            for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
+            hx[p2] *= idg;
+#pragma unroll
+            for (int j = p2 + 1; j < NQ; ++j) {
+#pragma unroll
+                for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
+                hx[j] -= a[j][p2] * hx[p2];
+            }
+            a[p2][p2] = idg;   // the diagonal keeps its reciprocal
+        }
+    }
+    // the side work of knot k: feedback column (or column of Lj^-1) by back substitution and its store, the sum of P+ b, the fused
+    // predictor step (wt: w~_k in, w~_{k-1} out)
+    UPR_HDI void sw2_side(int k, const double (&a)[NQ][NQ], const double (&hx)[NQ], const double (&pbv)[NQ], double& wt, int l, bool vl, int vj_,
+                          double ca0, double ca1, double ca2) {
+        constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
+                double kk[NQ];
+#pragma unroll
+        for (int i = NQ - 1; i >= 0; --i) {
+            double tt = hx[i];
+#pragma unroll
+            for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
+            kk[i] = vl ? tt * a[i][i] : hx[i];   // (lanes nx ..: their column of Lj^-1 is what is stored)
+        }
+        if (l < NX + NQ) {
+            double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + k * NQ * NX;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) dst[i * NX] = kk[i];
+        }
+        double pbs;
+        {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
+            pbs = (s0 + s1) + s2;
+            if (vl) L[O::Pbs + k * NX + l] = pbs;
+        }
+        if (FUSE) {
+            // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
+            const double gk = (k >= 1) ? L[O::gxs + k * NX + (vl ? l : 0)] + L[O::cs + k * NX + (vl ? l : 0)] : 0.0;
+            const double uk = L[O::gus + k * NU + vj_];
+            const double wk = wt + pbs;
+            if (vl) L[O::sw_w + l] = wk;
+            UPR_WSYNC();
+            const double w0 = L[O::sw_w + vj_], w1 = L[O::sw_w + NQ + vj_], w2 = L[O::sw_w + 2 * NQ + vj_];
+            const double rq = ((h3 * w0 + h2 * w1) + h * w2) + uk;
+            if (l < NQ) L[O::kffs + k * NQ + l] = rq;
+            double v0 = gk + ca0 * w0, v1 = ca1 * w1, v2 = ca2 * w2;
+#pragma unroll
+            for (int m = 0; m < NQ; m += 3) {
+                v0 -= kk[m] * upr_readlane(rq, m);
+                if (m + 1 < NQ) v1 -= kk[m + 1] * upr_readlane(rq, m + 1);
+                if (m + 2 < NQ) v2 -= kk[m + 2] * upr_readlane(rq, m + 2);
+            }
+            wt = (v0 + v1) + v2;
+            UPR_WSYNC();
+        }
+    }
     UPR_HDI void backward_mat_sw2() {
         constexpr int NBK = C::NH, HXS = O::HXS;
         static_assert(!SW2 || NT >= (C::VCPRE ? 128 : 256), "two waves (four where Vc is formed inside the sweep)");
         const int wave = wb >> 6;
         const int l = lane();
         constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
+        // OFFL (round 4): wave 0 only factors.  Its side work per knot -- the feedback column by back substitution and its store, the
+        // sum of P+ b, the fused predictor step -- sat between barrier B and the next barrier A on the wave every other wave waits
+        // for (measured: doing the back substitution twice costs 240 cycles per knot).  Waves 2 and 3 take it, a knot each in turn:
+        // the owner of knot k repeats the factorisation of knot k between A_k and B_k (the same instructions on the same operands:
+        // the same factor and column, no hand-over), picks up the partial sums of P+ b behind B_k and does the side work between
+        // A_{k-1} and B_{k-1}, while wave 0 factors the next knot.  The predictor's running costate passes between the two waves
+        // through the slot the step uses anyway (sw_w).  V goes to an area of its own (sw_v) so that Hux has readers only between
+        // A and B.  Same arithmetic, same order: bit-identical to the round-3 form (UPR_QP3_OFFLOAD=0).
+        // MEASURED (tools/exp_ab.py, headline B = 1024): 1.6 % (waves 2 / 3 at raised priority) to 2.1 % SLOWER than the round-3
+        // form: the third busy wave per workgroup (six latency-bound waves on the four SIMDs of a CU with its co-resident
+        // workgroup) costs the factoring waves more than the 700 cycles per knot taken off wave 0.  Off by default.
+        constexpr bool OFFL = C::VCPRE && NT >= 256 && UPR_QP3_OFFLOAD != 0;
         const double irho = 1.0 / UPR_QP_RHO_N;
         if (FUSE) terminal_residual();
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
@@ -1614,7 +1720,10 @@ struct upr_qp3 {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
-                        for (int m = 0; m < NQ; ++m) { vj[c][m] = L[O::sw_hx + (c * NQ + bj) * HXS + m]; vi[c][m] = L[O::sw_hx + (c * NQ + bi) * HXS + m]; }
+                        for (int m = 0; m < NQ; ++m) {
+                            vj[c][m] = OFFL ? L[O::sw_v + (c * NQ + bj) * NQ + m] : L[O::sw_hx + (c * NQ + bj) * HXS + m];
+                            vi[c][m] = OFFL ? L[O::sw_v + (c * NQ + bi) * NQ + m] : L[O::sw_hx + (c * NQ + bi) * HXS + m];
+                        }
 #pragma unroll
                     for (int a3 = 0; a3 < 3; ++a3)
 #pragma unroll
@@ -1643,97 +1752,69 @@ struct upr_qp3 {
             const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
             const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
             double wt = 0.0;
-            if (FUSE && vl) {
-                double v = L[O::gxs + N * NX + l];
-                if (neN > 0) {
-                    if (l < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + l] * (L[O::yN + q] + irho * L[O::eN + q]); }
-                    else v += L[O::yN + 3 + (l - NQ)] + irho * L[O::eN + 3 + (l - NQ)];
-                }
-                wt = v;
-            }
+            if (FUSE && vl && !OFFL) wt = wt_terminal(l);
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 UPR_SYNC_LDS();   // A
                 toc(6);
                 double a[NQ][NQ], hx[NQ];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
-#pragma unroll
-                for (int p2 = 0; p2 < NQ; ++p2) {
-                    const double piv = a[p2][p2];
-                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
-                    const double idg = upr_rsqrt(piv);
-#pragma unroll
-                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
-                    hx[p2] *= idg;
-#pragma unroll
-                    for (int j = p2 + 1; j < NQ; ++j) {
-#pragma unroll
-                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
-                        hx[j] -= a[j][p2] * hx[p2];
-                    }
-                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal
-                }
+                sw2_factor(a, hx, vcl, ok);
                 if (k > 0 && vl) {
 #pragma unroll
-                    for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
+                    for (int m = 0; m < NQ; ++m) { if (OFFL) L[O::sw_v + l * NQ + m] = hx[m]; else L[O::sw_hx + l * HXS + m] = hx[m]; }
                 }
                 toc(7);
                 UPR_SYNC_LDS();   // B
                 toc(8);
-                // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
-                double pbv[NQ];
+                if (!OFFL) {
+                    // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
+                    double pbv[NQ];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
-                double kk[NQ];
-#pragma unroll
-                for (int i = NQ - 1; i >= 0; --i) {
-                    double tt = hx[i];
-#pragma unroll
-                    for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
-                    kk[i] = vl ? tt * a[i][i] : hx[i];   // (lanes nx ..: their column of Lj^-1 is what is stored)
-                }
-                if (l < NX + NQ) {
-                    double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + k * NQ * NX;
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) dst[i * NX] = kk[i];
-                }
-                double pbs;
-                {
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
-                    pbs = (s0 + s1) + s2;
-                    if (vl) L[O::Pbs + k * NX + l] = pbs;
-                }
-                if (FUSE) {
-                    // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
-                    const double gk = (k >= 1) ? L[O::gxs + k * NX + (vl ? l : 0)] + L[O::cs + k * NX + (vl ? l : 0)] : 0.0;
-                    const double uk = L[O::gus + k * NU + vj_];
-                    const double wk = wt + pbs;
-                    if (vl) L[O::sw_w + l] = wk;
-                    UPR_WSYNC();
-                    const double w0 = L[O::sw_w + vj_], w1 = L[O::sw_w + NQ + vj_], w2 = L[O::sw_w + 2 * NQ + vj_];
-                    const double rq = ((h3 * w0 + h2 * w1) + h * w2) + uk;
-                    if (l < NQ) L[O::kffs + k * NQ + l] = rq;
-                    double v0 = gk + ca0 * w0, v1 = ca1 * w1, v2 = ca2 * w2;
-#pragma unroll
-                    for (int m = 0; m < NQ; m += 3) {
-                        v0 -= kk[m] * upr_readlane(rq, m);
-                        if (m + 1 < NQ) v1 -= kk[m + 1] * upr_readlane(rq, m + 1);
-                        if (m + 2 < NQ) v2 -= kk[m + 2] * upr_readlane(rq, m + 2);
-                    }
-                    wt = (v0 + v1) + v2;
-                    UPR_WSYNC();
+                    for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
+                    sw2_side(k, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
                 }
                 toc(9);
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
             UPR_SETPRIO(0);
+        } else if (OFFL) {
+            // the side work of the factoring wave, a knot each in turn (wave 2: knots N-1, N-3, ...; wave 3: N-2, N-4, ...)
+            const bool vl = l < NX;
+            const int vcl = (l < NX + NQ) ? l : 0;
+            const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
+            const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
+            const int par = wave - 2;
+            bool okw = true;
+#if UPR_QP3_OFFL_PRIO
+            UPR_SETPRIO(UPR_QP3_OFFL_PRIO);
+#endif
+            double a[NQ][NQ], hx[NQ], pbv[NQ];
+            if (FUSE && vl && par == 0) L[O::sw_w + l] = wt_terminal(l);   // (the running costate of the predictor: handed from wave to wave in sw_w)
+#pragma nounroll
+            for (int k = N - 1; k >= 0; --k) {
+                const bool mine = ((N - 1 - k) & 1) == par;
+                UPR_SYNC_LDS();   // A_k
+                if (mine) sw2_factor(a, hx, vcl, okw);
+                else if (k + 1 <= N - 1) {   // the side work of my knot k + 1 (its partial sums were picked up behind B_{k+1})
+                    double wt = (FUSE && vl) ? L[O::sw_w + l] : 0.0;
+                    UPR_WSYNC();
+                    sw2_side(k + 1, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
+                    if (FUSE && vl) L[O::sw_w + l] = wt;
+                }
+                UPR_SYNC_LDS();   // B_k
+                if (mine) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
+                }
+            }
+            if (((N - 1) & 1) == par) {   // the owner of knot 0: its side work has no later interval
+                double wt = (FUSE && vl) ? L[O::sw_w + l] : 0.0;
+                UPR_WSYNC();
+                sw2_side(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
+            }
+#if UPR_QP3_OFFL_PRIO
+            UPR_SETPRIO(0);
+#endif
         } else {
             vc_regs vq;
             vcm_regs vm;
