@@ -276,7 +276,11 @@ def main():
         names = sorted(bodies)            # the body order of the stacked residual (contact_constraints.h:179-192)
         index = mdl.compute_object_name_index(names)
         G = mdl.compute_grasp_matrix(index, [mdl.RobustContactPoint(cp) for cp in contacts])
-        grasp[name] = {"names": names, "G": G.tolist()}
+        # ... and the span form of every contact's friction cone (modelling.py:34-44): the four generators normal +- mu span_i.  The
+        # cone they span, {f_n >= 0, |t_0| + |t_1| <= mu f_n}, is the linearised cone of contact_constraints.h:50-77 -- a
+        # reference-held answer for the friction rows (a4)
+        grasp[name] = {"names": names, "G": G.tolist(), "S": [mdl.RobustContactPoint(cp).S.tolist() for cp in contacts],
+                       "mu": [float(cp.mu) for cp in contacts]}
     with open(OUT / "grasp.json", "w") as f:
         json.dump(grasp, f, indent=1)
 

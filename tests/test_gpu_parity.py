@@ -2047,3 +2047,21 @@ def test_unlisted_shape_is_instantiated_at_run_time(arrangements, monkeypatch, t
     assert np.abs(m2.solution()[1] - xs).max() < 2e-5
     m2.close()
     print("create with compile: %.1f s" % t_create)
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "box_arch"])
+def test_friction_rows_against_reference_cone_generators(arrangements, name):
+    """upr_core_friction_rows on the generators of the reference's own span form of the friction cone (upright_robust/modelling.py:
+    34-44, tests/golden/grasp.json "S"): (1, 0, 0, 2 mu, 2 mu) up to the order of the facets on every contact (see tests/test_oracle.py)."""
+    gr = json.load(open(Path(__file__).resolve().parent / "golden" / "grasp.json"))[name]
+    P = thing_problem(arrangements[name])
+    F = []
+    for ci, S in enumerate(gr["S"]):
+        for gi in range(4):
+            f = np.zeros(3 * P.nc); f[3 * ci:3 * ci + 3] = np.asarray(S)[:, gi]
+            F.append(f)
+    rows = core_friction_rows(P, np.array(F))
+    for ci, mu in enumerate(gr["mu"]):
+        for gi in range(4):
+            r = rows[4 * ci + gi, 5 * ci:5 * ci + 5]
+            assert abs(r[0] - 1.0) < 1e-14 and np.abs(np.sort(r[1:]) - np.array([0.0, 0.0, 2 * mu, 2 * mu])).max() < 1e-14, (ci, gi, r)

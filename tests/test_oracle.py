@@ -374,3 +374,31 @@ def test_inertial_half_against_reference_spatial_mass_matrix(arrangements, name)
             got = inertial_wrench_about_ee_origin(P, arr, rows)
             ref = np.stack([Ms[b] @ (A - G) for b in range(P.nb)])
             assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("name", ["pink_bottle", "box_arch"])
+def test_friction_rows_against_reference_cone_generators(arrangements, name):
+    """Fourth reference-held answer (a4): upright_robust/modelling.py:34-44 states every contact's linearised friction cone in SPAN
+    form, the four generators normal +- mu span_i (dumped by tests/golden/make_fixtures.py next to the grasp matrix).  The cone
+    they span is the face form of contact_constraints.h:50-77, so the oracle's five rows on generator g_i must read
+    (1, then mu -+ t_0 -+ t_1) = (1, 0, 0, 2 mu, 2 mu) up to the order of the facets: non-negative, exactly two facets active,
+    the other two at 2 mu -- on every contact; positive combinations stay inside, a step beyond a facet leaves."""
+    gr = json.load(open(Path(__file__).resolve().parent / "golden" / "grasp.json"))[name]
+    arr = arrangements[name]
+    P = thing_problem(arr)
+    O = Oracle(P)
+    rng = np.random.default_rng(3)
+    for ci, (S, mu) in enumerate(zip(gr["S"], gr["mu"])):
+        S = np.asarray(S)                       # 3 x 4
+        assert abs(mu - arr["contacts"][ci]["mu"]) < 1e-15
+        for gi in range(4):
+            f = np.zeros(3 * P.nc); f[3 * ci:3 * ci + 3] = S[:, gi]
+            rows = O.friction_rows(f)[5 * ci:5 * ci + 5]
+            assert abs(rows[0] - 1.0) < 1e-14                                   # normal component of a generator
+            srt = np.sort(rows[1:])
+            assert np.abs(srt - np.array([0.0, 0.0, 2 * mu, 2 * mu])).max() < 1e-14, (ci, gi, rows)
+        z = rng.uniform(0.1, 1.0, 4)
+        f = np.zeros(3 * P.nc); f[3 * ci:3 * ci + 3] = S @ z
+        assert O.friction_rows(f)[5 * ci:5 * ci + 5].min() > 0.0               # the interior of the span is inside the faces
+        f[3 * ci:3 * ci + 3] = S @ np.array([1.0, 1.0, -0.2, 0.0])
+        assert O.friction_rows(f)[5 * ci:5 * ci + 5].min() < 0.0               # outside the span: a facet is violated
