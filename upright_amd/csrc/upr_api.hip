@@ -577,7 +577,8 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
         const std::string inc = "-I" + dir, def = std::string("-DUPR_QP3_JIT_CFG=") + cfg;
         std::string defc = def;
         defc.erase(std::remove(defc.begin(), defc.end(), ' '), defc.end());
-        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), "-I/opt/rocm/include", defc.c_str()};
+        const std::string rinc = std::string("-I") + (getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm") + "/include";
+        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), rinc.c_str(), defc.c_str()};
         for (const std::string& w : xflags) opts.push_back(w.c_str());
         const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
         if (rc != HIPRTC_SUCCESS) {
