@@ -40,6 +40,9 @@
 // DENSE_ (with NB_ > 1): arrangements whose bodies share contact points (stacked objects): the Schur complement of a
 // knot is one dense 6 NB x 6 NB matrix, assembled, factored and inverted by the knot's lane in registers (the
 // instantiation runs one workgroup per CU and may use all 512 registers of a lane).
+#ifndef UPR_QP3_SOFT_ROWMEM
+#define UPR_QP3_SOFT_ROWMEM 1
+#endif
 template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true, bool SOFT_ = false, bool DENSE_ = false>
 struct upr_qp3_cfg {
     static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
@@ -330,6 +333,10 @@ struct upr_qp3 {
     // are parked in global memory [slot][lane]: written once per iteration after the step, read back behind the two
     // forward sweeps (by the idle waves during the sweep, by wave 0 right after it).
     static constexpr int NROWV = 4 * C::QX + 4 * C::QU;
+    // SOFT: ten values per box row pair and slot do not fit the registers two workgroups per CU leave a lane (the compiler kept
+    // them in scratch, one exposed round trip per use).  Every flat phase reads them from the parked copy instead, all requests
+    // together at its top, and they are dead in between.
+    static constexpr bool ROWMEM = C::SOFT && C::NB == 1 && C::QX >= 3 && UPR_QP3_SOFT_ROWMEM;   // (the shapes that spilled; the others measured 5 % slower with it)
     static constexpr int QO = ((C::N - 1) * UPR_QP3_NOMAX + C::NT - 1) / C::NT;   // state-polytopic rows per lane (at most)
     UPR_HDI void store_rows() const {
         const int tid_ = tid();
@@ -527,25 +534,30 @@ struct upr_qp3 {
         // (multi-body shapes have too many rows of C for a register prefetch: they read them where they are used)
         constexpr bool PRE_C = QR <= 4;
         double ckr[PRE_C ? QR : 1][CH], e0r[PRE_C ? QR : 1];
-        if (PRE_C && fresh) {
+        // (ROWMEM shapes: requested behind the box rows of phase A, which need the registers)
+        auto fetch_c = [&]() {
+            if (PRE_C && fresh) {
 #pragma unroll
-            for (int q = 0; q < QR; ++q) {
-                const int e4 = tid_ + q * NT;
-                if (e4 < N * NE * 4) {
-                    const int e = e4 >> 2, part = e4 & 3;
-                    const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
+                for (int q = 0; q < QR; ++q) {
+                    const int e4 = tid_ + q * NT;
+                    if (e4 < N * NE * 4) {
+                        const int e = e4 >> 2, part = e4 & 3;
+                        const double* Ck = rec(e / NE) + lin_gx + (e % NE) * NX + part * CH;
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) ckr[q % (PRE_C ? QR : 1)][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
-                    e0r[q % (PRE_C ? QR : 1)] = G[F::e0 + e];
+                        for (int c = 0; c < CH; ++c) ckr[q % (PRE_C ? QR : 1)][c] = (part * CH + c < NX) ? Ck[c] : 0.0;
+                        e0r[q % (PRE_C ? QR : 1)] = G[F::e0 + e];
+                    }
                 }
             }
-        }
+        };
+        if (!ROWMEM) fetch_c();
 #endif
         // state-polytopic rows d + G (q - q_lin) >= 0 of knots 1 .. N-1 (collision pairs, projectile path): multiplier s and
         // weight w of every row, staged in the LDS the sweeps use for Hux / V until the gradient and Hessian passes below
         if (no > 0) {
             // (the rows of a lane requested together: their Jacobian rows and far-array entries come out of global memory)
-            double gq[QO][NQ], od[QO], otv[QO], olv[QO];
+            constexpr int QOS = (C::SOFT && C::ROWS) ? QO : 1;
+            double gq[QO][NQ], od[QO], otv[QO], olv[QO], osv[QOS][3];
 #pragma unroll
             for (int q = 0; q < QO; ++q) {
                 const int e = tid_ + q * NT, ec = (e < (N - 1) * no) ? e : 0;
@@ -554,6 +566,10 @@ struct upr_qp3 {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) gq[q][i] = g[i];
                 od[q] = G[F::od0 + ei]; otv[q] = G[F::ot + ei]; olv[q] = G[F::ol + ei];
+                if (C::SOFT && C::ROWS && softp) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) osv[q % QOS][u] = G[F::sor + u * F::sos + ei];
+                }
             }
 #pragma unroll
             for (int q = 0; q < QO; ++q) {
@@ -566,7 +582,7 @@ struct upr_qp3 {
                 double sr, wr, ct_ = 0.0;
                 if (C::SOFT && C::ROWS && softp) {
                     double cts_ = 0.0;
-                    row_soft(c, ds, otv[q], olv[q], G[F::sor + ei], G[F::sor + F::sos + ei], G[F::sor + 2 * F::sos + ei], ZL, zL, ct_, cts_, sr, wr);
+                    row_soft(c, ds, otv[q], olv[q], osv[q % QOS][0], osv[q % QOS][1], osv[q % QOS][2], ZL, zL, ct_, cts_, sr, wr);
                     if (mode == 1) G[F::sor + 3 * F::sos + ei] = cts_;
                 } else row(c, ds, otv[q], olv[q], ct_, sr, wr);
                 if (mode == 1) G[F::oc + ei] = ct_;
@@ -574,6 +590,7 @@ struct upr_qp3 {
             }
         }
         ftoc(6, 2);
+        if (ROWMEM) load_rows();
         // A: box rows (registers)
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) {
@@ -601,7 +618,7 @@ struct upr_qp3 {
         ftoc(7, 2);
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
-            const int iu = tid_ + q * NT;
+            const int iu = tid() + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
@@ -622,6 +639,9 @@ struct upr_qp3 {
             }
         }
         ftoc(8, 2);
+#ifndef UPR_HOST_EMU
+        if (ROWMEM) fetch_c();
+#endif
         // dynamics residual of every knot in absolute variables (multiple-shooting defect of the iterate)
         if (fresh) UPR_FORT(e, N * NQ) {
             const int k = e / NQ, j = e % NQ;
@@ -2643,12 +2663,12 @@ struct upr_qp3 {
 #endif
             UPR_SETPRIO(0);
 #ifndef UPR_HOST_EMU
-            load_rows();   // (wave 0: in flight while the other waves run the tail)
+            if (!ROWMEM) load_rows();   // (wave 0: in flight while the other waves run the tail)
 #endif
         }
 #ifndef UPR_HOST_EMU
         else {
-            load_rows();
+            if (!ROWMEM) load_rows();
             if (PRE_V) {
 #pragma unroll
                 for (int q = 0; q < QV; ++q) {
@@ -3010,8 +3030,42 @@ struct upr_qp3 {
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
     }
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
+        if (ROWMEM) load_rows();
         double acc = 0.0;
         const int tid_ = tid();
+        // the far-array operands of the friction rows (one row per lane item) and of the state-polytopic rows, each class requested
+        // together (SOFT: with the rows' slack pairs and the pairs' corrector targets).  Requested in front of the box rows instead,
+        // so that the box rows cover the round trip, measured no gain on the hard kernels and 2 % slower on the SOFT ones.
+        constexpr int NR5 = 5 * C::NCI, QR5 = (NR5 + NT - 1) / NT, QS5 = C::SOFT ? QR5 : 1;
+        double tv[QR5], lv[QR5], cv5[QR5], ssv[QS5][4];
+        auto fetch_fr = [&]() {
+#pragma unroll
+            for (int q = 0; q < QR5; ++q) {
+                const int e = tid_ + q * NT, ec = (e < NR5) ? e : 0;
+                tv[q] = G[F::ct + ec]; lv[q] = G[F::cl + ec]; cv5[q] = G[F::cc + ec];
+                if (C::SOFT && softp) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ssv[q % QS5][u] = G[F::sfr + u * F::sfs + ec];
+                }
+            }
+        };
+        constexpr int QOS = (C::SOFT && C::ROWS) ? QO : 1;
+        double gq[QO][NQ], od[QO], otv[QO], olv[QO], ocv[QO], osv[QOS][4];
+        auto fetch_or = [&]() {
+#pragma unroll
+            for (int q = 0; q < QO; ++q) {
+                const int e = tid_ + q * NT, ec = (e < (N - 1) * no) ? e : 0;
+                const int k = 1 + ec / no, r = ec % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
+                const double* g = orow(k, r);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) gq[q][i] = g[i];
+                od[q] = G[F::od0 + ei]; otv[q] = G[F::ot + ei]; olv[q] = G[F::ol + ei]; ocv[q] = G[F::oc + ei];
+                if (C::SOFT && C::ROWS && softp) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) osv[q % QOS][u] = G[F::sor + u * F::sos + ei];
+                }
+            }
+        };
         // what == 4: the step of what == 2 and then, with the row's value cn at the NEW iterate, the residual terms of what == 3
         // (|cn - t| into acc, lam t into aux) -- what the next iteration's first residual pass would compute from the updated
         // iterate.  cn is formed exactly as that pass forms it: the new primal value z + alpha dz first (upr_step, the same
@@ -3048,7 +3102,7 @@ struct upr_qp3 {
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
-            const int iu = tid_ + q * NT;
+            const int iu = tid() + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
                 const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
@@ -3097,13 +3151,7 @@ struct upr_qp3 {
         if (NF == 3) {
             // one ROW per lane item (rounds 1 - 2: a contact, five rows, per lane -- all of them on the first NCI lanes, whose waves
             // then ran fifteen rows per sweep against ten on the others); the rows of a lane requested together
-            constexpr int NR5 = 5 * C::NCI, QR5 = (NR5 + NT - 1) / NT;
-            double tv[QR5], lv[QR5], cv5[QR5];
-#pragma unroll
-            for (int q = 0; q < QR5; ++q) {
-                const int e = tid_ + q * NT, ec = (e < NR5) ? e : 0;
-                tv[q] = G[F::ct + ec]; lv[q] = G[F::cl + ec]; cv5[q] = G[F::cc + ec];
-            }
+            fetch_fr();
 #pragma unroll
             for (int q = 0; q < QR5; ++q) {
                 const int e = tid_ + q * NT;
@@ -3114,9 +3162,9 @@ struct upr_qp3 {
                 double t = tv[q], lam = lv[q];
                 const double fn0 = w4 ? upr_step(f[0], alpha, sf[0]) : f[0], fn1 = w4 ? upr_step(f[1], alpha, sf[1]) : f[1], fn2 = w4 ? upr_step(f[2], alpha, sf[2]) : f[2];
                 if (C::SOFT && softp) {
-                    double sg = G[F::sfr + e], ta = G[F::sfr + F::sfs + e], ga = G[F::sfr + 2 * F::sfs + e];
+                    double sg = ssv[q % QS5][0], ta = ssv[q % QS5][1], ga = ssv[q % QS5][2];
                     soft(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, sg, ta, ga, ZL, zL,
-                         cv5[q], G[F::sfr + 3 * F::sfs + e]);
+                         cv5[q], ssv[q % QS5][3]);
                     if (wstep == 2) { G[F::sfr + e] = sg; G[F::sfr + F::sfs + e] = ta; G[F::sfr + 2 * F::sfs + e] = ga; }
                 } else
                 hard(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam, cv5[q]);
@@ -3124,16 +3172,7 @@ struct upr_qp3 {
             }
         }
         if (no > 0) {
-            double gq[QO][NQ], od[QO], otv[QO], olv[QO], ocv[QO];
-#pragma unroll
-            for (int q = 0; q < QO; ++q) {
-                const int e = tid_ + q * NT, ec = (e < (N - 1) * no) ? e : 0;
-                const int k = 1 + ec / no, r = ec % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
-                const double* g = orow(k, r);
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) gq[q][i] = g[i];
-                od[q] = G[F::od0 + ei]; otv[q] = G[F::ot + ei]; olv[q] = G[F::ol + ei]; ocv[q] = G[F::oc + ei];
-            }
+            fetch_or();
 #pragma unroll
             for (int q = 0; q < QO; ++q) {
                 const int e = tid_ + q * NT;
@@ -3148,8 +3187,8 @@ struct upr_qp3 {
                 }
                 double t = otv[q], lam = olv[q];
                 if (C::SOFT && C::ROWS && softp) {
-                    double sg = G[F::sor + ei], ta = G[F::sor + F::sos + ei], ga = G[F::sor + 2 * F::sos + ei];
-                    soft(c, ds, cn, t, lam, sg, ta, ga, ZL, zL, ocv[q], G[F::sor + 3 * F::sos + ei]);
+                    double sg = osv[q % QOS][0], ta = osv[q % QOS][1], ga = osv[q % QOS][2];
+                    soft(c, ds, cn, t, lam, sg, ta, ga, ZL, zL, ocv[q], osv[q % QOS][3]);
                     if (wstep == 2) { G[F::sor + ei] = sg; G[F::sor + F::sos + ei] = ta; G[F::sor + 2 * F::sos + ei] = ga; }
                 } else
                 hard(c, ds, cn, t, lam, ocv[q]);
