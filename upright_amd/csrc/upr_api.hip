@@ -239,6 +239,7 @@ struct upr_jit_kernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     size_t lds = 0, ws = 0;
+    int nt = 256;       // lanes per workgroup (UPR_JIT_NT: 128 | 256 | 512, experiments)
     std::string cfg;    // the template arguments, as rocprofv3 prints them
 };
 
@@ -532,7 +533,9 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
     for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) star = false;
     const bool rows = d.no > 0, soft = needs_soft(P, d), dense = !star;
     char cfg[128];
-    snprintf(cfg, sizeof(cfg), "%d, %d, %d, %d, %d, 256, %s, %s, %s", P.nq, P.nb, P.nc, P.nf, P.N, rows ? "true" : "false", soft ? "true" : "false", dense ? "true" : "false");
+    int nt = 256;
+    if (const char* e = getenv("UPR_JIT_NT")) { nt = atoi(e); if (nt != 128 && nt != 256 && nt != 512) return fail("UPR_JIT_NT must be 128, 256 or 512"); }
+    snprintf(cfg, sizeof(cfg), "%d, %d, %d, %d, %d, %d, %s, %s, %s", P.nq, P.nb, P.nc, P.nf, P.N, nt, rows ? "true" : "false", soft ? "true" : "false", dense ? "true" : "false");
     int dev = 0;
     UPR_HIP(hipGetDevice(&dev));
     const std::string key = std::string(cfg) + " @" + std::to_string(dev);
@@ -595,7 +598,7 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
         (void)rename(tmp.c_str(), path.c_str());
     }
     upr_jit_kernel k;
-    k.cfg = cfg;
+    k.cfg = cfg; k.nt = nt;
     UPR_HIP(hipModuleLoadData(&k.mod, code.data()));
     hipFunction_t info;
     UPR_HIP(hipModuleGetFunction(&k.fn, k.mod, "upr_qp3_jit"));
@@ -619,7 +622,7 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
     if (h->use_qp3 == 3) {
         upr_qp_args Ac = A;
         void* args[] = {&Ac};
-        UPR_HIP(hipModuleLaunchKernel(h->jit->fn, (unsigned)h->B, 1, 1, 256, 1, 1, (unsigned)h->jit->lds, h->stream, args, nullptr));
+        UPR_HIP(hipModuleLaunchKernel(h->jit->fn, (unsigned)h->B, 1, 1, (unsigned)h->jit->nt, 1, 1, (unsigned)h->jit->lds, h->stream, args, nullptr));
         return 0;
     }
     if (h->use_qp3 == 1) {

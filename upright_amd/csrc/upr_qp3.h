@@ -2724,6 +2724,7 @@ struct upr_qp3 {
             }
         }
 #endif
+        ftoc(6, 5);   // (-DUPR_QP3_PROF_FLAT=5: slot 6 = each wave's own time up to the barrier behind the forward sweep, 'fwd: sweep' then its wait)
         UPR_SYNC();
         toc(12);
         // flat: cv = C sx ; nu+ = Lsi'(Lsi cv + ys) ; su_f = -Lfi'(yf + Lfi Df' nu+) ; terminal multiplier step
@@ -3029,8 +3030,9 @@ struct upr_qp3 {
         else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
     }
-    UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT]) {
-        if (ROWMEM) load_rows();
+    UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT], bool reload = true) {
+        ftoc(10, 4);
+        if (ROWMEM && reload) load_rows();   // (reload == false: the rows are still those of the sweep just before)
         double acc = 0.0;
         const int tid_ = tid();
         // the far-array operands of the friction rows (one row per lane item) and of the state-polytopic rows, each class requested
@@ -3100,7 +3102,8 @@ struct upr_qp3 {
                 }
             }
         }
-#pragma unroll
+ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- slots 6 .. 9: state boxes, input boxes, friction rows, state-polytopic rows)
+        #pragma unroll
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid() + q * NT;
             if (iu < C::NUI) {
@@ -3116,6 +3119,7 @@ struct upr_qp3 {
                 }
             }
         }
+        ftoc(7, 4);
         if (NF == 3 && C::QC > 1) {
             // several contacts per lane (multi-body shapes): slack, multiplier and corrector term of all their rows requested
             // together (one exposed latency for the lot instead of one per contact)
@@ -3171,6 +3175,7 @@ struct upr_qp3 {
                 if (wstep == 2) { G[F::ct + e] = t; G[F::cl + e] = lam; }
             }
         }
+        ftoc(8, 4);
         if (no > 0) {
             fetch_or();
 #pragma unroll
@@ -3195,6 +3200,7 @@ struct upr_qp3 {
                 if (wstep == 2) { G[F::ot + ei] = t; G[F::ol + ei] = lam; }
             }
         }
+        ftoc(9, 4);
         if (what == 0) acc = acc > 1e-30 ? 1.0 / acc : 1e30;
         return acc;
     }
@@ -3347,7 +3353,7 @@ struct upr_qp3 {
 #endif
     }
     // -DUPR_QP3_PROF_FLAT (experiment builds): slots 6 .. 9 time the parts of a flat phase instead of the matrix sweep
-    // (-DUPR_QP3_PROF_FLAT=1: the update, = 2: prep A)
+    // (-DUPR_QP3_PROF_FLAT=1: the update, = 2: prep A, = 3: the dense Schur phase, = 4: the row classes of ineq_sweep, = 5: arrival at the forward sweep's barrier)
     UPR_HDI void ftoc(int id, int set = 1) {
 #ifdef UPR_QP3_PROF_FLAT
         if (set == UPR_QP3_PROF_FLAT) toc_raw(id);
@@ -3547,7 +3553,7 @@ struct upr_qp3 {
             { double unused[NCT]; forward<false>(unused); } toc(13);
             double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
             if (a_aff > 1.0) a_aff = 1.0;
-            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets()), 0) / ntot;
+            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets(), false), 0) / ntot;
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
@@ -3570,8 +3576,8 @@ struct upr_qp3 {
             constexpr bool FUSER = UPR_QP3_FUSERES && !C::SOFT;
             if (FUSER) {
                 res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
-                res_next[2] = ineq_sweep(4, a, &res_next[3], ctm);
-            } else ineq_sweep(2, a, nullptr, ctm);
+                res_next[2] = ineq_sweep(4, a, &res_next[3], ctm, false);
+            } else ineq_sweep(2, a, nullptr, ctm, false);
             store_rows();
             // (the multipliers' old values are requested in front of the barrier: their round trip overlaps it)
             constexpr int QPI = (N1 * NX + NT - 1) / NT, QNU = (N * NE + NT - 1) / NT;
