@@ -2578,7 +2578,12 @@ struct upr_qp3 {
         // (register prefetch of the rows of C only where they fit: the multi-body shapes read them behind the sweep)
         constexpr bool PRE_V = QV <= 6, PRE_K = QCS * NE <= 24;
         constexpr int SB = C::SB;
-        double ckq[PRE_V ? QV : 1][CH], lsr[SB * SB], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
+        // DIST (dense Schur complements, SB = 6 NB > 6): the two triangular products of a block are dealt out a ROW per lane with the
+        // factor's entries read where they are used.  One lane per block out of a register copy of the factor fetched during the
+        // sweep, as the star shapes do it, meant 171 registers for 20 lanes of one wave -- the compiler parked them in scratch
+        // (150 stores, 46 reloads per lane), and that wave, not the sweep, was what the barrier behind the sweep waited for.
+        constexpr bool DIST = SB > 6;
+        double ckq[PRE_V ? QV : 1][CH], lsr[DIST ? 1 : SB * SB], bkq[QCT][NF == 3 ? 9 : 1], yfq[QCT][NF == 3 ? 3 : 1];
         double heeq[QH][NQ], ckc[PRE_K ? QCS : 1][PRE_K ? NE : 1];
 #endif
         if (wave0()) {
@@ -2681,7 +2686,7 @@ struct upr_qp3 {
                     }
                 }
             }
-            if (tl < C::NKB) {
+            if (!DIST && tl < C::NKB) {
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -2794,6 +2799,35 @@ struct upr_qp3 {
         }
         UPR_SYNC_LDS();
         // nu+ of a knot by its lane: in place over cv (LDS, what the contact step and the costates read) and to global
+        if (DIST) {
+            constexpr int NROW = C::NKB * SB, QD = (NROW + NTL - 1) / NTL;
+            double tv1[QD];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int q = 0; q < QD; ++q) {
+                    const int e = tl + q * NTL;
+                    if (tl >= 0 && e < NROW) {
+                        const int kb = e / SB, r = e % SB;
+                        const double* Ls = G + F::lsi + kb * SB * SB;
+                        double lv[SB], xv[SB];
+#pragma unroll
+                        for (int m = 0; m < SB; ++m) { lv[m] = (pass == 0) ? Ls[r * SB + m] : Ls[m * SB + r]; xv[m] = L[O::cv + kb * SB + m]; }
+                        double v = (pass == 0) ? L[O::ys + e] : 0.0;
+#pragma unroll
+                        for (int m = 0; m < SB; ++m) v += (((pass == 0) ? (m <= r) : (m >= r)) ? lv[m] : 0.0) * xv[m];
+                        tv1[q] = v;
+                    }
+                }
+                UPR_SYNC_LDS();   // (every row of the block has read cv / the first product)
+#pragma unroll
+                for (int q = 0; q < QD; ++q) {
+                    const int e = tl + q * NTL;
+                    if (tl >= 0 && e < NROW) { L[O::cv + e] = tv1[q]; if (pass == 1) G[F::nun + e] = tv1[q]; }
+                }
+                if (pass == 0) UPR_SYNC_LDS();
+            }
+        } else
         if (tl >= 0 && tl < C::NKB) {
             const int kb = tl;   // Schur block: a knot, or a (knot, body) pair
             double cvr[SB], t1[SB];
