@@ -40,6 +40,12 @@
 // DENSE_ (with NB_ > 1): arrangements whose bodies share contact points (stacked objects): the Schur complement of a
 // knot is one dense 6 NB x 6 NB matrix, assembled, factored and inverted by the knot's lane in registers (the
 // instantiation runs one workgroup per CU and may use all 512 registers of a lane).
+#ifndef UPR_QP3_GQ
+#define UPR_QP3_GQ 5   /* rows of C a lane requests together in the multi-body shapes' passes over C (prep C, forward tail) */
+#endif
+#ifndef UPR_QP3_SCHUR_KQ
+#define UPR_QP3_SCHUR_KQ 1   /* knots a lane carries side by side in the cooperative Schur factorisation (2: measured 5x slower, see there) */
+#endif
 #ifndef UPR_QP3_SOFT_ROWMEM
 #define UPR_QP3_SOFT_ROWMEM 1
 #endif
@@ -798,7 +804,7 @@ struct upr_qp3 {
             } else {
                 // multi-body shapes: the rows of C come straight from the records, GQ rows of a lane requested together
                 // (one exposed latency per group instead of one per row)
-                constexpr int GQ = 5;
+                constexpr int GQ = UPR_QP3_GQ;
 #pragma unroll 1
                 for (int q0 = 0; q0 < QR; q0 += GQ) {
                     double cb[GQ][CH], e0b[GQ];
@@ -993,7 +999,7 @@ struct upr_qp3 {
             // (KQ: knots a lane carries side by side.  The chain of a pivot -- reciprocal square root, shuffle, LDS round trip: 640
             // cycles -- is latency, and two independent chains would share it; measured with KQ = 2 the 72 extra registers go to
             // scratch in this 512-register kernel and the phase takes 240 k cycles instead of 68 k: one knot per lane, two passes.)
-            constexpr int GP = 64 / SB, KW = GP * (NT / 64), KQ = 1, KPP = KW * KQ, NPS = (N + KPP - 1) / KPP, NPK = SB * (SB + 1) / 2;
+            constexpr int GP = 64 / SB, KW = GP * (NT / 64), KQ = UPR_QP3_SCHUR_KQ, KPP = KW * KQ, NPS = (N + KPP - 1) / KPP, NPK = SB * (SB + 1) / 2;
             static_assert(GP >= 1 && O::Pa + 64 * KQ * (NT / 64) <= O::yN, "a group per knot inside a wave; pivot-column slots in the sweeps' working set");
             const int ln = lane(), g = ln / SB, i = ln - g * SB, wv = wb >> 6;
             const int gc = (g < GP) ? g : 0, ri = i * (i + 1) / 2;
@@ -2757,7 +2763,7 @@ struct upr_qp3 {
                 if (act && part == 0) L[O::cv + e] = v;
             }
         } else {
-            constexpr int GQ = 5;   // (as in prep: GQ rows of a lane requested together)
+            constexpr int GQ = UPR_QP3_GQ;   // (as in prep: GQ rows of a lane requested together)
 #pragma unroll 1
             for (int q0 = 0; q0 < QV; q0 += GQ) {
                 double cb[GQ][CH];
