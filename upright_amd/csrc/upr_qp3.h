@@ -40,6 +40,9 @@
 // DENSE_ (with NB_ > 1): arrangements whose bodies share contact points (stacked objects): the Schur complement of a
 // knot is one dense 6 NB x 6 NB matrix, assembled, factored and inverted by the knot's lane in registers (the
 // instantiation runs one workgroup per CU and may use all 512 registers of a lane).
+#ifndef UPR_QP3_INCEK
+#define UPR_QP3_INCEK 1
+#endif
 #ifndef UPR_QP3_GQ
 #define UPR_QP3_GQ 5   /* rows of C a lane requests together in the multi-body shapes' passes over C (prep C, forward tail) */
 #endif
@@ -53,6 +56,13 @@ template <int NQ_, int NB_, int NC_, int NF_, int N_, int NT_, bool ROWS_ = true
 struct upr_qp3_cfg {
     static constexpr int NQ = NQ_, NB = NB_, NC = NC_, NF = NF_, N = N_, NT = NT_;
     static constexpr bool ROWS = ROWS_, SOFT = SOFT_, COUPLED = DENSE_ && NB_ > 1, MULTI = NB_ > 1 && !DENSE_;
+    // INCEK (star arrangements without friction: the upright_robust shape): the equality residual ek = e0 + C Zx + Df Zf is formed
+    // once and then follows the iterate, ek += alpha (C sx + Df sf), with the C sx the forward sweep's tail has at hand -- one
+    // pass over the rows of C (207 KB per instance) per interior-point iteration less: QP launch 6.31 -> 6.00 ms, same iteration
+    // counts, plans to 2e-11.  Not for the dense shapes (-2.6 %): their configs run early QPs at the iteration cap, where a change
+    // at rounding level moves the unconverged iterates by 1e-3 and with them test_config3_shape...'s comparison of whole SQP
+    // runs; those kernels stay bit-identical.  (BIGF keeps ek in the far arrays.)
+    static constexpr bool INCEK = UPR_QP3_INCEK && NB_ > 1 && !DENSE_ && NF_ == 1;
     // BIGF: star arrangements WITH friction (the paper's seven cups: nu = 93).  Their force-indexed arrays do not fit the LDS next
     // to the sweeps' working set: Df is kept compact ([force column][the six rows of the body its contact loads] instead of the
     // dense 6 nb x nf nc), Z = Lf^-1 Df' is not staged (the lane of a (knot, body) block forms its twelve columns from the contact
@@ -128,8 +138,9 @@ struct upr_qp3_lds {
     static constexpr int Z = 0, S = Z + r2(C::NZ), gxs = S + r2(C::NZ), wx = gxs + r2(C::N1 * C::NX), gus = wx + r2(C::N1 * C::NX),
                          wu = gus + r2(C::N * C::NU), cs = wu + r2(C::N * C::NU), hf = cs + r2(C::N * C::NX), ys = hf + r2(C::BIGF ? 0 : C::N * C::NFC),
                          zt = ys + r2(C::N * C::NE), cv = zt, ek = zt + r2(C::N * C::NE),
+                         dek = ek + r2(C::BIGF ? 0 : C::N * C::NE),   // INCEK: C sx of the step that was taken (the equality residual follows the iterate without a pass over C)
                          // constants
-                         xlb = ek + r2(C::BIGF ? 0 : C::N * C::NE), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
+                         xlb = dek + r2(C::INCEK ? C::N * C::NE : 0), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
                          rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
                          // working set of the sweeps
                          Pa = df + r2(C::BIGF ? 6 * C::NFC : C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX),
@@ -325,6 +336,7 @@ struct upr_qp3 {
     double rho_eq;          // 1 / Z for a softened equality (the row's residual is C dz + e - rho_eq nu), else 0
     double rho_px;          // proximal treatment of a hard equality the forces cannot span (upr_qp.h UPR_QP_RHO_S_PROX): C dz + e = rho_px (nu+ - nu)
     double soft_stat;       // running max of the slack stationarity |Z sigma + z - lam - gam| (residuals)
+    bool have_ek;           // INCEK: ek is current (updated with the step) -- prep does not form it again
     static constexpr int NCT0 = 2 * C::QX + 2 * C::QU;                // corrector targets of the rows per lane (F::cxr)
     static constexpr int NCT = (C::SOFT ? 2 : 1) * NCT0;             // SOFT: + the targets of the slack pairs, behind them
     struct zero_targets_t { double v[NCT]; };
@@ -780,8 +792,9 @@ struct upr_qp3 {
         }
         UPR_SYNC(); toc(2);
         // C: equality residual ek = e0 + C Zx + Df Zf, ee = ek - Df hf (-> ys slot); S lower triangle (-> lsi slot)
+        const bool fresh_ek = fresh && !(C::INCEK && have_ek);   // (INCEK: ek has followed the iterate since the first iteration)
 #ifndef UPR_HOST_EMU
-        if (fresh) {
+        if (fresh_ek) {
             // C Zx by quads (four column chunks of a row, summed by DPP)
             if (PRE_C) {
 #pragma unroll
@@ -837,7 +850,7 @@ struct upr_qp3 {
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             double v = ekp()[e], v2 = 0.0;
-            if (fresh) {
+            if (fresh_ek) {
                 v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
                 ekp()[e] = v;
             }
@@ -849,7 +862,7 @@ struct upr_qp3 {
             const int k = e / NE, r = e % NE;
             const double* Ck = rec(k) + lin_gx + r * NX;
             double v, v2 = 0.0;
-            if (fresh) {
+            if (fresh_ek) {
                 v = G[F::e0 + e];
                 for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
                 v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
@@ -2760,7 +2773,7 @@ struct upr_qp3 {
                     for (int c = 0; c < CH; ++c) v += (act ? ckq[q % (PRE_V ? QV : 1)][c] : 0.0) * sv[c];
                 }
                 v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                if (act && part == 0) L[O::cv + e] = v;
+                if (act && part == 0) { L[O::cv + e] = v; if (C::INCEK && COST) L[O::dek + e] = v; }
             }
         } else {
             constexpr int GQ = UPR_QP3_GQ;   // (as in prep: GQ rows of a lane requested together)
@@ -2786,7 +2799,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? sx[c] : 0.0);
                     v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                    if (act && part == 0) L[O::cv + e] = v;
+                    if (act && part == 0) { L[O::cv + e] = v; if (C::INCEK && COST) L[O::dek + e] = v; }
                 }
             }
         }
@@ -2903,6 +2916,7 @@ struct upr_qp3 {
             double v = 0.0;
             for (int c = 0; c < NX; ++c) v += Ck[c] * sx[c];
             L[O::cv + e] = v;
+            if (C::INCEK && COST) L[O::dek + e] = v;
         }
         UPR_SYNC();
         UPR_FORT(kb, C::NKB) {
@@ -3442,6 +3456,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
+        have_ek = false;
         softx = C::SOFT && P->soft_state_box != 0; softu = C::SOFT && P->soft_input_box != 0; softp = C::SOFT && P->soft_poly != 0;
         ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
         rho_eq = upr_qp_rho_soft(P); rho_s = upr_qp_rho_s(P, NE, NFC); rho_px = upr_qp_rho_prox(P, NE, NFC);
@@ -3646,6 +3661,10 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 }
 #pragma unroll
                 for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT; if (e < N * NE) ws[W::nu + e] = nuo[q] + a * (nun_[q] - nuo[q]); }
+            }
+            if (C::INCEK) {   // the equality residual at the new iterate: ek += a (C sx + Df sf)
+                UPR_FORT(e, N * NE) { const int k = e / NE, r = e % NE; L[O::ek + e] += a * (L[O::dek + e] + df_dot(r, L + O::S + N1 * NX + k * NU + NQ)); }
+                have_ek = true;
             }
             UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] = upr_step(L[O::Z + N1 * NX + e], a, L[O::S + N1 * NX + e]);
             UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
