@@ -250,6 +250,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_FUSERES
 #define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
 #endif
+#ifndef UPR_QP3_FUSERES_SOFT
+#define UPR_QP3_FUSERES_SOFT 1   // also in the SOFT instantiations (measured 4 % slower while their rows lived in scratch; now -4 % on the softened thrown-ball workload)
+#endif
 #ifndef UPR_QP3_COOP_SCHUR
 #define UPR_QP3_COOP_SCHUR 1   // dense Schur complement (stacked bodies): cooperative factorisation, SB lanes per knot (0: a lane per knot, rounds 2 - 3; A/B runs)
 #endif
@@ -3626,9 +3629,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             ftoc(7);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
-            // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass.  (Not for
-            // the SOFT instantiations: with the slack pairs' terms in the same sweep the kernel measured 4 % slower, 3.77 -> 3.92 ms.)
-            constexpr bool FUSER = UPR_QP3_FUSERES && !C::SOFT;
+            // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass.  (The SOFT
+            // instantiations too since their rows no longer live in scratch -- UPR_QP3_FUSERES_SOFT: 3.20 -> 3.07 ms; before: 3.77 -> 3.92.)
+            constexpr bool FUSER = UPR_QP3_FUSERES && (!C::SOFT || UPR_QP3_FUSERES_SOFT);
             if (FUSER) {
                 res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
                 res_next[2] = ineq_sweep(4, a, &res_next[3], ctm, false);
