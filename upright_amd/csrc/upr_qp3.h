@@ -250,6 +250,12 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_FUSERES
 #define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
 #endif
+#ifndef UPR_QP3_PREC_MAX
+#define UPR_QP3_PREC_MAX 4   /* quad slots of rows of C per lane up to which prep fetches them into registers ahead of phase C */
+#endif
+#ifndef UPR_QP3_PREV_MAX
+#define UPR_QP3_PREV_MAX 8   /* the same for the forward sweep's tail (fetched during the sweep; 8: box_arch since its kernel has no spills, -1 %) */
+#endif
 #ifndef UPR_QP3_FUSERES_SOFT
 #define UPR_QP3_FUSERES_SOFT 1   // also in the SOFT instantiations (measured 4 % slower while their rows lived in scratch; now -4 % on the softened thrown-ball workload)
 #endif
@@ -553,7 +559,7 @@ struct upr_qp3 {
 #ifndef UPR_HOST_EMU
         constexpr int CH = (NX + 3) / 4, QR = (N * NE * 4 + NT - 1) / NT;
         // (multi-body shapes have too many rows of C for a register prefetch: they read them where they are used)
-        constexpr bool PRE_C = QR <= 4;
+        constexpr bool PRE_C = QR <= UPR_QP3_PREC_MAX;
         double ckr[PRE_C ? QR : 1][CH], e0r[PRE_C ? QR : 1];
         // (ROWMEM shapes: requested behind the box rows of phase A, which need the registers)
         auto fetch_c = [&]() {
@@ -2598,7 +2604,7 @@ struct upr_qp3 {
         constexpr int QCS = (N * NX + NTL - 1) / NTL;
         constexpr int QH = (N * NQ + NTL - 1) / NTL;
         // (register prefetch of the rows of C only where they fit: the multi-body shapes read them behind the sweep)
-        constexpr bool PRE_V = QV <= 6, PRE_K = QCS * NE <= 24;
+        constexpr bool PRE_V = QV <= UPR_QP3_PREV_MAX, PRE_K = QCS * NE <= 24;
         constexpr int SB = C::SB;
         // DIST (dense Schur complements, SB = 6 NB > 6): the two triangular products of a block are dealt out a ROW per lane with the
         // factor's entries read where they are used.  One lane per block out of a register copy of the factor fetched during the
