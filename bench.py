@@ -328,15 +328,29 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None, force_exch
         return np.concatenate([q + dt * v + dt ** 2 / 2 * a + dt ** 3 / 6 * j, v + dt * a + dt ** 2 / 2 * j, a + dt * j,
                                ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
 
-    x = tick(x, t); t += dt          # first solve: cold start + allocation effects, untimed
-    lat.clear(); lat_x.clear()
-    mpc.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(ticks):
-        x = tick(x, t); t += dt
-        stq = stq_[0]
-        failed += int(np.sum(stq != 0)); broke[0] += int(np.sum(stq == 2))
-    elapsed = time.perf_counter() - t0
+    def run_pass(events):
+        # one run of the closed loop from the workload's start states.  events: per-kernel HIP events on (kernel_ms of the line);
+        # off, the engine replays each control period as one captured HIP graph (upr_batch_tick)
+        nf = nb = 0
+        mpc.reset_async()
+        x, t = w["x0"].copy(), 0.0
+        x = tick(x, t); t += dt          # first solve: cold start + allocation effects, untimed
+        lat.clear(); lat_x.clear()
+        mpc.enable_timing(events)
+        t0 = time.perf_counter()
+        for _ in range(ticks):
+            x = tick(x, t); t += dt
+            stq = stq_[0]
+            nf += int(np.sum(stq != 0)); nb += int(np.sum(stq == 2))
+        return time.perf_counter() - t0, nf, nb, x
+
+    # the kernels' own times come from a SECOND, identical run with events (they cost ~20 us per period and switch the graph
+    # replay off); the rate, the latencies and the status counts are the first run's
+    _, _, _, _ = run_pass(True)
+    kt = mpc.kernel_times()
+    elapsed, failed, nbroke, x = run_pass(False)
+    broke[0] = nbroke
+    graph_replays = mpc.tick_graph_replays() if hasattr(mpc, "tick_graph_replays") else 0
     if world > 1:
         import torch
 
@@ -345,7 +359,6 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None, force_exch
         dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
         elapsed, failed, broke[0] = float(tt[0].item()), int(tt[1].item()), int(tt[2].item())
         assert u0_all[0].shape == (world * B, P.nu)
-    kt = mpc.kernel_times()
     roof, lin = roofline_objects(P, B, kt, mpc.stats(), 1, headline=False, key=w.get("key"))   # (kernel times: means over the ticks; IPM iterations: the last tick's)
     goal_err = np.linalg.norm(np.array([P.chain.forward(x[b, :9])[0] for b in range(0, B, max(1, B // 64))])
                               - w["way"][::max(1, B // 64), 0], axis=1)
@@ -353,7 +366,8 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None, force_exch
         "workload": w["name"], "value": B * world * ticks / elapsed, "unit": "solves/s", "n_gpus": world, "ms_per_tick": 1e3 * elapsed / ticks,
         "ms_per_tick_p99_engine": 1e3 * float(np.quantile(lat, 0.99)),
         "ms_per_tick_p99_with_exchange": 1e3 * float(np.quantile(lat_x, 0.99)) if lat_x else None,
-        "control_period_ms": 10.0, "ticks": ticks,
+        "control_period_ms": 10.0, "ticks": ticks, "periods_replayed_as_hip_graph": graph_replays,
+        "kernel_ms_source": "a second, identical run of the loop with per-kernel HIP events (the timed run has none)",
         "real_time_factor": 0.01 * ticks / elapsed,
         "exchange": "all-gather of u_0 per tick" if exchange else None,
         "qp_not_converged_fraction": failed / (B * world * ticks),

@@ -212,8 +212,12 @@ int upr_batch_evaluate_policy(upr_batch* h, const double* t, int t_stride, const
  * every period.  The observation is uploaded once (the policy is evaluated at the state that was just observed, at its own time),
  * transfers go through the engine's pinned staging buffer, and the statistics of the solve come back with the result.
  * x[B][nx_full] observed states, x_out[B][nx_full], u_out[B][nu] as upr_batch_evaluate[_policy]; stats_out[B][UPR_NSTATS] or NULL.
- * Results are bit-identical to the three calls. */
+ * Results are bit-identical to the three calls.
+ * From the third period in a row that enqueues the same operations (warm start, same SQP iteration count, no event timing ...)
+ * the period's stream operations -- copies in, prepare, linearise, QP, line search, policy, copies out -- are replayed as ONE HIP
+ * graph launch (UPR_TICK_GRAPH=0: never); upr_batch_tick_graph_replays counts the periods served that way. */
 int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x, double* x_out, double* u_out, double* stats_out);
+long long upr_batch_tick_graph_replays(upr_batch* h);
 
 /* ControllerInterface.getLinearFeedbackGain (pybindings.cpp:382-384) at the knots: K[B][N][nu][nx]; jerk rows from the
  * Riccati recursion, contact-force rows from the elimination of the object-dynamics equality

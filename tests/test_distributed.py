@@ -147,7 +147,8 @@ def _extra_worker(rank, world, port, q):
     t_last = 0.01 * ticks                       # (one untimed tick at t = 0, then `ticks` timed ones)
     ok = ok and u0.shape == (world * B, P5.nu) and out5["n_gpus"] == world and out5["exchange"] == "all-gather of u_0 per tick"
     ok = ok and bool(torch.allclose(u0[:, 0], -(torch.arange(world * B, dtype=torch.float64) + t_last)))
-    ok = ok and eng5.calls.count("advance") == ticks + 1 and eng5.calls.count("obs") == ticks + 1 and out5["finite"]
+    # (two identical runs of the loop: one with per-kernel events for kernel_ms, the timed one without)
+    ok = ok and eng5.calls.count("advance") == 2 * (ticks + 1) and eng5.calls.count("obs") == 2 * (ticks + 1) and eng5.calls.count("reset") == 2 and out5["finite"]
     q.put((rank, ok))
     dist.destroy_process_group()
 

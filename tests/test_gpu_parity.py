@@ -1916,7 +1916,7 @@ def test_closed_loop_thrown_ball_with_soft_rows(arrangements):
 def test_tick_equals_the_three_calls(arrangements, case):
     """upr_batch_tick = set_observation + advance + evaluate at the observation (manager.py:156-176) in one call: bit-identical
     plan, policy output and statistics over a short closed loop, for the plain state and for interface states with a dynamic
-    obstacle."""
+    obstacle -- also once the period is replayed as a captured HIP graph (upr_batch_tick_graph_replays)."""
     B = 8
     if case.startswith("headline"):   # (feedforward: sqp.use_feedback_policy off, the plan's input at the observation time)
         P = thing_problem(arrangements["pink_bottle"], use_feedback_policy=(case == "headline"))
@@ -1929,7 +1929,7 @@ def test_tick_equals_the_three_calls(arrangements, case):
     if case == "thrown_ball":
         a.set_projectile_flag(1.0); b.set_projectile_flag(1.0)
     t, dt = 0.0, 0.01
-    for tick in range(5):
+    for tick in range(8):   # (from its fourth steady period on, tick() replays the period as one HIP graph)
         a.set_observation(t, x); a.advance(); xa, ua = a.evaluate(t, x_obs=x)
         xb, ub, sb = b.tick(t, x, want_stats=True)
         sa = a.stats()
@@ -1944,6 +1944,7 @@ def test_tick_equals_the_three_calls(arrangements, case):
             ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
             xn = np.concatenate([xn, ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
         x = xn; t += dt
+    assert b.tick_graph_replays() >= 3 and a.tick_graph_replays() == 0
     a.close(); b.close()
 
 

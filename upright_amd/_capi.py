@@ -129,6 +129,7 @@ PROTOTYPES = [
     ("upr_batch_evaluate", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp]),
     ("upr_batch_evaluate_policy", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp, dp]),
     ("upr_batch_tick", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp, dp, dp]),
+    ("upr_batch_tick_graph_replays", C.c_longlong, [C.c_void_p]),
     ("upr_batch_get_feedback", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
     ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),

@@ -267,6 +267,14 @@ struct upr_batch {
     double *dyn0 = nullptr, *pflag = nullptr;
     std::vector<double> hdyn0, hdyn_prev, htprev;
     double* pin = nullptr;   // pinned host staging of upr_batch_tick
+    // upr_batch_tick as a HIP graph: the eleven stream operations of a control period (three copies in, prepare, linearise, QP,
+    // line search, policy, three copies out) captured once the handle is in its steady state and replayed while that state --
+    // tick_sig: everything on the host that decides WHICH operations a tick enqueues -- stays the same
+    hipGraphExec_t tick_exec = nullptr;
+    unsigned long long tick_sig = 0;
+    int tick_steady = 0;        // ticks in a row with the same signature
+    int tick_graph_on = -1;     // UPR_TICK_GRAPH (default 1), read once
+    long long tick_replays = 0;
     int nxf = 0;   // interface state dimension 3 nq + 9 n_dyn
     bool guess_set = false;
     int sqp_iters_next = 0;   // > 0: SQP iterations of the next advance only (init_sqp_iteration of the first solve)
@@ -937,7 +945,7 @@ void upr_batch_destroy(upr_batch* h) {
     if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
-    hipFree(h->done); hipFree(h->order); hipFree(h->iter_key); if (h->pin) (void)hipHostFree(h->pin); hipFree(h->prof); hipFree(h->kkt);
+    hipFree(h->done); hipFree(h->order); hipFree(h->iter_key); if (h->pin) (void)hipHostFree(h->pin); if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec); hipFree(h->prof); hipFree(h->kkt);
     hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1410,18 +1418,55 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
         std::memcpy(px + b * nx, x + b * (size_t)h->nxf, sizeof(double) * nx);
         if (ndyn) { std::memcpy(pd + b * ndyn, x + b * (size_t)h->nxf + nx, sizeof(double) * ndyn); std::memcpy(h->hdyn0.data() + b * ndyn, pd + b * ndyn, sizeof(double) * ndyn); }
     }
-    UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-    UPR_HIP(hipMemcpyAsync(h->x0, px, sizeof(double) * B * nx, hipMemcpyHostToDevice, h->stream));
-    if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * ndyn, hipMemcpyHostToDevice, h->stream));
     auto t0c = std::chrono::steady_clock::now();
-    if (advance_impl(h)) return 1;
-    // the policy at the observation: time t0, state x0 (both already on the device)
-    if (h->fb) hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, h->t0, h->x0, h->ev_x, h->ev_u);
-    else hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->t0, 1, h->ev_x, h->ev_u);
-    UPR_HIP(hipGetLastError());
-    UPR_HIP(hipMemcpyAsync(ox, h->ev_x, sizeof(double) * B * nx, hipMemcpyDeviceToHost, h->stream));
-    UPR_HIP(hipMemcpyAsync(ou, h->ev_u, sizeof(double) * B * nu, hipMemcpyDeviceToHost, h->stream));
-    if (stats_out) UPR_HIP(hipMemcpyAsync(os, h->stats, sizeof(double) * B * UPR_NSTATS, hipMemcpyDeviceToHost, h->stream));
+    // the stream operations of one control period
+    auto enqueue = [&]() -> int {
+        UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+        UPR_HIP(hipMemcpyAsync(h->x0, px, sizeof(double) * B * nx, hipMemcpyHostToDevice, h->stream));
+        if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * ndyn, hipMemcpyHostToDevice, h->stream));
+        if (advance_impl(h)) return 1;
+        // the policy at the observation: time t0, state x0 (both already on the device)
+        if (h->fb) hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, h->t0, h->x0, h->ev_x, h->ev_u);
+        else hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->t0, 1, h->ev_x, h->ev_u);
+        UPR_HIP(hipGetLastError());
+        UPR_HIP(hipMemcpyAsync(ox, h->ev_x, sizeof(double) * B * nx, hipMemcpyDeviceToHost, h->stream));
+        UPR_HIP(hipMemcpyAsync(ou, h->ev_u, sizeof(double) * B * nu, hipMemcpyDeviceToHost, h->stream));
+        if (stats_out) UPR_HIP(hipMemcpyAsync(os, h->stats, sizeof(double) * B * UPR_NSTATS, hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    };
+    if (h->tick_graph_on < 0) { const char* e = getenv("UPR_TICK_GRAPH"); h->tick_graph_on = (e && atoi(e) == 0) ? 0 : 1; }
+    // what decides which operations a tick enqueues (advance_impl): warm start or not, a guess handed in, the SQP iteration count,
+    // the dispatch order being valid, the feedback policy and who writes it, event timing, the statistics copy
+    const int sqp_now = h->sqp_iters_next > 0 ? h->sqp_iters_next : h->P.sqp_iters;
+    unsigned long long sig = 1469598103934665603ull;
+    for (unsigned long long v : {(unsigned long long)h->has_prev, (unsigned long long)h->guess_set, (unsigned long long)sqp_now, (unsigned long long)(h->order_on && h->order_valid),
+                                 (unsigned long long)(h->fb != nullptr), (unsigned long long)h->fb_fused, (unsigned long long)h->timing, (unsigned long long)(stats_out != nullptr),
+                                 (unsigned long long)h->use_qp3, (unsigned long long)h->use_qp2, (unsigned long long)h->qp_nt, (unsigned long long)(uintptr_t)h->pin}) { sig ^= v; sig *= 1099511628211ull; }
+    const bool steady = h->tick_graph_on && !h->timing && h->has_prev && !h->guess_set && h->sqp_iters_next == 0 && (!h->order_on || h->order_valid);
+    if (steady && h->tick_exec && sig == h->tick_sig) {
+        UPR_HIP(hipGraphLaunch(h->tick_exec, h->stream));
+        // (what advance_impl does on the host besides enqueueing)
+        h->hdyn_prev = h->hdyn0;
+        ++h->tick_replays;
+    } else {
+        if (h->tick_exec && sig != h->tick_sig) { (void)hipGraphExecDestroy(h->tick_exec); h->tick_exec = nullptr; h->tick_steady = 0; }
+        h->tick_steady = (steady && sig == h->tick_sig) ? h->tick_steady + 1 : 0;
+        h->tick_sig = sig;
+        if (steady && h->tick_steady >= 2 && !h->tick_exec) {
+            // third steady tick in a row: capture it, run the captured graph for this tick
+            hipGraph_t g = nullptr;
+            UPR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue();
+            const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+            if (rc || ec != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); h->tick_graph_on = 0; if (rc) return 1; if (enqueue()) return 1; }
+            else {
+                const hipError_t ei = hipGraphInstantiate(&h->tick_exec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ei != hipSuccess) { h->tick_exec = nullptr; h->tick_graph_on = 0; if (enqueue()) return 1; }
+                else UPR_HIP(hipGraphLaunch(h->tick_exec, h->stream));
+            }
+        } else if (enqueue()) return 1;
+    }
     UPR_HIP(hipStreamSynchronize(h->stream));
     h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
     for (size_t b = 0; b < B; ++b) {
@@ -1433,6 +1478,8 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     if (stats_out) std::memcpy(stats_out, os, sizeof(double) * B * UPR_NSTATS);
     return 0;
 }
+
+long long upr_batch_tick_graph_replays(upr_batch* h) { return h ? h->tick_replays : 0; }
 
 int upr_batch_get_feedback(upr_batch* h, double* K) {
     UPR_ENTER(h);

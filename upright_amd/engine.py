@@ -101,6 +101,10 @@ class BatchMPC:
             return xr, u, {name: s[:, i] for i, name in enumerate(_capi.STAT_NAMES)}
         return xr, u
 
+    def tick_graph_replays(self):
+        """Control periods upr_batch_tick served by replaying its captured HIP graph."""
+        return int(self._lib.upr_batch_tick_graph_replays(self._h))
+
     def evaluate(self, t, x_obs=None):
         """Plan state and input at time t.  With x_obs (B, nx) and use_feedback_policy the input is the linear
         policy u*(t) + K(t) (x_obs - x*(t)) of the last solve (ocs2::LinearController), else the feed-forward input."""
