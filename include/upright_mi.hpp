@@ -66,6 +66,8 @@ class ControllerInterface {
         x_opt.assign((size_t)B_ * nx_, 0.0); u_opt.assign((size_t)B_ * nu_, 0.0);
         check(upr_batch_tick(h_, t.data(), t.size() == 1 ? 0 : 1, x.data(), x_opt.data(), u_opt.data(), nullptr));
     }
+    // control periods step() served by replaying its captured HIP graph (steady state: from the fourth period on)
+    long long tick_graph_replays() const { return upr_batch_tick_graph_replays(h_); }
     Solution solution() {
         Solution s;
         s.ts.assign((size_t)B_ * (P_.N + 1), 0.0); s.xs.assign((size_t)B_ * (P_.N + 1) * nx_, 0.0); s.us.assign((size_t)B_ * P_.N * nu_, 0.0);

@@ -23,5 +23,5 @@ for l in open(out):
     if cur and ('scratch_load' in l or 'scratch_store' in l):
         cnt[fn][(cur[0], cur[1] // 25 * 25, 'load' if 'load' in l else 'store')] += 1
 for f, c in sorted(cnt.items(), key=lambda x: -sum(x[1].values())):
-    print(subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", f], capture_output=True, text=True).stdout.strip()[:110], "| scratch instructions:", sum(c.values()))
+    print(subprocess.run(["c++filt", f], capture_output=True, text=True).stdout.strip()[:110], "| scratch instructions:", sum(c.values()))
     for (file, line, kind), n in sorted(c.items(), key=lambda x: -x[1])[:top]: print("     %-18s lines %4d-%4d  %-5s %d" % (file, line, line + 24, kind, n))
