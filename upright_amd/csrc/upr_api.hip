@@ -290,7 +290,7 @@ struct upr_batch {
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
     std::string qp_name;   // the QP kernel instantiation this handle launches
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pool, ev_free;   // events in use (pairs, in launch order) / harvested ones waiting for reuse
     std::vector<int> ev_slot;
 };
 
@@ -709,7 +709,9 @@ struct KernelTimer {
     KernelTimer(upr_batch* h_, int s) : h(h_), slot(s), idx(0) {
         if (!h->timing) return;
         hipEvent_t a, b;
-        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        // (reused: upr_batch_enable_timing stocks the free list, so that a timed loop creates none)
+        if (h->ev_free.size() >= 2) { a = h->ev_free.back(); h->ev_free.pop_back(); b = h->ev_free.back(); h->ev_free.pop_back(); }
+        else { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
         idx = h->ev_pool.size();
         h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_slot.push_back(slot);
         (void)hipEventRecord(a, h->stream);
@@ -948,6 +950,7 @@ void upr_batch_destroy(upr_batch* h) {
     hipFree(h->done); hipFree(h->order); hipFree(h->iter_key); if (h->pin) (void)hipHostFree(h->pin); if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec); hipFree(h->prof); hipFree(h->kkt);
     hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1266,6 +1269,7 @@ int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
 int upr_batch_enable_timing(upr_batch* h, int on) {
     UPR_ENTER(h);
     h->timing = on != 0;
+    if (h->timing) while (h->ev_free.size() < 512) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->ev_free.push_back(e); }
     for (int i = 0; i < 3; ++i) { h->k_ms[i] = 0; h->k_launches[i] = 0; }
     return 0;
 }
@@ -1276,7 +1280,7 @@ int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches) {
     for (size_t i = 0; i < h->ev_slot.size(); ++i) {
         float t = 0;
         if (hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]) == hipSuccess) { h->k_ms[h->ev_slot[i]] += t; h->k_launches[h->ev_slot[i]] += 1; }
-        (void)hipEventDestroy(h->ev_pool[2 * i]); (void)hipEventDestroy(h->ev_pool[2 * i + 1]);
+        h->ev_free.push_back(h->ev_pool[2 * i]); h->ev_free.push_back(h->ev_pool[2 * i + 1]);
     }
     h->ev_pool.clear(); h->ev_slot.clear();
     for (int i = 0; i < 3; ++i) {
