@@ -1929,7 +1929,13 @@ def test_tick_equals_the_three_calls(arrangements, case):
     if case == "thrown_ball":
         a.set_projectile_flag(1.0); b.set_projectile_flag(1.0)
     t, dt = 0.0, 0.01
-    for tick in range(8):   # (from its fourth steady period on, tick() replays the period as one HIP graph)
+    replays = []
+    for tick in range(20):   # (from its fourth steady period on, tick() replays the period as one HIP graph)
+        # what suspends the replay -- event timing on (periods 8, 9), a reset of both engines (14) -- and that it comes back: a
+        # change of what a period enqueues drops the captured graph, three steady periods later the next one is captured
+        if tick == 8: b.enable_timing(True)
+        if tick == 10: b.enable_timing(False)
+        if tick == 14: a.reset(); b.reset()
         a.set_observation(t, x); a.advance(); xa, ua = a.evaluate(t, x_obs=x)
         xb, ub, sb = b.tick(t, x, want_stats=True)
         sa = a.stats()
@@ -1943,8 +1949,13 @@ def test_tick_equals_the_three_calls(arrangements, case):
         if x.shape[1] > 27:
             ro, vo, ao = x[:, 27:30], x[:, 30:33], x[:, 33:36]
             xn = np.concatenate([xn, ro + dt * vo + 0.5 * dt * dt * ao, vo + dt * ao, ao], axis=1)
+        replays.append(b.tick_graph_replays())
         x = xn; t += dt
-    assert b.tick_graph_replays() >= 3 and a.tick_graph_replays() == 0
+    d = np.diff([0] + replays)          # 1 where the period was a replay
+    assert list(d[:4]) == [0, 0, 0, 0] and list(d[4:8]) == [1, 1, 1, 1]      # cold, two steady periods, the capturing one; then replays
+    assert list(d[8:13]) == [0, 0, 0, 0, 0] and d[13] == 1                    # events on: none; off: two steady periods, capture, replay
+    assert list(d[14:18]) == [0, 0, 0, 0] and list(d[18:]) == [1, 1]          # the same behind the reset
+    assert a.tick_graph_replays() == 0
     a.close(); b.close()
 
 
