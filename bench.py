@@ -379,6 +379,7 @@ def time_closed_loop(w, ticks, dist=None, device="cuda", engine=None, force_exch
     }
     if u0_all[0] is not None:
         out["u0_gathered"] = u0_all[0]        # (for the tests; dropped before the line is printed)
+        out["gathered_rows"] = int(u0_all[0].shape[0])   # first inputs of every instance of every rank, on this rank
     mpc.close()
     return out
 
@@ -584,6 +585,7 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
     }
     if gathered is not None:
         out["gathered"] = gathered            # (for the tests; dropped before the line is printed)
+        out["gathered_rows"] = int(gathered[0].shape[0])   # trajectories of every instance of every rank, on this rank
     if st["qp_iters_last"].size and float(np.mean(st["qp_status_last"] == 0)) == 0.0 and float(np.mean(st["qp_iters_last"])) >= w["P"].qp_iter_max:
         out["note"] = "QPs AT THE ITERATION CAP: this figure times capped interior-point iterations of sub-problems that do not converge (not a solve rate)"
     if warm is not None:
@@ -768,7 +770,8 @@ def main():
             e = make_engine(w, device_index=local_rank)
             assert e.device_index() == local_rank, (e.device_index(), local_rank)
         else:
-            from upright_amd.distributed import StandInEngine
+            sys.path.insert(0, str(ROOT / "tests"))
+            from standin import StandInEngine   # (test infrastructure: tests/standin.py)
 
             Pw = w["P"]
             e = StandInEngine(len(w["x0"]), rank * len(w["x0"]), Pw.N, Pw.nx, Pw.nu, nxf=w["x0"].shape[1], device=local_rank)

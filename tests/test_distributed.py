@@ -4,6 +4,8 @@ workload, for configs[3] (sharded upright_robust scenarios, all-gather of trajec
 sweep in closed loop, all-gather of u_0 per tick) with stand-in engines; and bench.py --gpus 2 --dry-run end to end."""
 import os
 import socket
+import sys
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -11,6 +13,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from upright_amd.distributed import all_gather_solutions, shard_range
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 
 def _free_port():
@@ -59,7 +63,7 @@ def test_all_gather_ragged_split():
     _run(7)
 
 
-from upright_amd.distributed import StandInEngine
+from standin import StandInEngine
 
 
 def _bench_worker(rank, world, port, q):
@@ -188,3 +192,62 @@ def test_bench_dry_run_two_ranks():
     assert out["rank_devices"] == [[0], [1]]
     names = [e["workload"][:10] for e in out["extra_workloads"]]
     assert names == ["configs[3]", "configs[4]"] and all(e["n_gpus"] == 2 for e in out["extra_workloads"])
+
+
+def test_bench_dry_run_eight_ranks():
+    """`python bench.py --gpus 8 --dry-run --batch 1024`: the shape of the driver's 8-GPU run (8 x 1024 = BASELINE's 8192 upright_robust
+    scenarios, 8192 goals of the thrown-ball sweep) over gloo with stand-in engines.  Every rank creates its engines for device
+    LOCAL_RANK = 0 ... 7; the gathered trajectories / first inputs have 8192 rows on rank 0."""
+    import json
+    import subprocess
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parents[1] / "bench.py"), "--gpus", "8", "--dry-run", "--no-cpu-baseline",
+                        "--batch", "1024", "--steps", "2", "--warmup", "1", "--closed-loop-ticks", "2", "--extra-steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["value"] == 0.0 and out["config"]["batch_per_gpu"] == 1024
+    assert out["rank_devices"] == [[i] for i in range(8)]
+    e3, e4 = out["extra_workloads"]
+    assert e3["n_gpus"] == 8 and e4["n_gpus"] == 8
+    assert e3["gathered_rows"] == 8192 and e4["gathered_rows"] == 8192
+    assert time.time() - t0 < 120
+
+
+def _ragged_worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    # a global sample that does not divide by the world: shard_range gives the earlier ranks one more; each rank's shard is the slice
+    # of the one global sample, and the ragged all-gather returns them in instance order
+    lo, hi = shard_range(total, rank, world)
+    wg = bench.config4_workload(total, 0, 1)
+    x0, bp = wg["x0"][lo:hi], wg["body_params"][lo:hi]
+    P = wg["P"]
+    eng = StandInEngine(hi - lo, lo, P.N, P.nx, P.nu)
+    xs = torch.from_numpy(eng.xs); us = torch.from_numpy(eng.us)
+    gx, gu, counts = all_gather_solutions(xs, us)
+    ok = counts == [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)] and sum(counts) == total
+    ok = ok and gx.shape == (total, P.N + 1, P.nx) and bool(torch.all(gx[:, 0, 0] == torch.arange(total, dtype=torch.float64)))
+    ok = ok and len(x0) == hi - lo and len(bp) == hi - lo
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_ragged_shards_eight_ranks():
+    """8 ranks, 8192 + 5 scenarios: five ranks own 1025, three 1024; the gather trims the padding and keeps instance order."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, 8197, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]

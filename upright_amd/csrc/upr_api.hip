@@ -241,6 +241,7 @@ struct upr_jit_kernel {
     size_t lds = 0, ws = 0;
     int nt = 256;       // lanes per workgroup (UPR_JIT_NT: 128 | 256 | 512, experiments)
     std::string cfg;    // the template arguments, as rocprofv3 prints them
+    int fbo[7] = {0, 0, 0, 0, 0, 0, 0};   // where this instantiation leaves K, Lf^-1, Ls^-1 (fb_source): far + Ks, nq nx, far + lfi, NLF, far + lsi, NLS, SB
 };
 
 struct upr_batch {
@@ -551,46 +552,75 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
     auto it = g_jit.find(key);
     if (it != g_jit.end()) { *out = &it->second; return 0; }
     const std::string dir = jit_csrc_dir();
-    // source version: FNV-1a over the headers the kernel is made of
+    // the translation unit and its options
+    const std::string src =
+        "#include \"upr_qp3.h\"\n"
+        "typedef upr_qp3_cfg<UPR_QP3_JIT_CFG> upr_jit_cfg;\n"
+        "extern \"C\" __global__ void __launch_bounds__(upr_jit_cfg::NT, (upr_jit_cfg::NT <= 256 && upr_jit_cfg::NB == 1) ? 2 : 1) upr_qp3_jit(upr_qp_args A) {\n"
+        "    extern __shared__ __attribute__((aligned(16))) double smem[];\n"
+        "    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = upr_jit_cfg::NT;\n"
+        "    upr_qp3_solve<upr_jit_cfg>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);\n"
+        "}\n"
+        "extern \"C\" __global__ void upr_qp3_jit_info(int* out) {\n"
+        "    typedef upr_qp3_ws<upr_jit_cfg> W; typedef upr_qp3_far<upr_jit_cfg> F;\n"
+        "    out[0] = upr_qp3_lds<upr_jit_cfg>::total; out[1] = W::total;\n"
+        "    out[2] = W::far + F::Ks; out[3] = upr_jit_cfg::NQ * upr_jit_cfg::NX; out[4] = W::far + F::lfi; out[5] = upr_jit_cfg::NLF;\n"
+        "    out[6] = W::far + F::lsi; out[7] = upr_jit_cfg::NLS; out[8] = upr_jit_cfg::SB;\n"
+        "}\n";
+    const std::string inc = "-I" + dir;
+    std::string defc = std::string("-DUPR_QP3_JIT_CFG=") + cfg;
+    defc.erase(std::remove(defc.begin(), defc.end(), ' '), defc.end());
+    const std::string rinc = std::string("-I") + (getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm") + "/include";
+    std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc, rinc, defc};
+    // UPR_JIT_FLAGS: extra compiler options for experiments (e.g. "-DUPR_QP3_PROF_FLAT=3")
+    if (const char* e = getenv("UPR_JIT_FLAGS")) { std::stringstream ss(e); std::string w; while (ss >> w) optv.push_back(w); }
+    // version of the code object: FNV-1a over every header the kernel is made of (the C-ABI header with the upr_problem layout
+    // among them -- ADVICE r04: a cached kernel compiled for an older layout would read the new struct wrongly), the wrapper
+    // above, the options (the include directories excepted: they name a place, not a content) and the compiler's version
     unsigned long long hsh = 1469598103934665603ull;
-    for (const char* f : {"upr_common.h", "upr_kin.h", "upr_qp.h", "upr_qp2.h", "upr_qp3.h"}) {
+    auto mix = [&](const std::string& t) { for (unsigned char c : t) { hsh ^= c; hsh *= 1099511628211ull; } hsh ^= 0xff; hsh *= 1099511628211ull; };
+    for (const char* f : {"../../include/upright_mi.h", "upr_common.h", "upr_kin.h", "upr_qp.h", "upr_qp2.h", "upr_qp3.h"}) {
         std::string txt;
         if (!jit_read(dir + "/" + f, &txt)) return fail("run-time instantiation: cannot read " + dir + "/" + f + " (set UPR_CSRC_DIR)");
-        for (unsigned char c : txt) { hsh ^= c; hsh *= 1099511628211ull; }
+        mix(txt);
     }
-    // UPR_JIT_FLAGS: extra compiler options for experiments (e.g. "-DUPR_QP3_PROF_FLAT=3"), part of the cache key
-    std::vector<std::string> xflags;
-    if (const char* e = getenv("UPR_JIT_FLAGS")) {
-        std::stringstream ss(e); std::string w;
-        while (ss >> w) { xflags.push_back(w); for (unsigned char c : w) { hsh ^= c; hsh *= 1099511628211ull; } }
+    mix(src);
+    for (const std::string& o : optv) if (o != inc && o != rinc) mix(o);
+    { int vmaj = 0, vmin = 0; (void)hiprtcVersion(&vmaj, &vmin); mix(std::to_string(vmaj) + "." + std::to_string(vmin)); }
+    // disk cache: $UPR_JIT_CACHE, else ~/.cache/upright_amd; none when neither is known (no predictable world-writable default)
+    std::string cache;
+    if (const char* e = getenv("UPR_JIT_CACHE")) cache = e;
+    else if (const char* hm = getenv("HOME")) { if (*hm) cache = std::string(hm) + "/.cache/upright_amd"; }
+    std::string path;
+    if (!cache.empty()) {
+        (void)mkdir((cache.substr(0, cache.rfind('/'))).c_str(), 0755);
+        (void)mkdir(cache.c_str(), 0755);
+        std::string fname = cfg;
+        for (char& c : fname) if (c == ',' || c == ' ') c = '_';
+        char hx[32]; snprintf(hx, sizeof(hx), "%016llx", hsh);
+        path = cache + "/qp3_" + fname + "_" + hx + ".hsaco";
     }
-    std::string cache = getenv("UPR_JIT_CACHE") ? getenv("UPR_JIT_CACHE") : (std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/upright_amd");
-    (void)mkdir((cache.substr(0, cache.rfind('/'))).c_str(), 0755);
-    (void)mkdir(cache.c_str(), 0755);
-    std::string fname = cfg;
-    for (char& c : fname) if (c == ',' || c == ' ') c = '_';
-    char hx[32]; snprintf(hx, sizeof(hx), "%016llx", hsh);
-    const std::string path = cache + "/qp3_" + fname + "_" + hx + ".hsaco";
+    upr_jit_kernel k;
+    k.cfg = cfg; k.nt = nt;
     std::string code;
-    if (!jit_read(path, &code)) {
-        const std::string src =
-            "#include \"upr_qp3.h\"\n"
-            "typedef upr_qp3_cfg<UPR_QP3_JIT_CFG> upr_jit_cfg;\n"
-            "extern \"C\" __global__ void __launch_bounds__(upr_jit_cfg::NT, (upr_jit_cfg::NT <= 256 && upr_jit_cfg::NB == 1) ? 2 : 1) upr_qp3_jit(upr_qp_args A) {\n"
-            "    extern __shared__ __attribute__((aligned(16))) double smem[];\n"
-            "    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = upr_jit_cfg::NT;\n"
-            "    upr_qp3_solve<upr_jit_cfg>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);\n"
-            "}\n"
-            "extern \"C\" __global__ void upr_qp3_jit_info(int* out) { out[0] = upr_qp3_lds<upr_jit_cfg>::total; out[1] = upr_qp3_ws<upr_jit_cfg>::total; }\n";
-        fprintf(stderr, "libupright_mi: instantiating the production QP kernel for upr_qp3_cfg<%s> (once per machine: %s)\n", cfg, path.c_str());
+    bool loaded = false;
+    // cache file = [magic "UPRJIT01"][length of the code object][FNV-1a of it][code object]: a truncated or foreign file is recognised
+    // HERE -- the loader does not return an error for a cut-off ELF, it crashes -- dropped, and the shape compiled anew
+    auto fnv = [](const char* p, size_t n) { unsigned long long h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } return h; };
+    if (!path.empty() && jit_read(path, &code)) {
+        bool good = code.size() > 24 && memcmp(code.data(), "UPRJIT01", 8) == 0;
+        unsigned long long len = 0, sum = 0;
+        if (good) { memcpy(&len, code.data() + 8, 8); memcpy(&sum, code.data() + 16, 8); good = len == code.size() - 24 && sum == fnv(code.data() + 24, (size_t)len); }
+        if (good) code.erase(0, 24);
+        if (good && hipModuleLoadData(&k.mod, code.data()) == hipSuccess) loaded = true;
+        else { (void)hipGetLastError(); (void)unlink(path.c_str()); code.clear(); }
+    }
+    if (!loaded) {
+        fprintf(stderr, "libupright_mi: instantiating the production QP kernel for upr_qp3_cfg<%s> (once per machine: %s)\n", cfg, path.empty() ? "no disk cache" : path.c_str());
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, src.c_str(), "upr_qp3_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
-        const std::string inc = "-I" + dir, def = std::string("-DUPR_QP3_JIT_CFG=") + cfg;
-        std::string defc = def;
-        defc.erase(std::remove(defc.begin(), defc.end(), ' '), defc.end());
-        const std::string rinc = std::string("-I") + (getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm") + "/include";
-        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", inc.c_str(), rinc.c_str(), defc.c_str()};
-        for (const std::string& w : xflags) opts.push_back(w.c_str());
+        std::vector<const char*> opts;
+        for (const std::string& o : optv) opts.push_back(o.c_str());
         const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
         if (rc != HIPRTC_SUCCESS) {
             size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
@@ -601,24 +631,31 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
         size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
         code.resize(cs); hiprtcGetCode(prog, &code[0]);
         hiprtcDestroyProgram(&prog);
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        { std::ofstream f(tmp, std::ios::binary); f.write(code.data(), (std::streamsize)code.size()); }
-        (void)rename(tmp.c_str(), path.c_str());
+        if (!path.empty()) {   // written next to its final name and renamed only when every byte arrived (a full disk leaves no stub behind)
+            const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+            bool ok;
+            {
+                const unsigned long long len = code.size(), sum = fnv(code.data(), code.size());
+                std::ofstream f(tmp, std::ios::binary);
+                f.write("UPRJIT01", 8); f.write((const char*)&len, 8); f.write((const char*)&sum, 8);
+                f.write(code.data(), (std::streamsize)code.size()); f.flush(); ok = f.good();
+            }
+            if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+        }
+        UPR_HIP(hipModuleLoadData(&k.mod, code.data()));
     }
-    upr_jit_kernel k;
-    k.cfg = cfg; k.nt = nt;
-    UPR_HIP(hipModuleLoadData(&k.mod, code.data()));
     hipFunction_t info;
     UPR_HIP(hipModuleGetFunction(&k.fn, k.mod, "upr_qp3_jit"));
     UPR_HIP(hipModuleGetFunction(&info, k.mod, "upr_qp3_jit_info"));
     DevBuf<int> di;
-    if (di.alloc(2)) return 1;
+    if (di.alloc(9)) return 1;
     int* dp = di;
     void* args[] = {&dp};
     UPR_HIP(hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
-    int hi[2] = {0, 0};
+    int hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     UPR_HIP(hipMemcpy(hi, dp, sizeof(hi), hipMemcpyDeviceToHost));
     k.lds = (size_t)hi[0] * sizeof(double); k.ws = (size_t)hi[1];
+    for (int i = 0; i < 7; ++i) k.fbo[i] = hi[2 + i];
     if (k.lds > 160 * 1024) { (void)hipModuleUnload(k.mod); return fail("run-time instantiation: the working set of upr_qp3_cfg<" + std::string(cfg) + "> exceeds 160 KiB of LDS"); }
     if (k.lds > 64 * 1024) UPR_HIP(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds));
     auto ins = g_jit.emplace(key, k);
@@ -721,7 +758,7 @@ struct KernelTimer {
 
 // where the QP kernel selected for this handle keeps its per-knot factors
 upr_fb_src fb_source(const upr_batch* h) {
-    upr_fb_src s;
+    upr_fb_src s{};   // (kind 0 = no source: the caller refuses to launch)
     const upr_dims& d = h->d;
     if (h->use_qp3) {
         auto fill = [&](auto cfg) {
@@ -730,7 +767,12 @@ upr_fb_src fb_source(const upr_batch* h) {
             s.lfi_base = W::far + F::lfi; s.lfi_stride = C::NLF; s.lsi_base = W::far + F::lsi; s.lsi_stride = C::NLS; s.lsi_sb = C::SB;
         };
         // (these offsets lie in front of everything that depends on the workgroup size or on ROWS / SOFT)
-        if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
+        if (h->use_qp3 == 3 && h->jit) {   // a run-time instantiated shape: the offsets its own info kernel reported
+            const int* o = h->jit->fbo;
+            s.kind = 3; s.k_base = o[0]; s.k_stride = o[1]; s.lji_base = 0; s.lji_stride = 0;
+            s.lfi_base = o[2]; s.lfi_stride = o[3]; s.lsi_base = o[4]; s.lsi_stride = o[5]; s.lsi_sb = o[6];
+        }
+        else if (h->use_qp3 == 1) fill(upr_qp3_cfg<9, 1, 4, 3, 20, 256>());
 #define X(a, b, c, e, n, rows, sf, dense) else if (qp3_match(h->P, h->d, a, b, c, e, n, rows, sf, dense)) fill(upr_qp3_cfg<a, b, c, e, n, 256, rows, sf, dense>());
         UPR_QP3_EXTRA(X)
 #undef X
@@ -788,6 +830,7 @@ int advance_impl(upr_batch* h) {
         if (h->order_on) h->order_valid = true;
     }
     if (h->fb && !(h->fb_fused && sqp_iters > 0)) {   // sqp.use_feedback_policy: gains of the last QP, before anything overwrites its factors
+        if (fb_source(h).kind == 0) return fail("feedback gains: the selected QP kernel names no source for them");
         if (d.ne <= 6 && d.nfc <= 12) hipLaunchKernelGGL((feedback_kernel<6, 12>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
         else hipLaunchKernelGGL((feedback_kernel<6 * UPR_MAX_BODIES, 3 * UPR_MAX_CONTACTS>), dim3(h->B), dim3(256), 0, h->stream, h->dP, d, fb_source(h), h->ws, h->lin, h->Df, h->stats, h->fb);
         UPR_HIP(hipGetLastError());
@@ -1445,7 +1488,8 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     unsigned long long sig = 1469598103934665603ull;
     for (unsigned long long v : {(unsigned long long)h->has_prev, (unsigned long long)h->guess_set, (unsigned long long)sqp_now, (unsigned long long)(h->order_on && h->order_valid),
                                  (unsigned long long)(h->fb != nullptr), (unsigned long long)h->fb_fused, (unsigned long long)h->timing, (unsigned long long)(stats_out != nullptr),
-                                 (unsigned long long)h->use_qp3, (unsigned long long)h->use_qp2, (unsigned long long)h->qp_nt, (unsigned long long)(uintptr_t)h->pin}) { sig ^= v; sig *= 1099511628211ull; }
+                                 (unsigned long long)h->use_qp3, (unsigned long long)h->use_qp2, (unsigned long long)h->qp_nt, (unsigned long long)(uintptr_t)h->pin,
+                                 (unsigned long long)(uintptr_t)h->prof /* (passed BY VALUE in upr_qp_args: a graph captured before upr_batch_qp_profile allocated it would keep nullptr) */}) { sig ^= v; sig *= 1099511628211ull; }
     const bool steady = h->tick_graph_on && !h->timing && h->has_prev && !h->guess_set && h->sqp_iters_next == 0 && (!h->order_on || h->order_valid);
     if (steady && h->tick_exec && sig == h->tick_sig) {
         UPR_HIP(hipGraphLaunch(h->tick_exec, h->stream));

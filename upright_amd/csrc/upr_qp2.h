@@ -625,7 +625,7 @@ struct upr_qp2 {
     //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t
     UPR_HD double ineq_sweep(int what, double alpha, double* aux) {
         double* t = ws + w.t; double* lam = ws + w.lam; const double* rcg = ws + w.rc;
-        double acc = (what == 0) ? 1e30 : 0.0;
+        double acc = (what == 0) ? 1e30 : (what == 5 ? 1e300 : 0.0);   // (what 5: min of the trial products, aux += their sum -- UPR_QP_NGAM)
         UPR_FOR(e, n1 * D::NI) {
             const int k = e / D::NI, j = e % D::NI;
             if (!active(N, k, j)) continue;
@@ -640,6 +640,7 @@ struct upr_qp2 {
                 if (dt < 0.0) { const double a = -tj / dt; if (a < acc) acc = a; }
                 if (dl < 0.0) { const double a = -lj / dl; if (a < acc) acc = a; }
             } else if (what == 1) acc += (lj + alpha * dl) * (tj + alpha * dt);
+            else if (what == 5) { const double v = (lj + alpha * dl) * (tj + alpha * dt); acc = fmin(acc, v); *aux += v; }
             else { t[e] = tj + alpha * dt; lam[e] = lj + alpha * dl; }
         }
         UPR_SYNC();
@@ -773,6 +774,12 @@ struct upr_qp2 {
             double a = upr_reduce(ctx, L + o.red, ineq_sweep(0, 0.0, nullptr), 2);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
+            if (UPR_QP_NGAM > 0.0 && it < UPR_QP_NIT) {   // centrality safeguard (see UPR_QP_NGAM)
+                double sm = 0.0;
+                const double mn = upr_reduce(ctx, L + o.red, ineq_sweep(5, a, &sm), 2);
+                sm = upr_reduce(ctx, L + o.red, sm, 0);
+                if (!(mn >= UPR_QP_NGAM * (sm / (ntot > 0 ? ntot : 1)))) a *= UPR_QP_NBT;
+            }
             ineq_sweep(2, a, nullptr);
             UPR_FOR(e, n1 * NX) {
                 const double s = L[o.S + e];

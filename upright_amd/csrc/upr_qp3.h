@@ -25,7 +25,7 @@
 #define UPR_QP3_OFFL_PRIO 0
 #endif
 #ifndef UPR_QP3_OFFLOAD
-#define UPR_QP3_OFFLOAD 0   // 1: two-wave matrix sweep, one-body shapes: the side work of the factoring wave (feedback column, P+ b, fused predictor step) on waves 2 / 3 -- bit-identical and MEASURED SLOWER (round 4: 2.195 -> 2.235 .. 2.244 ms per headline launch), kept for A/B runs
+#define UPR_QP3_OFFLOAD 0   // 2 (round 5): the side work of the factoring wave on WAVE 2, handed over through LDS (V and the columns of Lj^-1) -- measured no gain, see backward_mat_sw2;  1 (round 4): on waves 2 / 3 with the factorisation repeated there -- bit-identical and MEASURED SLOWER (2.195 -> 2.235 .. 2.244 ms per headline launch); both kept for A/B runs
 #endif
 // ROWS_: the instantiation takes state-polytopic rows (collision / projectile).  Problems without such rows run the
 // ROWS_ = false instantiation, in which every trace of them folds away (their runtime trip counts and the runtime
@@ -159,7 +159,11 @@ struct upr_qp3_lds {
                          // OFFL (one-body shapes at 256 lanes and more, UPR_QP3_OFFLOAD): V = Lj^-1 Hux in an area of its own, [column][nq] -- Hux
                          // then has one writer (wave 1, before barrier A) and readers only between A and B (wave 0 and the wave that repeats
                          // the factorisation for the side work)
-                         sw_v = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64), sw_end = sw_v + ((C::VCPRE && C::NT >= 256 && UPR_QP3_OFFLOAD) ? r2(C::NX * C::NQ) : 0),
+                         sw_v = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
+                         // (UPR_QP3_OFFLOAD == 2: the side work's wave also needs the nq columns of Lj^-1: those live where the four-wave form
+                         // keeps Ls^-1 and Hee of the knot in work (lsik, heek: unused by the one- / two-wave sweeps) -- a separate area would
+                         // put the headline shapes over the 80 KB that two workgroups per CU leave)
+                         sw_end = sw_v + ((C::VCPRE && C::NT >= 256 && UPR_QP3_OFFLOAD) ? r2(C::NX * C::NQ) : 0),
                          // the scratch region Pa .. yN serves, at different times: the four-wave sweep's working set (Pa .. ck), the
                          // one- / two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
                          // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
@@ -172,7 +176,7 @@ struct upr_qp3_lds {
                          yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
-                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), sw_vi = lsik /* (UPR_QP3_OFFLOAD == 2, see sw_v) */, Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
                          // multi-body shapes: the contacts that load each body (indices as doubles) and their number
                          clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
@@ -737,7 +741,9 @@ struct upr_qp3 {
                     const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
                     double guf[3] = {L[O::gus + uo], L[O::gus + uo + 1], L[O::gus + uo + 2]};
                     double Hc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
                     for (int a = 0; a < 3; ++a) Hc[4 * a] = h * L[O::rd + NQ + 3 * ci + a] + L[O::wu + uo + a];
+#pragma unroll
                     for (int r = 0; r < 5; ++r) {
                         const double* e3 = L + O::erow + 3 * (5 * ci + r);
                         const double c = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
@@ -749,13 +755,20 @@ struct upr_qp3 {
                             if (mode == 1) G[F::sfr + 3 * F::sfs + 5 * ic + r] = cts_;
                         } else row(c, ds, ctP[q][r], clP[q][r], ct_, s, wgt);
                         if (mode == 1) G[F::cc + 5 * ic + r] = ct_;
-                        for (int a = 0; a < 3; ++a) { guf[a] += e3[a] * s; for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2]; }
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            guf[a] += e3[a] * s;
+#pragma unroll
+                            for (int b2 = 0; b2 < 3; ++b2) Hc[3 * a + b2] += wgt * e3[a] * e3[b2];
+                        }
                     }
+#pragma unroll
                     for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
                     if (level == 0) continue;
                     double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
                     if (factor) {
                         if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
+#pragma unroll
                         for (int a = 0; a < 9; ++a) Bk[a] = Hc[a];
                         // Z = Lf^-1 Df' of this contact (S = Z'Z + rho I is assembled in phase C); staged where the sweeps keep P
                         if (C::BIGF) {
@@ -781,8 +794,21 @@ struct upr_qp3 {
                         }
                     }
                     double yv[3], hv[3];
-                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = 0; b2 <= a; ++b2) v += Bk[3 * a + b2] * guf[b2]; yv[a] = v; }
-                    for (int a = 0; a < 3; ++a) { double v = 0.0; for (int b2 = a; b2 < 3; ++b2) v += Bk[3 * b2 + a] * yv[b2]; hv[a] = v; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int b2 = 0; b2 < 3; ++b2) if (b2 <= a) v += Bk[3 * a + b2] * guf[b2];
+                        yv[a] = v;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int b2 = 0; b2 < 3; ++b2) if (b2 >= a) v += Bk[3 * b2 + a] * yv[b2];
+                        hv[a] = v;
+                    }
+#pragma unroll
                     for (int a = 0; a < 3; ++a) { G[F::yf + k * NFC + 3 * ci + a] = yv[a]; hfp()[k * NFC + 3 * ci + a] = hv[a]; }
                 } else {
                     if (level == 0) continue;
@@ -1567,10 +1593,22 @@ struct upr_qp3 {
     }
     // the side work of knot k: feedback column (or column of Lj^-1) by back substitution and its store, the sum of P+ b, the fused
     // predictor step (wt: w~_k in, w~_{k-1} out)
+    // LINV (UPR_QP3_OFFLOAD == 2): a holds Lj^-1 (lower triangle, from the identity columns) instead of the factor: K = Lj^-T V as a
+    // triangular PRODUCT, the way the feed-forward phase forms kff (the factor itself stays in the factoring wave's registers)
+    template <bool LINV = false>
     UPR_HDI void sw2_side(int k, const double (&a)[NQ][NQ], const double (&hx)[NQ], const double (&pbv)[NQ], double& wt, int l, bool vl, int vj_,
                           double ca0, double ca1, double ca2) {
         constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
                 double kk[NQ];
+        if (LINV) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                double tt = a[i][i] * hx[i];
+#pragma unroll
+                for (int m = i + 1; m < NQ; ++m) tt += a[m][i] * hx[m];
+                kk[i] = vl ? tt : hx[i];
+            }
+        } else
 #pragma unroll
         for (int i = NQ - 1; i >= 0; --i) {
             double tt = hx[i];
@@ -1630,6 +1668,20 @@ struct upr_qp3 {
         // form: the third busy wave per workgroup (six latency-bound waves on the four SIMDs of a CU with its co-resident
         // workgroup) costs the factoring waves more than the 700 cycles per knot taken off wave 0.  Off by default.
         constexpr bool OFFL = C::VCPRE && NT >= 256 && UPR_QP3_OFFLOAD != 0;
+        // OFFL2 (round 5, UPR_QP3_OFFLOAD == 2): the same division of labour WITHOUT the repeated factorisation: wave 0 leaves what the
+        // side work needs in LDS -- its column of V = Lj^-1 [Hux | I] (it writes V for wave 1 anyway; now all nx + nq columns, the
+        // last nq of them, Lj^-1 itself, where the four-wave form keeps lsik / heek) -- and WAVE 2 alone does the side work of knot k
+        // between barriers A and B of knot k - 1 out of registers it loaded behind barrier B of knot k (before wave 0 overwrites the
+        // areas behind the next barrier A), the feedback column as the triangular PRODUCT Lj^-T V (as kff is formed) instead of a back
+        // substitution with the factor, which stays in wave 0's registers (handing the packed factor over as well -- 45 stores by one
+        // lane -- cost wave 0 1.1 k cycles per knot: 2.16 against 1.99 ms per launch).  The predictor's costate recursion stays in
+        // wave 2's registers.  Plans equal to 3e-11, iteration counts equal.
+        // MEASURED (tools/exp_flags.py, headline B = 1024): 1.9633 against 1.9705 ms per launch, i.e. nothing -- and the per-wave
+        // table (tools/r5_prof.sh, profiles/r05_offl2_phase_cycles.txt) says why: with the side work gone wave 0 waits 1.65 k cycles
+        // per knot at barrier A for wave 1, whose interval B -> A (reads of V, update of its block of P, the next Hjj / Hux: 1.3 k
+        // cycles net of the counters) was the longer of the two all along; the side work ran in its shadow.  What a knot of the sweep
+        // costs is the factorisation on wave 0 (1.8 k) plus that interval on wave 1 (1.3 k), strictly in turn.  Off by default.
+        constexpr bool OFFL2 = OFFL && UPR_QP3_OFFLOAD == 2;
         const double irho = 1.0 / UPR_QP_RHO_N;
         if (FUSE) terminal_residual();
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
@@ -1807,6 +1859,14 @@ struct upr_qp3 {
                 toc(6);
                 double a[NQ][NQ], hx[NQ];
                 sw2_factor(a, hx, vcl, ok);
+                if (OFFL2) {
+                    static_assert(!OFFL2 || (C::NQ * C::NQ <= O::r2(C::NLS) + 2 * O::r2(C::NH)), "the columns of Lj^-1 fit the area of lsik, heek");
+                    if (l < NX + NQ) {
+                        double* const dst = L + (vl ? O::sw_v + l * NQ : O::sw_vi + (l - NX) * NQ);
+#pragma unroll
+                        for (int m = 0; m < NQ; ++m) dst[m] = hx[m];
+                    }
+                } else
                 if (k > 0 && vl) {
 #pragma unroll
                     for (int m = 0; m < NQ; ++m) { if (OFFL) L[O::sw_v + l * NQ + m] = hx[m]; else L[O::sw_hx + l * HXS + m] = hx[m]; }
@@ -1825,6 +1885,42 @@ struct upr_qp3 {
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
             UPR_SETPRIO(0);
+        } else if (OFFL2) {
+            if (wave == 2) {
+                const bool vl = l < NX;
+                const int vcl = (l < NX + NQ) ? l : 0;
+                const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
+                const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
+#if UPR_QP3_OFFL_PRIO
+                UPR_SETPRIO(UPR_QP3_OFFL_PRIO);
+#endif
+                double a[NQ][NQ], hx[NQ], pbv[NQ];
+                double wt = (FUSE && vl) ? wt_terminal(l) : 0.0;
+#pragma nounroll
+                for (int k = N - 1; k >= 0; --k) {
+                    UPR_SYNC_LDS();   // A_k
+                    toc(6);
+                    if (k + 1 <= N - 1) sw2_side<true>(k + 1, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);   // (its operands were loaded behind B_{k+1})
+                    toc(7);
+                    UPR_SYNC_LDS();   // B_k: V, the factor and the partial sums of P+ b of knot k are in LDS until the next barrier A
+                    toc(8);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_vi + j * NQ + i];   // (Lj^-1)[i][j]: row i of the identity column j
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m) { hx[m] = L[(vl ? O::sw_v + l * NQ : O::sw_vi + ((l < NX + NQ) ? l - NX : 0) * NQ) + m]; pbv[m] = L[O::sw_pb + (vl ? l : 0) * HXS + m]; }
+                    // (the loads are complete before this wave arrives at the next barrier A: UPR_SYNC_LDS waits for them)
+                    toc(9);
+                }
+                sw2_side<true>(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
+#if UPR_QP3_OFFL_PRIO
+                UPR_SETPRIO(0);
+#endif
+            } else {
+#pragma nounroll
+                for (int k = N - 1; k >= 0; --k) { UPR_SYNC_LDS(); toc(6); toc(7); UPR_SYNC_LDS(); toc(8); toc(9); }
+            }
         } else if (OFFL) {
             // the side work of the factoring wave, a knot each in turn (wave 2: knots N-1, N-3, ...; wave 3: N-2, N-4, ...)
             const bool vl = l < NX;
@@ -3057,7 +3153,8 @@ struct upr_qp3 {
     }
 
     // ---- sweeps over the lane-owned rows with the current step ------------------------------------------------
-    //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t
+    //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t ;
+    //   5: partial MIN of the trial products (lam + a dlam)(t + a dt), aux += their sum (the centrality safeguard, UPR_QP_NGAM)
     UPR_HDI void sweep_row(int what, double alpha, double c, double ds, double& t, double& lam, double cterm, double& acc, double* aux) const {
         const double rp = c - t;
         if (what == 3) { const double a = fabs(rp); if (a > acc) acc = a; *aux += lam * t; return; }
@@ -3069,6 +3166,7 @@ struct upr_qp3 {
             // acc carries 1 / alpha_max: the row's limits are t / -dt and lam / -dlam (no division, no branch)
             acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
+        else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt); acc = fmin(acc, v); *aux += v; }
         else { t += alpha * dt; lam += alpha * dl; }
     }
     // softened row (see row_soft): what 3 also folds the slack pair into the residuals (|sigma - tau| into acc, gam tau into
@@ -3091,12 +3189,13 @@ struct upr_qp3 {
         const double dl = -(rc + lam * dt) * rt, dg = -(rcs + gam * dtau) * rtau;
         if (what == 0) acc = fmax(fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam))), fmax(-dtau * rtau, -dg * upr_rcp(gam)));
         else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
+        else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt), vs = (gam + alpha * dg) * (tau + alpha * dtau); acc = fmin(acc, fmin(v, vs)); *aux += v + vs; }
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
     }
     UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT], bool reload = true) {
         ftoc(10, 4);
         if (ROWMEM && reload) load_rows();   // (reload == false: the rows are still those of the sweep just before)
-        double acc = 0.0;
+        double acc = (what == 5) ? 1e300 : 0.0;
         const int tid_ = tid();
         // the far-array operands of the friction rows (one row per lane item) and of the state-polytopic rows, each class requested
         // together (SOFT: with the rows' slack pairs and the pairs' corrector targets).  Requested in front of the box rows instead,
@@ -3635,6 +3734,14 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             ftoc(7);
             if (a > 1.0) a = 1.0;
             a *= 0.995;   // see upr_qp.h
+            // centrality safeguard of the first iterations (UPR_QP_NGAM, upr_qp.h): one more pass over the rows -- the smallest trial
+            // product and their sum through one combined reduction
+            if (UPR_QP_NGAM > 0.0 && it < UPR_QP_NIT) {
+                double v4[4] = {0.0, 0.0, 0.0, 0.0};
+                v4[0] = -ineq_sweep(5, a, &v4[3], ctm, ROWMEM);   // (ROWMEM: the rows come from their parked copy again -- kept live across the reduction they go to scratch)
+                reduce4(v4);
+                if (!(-v4[0] >= UPR_QP_NGAM * (v4[3] / (ntot > 0 ? ntot : 1)))) a *= UPR_QP_NBT;
+            }
             // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass.  (The SOFT
             // instantiations too since their rows no longer live in scratch -- UPR_QP3_FUSERES_SOFT: 3.20 -> 3.07 ms; before: 3.77 -> 3.92.)
             constexpr bool FUSER = UPR_QP3_FUSERES && (!C::SOFT || UPR_QP3_FUSERES_SOFT);
