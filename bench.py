@@ -531,6 +531,15 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
         roof["achieved_issued"] = issued / (kt["qp_ms"] * 1e-3) / 1e12
         roof["frac_issued"] = roof["achieved_issued"] / PEAK_FP64_TFLOPS
         roof["issued_source"] = issued_src
+    # where the SURVEY 8(d) dense count is more than 3x what the structured kernel executes (configs[2]: the barrier
+    # term of 80 friction + 20 collision rows over (nx + nu)^2 = 84^2 entries -- a structure-exploiting kernel never forms it), a
+    # fraction of the fp64 peak priced on that count says nothing about the kernel: `frac` is then the ISSUED fraction and the
+    # model-count figure is kept beside it as `frac_model`
+    roof["frac_model"] = frac
+    roof["frac_basis"] = "SURVEY 8(d) algorithmic count"
+    if roof.get("issued_flops_per_launch") and qp_flops / roof["issued_flops_per_launch"] > 3.0:
+        roof["frac"] = roof["frac_issued"]
+        roof["frac_basis"] = "issued flops (the SURVEY 8(d) dense count is %.1fx what the structured kernel executes)" % (qp_flops / roof["issued_flops_per_launch"])
     f_exec = roof.get("frac_issued", frac)
     roof["nearest_roofline"] = "hbm" if (frac_hbm is not None and frac_hbm > f_exec) else "mfma"
     if max(f_exec, frac_hbm or 0.0) >= 0.5:
@@ -610,6 +619,16 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
             "roofline": roof_w,
             "kernel_ms": {"linearize": kw["linearize_ms"], "qp": kw["qp_ms"], "linesearch": kw["linesearch_ms"], "launches": kw["launches"]},
         }
+        if "note" in out:
+            # the cold launch of this workload times QPs that all end at the iteration cap -- not a solve rate.  The
+            # workload's `value` is the rate of the converging regime; the cap-bound launch is kept beside it, labelled
+            cold = {k: out[k] for k in ("value", "unit", "ms_per_step", "ms_per_sqp_iter", "steps", "warmup", "qp_converged_fraction", "qp_iters_mean", "roofline", "kernel_ms", "note")}
+            out["cold_start_at_the_iteration_cap"] = cold
+            wv = out["warm"]
+            out.update(value=wv["value"], ms_per_step=wv["ms_per_step"], ms_per_sqp_iter=wv["ms_per_step"], qp_converged_fraction=wv["qp_converged_fraction"],
+                       qp_iters_mean=wv["qp_iters_mean"], roofline=wv["roofline"], kernel_ms=wv["kernel_ms"], steps=n_timed)
+            out["value_is"] = "the converging regime (`warm`): " + wv["what"]
+            del out["note"]
     mpc.close()
     return out
 

@@ -350,16 +350,19 @@ def test_full_size_properties(arrangements):
     mpc.close(); mpc2.close()
 
 
-def test_closed_loop_mpc(arrangements):
+@pytest.mark.parametrize("seed", [52, 51])
+def test_closed_loop_mpc(arrangements, seed):
     """Closed loop at the reference's cadence (re-solve every 10 ms, tracking.min_policy_update_time,
     controller.yaml:33; one SQP iteration per solve, warm start from the previous plan).  The plant is the
     exact triple integrator driven by the planned jerk (mrt_node.cpp:337-345 integrates the same way), so the
     observed state is dynamically consistent.  The end effector moves toward the target, every QP converges,
-    the executed trajectory keeps the object balanced.  (Seeds 52 - 56 run clean, tools/dbg_closed_loop.py; with seed 51 and the
-    round-4 arm mount one instance spends ticks 31 - 34 with its observed state 1e-5 .. 7e-5 outside what the fixed first knot
-    allows: those four QPs end at the iteration cap, the plan is kept.)"""
+    the executed trajectory keeps the object balanced.  Seeds 52 - 56 run clean (tools/dbg_closed_loop.py).  Seed 51 (kept as
+    its own case): with the round-4 arm mount instance 3 spends ticks 31 - 34 with its observed state 1e-5 .. 7e-5
+    outside what the fixed first knot allows -- exactly those four QPs end at the iteration cap with the equality residual at
+    that size and every other residual converged, the plan is kept; asserted tick by tick."""
     B = 4
-    P, x0, way = _setup(arrangements, B, seed=52)
+    P, x0, way = _setup(arrangements, B, seed=seed)
+    capped = []
     mpc = BatchMPC(P, B, way_p=way)
     x = x0.copy()
     d0 = None
@@ -368,7 +371,12 @@ def test_closed_loop_mpc(arrangements):
         mpc.set_observation(t, x)
         mpc.advance()
         st = mpc.stats()
-        assert np.all(st["qp_status_last"] == 0), (tick, st["qp_status_last"], st["qp_iters_last"], st["qp_res_stat"], st["qp_res_eq"], st["qp_res_ineq"], st["qp_res_comp"])
+        if seed == 52:
+            assert np.all(st["qp_status_last"] == 0), (tick, st["qp_status_last"], st["qp_iters_last"], st["qp_res_stat"], st["qp_res_eq"], st["qp_res_ineq"], st["qp_res_comp"])
+        else:
+            for b in np.nonzero(st["qp_status_last"] != 0)[0]:
+                capped.append((tick, int(b)))
+                assert st["qp_status_last"][b] == 1 and 1e-6 < st["qp_res_eq"][b] < 1e-3 and st["qp_res_ineq"][b] < 1e-8 and st["qp_res_comp"][b] < 1e-8, (tick, b, st)
         assert np.all(st["step_alpha_last"] > 0)
         _, u = mpc.evaluate(t)
         j = u[:, :9]
@@ -382,6 +390,8 @@ def test_closed_loop_mpc(arrangements):
             assert core_friction_rows(P, u[:, 9:]).min() > -1e-6
     assert np.all(d < d0)                      # moved toward the target
     assert np.all(st["constraint_violation"] < 1e-2)
+    if seed == 51:
+        assert capped == [(31, 3), (32, 3), (33, 3), (34, 3)], capped
     mpc.close()
 
 
@@ -528,6 +538,24 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
     xd, u = m.step(0.012, x0)
     assert len(m.replanning_times) == n0 + 1 and xd.shape == (P.nx,) and u.shape == (P.nu,)
     assert np.all(np.isfinite(u))
+    # status of the re-plan's QP (it was not looked at).  Measured per case with tools/dbg_replan.py:
+    # * problems with friction, and frictionless ones with HPIPM slacks: converged (status 0) as the first solve;
+    # * frictionless problems with HARD object-dynamics rows on a levelled tray (ur10_demo, thing_demo without slacks): the force block
+    #   cannot span the six rows, so the stage equality gets the proximal treatment of upr_qp.h (rho = 1e-6, the interior-point
+    #   iterations double as proximal iterations).  The first solve starts on a trajectory that satisfies the rows exactly (e = 0)
+    #   and converges; the re-plan starts from a plan with a nonlinear violation of 3e-3 .. 5e-2, its proximal iteration contracts
+    #   linearly and reaches the cap (30) with the equality residual at 2e-8 .. 5e-5 and every other residual at its tolerance:
+    #   status 1 with a plan that is feasible to 1e-4 -- asserted as such;
+    # * the same with the tray 1 degree off level: infeasible first knot, cap with a residual of 6e-2 (as the first solve).
+    st2 = {k: v[0] for k, v in m.mpc._mpc.stats().items()}
+    hard_frictionless = P.nf == 1 and P.slacks is None
+    if hard_frictionless and not level:
+        assert st2["qp_status_last"] == 1
+    elif hard_frictionless:
+        assert st2["qp_status_last"] in (0, 1)
+        assert st2["qp_res_eq"] < 1e-4 and st2["qp_res_stat"] < 1e-6 and st2["qp_res_ineq"] < 1e-8 and st2["qp_res_comp"] < 1e-8, st2
+    else:
+        assert st2["qp_status_last"] == 0, st2
 
 
 # (The dice -- two stacked 20 g foam dice -- as shipped drive several friction rows of the light bodies to their bounds in the first
