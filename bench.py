@@ -583,7 +583,8 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
     B = mpc.B
     if world > 1:
         assert gathered is not None and gathered[0].shape[0] == world * B
-    roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False, key=w.get("key"))
+    cold_key = (w.get("key") + "_cold") if (warm is not None and w.get("key")) else w.get("key")   # (the counter pass keeps cold and warm launches apart)
+    roof, lin = roofline_objects(w["P"], B, kt, st, w["P"].sqp_iters, headline=False, key=cold_key)
     out = {
         "workload": w["name"], "value": B * world * steps / elapsed, "unit": "solves/s", "n_gpus": world,
         "exchange": "all-gather of solved trajectories" if world > 1 else None, "ms_per_step": 1e3 * elapsed / steps,

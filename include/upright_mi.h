@@ -266,6 +266,12 @@ int upr_batch_qp_step(upr_batch* h, double* dxs, double* dus);
  * terminal equality, lam[B][N+1][ni] of the inequality rows with ni = 2 nx + 2 nu + np + no in the slot order
  * [x lower][x upper][u lower][u upper][friction rows][collision / projectile rows]; *ni_out = ni.  Pointers may be NULL. */
 int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double* nu, double* yN, double* lam, int* ni_out);
+/* Slacks t[B][N+1][ni] of the inequality rows at the exit of the QP the last upr_batch_qp_kkt call solved (slot order of lam; 1 in
+ * slots that are not rows of the knot).  lam / t are the barrier weights of the last interior-point iterate: with the costates they
+ * are what the reference's solver-level queries -- valueFunction, valueFunctionStateDerivative,
+ * stateInputEqualityConstraintLagrangian, upright_control/src/pybindings.cpp:398-412 (ocs2 getValueFunction = the Riccati
+ * cost-to-go of the last QP, HPIPM's barrier-augmented P_k) -- are served from (upright_amd/value_function.py). */
+int upr_batch_qp_slacks(upr_batch* h, double* t);
 
 /* raw device pointers for zero-copy consumers (torch / RCCL all-gather of solved trajectories):
  * xs (B*(N+1)*nx doubles) and us (B*N*nu doubles) */

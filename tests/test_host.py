@@ -438,13 +438,13 @@ def test_production_kernels_keep_their_registers_out_of_scratch():
 
     # template arguments (nq, nb, nc, nf, N, NT, ROWS, SOFT, DENSE) -> (spilled VGPRs, scratch bytes per lane) allowed
     bounds = {
-        0: {"9ELi1ELi4ELi3ELi20ELi256ELb0ELb0ELb0": (32, 128), "9ELi1ELi4ELi3ELi20ELi256ELb1ELb0ELb0": (40, 160)},            # headline, with state-polytopic rows
+        0: {"9ELi1ELi4ELi3ELi20ELi256ELb0ELb0ELb0": (40, 160), "9ELi1ELi4ELi3ELi20ELi256ELb1ELb0ELb0": (48, 192)},            # headline, with state-polytopic rows
         1: {"9ELi1ELi4ELi3ELi20ELi256ELb0ELb1ELb0": (24, 96), "9ELi1ELi4ELi3ELi20ELi256ELb1ELb1ELb0": (48, 192),              # SOFT (313 / 404 / 196 before round 4)
             "9ELi1ELi4ELi1ELi20ELi256ELb0ELb1ELb0": (8, 32)},
-        2: {"9ELi8ELi32ELi1ELi20ELi256ELb0ELb1ELb0": (40, 0)},                                                                 # upright_robust (spills go to the other register file: no scratch)
-        3: {"9ELi3ELi16ELi3ELi20ELi256ELb1ELb0ELb1": (0, 0)},                                                                  # box_arch (811 before round 4)
-        4: {"6ELi1ELi4ELi1ELi20ELi256ELb0ELb1ELb0": (8, 32), "6ELi1ELi4ELi1ELi10ELi256ELb0ELb1ELb0": (0, 0), "6ELi1ELi4ELi3ELi20ELi256ELb0ELb0ELb0": (0, 0)},
-        5: {"9ELi2ELi8ELi3ELi20ELi256ELb0ELb0ELb1": (200, 800), "9ELi7ELi28ELi3ELi20ELi256ELb0ELb0ELb0": (0, 384)},           # dice / cups: exit code only (see the docstring)
+        2: {"9ELi8ELi32ELi1ELi20ELi256ELb0ELb1ELb0": (64, 0)},                                                                 # upright_robust (spills go to the other register file: no scratch)
+        3: {"9ELi3ELi16ELi3ELi20ELi256ELb1ELb0ELb1": (32, 0)},                                                                  # box_arch (811 before round 4; as for upright_robust: one workgroup per CU, what the allocator moves goes to the other register file -- scratch must stay 0)
+        4: {"6ELi1ELi4ELi1ELi20ELi256ELb0ELb1ELb0": (8, 32), "6ELi1ELi4ELi1ELi10ELi256ELb0ELb1ELb0": (0, 0), "6ELi1ELi4ELi3ELi20ELi256ELb0ELb0ELb0": (8, 32)},
+        5: {"9ELi2ELi8ELi3ELi20ELi256ELb0ELb0ELb1": (256, 1024), "9ELi7ELi28ELi3ELi20ELi256ELb0ELb0ELb0": (16, 448)},           # dice / cups: exit code only (see the docstring)
     }
     with ThreadPoolExecutor(3) as ex:
         res = dict(zip(bounds, ex.map(usage, [str(k) for k in bounds])))

@@ -139,6 +139,7 @@ PROTOTYPES = [
     ("upr_batch_eq_input_jacobian", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("upr_batch_qp_step", C.c_int, [C.c_void_p, dp, dp]),
     ("upr_batch_qp_kkt", C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, ip]),
+    ("upr_batch_qp_slacks", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_device_ptrs", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("upr_batch_kernel_times", C.c_int, [C.c_void_p, dp, ip]),
     ("upr_batch_enable_timing", C.c_int, [C.c_void_p, C.c_int]),

@@ -569,18 +569,33 @@ class ControllerInterface:
             c.timeStamp.push_back(ts[0, k]); c.gainArray.push_back(K[k]); c.biasArray.push_back(us[0, k] - K[k] @ xs[0, k])
         return c
 
-    # -- solver internals the accelerated path does not expose (pybindings.cpp:398-403,409-412,420-427) ------------
+    # -- solver-level queries (pybindings.cpp:398-403,409-412): answered from the last QP of the last solve ---------------------------
     def _outside(self, name):
         raise RuntimeError(f"ControllerInterface.{name} is outside the accelerated path of the MI355X engine")
 
+    def _value_function(self):
+        """upright_amd/value_function.py: the Riccati cost-to-go of the QP at the plan the last advanceMpc ended with, rebuilt on the
+        host from the primal-dual point the kernel exports (costates, multipliers and slacks); cached per solve."""
+        from .value_function import ValueFunction
+
+        key = self._mpc.last_solve_ms(), float(self._mpc.solution()[0][0, 0])
+        if getattr(self, "_vf_key", None) != key:
+            self._vf, self._vf_key = ValueFunction(self._mpc, 0), key
+        return self._vf
+
     def valueFunction(self, t, x):
-        self._outside("valueFunction")
+        """pybindings.cpp:398-399 (ocs2 getValueFunction(t, x).f): cost-to-go of the plan from t, expanded to second order in x."""
+        return float(self._value_function().value(t, x))
 
     def valueFunctionStateDerivative(self, t, x):
-        self._outside("valueFunctionStateDerivative")
+        """pybindings.cpp:400-402 (ocs2 getValueFunction(t, x).dfdx): costate of the plan at t plus P(t) (x - x*(t))."""
+        g = np.zeros(self.problem.nx_full)
+        g[:self.problem.nx] = self._value_function().gradient(t, x)
+        return g
 
     def stateInputEqualityConstraintLagrangian(self, t, x, u):
-        self._outside("stateInputEqualityConstraintLagrangian")
+        """pybindings.cpp:409-412: multipliers of the state-input equality (the object-dynamics rows) of the last QP at time t."""
+        return self._value_function().equality_multiplier(t).copy()
 
     def getStateInequalityConstraintValue(self, name, t, x):
         # the reference looks `name` up among the STATE-ONLY constraints, of which the OCP has none

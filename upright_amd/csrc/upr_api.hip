@@ -290,6 +290,7 @@ struct upr_batch {
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
+    std::vector<double> kkt_slack;   // slacks of the rows at the exit of the last upr_batch_qp_kkt ([B][N+1][ni]; upr_batch_qp_slacks)
     std::string qp_name;   // the QP kernel instantiation this handle launches
     std::vector<hipEvent_t> ev_pool, ev_free;   // events in use (pairs, in launch order) / harvested ones waiting for reuse
     std::vector<int> ev_slot;
@@ -1257,9 +1258,9 @@ int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double*
     UPR_HIP(hipMemcpy(ws.data(), h->ws, sizeof(double) * ws.size(), hipMemcpyDeviceToHost));
     if (h->use_qp3) { kk.resize((size_t)h->B * kdoubles); UPR_HIP(hipMemcpy(kk.data(), h->kkt, sizeof(double) * kk.size(), hipMemcpyDeviceToHost)); }
     const int n1 = d.N + 1;
-    int o_pi = d.ws_pi, o_nu = d.ws_nu, o_y = d.ws_yN, o_lam = d.ws_lam;
+    int o_pi = d.ws_pi, o_nu = d.ws_nu, o_y = d.ws_yN, o_lam = d.ws_lam, o_t = d.ws_t;
     if (!h->use_qp3 && h->use_qp2) {
-#define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) { upr_qp2_ws<upr_qp2_dims<a, b, c, e>> w(d.N, d.neN); o_pi = w.pi; o_nu = w.nu; o_y = w.yN; o_lam = w.lam; }
+#define X(a, b, c, e) if (h->P.nq == a && h->P.nb == b && h->P.nc == c && h->P.nf == e) { upr_qp2_ws<upr_qp2_dims<a, b, c, e>> w(d.N, d.neN); o_pi = w.pi; o_nu = w.nu; o_y = w.yN; o_lam = w.lam; o_t = w.t; }
         UPR_QP2_SHAPES(X)
 #undef X
     }
@@ -1267,9 +1268,12 @@ int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double*
         const double* w = ws.data() + (size_t)b * d.ws_stride;
         if (dxs) std::memcpy(dxs + (size_t)b * n1 * d.nx, w + d.ws_dx, sizeof(double) * n1 * d.nx);
         if (dus) std::memcpy(dus + (size_t)b * d.N * d.nu, w + d.ws_du, sizeof(double) * d.N * d.nu);
-        const double *spi, *snu, *sy, *sl;
-        if (h->use_qp3) { const double* k = kk.data() + (size_t)b * kdoubles; spi = k; snu = spi + n1 * d.nx; sy = snu + d.N * d.ne; sl = sy + d.neN; }
-        else { spi = w + o_pi; snu = w + o_nu; sy = w + o_y; sl = w + o_lam; }
+        const double *spi, *snu, *sy, *sl, *st;
+        if (h->use_qp3) { const double* k = kk.data() + (size_t)b * kdoubles; spi = k; snu = spi + n1 * d.nx; sy = snu + d.N * d.ne; sl = sy + d.neN; st = sl + (size_t)n1 * d.ni_stage; }
+        else { spi = w + o_pi; snu = w + o_nu; sy = w + o_y; sl = w + o_lam; st = w + o_t; }
+        if (b == 0) h->kkt_slack.assign((size_t)h->B * n1 * d.ni_stage, 1.0);
+        for (int k = 0; k < n1; ++k) for (int j = 0; j < d.ni_stage; ++j)
+            if (upr_ineq_active(d, k, j)) h->kkt_slack[((size_t)b * n1 + k) * d.ni_stage + j] = st[(size_t)k * d.ni_stage + j];
         if (pi) std::memcpy(pi + (size_t)b * n1 * d.nx, spi, sizeof(double) * n1 * d.nx);
         if (nu) std::memcpy(nu + (size_t)b * d.N * d.ne, snu, sizeof(double) * d.N * d.ne);
         if (yN && d.neN) std::memcpy(yN + (size_t)b * d.neN, sy, sizeof(double) * d.neN);
@@ -1280,6 +1284,15 @@ int upr_batch_qp_kkt(upr_batch* h, double* dxs, double* dus, double* pi, double*
                 lam[((size_t)b * n1 + k) * d.ni_stage + j] = upr_ineq_active(d, k, j) ? sl[(size_t)k * d.ni_stage + j] : 0.0;
         }
     }
+    return 0;
+}
+
+/* Slacks t of the inequality rows at the exit of the QP the last upr_batch_qp_kkt call solved, t[B][N+1][ni] in the slot order of its
+ * lam (1 where a slot is not a row of the knot): lam / t are the barrier weights of the last interior-point iterate. */
+int upr_batch_qp_slacks(upr_batch* h, double* t) {
+    UPR_ENTER(h);
+    if (h->kkt_slack.empty()) return fail("upr_batch_qp_slacks: no upr_batch_qp_kkt call on this handle yet");
+    if (t) std::memcpy(t, h->kkt_slack.data(), sizeof(double) * h->kkt_slack.size());
     return 0;
 }
 

@@ -87,7 +87,9 @@ struct upr_qp_args {
 };
 static UPR_HDI void upr_qp_store_key(const upr_qp_args& A, int b, int it) { if (A.iter_key) A.iter_key[b] = (unsigned char)(it < 0 ? 0 : (it > 255 ? 255 : it)); }
 static UPR_HDI int upr_qp_instance(const upr_qp_args& A, int wg) { return A.order ? A.order[wg] : wg; }
-static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + (d.N + 1) * d.ni_stage; }
+// (round 5: the slacks t of the rows behind their multipliers, same slot layout -- the barrier weights lam / t of the last iterate are
+// what the value function of the QP is built from, upright_amd/value_function.py)
+static inline UPR_HD int upr_kkt_doubles(const upr_dims& d) { return (d.N + 1) * d.nx + d.N * d.ne + d.neN + 2 * (d.N + 1) * d.ni_stage; }
 
 // LDS layout (doubles)
 struct upr_qp_lds {

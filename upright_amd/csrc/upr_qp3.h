@@ -3795,24 +3795,36 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         if (A.fb) write_feedback(A.fb + (size_t)b * N * NU * NX, status);
         if (A.kkt) {   // multipliers for upr_batch_qp_kkt, in the generic kernel's slot layout
             double* K = A.kkt + (size_t)b * A.kkt_stride;
-            const int ni = A.d.ni_stage, o_nu = N1 * NX, o_y = o_nu + N * NE, o_l = o_y + neN;
+            const int ni = A.d.ni_stage, o_nu = N1 * NX, o_y = o_nu + N * NE, o_l = o_y + neN, o_t = o_l + N1 * ni;   // (o_t: the rows' slacks, same slots)
             UPR_FORT(e, N1 * NX) K[e] = ws[W::pi + e];
             UPR_FORT(e, N * NE) K[o_nu + e] = ws[W::nu + e];
             UPR_FORT(q, neN) K[o_y + q] = L[O::yN + q];
-            UPR_FORT(e, N1 * ni) K[o_l + e] = 0.0;
+            UPR_FORT(e, N1 * ni) { K[o_l + e] = 0.0; K[o_t + e] = 1.0; }
             UPR_SYNC();
+            // (the box rows out of their parked copy -- store_rows() behind the last step, or the initial point -- not out of the
+            //  registers: an export that keeps (t, lam) alive behind the loop moves the register allocation of the loop itself,
+            //  measured + 1 % on the headline launch)
+            const double* R = G + F::rows + tid();
 #pragma unroll
             for (int q = 0; q < C::QX; ++q) {
                 const int ix = tid() + q * NT;
-                if (ix < C::NXI) { const int k = 1 + ix / NX, i = ix % NX; K[o_l + k * ni + i] = lx[q][0]; K[o_l + k * ni + NX + i] = lx[q][1]; }
+                if (ix < C::NXI) {
+                    const int k = 1 + ix / NX, i = ix % NX;
+                    K[o_t + k * ni + i] = R[(4 * q) * NT]; K[o_t + k * ni + NX + i] = R[(4 * q + 1) * NT];
+                    K[o_l + k * ni + i] = R[(4 * q + 2) * NT]; K[o_l + k * ni + NX + i] = R[(4 * q + 3) * NT];
+                }
             }
 #pragma unroll
             for (int q = 0; q < C::QU; ++q) {
                 const int iu = tid() + q * NT;
-                if (iu < C::NUI) { const int k = iu / NU, i = iu % NU; K[o_l + k * ni + 2 * NX + i] = lu[q][0]; K[o_l + k * ni + 2 * NX + NU + i] = lu[q][1]; }
+                if (iu < C::NUI) {
+                    const int k = iu / NU, i = iu % NU;
+                    K[o_t + k * ni + 2 * NX + i] = R[(4 * C::QX + 4 * q) * NT]; K[o_t + k * ni + 2 * NX + NU + i] = R[(4 * C::QX + 4 * q + 1) * NT];
+                    K[o_l + k * ni + 2 * NX + i] = R[(4 * C::QX + 4 * q + 2) * NT]; K[o_l + k * ni + 2 * NX + NU + i] = R[(4 * C::QX + 4 * q + 3) * NT];
+                }
             }
-            if (NF == 3) UPR_FORT(e, 5 * C::NCI) { const int ic = e / 5, k = ic / NC, ci = ic % NC; K[o_l + k * ni + 2 * NX + 2 * NU + 5 * ci + e % 5] = G[F::cl + e]; }
-            if (no > 0) UPR_FORT(e, (N - 1) * no) { const int k = 1 + e / no, r = e % no; K[o_l + k * ni + 2 * NX + 2 * NU + C::NP + r] = G[F::ol + (k - 1) * UPR_QP3_NOMAX + r]; }
+            if (NF == 3) UPR_FORT(e, 5 * C::NCI) { const int ic = e / 5, k = ic / NC, ci = ic % NC, sl = k * ni + 2 * NX + 2 * NU + 5 * ci + e % 5; K[o_l + sl] = G[F::cl + e]; K[o_t + sl] = G[F::ct + e]; }
+            if (no > 0) UPR_FORT(e, (N - 1) * no) { const int k = 1 + e / no, r = e % no, sl = k * ni + 2 * NX + 2 * NU + C::NP + r, ei = (k - 1) * UPR_QP3_NOMAX + r; K[o_l + sl] = G[F::ol + ei]; K[o_t + sl] = G[F::ot + ei]; }
         }
         if (tid() == 0) {
             double* st = A.stats + (size_t)b * UPR_NSTATS;

@@ -184,6 +184,8 @@ class BatchMPC:
         check(self._lib.upr_batch_qp_kkt(self._h, ptr(out["dx"]), ptr(out["du"]), ptr(out["pi"]), ptr(out["nu"]),
                                          ptr(out["yN"]) if out["yN"].size else None, ptr(out["lam"]), C.byref(ni)))
         assert ni.value == nin, (ni.value, nin)
+        out["slack"] = np.ones((self.B, self.N + 1, nin))   # the rows' slacks at the exit (lam / slack = barrier weights of the last iterate)
+        check(self._lib.upr_batch_qp_slacks(self._h, ptr(out["slack"])))
         return out
 
     def device_ptrs(self):
