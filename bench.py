@@ -634,6 +634,42 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
     return out
 
 
+def softened_row_violation(mpc, w):
+    """Largest |object-dynamics row| along every instance's plan (the rows configs[3] softens with HPIPM slacks): evaluated by the
+    constraint kernel at the plan's own knots (xs_k, us_k), k < N, with each instance's inertial parameters."""
+    P = w["P"]
+    _, xs, us = mpc.solution()
+    B, N = xs.shape[0], P.N
+    x = xs[:, :N].reshape(B * N, -1); u = us.reshape(B * N, -1)
+    out = mpc.linearize_points(x, u, t=np.tile(P.dt * np.arange(N), B), inst=np.repeat(np.arange(B), N))
+    return np.abs(out["g"]).reshape(B, N, -1).max(axis=2)      # [B][N]
+
+
+def config4_horizon_entry(B_long=64):
+    """configs[3] at BASELINE's horizon (N = 20, production kernel) and at the reference's own horizon for upright_robust
+    (upright_robust/config/demos/_base.yaml:62: T = 10 s, N = 100 -- the production kernel keeps the whole horizon in LDS and cannot
+    take it, DESIGN.md 7: the generic kernel runs it): how far the plans violate the softened balance rows.  At 2 s for a 2.2 m move
+    the rows are traded against the end-effector cost; at 10 s the same move balances."""
+    out = {"workload": "configs[3] plans at N = 20 (BASELINE) and N = 100 (the reference's own horizon): violation of the softened object-dynamics rows along the plan",
+           "unit": "max |row| (rows normalised as balancing_constraints.cpp:144-151)"}
+    for N, B in ((20, 256), (100, B_long)):
+        w = config4_workload(B)
+        w["P"].N = N
+        mpc = make_engine(w)
+        mpc.enable_timing(True)
+        t0 = time.perf_counter()
+        mpc.advance()
+        el = time.perf_counter() - t0
+        st, kt = mpc.stats(), mpc.kernel_times()
+        v = softened_row_violation(mpc, w)
+        out[f"N{N}"] = {"batch": B, "qp_kernel": kt["qp_kernel"], "ms_per_solve_of_the_batch": 1e3 * el, "qp_launch_ms": kt["qp_ms"],
+                        "qp_converged_fraction": float(np.mean(st["qp_status_last"] == 0)), "qp_iters_mean": float(np.mean(st["qp_iters_last"])),
+                        "violation_max": float(v.max()), "violation_mean_over_instances_of_max_over_knots": float(v.max(axis=1).mean()),
+                        "violation_max_first_half_of_the_plan": float(v[:, :N // 2].max()), "violation_max_last_quarter": float(v[:, 3 * N // 4:].max())}
+        mpc.close()
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -745,7 +781,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (configs[2], configs[3], configs[4])")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--closed-loop-ticks", type=int, default=150, help="control periods of the configs[4] closed-loop run")
-    ap.add_argument("--only", default=None, choices=["config3", "config4", "config5", "config5s", "contract", "headline_r03"],
+    ap.add_argument("--only", default=None, choices=["config3", "config4", "config5", "config5s", "contract", "headline_r03", "config4_horizon"],
                     help="run ONE of the other workloads alone and print its entry (the per-workload counter passes of tools/profile_all.sh)")
     ap.add_argument("--dry-run", action="store_true", help="control flow only: gloo on the CPU, stand-in engines with fake solutions; prints a line marked dry_run (never a measurement)")
     args = ap.parse_args()
@@ -801,6 +837,9 @@ def main():
     if args.only:
         if world != 1 or dry:
             raise SystemExit("bench.py --only runs on one GPU")
+        if args.only == "config4_horizon":
+            print(json.dumps(config4_horizon_entry()))
+            return
         wo = {"config3": lambda: config3_workload(4096), "config4": lambda: config4_workload(1024), "config5": lambda: config5_workload(1024),
               "config5s": lambda: config5_workload(1024, slacks=True), "contract": lambda: contract_workload(1024),
               "headline_r03": lambda: headline_r03_geometry_workload(1024)}[args.only]()
@@ -837,6 +876,7 @@ def main():
         if world == 1 and not dry:
             extra.append(contract_entry(contract_workload(1024), args.extra_steps, 1))
             extra.append(time_extra(headline_r03_geometry_workload(1024), 10, 3))
+            extra.append(config4_horizon_entry())
         extra = [_strip(e) for e in extra]
 
     rank_devices = [sorted(set(engine_devices))]
