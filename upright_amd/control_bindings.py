@@ -429,6 +429,7 @@ class ControllerInterface:
         self._mpc.set_observation(self._t, self._x)
         self._mpc.advance()
         self._first = False
+        self._solves = getattr(self, "_solves", 0) + 1   # (what the value function of the last QP is cached against)
         self.last_qp_status = int(self._mpc.stats()["qp_status_last"][0])
         if self.last_qp_status != 0 and self.settings.sqp.print_solver_status:
             # what ocs2 prints from hpipm's return code when print_solver_status is set
@@ -578,8 +579,11 @@ class ControllerInterface:
         host from the primal-dual point the kernel exports (costates, multipliers and slacks); cached per solve."""
         from .value_function import ValueFunction
 
-        key = self._mpc.last_solve_ms(), float(self._mpc.solution()[0][0, 0])
+        if self._mpc is None or getattr(self, "_solves", 0) == 0:
+            raise RuntimeError("no MPC solve yet: call advanceMpc first")
+        key = (id(self._mpc), self._solves)
         if getattr(self, "_vf_key", None) != key:
+            # (one more QP is solved at the plan: the handle's QP statistics afterwards describe that QP; last_qp_status keeps the solve's)
             self._vf, self._vf_key = ValueFunction(self._mpc, 0), key
         return self._vf
 
