@@ -716,6 +716,8 @@ int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
     // exactly the headline's contact structure (one body on the tray, four frictional contacts): every bound a constant
     if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(upr_linesearch_kernel<NQ, 64, 12, 1, true>);
+    // ... the same with collision / projectile rows (configs[4], the obstacle experiments: round 5)
+    else if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4) launch(upr_linesearch_kernel<NQ, 64, 12, 1, true, true>);
     else if (h->d.nfc <= 12 && h->d.nb == 1) launch(upr_linesearch_kernel<NQ, 64, 12, 1>);
     else launch(upr_linesearch_kernel<NQ, 64>);
     UPR_HIP(hipGetLastError());

@@ -40,7 +40,7 @@ struct upr_ls_args {
 // performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
 // NFM / NBM: compile-time bounds of nf nc / nb (the per-lane input vector and body wrenches stay in registers for the
 // small shapes: with the library-wide maxima they lived in scratch, 2 KB per lane)
-// EXACT: the problem has exactly nf = 3, nc = NFM / 3 contacts, nb = NBM bodies and no collision rows (checked by the launcher): every
+// EXACT: the problem has exactly nf = 3, nc = NFM / 3 contacts, nb = NBM bodies (checked by the launcher; OBS: with collision / projectile rows -- round 5, the thrown-ball shape): every
 // loop bound below is then a compile-time constant, the trial state, input and wrenches stay in registers (with
 // run-time bounds they were indexed dynamically: 1.2 KB of scratch per lane)
 // contact wrench on the single balanced body (contact_constraints.h:107-157 with nb = 1: every contact joins tray and body)
@@ -57,7 +57,7 @@ static UPR_HDI void upr_object_wrench_single(const upr_problem* P, const double*
         W[3] -= l1 * f2 - l2 * f1; W[4] -= l2 * f0 - l0 * f2; W[5] -= l0 * f1 - l1 * f0;
     }
 }
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
 // Xt / Ut: the trial trajectory xs + alpha dx, us + alpha du of the instance (staged by the workgroup, LDS on the device);
 // sc: (sin, cos) of the trial joint angles of every knot, [N + 1][NQ][2]
 static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double* Xt, const double* Ut, const double* sc, double* out) {
@@ -82,7 +82,7 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
             iq += wt * v * v;
         }
     }
-    if (!EXACT && d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1); EXACT: the problem has none
+    if (OBS && d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1); !OBS: the problem has none
         double dd[UPR_MAX_PAIRS + 8], xo[9 * UPR_MAX_DYN];
         if (A.dyn) for (int oi = 0; oi < P->n_dyn; ++oi) upr_obstacle_at(A.dyn + ((size_t)b * P->n_dyn + oi) * 9, k * h, xo + 9 * oi, xo + 9 * oi + 3, xo + 9 * oi + 6);
         upr_obstacle_values<NQ>(P, X, A.dyn ? xo : nullptr, A.pflag ? A.pflag[b] : 0.0, dd);
@@ -156,7 +156,7 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
 // the same terms at the CURRENT iterate (alpha = 0), where the linearisation kernel has just been: the end-effector cost, the
 // object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
 // of walking the chain again
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, bool EXACT = false>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, bool EXACT = false, bool OBS = !EXACT>
 static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, const double* xs_l, const double* us_l, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N;
@@ -182,7 +182,7 @@ static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, const d
             iq += wt * v * v;
         }
     }
-    if (!EXACT && d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
+    if (OBS && d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
     if (k < N) {
         const double* U = us_l + k * nu;
         const double* xn = X + nx;
@@ -260,7 +260,7 @@ static __device__ __forceinline__ void upr_ls_reduce4_wave(const double* part, d
 // (stage_full = 0 -- long horizons of the large shapes, where three copies do not fit: only the trial trajectory and the
 // sines / cosines live in LDS, the trajectory and the step are read where they lie)
 static UPR_HDI int upr_ls_lds_doubles(const upr_dims& d, int nt, bool full = true) { return 4 * nt + 8 + (full ? 3 : 1) * ((d.N + 1) * d.nx + d.N * d.nu) + 2 * (d.N + 1) * d.nq + 8; }
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
 static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
@@ -294,7 +294,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
     double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
     // (one pass over the knots for both sets of sums: the requests of the second set are in flight beside the first's)
     UPR_FOR(k, N + 1) {
-        upr_ls_knot_base<NQ, NFM, EXACT>(A, b, k, xs_l, us_l, part);
+        upr_ls_knot_base<NQ, NFM, EXACT, OBS>(A, b, k, xs_l, us_l, part);
         constexpr int nxc = 3 * NQ;
         double sx[nxc], xv[nxc], gq[NQ];
 #pragma unroll
@@ -346,7 +346,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
                 sc[2 * e] = s_; sc[2 * e + 1] = c_;
             }
             UPR_SYNC();
-            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT>(A, b, k, Xt, Ut, sc, p2);
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT, OBS>(A, b, k, Xt, Ut, sc, p2);
             UPR_LS_REDUCE4(p2, perf);
             double viol = sqrt(perf[1] + perf[2] + perf[3]);
             if (viol > g_max) accepted = false;
@@ -378,7 +378,7 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
 }
 
 #ifndef UPR_HOST_EMU
-template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false>
+template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
 __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
         __syncthreads();
         A.P = reinterpret_cast<const upr_problem*>(smem);
     }
-    upr_ls_instance<NQ, NFM, NBM, EXACT>(ctx, A, blockIdx.x, smem + ((NPD + 1) & ~1));
+    upr_ls_instance<NQ, NFM, NBM, EXACT, OBS>(ctx, A, blockIdx.x, smem + ((NPD + 1) & ~1));
     if (A.xs_prev) {
         __syncthreads();
         const int b = blockIdx.x, nxs = (A.d.N + 1) * A.d.nx, nus = A.d.N * A.d.nu;
