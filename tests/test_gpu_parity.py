@@ -217,7 +217,7 @@ def test_mpc_solve_one_iteration(arrangements, kernel, nt, monkeypatch):
     st = mpc.stats()
     for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
         assert np.abs(xs[b] - xo).max() < 2e-5, b
-        assert np.abs(us[b] - uo).max() < 2e-4, b
+        assert np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max()), b
         assert st["step_alpha_last"][b] == so.step_alpha_last
         assert abs(st["cost"][b] - so.cost) < 1e-6 * max(1, abs(so.cost))
         # north_star tolerance on norms
@@ -244,7 +244,7 @@ def test_mpc_solve_other_arrangements(arrangements, name, offset):
     assert np.all(st["qp_status_last"] == 0)
     for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
         assert rc == 0
-        assert np.abs(xs[b] - xo).max() < 5e-5 and np.abs(us[b] - uo).max() < 5e-4
+        assert np.abs(xs[b] - xo).max() < 5e-5 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
         assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo)) < 1e-4
         assert abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
         assert st["step_alpha_last"][b] == so.step_alpha_last
@@ -309,7 +309,7 @@ def test_warm_start_and_policy(arrangements):
         P.way_p = way[b]
         xo, uo, so, rc = Oracle(P).solve(t1, x1[b], xg, ug)
         assert np.abs(xs2[b] - xo).max() < 2e-5
-        assert np.abs(us2[b] - uo).max() < 2e-4
+        assert np.abs(us2[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
     mpc.close()
 
 
@@ -451,7 +451,7 @@ def test_soft_constraints_absorb_an_infeasible_first_knot(arrangements):
             assert np.abs(xs[b] - xo).max() < 1e-3 and st["step_alpha_last"][b] > 0
         else:
             assert st["qp_status_last"][b] == 0 and so.qp_status_last == 0
-            assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+            assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
             assert np.abs(xs[b] - xh[b]).max() < 2e-2       # L2 penalty 100: active rows give by lam / 100
     mpc.close()
 
@@ -529,7 +529,7 @@ def test_reference_call_sequence_other_configs(arrangements, name, override, lev
         assert np.abs(xs - xo).max() < 1e-3 and np.all(np.isfinite(us))
     else:
         assert rc == 0 and so.qp_status_last == 0 and st["qp_status_last"][0] == 0
-        assert np.abs(xs - xo).max() < 2e-5 and np.abs(us[:-1] - uo).max() < 2e-4
+        assert np.abs(xs - xo).max() < 2e-5 and np.abs(us[:-1] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
         assert abs(np.linalg.norm(xs) - np.linalg.norm(xo)) < 1e-4 and abs(np.linalg.norm(us[:-1]) - np.linalg.norm(uo)) < 1e-4
     # replan cadence (manager.py:158-168): no new solve before min_policy_update_time has passed
     n0 = len(m.replanning_times)
@@ -614,7 +614,7 @@ def test_paper_arrangements_through_the_manager(arrangements, name, arr, kernel,
     st = m.mpc._mpc.stats()
     assert rc == 0 and so.qp_status_last == 0 and st["qp_status_last"][0] == 0
     assert st["qp_iters_last"][0] == so.qp_iters_last
-    assert np.abs(xs - xo).max() < 1e-4 and np.abs(us[:-1] - uo).max() < 1e-3
+    assert np.abs(xs - xo).max() < 1e-4 and np.abs(us[:-1] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
     assert abs(np.linalg.norm(xs) - np.linalg.norm(xo)) < 1e-4 and abs(np.linalg.norm(us[:-1]) - np.linalg.norm(uo)) < 1e-4
 
 
@@ -857,7 +857,7 @@ def test_collision_avoidance(arrangements):
         P.way_p = way[b]
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert rc == 0 and st["qp_status_last"][b] == 0 and st["sqp_iters_done"][b] == so.sqp_iters_done
-        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b] - uo).max() < 1e-3 * max(1.0, np.abs(uo).max())   # jerks and forces
+        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())   # jerks and forces
         rows = np.array([O.obstacle_rows(xs[b, k], jac=False) for k in range(1, P.N)])
         rows_free = np.array([O.obstacle_rows(xf[b, k], jac=False) for k in range(1, P.N)])
         assert rows.min() > -1e-6 and rows[:, 0].min() < 1e-5       # base row active, nothing violated
@@ -1198,7 +1198,7 @@ def test_two_waypoint_target_interpolation(arrangements):
     _, xs, us = mpc.solution()
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
     for b, (xo, uo, so, rc) in enumerate(_oracle_solve(P, way, x0, xs0, us0)):
-        assert rc == 0 and np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+        assert rc == 0 and np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
     mpc.close()
 
 
@@ -1376,7 +1376,7 @@ def test_survey_start_distribution_status_by_status(arrangements):
     assert np.mean(gpu_status == orc_status) > 0.9
     assert 0.2 < conv.mean() < 0.45                         # 31 % of this distribution is feasible
     for b in np.flatnonzero(conv):
-        assert np.abs(xo[b] - xs[b]).max() < 1e-4 and np.abs(uo[b] - us[b]).max() < 1e-3
+        assert np.abs(xo[b] - xs[b]).max() < 1e-4 and np.abs(uo[b] - us[b]).max() < 1e-4 * max(1.0, np.abs(uo[b]).max())
         assert abs(np.linalg.norm(xo[b]) - np.linalg.norm(xs[b])) < 1e-4 and abs(np.linalg.norm(uo[b]) - np.linalg.norm(us[b])) < 1e-4
     assert np.mean(st["qp_iters_last"][conv].astype(int) == orc_iters[conv]) > 0.97    # (borderline-feasible starts sit near the tolerance)
 
@@ -1475,7 +1475,7 @@ def test_production_kernel_soft_boxes_headline_shape(arrangements):
         P.way_p = way[b]
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert rc == 0 and st["qp_status_last"][b] == 0
-        assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 2e-4
+        assert np.abs(xs[b] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
     mpc.close()
 
 
@@ -1563,7 +1563,7 @@ def test_end_effector_orientation_cost(arrangements):
         P.way_p, P.way_q = way[b], q[b]
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
         assert rc == 0 and st["qp_status_last"][b] == 0 and st["sqp_iters_done"][b] == so.sqp_iters_done
-        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b] - uo).max() < 1e-3
+        assert np.abs(xs[b] - xo).max() < 1e-4 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
         # the orientation term acts: the plan is not the position-only plan
         P0 = thing_problem(arrangements["pink_bottle"], sqp_iters=8); P0.way_t, P0.way_p = P.way_t, way[b]
         xp, _, _, _ = Oracle(P0).solve(0.0, x0[b], xs0[b], us0[b])
@@ -1731,7 +1731,7 @@ def test_edge_sizes_single_instances_and_other_horizons(arrangements, B, N):
             continue
         nconv += 1
         assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo[b])) < 1e-4 and abs(np.linalg.norm(us[b]) - np.linalg.norm(uo[b])) < 1e-4
-        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-3
+        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-4 * max(1.0, np.abs(uo[b]).max())
     assert nconv >= (B + 1) // 2
     mpc.close()
     with pytest.raises(Exception):
@@ -2041,7 +2041,7 @@ def test_two_dynamic_obstacles(arrangements):
         O = Oracle(P); O.set_dynamic_obstacle(x[b, 27:], 1.0)
         xo, uo, so, rc = O.solve(0.0, x[b, :27], xs0[b], us0[b])
         assert st["qp_status_last"][b] == so.qp_status_last == 0
-        assert np.abs(xs[b, :, :27] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 1e-3
+        assert np.abs(xs[b, :, :27] - xo).max() < 2e-5 and np.abs(us[b] - uo).max() < 1e-4 * max(1.0, np.abs(uo).max())
         assert abs(np.linalg.norm(xs[b, :, :27]) - np.linalg.norm(xo)) < 1e-4 and abs(np.linalg.norm(us[b]) - np.linalg.norm(uo)) < 1e-4
         for k in range(P.N + 1):
             t = k * P.dt
@@ -2082,7 +2082,7 @@ def test_unlisted_shape_is_instantiated_at_run_time(arrangements, monkeypatch, t
     xo, uo, so, _ = Oracle(P).solve_batch(0.0, x0, xs0, us0, way_p=way, nthreads=1)
     for b in range(B):
         assert st["qp_status_last"][b] == 0 == so[b].qp_status_last and st["qp_iters_last"][b] == so[b].qp_iters_last
-        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-3
+        assert np.abs(xs[b] - xo[b]).max() < 1e-4 and np.abs(us[b] - uo[b]).max() < 1e-4 * max(1.0, np.abs(uo[b]).max())
         assert abs(np.linalg.norm(xs[b]) - np.linalg.norm(xo[b])) < 1e-4 and abs(np.linalg.norm(us[b]) - np.linalg.norm(uo[b])) < 1e-4
     mpc.close()
     # the same shape with the switch off: the second-structure kernel, same plan
