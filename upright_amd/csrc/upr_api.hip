@@ -951,14 +951,18 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
     if (hipMalloc((void**)&h->dP, sizeof(upr_problem)) != hipSuccess) { fail("hipMalloc failed"); return bad(); }
     hipMemcpy(h->dP, P, sizeof(upr_problem), hipMemcpyHostToDevice);
     const size_t n1 = d.N + 1;
-    if (dev_alloc(&h->body_params, (size_t)B * d.nb * 10) || dev_alloc(&h->way_p, (size_t)B * P->n_way * 3) || dev_alloc(&h->way_q, (size_t)B * P->n_way * 4) || dev_alloc(&h->t0, B) ||
-        dev_alloc(&h->x0, (size_t)B * d.nx) || dev_alloc(&h->xs, (size_t)B * n1 * d.nx) || dev_alloc(&h->us, (size_t)B * d.N * d.nu) ||
+    if (dev_alloc(&h->body_params, (size_t)B * d.nb * 10) || dev_alloc(&h->way_p, (size_t)B * P->n_way * 3) || dev_alloc(&h->way_q, (size_t)B * P->n_way * 4) ||
+        // (observation: time, state and the dynamic obstacles' states in ONE block, [t B][x B nx][dyn B 9 n_dyn] -- a control period
+        //  copies it in one piece, upr_batch_tick)
+        dev_alloc(&h->t0, (((size_t)B + 1) & ~(size_t)1) + (size_t)B * d.nx + (size_t)B * 9 * P->n_dyn) || dev_alloc(&h->xs, (size_t)B * n1 * d.nx) || dev_alloc(&h->us, (size_t)B * d.N * d.nu) ||
         dev_alloc(&h->xs_prev, (size_t)B * n1 * d.nx) || dev_alloc(&h->us_prev, (size_t)B * d.N * d.nu) || dev_alloc(&h->tprev, B) ||
         dev_alloc(&h->lin, (size_t)B * n1 * d.lin_stride) || dev_alloc(&h->Df, (size_t)B * d.ne * d.nfc) ||
         dev_alloc(&h->ws, (size_t)B * d.ws_stride) || dev_alloc(&h->stats, (size_t)B * UPR_NSTATS) || dev_alloc(&h->done, B) || dev_alloc(&h->order, B) || dev_alloc(&h->iter_key, ((size_t)B + 3) & ~(size_t)3) ||
         (P->use_feedback_policy && dev_alloc(&h->fb, (size_t)B * d.N * d.nu * d.nx)) ||
-        (P->n_dyn && (dev_alloc(&h->dyn0, (size_t)B * 9 * P->n_dyn) || dev_alloc(&h->pflag, B))))
+        (P->n_dyn && dev_alloc(&h->pflag, B)))
         return bad();
+    h->x0 = h->t0 + (((size_t)B + 1) & ~(size_t)1);   // (the states stay 16-byte aligned)
+    if (P->n_dyn) h->dyn0 = h->x0 + (size_t)B * d.nx;
     hipMemcpy(h->body_params, body_params, sizeof(double) * B * d.nb * 10, hipMemcpyHostToDevice);
     hipMemcpy(h->way_p, way_p, sizeof(double) * B * P->n_way * 3, hipMemcpyHostToDevice);
     {   // target orientations default to the identity quaternion (xyzw) until upr_batch_set_target_orientations
@@ -988,13 +992,12 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
 
 void upr_batch_destroy(upr_batch* h) {
     if (!h) return;
-    hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->way_q); hipFree(h->t0); hipFree(h->x0); hipFree(h->xs); hipFree(h->us);
+    hipFree(h->dP); hipFree(h->body_params); hipFree(h->way_p); hipFree(h->way_q); hipFree(h->t0) /* (x0 and dyn0 live in the same block) */; hipFree(h->xs); hipFree(h->us);
     if (h->fb) hipFree(h->fb);
-    if (h->dyn0) hipFree(h->dyn0);
     if (h->pflag) hipFree(h->pflag);
     hipFree(h->xs_prev); hipFree(h->us_prev); hipFree(h->tprev); hipFree(h->lin); hipFree(h->Df); hipFree(h->ws); hipFree(h->stats);
     hipFree(h->done); hipFree(h->order); hipFree(h->iter_key); if (h->pin) (void)hipHostFree(h->pin); if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec); hipFree(h->prof); hipFree(h->kkt);
-    hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x); hipFree(h->ev_u);
+    hipFree(h->ev_t); hipFree(h->ev_xo); hipFree(h->ev_x) /* (ev_u: same block) */;
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1089,7 +1092,8 @@ static int evaluate_core(upr_batch* h, const double* t, int t_stride, double* x_
     UPR_ENTER(h);
     const upr_dims& d = h->d;
     // (per-tick path of the closed loop: scratch preallocated in the handle on first use)
-    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * (d.nx + d.nu)))) return 1;
+    h->ev_u = h->ev_x + (size_t)h->B * d.nx;   // (one block: a control period copies both out in one piece)
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
     UPR_HIP(hipMemcpyAsync(h->ev_t, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
@@ -1105,7 +1109,8 @@ static int evaluate_policy_core(upr_batch* h, const double* t, int t_stride, con
     UPR_ENTER(h);
     if (!h->fb) return fail("upr_batch_evaluate_policy: the batch was created with use_feedback_policy = 0");
     const upr_dims& d = h->d;
-    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * d.nx) || dev_alloc(&h->ev_u, (size_t)h->B * d.nu))) return 1;
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, (size_t)h->B * d.nx) || dev_alloc(&h->ev_x, (size_t)h->B * (d.nx + d.nu)))) return 1;
+    h->ev_u = h->ev_x + (size_t)h->B * d.nx;   // (one block: a control period copies both out in one piece)
     std::vector<double> tt(h->B);
     for (int b = 0; b < h->B; ++b) tt[b] = t[(size_t)b * (t_stride ? 1 : 0)];
     UPR_HIP(hipMemcpyAsync(h->ev_t, tt.data(), sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
@@ -1467,13 +1472,15 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     if (!t || !x || !x_out || !u_out) return fail("upr_batch_tick: null argument");
     const upr_dims& d = h->d;
     const size_t B = (size_t)h->B, nx = (size_t)d.nx, nu = (size_t)d.nu, ndyn = 9 * (size_t)h->P.n_dyn;
-    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, B * nx) || dev_alloc(&h->ev_x, B * nx) || dev_alloc(&h->ev_u, B * nu))) return 1;
-    // pinned staging: [t B][x B nx][dyn B 9 n_dyn] in, [x B nx][u B nu][stats B NSTATS] out
-    const size_t n_in = B + B * nx + B * ndyn, n_out = B * nx + B * nu + B * UPR_NSTATS;
+    if (!h->ev_t && (dev_alloc(&h->ev_t, h->B) || dev_alloc(&h->ev_xo, B * nx) || dev_alloc(&h->ev_x, B * (nx + nu)))) return 1;
+    h->ev_u = h->ev_x + B * nx;
+    // pinned staging: [t B (+ pad)][x B nx][dyn B 9 n_dyn] in (the layout of the device block h->t0), [x B nx][u B nu][stats B NSTATS] out
+    const size_t Bt = (B + 1) & ~(size_t)1;   // (the block of times is padded to an even count, as on the device)
+    const size_t n_in = Bt + B * nx + B * ndyn, n_out = B * nx + B * nu + B * UPR_NSTATS;
     if (!h->pin) {
         UPR_HIP(hipHostMalloc((void**)&h->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
     }
-    double* pt = h->pin; double* px = pt + B; double* pd = px + B * nx;
+    double* pt = h->pin; double* px = pt + Bt; double* pd = px + B * nx;
     double* ox = h->pin + n_in; double* ou = ox + B * nx; double* os = ou + B * nu;
     for (size_t b = 0; b < B; ++b) {
         pt[b] = t[b * (t_stride ? 1 : 0)];
@@ -1483,16 +1490,15 @@ int upr_batch_tick(upr_batch* h, const double* t, int t_stride, const double* x,
     auto t0c = std::chrono::steady_clock::now();
     // the stream operations of one control period
     auto enqueue = [&]() -> int {
-        UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-        UPR_HIP(hipMemcpyAsync(h->x0, px, sizeof(double) * B * nx, hipMemcpyHostToDevice, h->stream));
-        if (ndyn) UPR_HIP(hipMemcpyAsync(h->dyn0, pd, sizeof(double) * B * ndyn, hipMemcpyHostToDevice, h->stream));
+        // (round 5: one copy in and one out -- device and pinned host blocks have the same layout -- instead of three each: a copy
+        //  node of the period's graph costs about as much as a small kernel launch)
+        UPR_HIP(hipMemcpyAsync(h->t0, pt, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
         if (advance_impl(h)) return 1;
         // the policy at the observation: time t0, state x0 (both already on the device)
         if (h->fb) hipLaunchKernelGGL(evaluate_policy_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->fb, h->t0, h->x0, h->ev_x, h->ev_u);
         else hipLaunchKernelGGL(evaluate_kernel, dim3(h->B), dim3(64), 0, h->stream, h->dP, d, h->B, h->tprev, h->xs_prev, h->us_prev, h->t0, 1, h->ev_x, h->ev_u);
         UPR_HIP(hipGetLastError());
-        UPR_HIP(hipMemcpyAsync(ox, h->ev_x, sizeof(double) * B * nx, hipMemcpyDeviceToHost, h->stream));
-        UPR_HIP(hipMemcpyAsync(ou, h->ev_u, sizeof(double) * B * nu, hipMemcpyDeviceToHost, h->stream));
+        UPR_HIP(hipMemcpyAsync(ox, h->ev_x, sizeof(double) * (B * nx + B * nu), hipMemcpyDeviceToHost, h->stream));
         if (stats_out) UPR_HIP(hipMemcpyAsync(os, h->stats, sizeof(double) * B * UPR_NSTATS, hipMemcpyDeviceToHost, h->stream));
         return 0;
     };
