@@ -252,6 +252,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
 #endif
 #ifndef UPR_QP3_FUSERES
+#ifndef UPR_QP3_FUSEAFF
+#define UPR_QP3_FUSEAFF 1   // (round 5) the predictor's complementarity average from the SAME pass over the rows that finds its step length: for the affine direction lam dt + t dlam = -lam t row by row, so sum (lam + a dlam)(t + a dt) = (1 - a) sum lam t + a^2 sum dt dlam -- the pass of what == 1 and its reduction are gone (0: the two-pass form, A/B runs)
+#endif
 #define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
 #endif
 #ifndef UPR_QP3_PREC_MAX
@@ -3165,6 +3168,7 @@ struct upr_qp3 {
         if (what == 0) {
             // acc carries 1 / alpha_max: the row's limits are t / -dt and lam / -dlam (no division, no branch)
             acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
+            if (aux) *aux += dt * dl;   // (predictor, UPR_QP3_FUSEAFF: the second-order term of the complementarity average)
         } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
         else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt); acc = fmin(acc, v); *aux += v; }
         else { t += alpha * dt; lam += alpha * dl; }
@@ -3187,7 +3191,7 @@ struct upr_qp3 {
         const double dsg = -(a + w0 * ds) * rD;
         const double dt = ds + rp + dsg, dtau = dsg + rps;
         const double dl = -(rc + lam * dt) * rt, dg = -(rcs + gam * dtau) * rtau;
-        if (what == 0) acc = fmax(fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam))), fmax(-dtau * rtau, -dg * upr_rcp(gam)));
+        if (what == 0) { acc = fmax(fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam))), fmax(-dtau * rtau, -dg * upr_rcp(gam))); if (aux) *aux += dt * dl + dtau * dg; }
         else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
         else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt), vs = (gam + alpha * dg) * (tau + alpha * dtau); acc = fmin(acc, fmin(v, vs)); *aux += v + vs; }
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
@@ -3714,9 +3718,19 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 break;
             }
             { double unused[NCT]; forward<false>(unused); } toc(13);
-            double a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
-            if (a_aff > 1.0) a_aff = 1.0;
-            const double mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets(), false), 0) / ntot;
+            double a_aff, mu_aff;
+            if (UPR_QP3_FUSEAFF) {
+                double v4[4] = {0.0, 0.0, 0.0, 0.0};
+                v4[0] = -ineq_sweep(0, 0.0, &v4[3], zero_targets());   // (max of -alpha = -min alpha; v4[3]: sum of dt dlam)
+                reduce4(v4);
+                a_aff = -v4[0];
+                if (a_aff > 1.0) a_aff = 1.0;
+                mu_aff = (1.0 - a_aff) * mu + a_aff * a_aff * (v4[3] / ntot);
+            } else {
+                a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
+                if (a_aff > 1.0) a_aff = 1.0;
+                mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets(), false), 0) / ntot;
+            }
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
             if (sigma_mu < UPR_QP_SIGMA_FLOOR * tol) sigma_mu = UPR_QP_SIGMA_FLOOR * tol;
