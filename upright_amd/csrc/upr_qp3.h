@@ -733,6 +733,7 @@ struct upr_qp3 {
             G[F::heew + k * C::NH + t] = hee_kt + v / h;
         }
         // B: contacts -- friction rows, contact block and its factor, force part of the back-substitution
+        ftoc(6, 6);
         if ((C::MULTI || O::sst > O::hux) && no > 0) UPR_SYNC();   // (Z of these shapes extends over the LDS the row multipliers above were staged in)
 #pragma unroll
         for (int q = 0; q < C::QC; ++q) {
@@ -767,12 +768,21 @@ struct upr_qp3 {
                     }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
+                    ftoc(7, 6);   // (-DUPR_QP3_PROF_FLAT=6: prep B -- 6: up to its start, 7: the five rows, 8: contact factor and Z, 9: the two products)
                     if (level == 0) continue;
                     double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
+                    // (round 5: the two products below take the inverse factor out of registers where this call has just formed it
+                    //  instead of reading it back through Bk; measured neutral on the headline launch -- the compiler had forwarded
+                    //  the stores -- and kept for clarity.  Sub-stamps of this phase: tools/r5_prof.sh "-DUPR_QP3_PROF_FLAT=6")
+                    double Bv[9];
+                    if (!factor) {
+#pragma unroll
+                        for (int a = 0; a < 9; ++a) Bv[a] = Bk[a];
+                    }
                     if (factor) {
                         if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
 #pragma unroll
-                        for (int a = 0; a < 9; ++a) Bk[a] = Hc[a];
+                        for (int a = 0; a < 9; ++a) { Bk[a] = Hc[a]; Bv[a] = Hc[a]; }
                         // Z = Lf^-1 Df' of this contact (S = Z'Z + rho I is assembled in phase C); staged where the sweeps keep P
                         if (C::BIGF) {
                             // (Z is formed by the block's lane in phase D out of the factor stored above)
@@ -796,23 +806,25 @@ struct upr_qp3 {
                         }
                         }
                     }
+                    ftoc(8, 6);
                     double yv[3], hv[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         double v = 0.0;
 #pragma unroll
-                        for (int b2 = 0; b2 < 3; ++b2) if (b2 <= a) v += Bk[3 * a + b2] * guf[b2];
+                        for (int b2 = 0; b2 < 3; ++b2) if (b2 <= a) v += Bv[3 * a + b2] * guf[b2];
                         yv[a] = v;
                     }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         double v = 0.0;
 #pragma unroll
-                        for (int b2 = 0; b2 < 3; ++b2) if (b2 >= a) v += Bk[3 * b2 + a] * yv[b2];
+                        for (int b2 = 0; b2 < 3; ++b2) if (b2 >= a) v += Bv[3 * b2 + a] * yv[b2];
                         hv[a] = v;
                     }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { G[F::yf + k * NFC + 3 * ci + a] = yv[a]; hfp()[k * NFC + 3 * ci + a] = hv[a]; }
+                    ftoc(9, 6);
                 } else {
                     if (level == 0) continue;
                     const int uo = k * NU + NQ + ci;
