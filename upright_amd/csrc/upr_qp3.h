@@ -252,6 +252,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
 #endif
 #ifndef UPR_QP3_FUSERES
+#ifndef UPR_QP3_KFF_ROWS
+#define UPR_QP3_KFF_ROWS 0   // 1 (round 5): feed-forward phase with the two triangular products a row per lane, Lj^-1 staged in LDS -- bit-identical and MEASURED SLOWER (headline launch + 1.6 % fetching the factor by the row lanes themselves: eleven cache lines per lane; + 4.8 % with the staging: its index arithmetic and one more barrier cost more than twenty lanes running 90 operations behind 45 requests); kept for A/B runs
+#endif
 #ifndef UPR_QP3_FUSEAFF
 #define UPR_QP3_FUSEAFF 1   // (round 5) the predictor's complementarity average from the SAME pass over the rows that finds its step length: for the affine direction lam dt + t dlam = -lam t row by row, so sum (lam + a dlam)(t + a dt) = (1 - a) sum lam t + a^2 sum dt dlam -- the pass of what == 1 and its reduction are gone (0: the two-pass form, A/B runs)
 #endif
@@ -2654,7 +2657,45 @@ struct upr_qp3 {
         toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
 #ifndef UPR_HOST_EMU
-        if constexpr (SWANY) {
+        if constexpr (SWANY && UPR_QP3_KFF_ROWS && (NT / 64) * (64 / NQ) >= N) {
+            // (round 5, OFF: measured slower, see UPR_QP3_KFF_ROWS) the two triangular products a ROW per lane: lane (k, i) forms
+            // y_i = sum_{m <= i} Li[i][m] tv[m] and then kff_i = sum_{m >= i} Li[m][i] y[m] -- 18 of the 45 entries of Lj^-1 and 18
+            // operations where the lane-per-knot form below fetches all 45 into twenty lanes and runs 90 operations behind them.
+            // The lanes of a knot sit in one wave: the vectors cross through the feed-forward slots with wave-local ordering
+            // points.  Every sum in the order of the one-lane form: bit-identical.
+            constexpr int KPW = 64 / NQ;
+            const int ln = lane(), kl = ln / NQ, i = ln - kl * NQ;
+            const int k = (wb >> 6) * KPW + kl;
+            const bool act = kl < KPW && k < N;
+            const int kc = act ? k : 0;
+            // Lj^-1 of every knot staged in the sweeps' working set (dead here) with coalesced requests: fetched by the row lanes
+            // themselves, every lane touched eleven cache lines of its own (measured 1.6 % slower than the lane-per-knot form)
+            static_assert(O::Pa + N * NQ * NQ <= O::yN, "staging of Lj^-1");
+            UPR_FORT(e, N * NQ * NQ) { const int kk = e / (NQ * NQ), r = (e % (NQ * NQ)) / NQ, c = e % NQ; L[O::Pa + e] = G[F::Ljis + kk * NQ * NX + r * NX + c]; }
+            UPR_SYNC_LDS();
+            const double* Li = L + O::Pa + kc * NQ * NQ;
+            double lrow[NQ], lcol[NQ];
+#pragma unroll
+            for (int m = 0; m < NQ; ++m) { lrow[m] = Li[i * NQ + m]; lcol[m] = Li[m * NQ + i]; }
+            if (!fused) {
+                const double* w = Wk(kc);
+                const double tvi = L[O::gus + kc * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+                UPR_WSYNC_LDS();
+                if (act) L[O::kffs + kc * NQ + i] = tvi;
+            }
+            UPR_WSYNC_LDS();
+            double y = 0.0;
+#pragma unroll
+            for (int m = 0; m < NQ; ++m) { const double tv = L[O::kffs + kc * NQ + m]; const double yn = y + lrow[m] * tv; y = (m <= i) ? yn : y; }
+            UPR_WSYNC_LDS();
+            if (act) L[O::kffs + kc * NQ + i] = y;
+            UPR_WSYNC_LDS();
+            double t = 0.0;
+#pragma unroll
+            for (int m = 0; m < NQ; ++m) { const double ym = L[O::kffs + kc * NQ + m]; const double tn = t + lcol[m] * ym; t = (m >= i) ? tn : t; }
+            UPR_WSYNC_LDS();
+            if (act) L[O::kffs + kc * NQ + i] = t;
+        } else if constexpr (SWANY) {
             // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
             UPR_FORT(k, N) {
                 const double* Li = G + F::Ljis + k * NQ * NX;
