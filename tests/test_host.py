@@ -456,3 +456,65 @@ def test_production_kernels_keep_their_registers_out_of_scratch():
             assert len(name) == 1, (part, key, list(kernels))
             u = kernels[name[0]]
             assert u["spill"] <= spill_max and u["scratch"] <= scratch_max, (part, key, u)
+
+
+def test_value_function_recursion_against_a_dense_solve():
+    """upright_amd/value_function.py::riccati_value_function (the host-side Riccati recursion behind ControllerInterface.valueFunction*)
+    on a small synthetic problem against the brute-force answer: the Hessian of the minimised quadratic in x_0 computed by condensing
+    the whole horizon into one dense system (dynamics eliminated, softened equality rows as the penalty Z, barrier weights lam / t on
+    boxes and friction rows, proximal terminal equality).  No GPU, no oracle."""
+    import types
+
+    from upright_amd.value_function import _dynamics, record_layout, riccati_value_function
+
+    rng = np.random.default_rng(3)
+    nq, nb, nc, nf, N, h = 2, 1, 1, 3, 4, 0.1
+    nx, nfc, ne = 3 * nq, nf * nc, 6 * nb
+    nu = nq + nfc
+    P = types.SimpleNamespace(nq=nq, nx=nx, nu=nu, N=N, dt=h, nb=nb, nf=nf, nc=nc, pair_a=[], proj_sph=[], terminal_constraint=True,
+                              slacks={"poly_ineq": True, "lower_L2_penalty": 100.0}, Qdiag=rng.uniform(0.1, 1.0, nx), Rdiag=rng.uniform(0.1, 1.0, nu),
+                              xd=rng.normal(size=nx))
+    o = record_layout(P)
+    stride = o["hess"] + max(o["nh"], 3 * nq)   # (the terminal record keeps the 3 x nq position Jacobian in the Hessian slot)
+    lin = np.zeros((N + 1, stride))
+    iu = np.triu_indices(nq)
+    Hee, Cs = [], []
+    for k in range(N):
+        J = rng.normal(size=(3, nq)); Hk = J.T @ J
+        lin[k, o["hess"]:o["hess"] + o["nh"]] = Hk[iu]
+        Ck = rng.normal(size=(ne, nx)); lin[k, o["gx"]:o["gx"] + ne * nx] = Ck.ravel()
+        Hee.append(Hk); Cs.append(Ck)
+    Jp = rng.normal(size=(3, nq)); lin[N, o["hess"]:o["hess"] + 3 * nq] = Jp.ravel()
+    E = rng.normal(size=(5 * nc, nfc)); Df = rng.normal(size=(ne, nfc))
+    ni = 2 * nx + 2 * nu + 5 * nc
+    lam = rng.uniform(0.0, 2.0, (N + 1, ni)); t = rng.uniform(0.05, 2.0, (N + 1, ni))
+    sol = dict(dx=np.zeros((N + 1, nx)), du=np.zeros((N, nu)), pi=rng.normal(size=(N + 1, nx)), nu=rng.normal(size=(N, ne)), lam=lam, slack=t)
+    xs, us = rng.normal(size=(N + 1, nx)), rng.normal(size=(N, nu))
+    Pk, pk, X, U = riccati_value_function(P, xs, us, lin, sol, E, Df)
+    # ---- brute force: z = [x_0; u_0 .. u_{N-1}], x_k = Phi_k x_0 + sum Gamma_kj u_j; total quadratic 1/2 z' Hz z; V_xx = Schur complement in x_0
+    A, Bq = _dynamics(nq, h)
+    Bf = np.hstack([Bq, np.zeros((nx, nfc))])
+    nz = nx + N * nu
+    T = [np.hstack([np.eye(nx), np.zeros((nx, N * nu))])]          # x_k = T[k] z
+    for k in range(N):
+        Sel = np.zeros((nu, nz)); Sel[:, nx + k * nu:nx + (k + 1) * nu] = np.eye(nu)
+        T.append(A @ T[k] + Bf @ Sel)
+    w = lam / t
+    Hz = np.zeros((nz, nz))
+    D = np.hstack([np.zeros((ne, nq)), Df])
+    for k in range(N):
+        Sel = np.zeros((nu, nz)); Sel[:, nx + k * nu:nx + (k + 1) * nu] = np.eye(nu)
+        Hxx = h * np.diag(P.Qdiag); Hxx[:nq, :nq] += h * Hee[k]
+        if k >= 1:
+            Hxx += np.diag(w[k][:nx] + w[k][nx:2 * nx])
+        Huu = h * np.diag(P.Rdiag) + np.diag(w[k][2 * nx:2 * nx + nu] + w[k][2 * nx + nu:2 * nx + 2 * nu])
+        Huu[nq:, nq:] += E.T @ (w[k][2 * nx + 2 * nu:, None] * E)
+        R = Cs[k] @ T[k] + D @ Sel                                  # softened equality rows: penalty Z / 2 |C x + D u|^2
+        Hz += T[k].T @ Hxx @ T[k] + Sel.T @ Huu @ Sel + 100.0 * R.T @ R
+    CN = np.zeros((3 + 2 * nq, nx)); CN[:3, :nq] = -Jp; CN[3:, nq:] = np.eye(2 * nq)
+    Hz += T[N].T @ (np.diag(w[N][:nx] + w[N][nx:2 * nx]) + CN.T @ CN / 1e-6) @ T[N]
+    Hxx0, Hxu, Huu0 = Hz[:nx, :nx], Hz[:nx, nx:], Hz[nx:, nx:]
+    V = Hxx0 - Hxu @ np.linalg.solve(Huu0, Hxu.T)
+    assert np.abs(Pk[0] - V).max() < 1e-7 * np.abs(V).max(), (np.abs(Pk[0] - V).max(), np.abs(V).max())
+    assert np.abs(Pk[N] - (np.diag(w[N][:nx] + w[N][nx:2 * nx]) + CN.T @ CN / 1e-6)).max() == 0.0
+    assert np.array_equal(pk[2], sol["pi"][2])
