@@ -1059,6 +1059,15 @@ def test_kkt_conditions_of_gpu_solution_checked_in_numpy(arrangements, kernel, m
     for b in range(B):
         res = kkt_residuals(P, P.body_params, x0[b], xs0[b], us0[b], lin[b], {k: v[b] for k, v in sol.items()})
         assert res.max() < 1e-7, (b, res)
+    # the rows' slacks of the same primal-dual point (upr_batch_qp_slacks, round 5: every kernel exports them in the slot layout of
+    # lam): positive, equal to the rows' values at the solution where the kernel ended (box rows checked here), complementary
+    t, lam = sol["slack"], sol["lam"]
+    nx, nu, N = P.nx, P.nu, P.N
+    assert t.shape == lam.shape and np.all(t > 0) and np.all(lam >= 0)
+    X = xs0 + sol["dx"]; U = us0 + sol["du"]
+    assert np.abs(t[:, 1:, :nx] - (X[:, 1:] - P.x_lb)).max() < 1e-7 and np.abs(t[:, 1:, nx:2 * nx] - (P.x_ub - X[:, 1:])).max() < 1e-7
+    assert np.abs(t[:, :N, 2 * nx:2 * nx + nu] - (U - P.u_lb)).max() < 1e-7 and np.abs(t[:, :N, 2 * nx + nu:2 * nx + 2 * nu] - (P.u_ub - U)).max() < 1e-7
+    assert (t * lam).max() < 1e-7
     mpc.close()
 
 
