@@ -252,6 +252,25 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
 #endif
 #ifndef UPR_QP3_FUSERES
+#ifndef UPR_QP3_PRIO_W0
+#define UPR_QP3_PRIO_W0 3   // s_setprio of the factoring wave / of the wave that holds P in the two-wave matrix sweep (A/B runs)
+#endif
+#ifndef UPR_QP3_PRIO_FLAT
+#define UPR_QP3_PRIO_FLAT 0   // ... of every wave outside the sweeps (the knot-parallel phases)
+#endif
+#ifndef UPR_QP3_PRIO_VEC
+#define UPR_QP3_PRIO_VEC 3   // ... of the wave that runs the corrector's vector sweep / the forward sweeps
+#endif
+#ifndef UPR_QP3_PRIO_FWD
+#define UPR_QP3_PRIO_FWD 3
+#endif
+#ifndef UPR_QP3_PRIO_W1
+// (round 5) 1 for the hard-row kernels: the dispatcher puts wave 1 of one workgroup and wave 0 of its co-resident neighbour on the same
+// SIMD (tools/probe/simd_probe.hip) -- the wave every other wave waits for is the factoring wave, and with the block wave one step
+// below it the headline launch is 0.6 - 1.1 % shorter in six A/B pairs (tools/exp_flags.py; W1 = 2: -1.0 %, 0: -0.6 %, W0 = 2 with
+// W1 = 3: + 2.2 %; the vector / forward sweep waves at 2 or 1: no change).  The SOFT kernels measured 1.1 % slower with it and keep 3.
+#define UPR_QP3_PRIO_W1 (C::SOFT ? 3 : 1)
+#endif
 #ifndef UPR_QP3_KFF_ROWS
 #define UPR_QP3_KFF_ROWS 0   // 1 (round 5): feed-forward phase with the two triangular products a row per lane, Lj^-1 staged in LDS -- bit-identical and MEASURED SLOWER (headline launch + 1.6 % fetching the factor by the row lanes themselves: eleven cache lines per lane; + 4.8 % with the staging: its index arithmetic and one more barrier cost more than twenty lanes running 90 operations behind 45 requests); kept for A/B runs
 #endif
@@ -1561,7 +1580,7 @@ struct upr_qp3 {
                 for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         }
         UPR_SYNC();
     }
@@ -1705,7 +1724,7 @@ struct upr_qp3 {
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
         UPR_SYNC_LDS();
         if (wave == 1) {
-            UPR_SETPRIO(3);
+            UPR_SETPRIO(UPR_QP3_PRIO_W1);
             const bool blk = l < NBK;
             const int lc = blk ? l : NBK - 1;      // = upr_tri(NQ, bi, bj)
             int bi = 0, b0 = 0;
@@ -1856,9 +1875,9 @@ struct upr_qp3 {
                 UPR_WSYNC();   // (the reads of V precede the next knot's stores of Hux: same wave, in order)
                 toc(9);
             }
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         } else if (wave == 0) {
-            UPR_SETPRIO(3);
+            UPR_SETPRIO(UPR_QP3_PRIO_W0);
             const bool vl = l < NX;                // lanes that carry a column of Hux
             const int vcl = (l < NX + NQ) ? l : 0;  // (lanes nx .. nx + nq - 1 read a column of the identity, kept behind Hux)
             if (l >= NX && l < NX + NQ) {
@@ -1902,7 +1921,7 @@ struct upr_qp3 {
                 toc(9);
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         } else if (OFFL2) {
             if (wave == 2) {
                 const bool vl = l < NX;
@@ -1933,7 +1952,7 @@ struct upr_qp3 {
                 }
                 sw2_side<true>(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
 #if UPR_QP3_OFFL_PRIO
-                UPR_SETPRIO(0);
+                UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
 #endif
             } else {
 #pragma nounroll
@@ -1975,7 +1994,7 @@ struct upr_qp3 {
                 sw2_side(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
             }
 #if UPR_QP3_OFFL_PRIO
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
 #endif
         } else {
             vc_regs vq;
@@ -2550,7 +2569,7 @@ struct upr_qp3 {
             UPR_SYNC_LDS();
             toc(9);
         }
-        UPR_SETPRIO(0);
+        UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
         if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
@@ -2577,7 +2596,7 @@ struct upr_qp3 {
         }
         toc(11);
         if (!fused && wave0()) {
-            UPR_SETPRIO(3);
+            UPR_SETPRIO(UPR_QP3_PRIO_VEC);
             UPR_FORT(i, NX) {
                 double v = L[O::gxs + N * NX + i];
                 if (neN > 0) {
@@ -2651,7 +2670,7 @@ struct upr_qp3 {
                 }
             }
 #endif
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         }
         UPR_SYNC();
         toc(10);
@@ -2767,7 +2786,7 @@ struct upr_qp3 {
         double heeq[QH][NQ], ckc[PRE_K ? QCS : 1][PRE_K ? NE : 1];
 #endif
         if (wave0()) {
-            UPR_SETPRIO(3);
+            UPR_SETPRIO(UPR_QP3_PRIO_FWD);
             // knot 0: sx_0 = 0
             UPR_FORT(i, NX) {
                 const int b = i / NQ, j = i % NQ;
@@ -2846,7 +2865,7 @@ struct upr_qp3 {
                 }
             }
 #endif
-            UPR_SETPRIO(0);
+            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
 #ifndef UPR_HOST_EMU
             if (!ROWMEM) load_rows();   // (wave 0: in flight while the other waves run the tail)
 #endif
@@ -3626,6 +3645,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
         rho_eq = upr_qp_rho_soft(P); rho_s = upr_qp_rho_s(P, NE, NFC); rho_px = upr_qp_rho_prox(P, NE, NFC);
         prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
+        if (UPR_QP3_PRIO_FLAT != 0) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         if (prof) UPR_FORT(i, 64) L[O::prf + i] = 0.0;
         tic();
         // ---- constants and linearisation-point data into LDS
