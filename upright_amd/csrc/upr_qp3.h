@@ -255,6 +255,12 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_PRIO_W0
 #define UPR_QP3_PRIO_W0 3   // s_setprio of the factoring wave / of the wave that holds P in the two-wave matrix sweep (A/B runs)
 #endif
+#ifndef UPR_QP3_PRIO_SERIAL
+#define UPR_QP3_PRIO_SERIAL 0   // s_setprio of wave 0 in the flat phases whose work sits on a few lanes of that wave (Schur factors, feed-forward); 2 / 3 measured 0.7 - 1.1 % SLOWER (headline, round 5): off
+#endif
+#ifndef UPR_QP3_PWAVE
+#define UPR_QP3_PWAVE 1   // which physical wave holds the blocks of P in the two-wave matrix sweep; 2: + 0.8 %, 3: no change (headline, round 5)
+#endif
 #ifndef UPR_QP3_PRIO_FLAT
 #define UPR_QP3_PRIO_FLAT 0   // ... of every wave outside the sweeps (the knot-parallel phases)
 #endif
@@ -1198,6 +1204,7 @@ struct upr_qp3 {
             if (!ok) L[O::misc] = 1.0;
         } else
 #endif
+        if (UPR_QP3_PRIO_SERIAL != 0 && C::NKB <= 64 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_SERIAL);
         UPR_FORT(kb, C::NKB) {
             double* Ls = G + F::lsi + kb * SB * SB;
             double Lr[SB * SB];                                   // the inverse factor stays in registers for the two products
@@ -1294,6 +1301,7 @@ struct upr_qp3 {
                 for (int m = r; m < SB; ++m) v += Lr[m * SB + r] * yv[m];
                 L[O::ys + kb * SB + r] = yv[r]; L[O::zt + kb * SB + r] = v; }
         }
+        if (UPR_QP3_PRIO_SERIAL != 0 && C::NKB <= 64 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         UPR_SYNC(); toc(4);
         // E: cs = C' zt
 #pragma unroll
@@ -1690,7 +1698,9 @@ struct upr_qp3 {
     UPR_HDI void backward_mat_sw2() {
         constexpr int NBK = C::NH, HXS = O::HXS;
         static_assert(!SW2 || NT >= (C::VCPRE ? 128 : 256), "two waves (four where Vc is formed inside the sweep)");
-        const int wave = wb >> 6;
+        // (UPR_QP3_PWAVE: which PHYSICAL wave holds the blocks of P -- the roles of waves 1 and PWAVE are exchanged, A/B runs)
+        const int pw_ = wb >> 6;
+        const int wave = (NT >= 256 && UPR_QP3_PWAVE != 1) ? (pw_ == 1 ? UPR_QP3_PWAVE : (pw_ == UPR_QP3_PWAVE ? 1 : pw_)) : pw_;
         const int l = lane();
         constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
         // OFFL (round 4): wave 0 only factors.  Its side work per knot -- the feedback column by back substitution and its store, the
@@ -2716,6 +2726,7 @@ struct upr_qp3 {
             if (act) L[O::kffs + kc * NQ + i] = t;
         } else if constexpr (SWANY) {
             // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
+            if (UPR_QP3_PRIO_SERIAL != 0 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_SERIAL);   // (the lanes with work sit in wave 0: A/B runs)
             UPR_FORT(k, N) {
                 const double* Li = G + F::Ljis + k * NQ * NX;
                 const double* w = Wk(k);
@@ -2737,6 +2748,7 @@ struct upr_qp3 {
                     for (int m = i; m < NQ; ++m) t += li[m][i] * y[m];
                     L[O::kffs + k * NQ + i] = t; }
             }
+            if (UPR_QP3_PRIO_SERIAL != 0 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         } else
 #endif
         UPR_FORT(k, N) {
