@@ -256,7 +256,7 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #define UPR_QP3_PRIO_W0 3   // s_setprio of the factoring wave / of the wave that holds P in the two-wave matrix sweep (A/B runs)
 #endif
 #ifndef UPR_QP3_PRIO_SERIAL
-#define UPR_QP3_PRIO_SERIAL 0   // s_setprio of wave 0 in the flat phases whose work sits on a few lanes of that wave (Schur factors, feed-forward); 2 / 3 measured 0.7 - 1.1 % SLOWER (headline, round 5): off
+#define UPR_QP3_PRIO_SERIAL 0   // s_setprio of wave 0 in the feed-forward phase, whose work sits on twenty lanes of that wave (round 5: with the Schur-factor phase as well, 2 / 3 measured 0.7 - 1.1 % SLOWER on the headline): off
 #endif
 #ifndef UPR_QP3_PWAVE
 #define UPR_QP3_PWAVE 1   // which physical wave holds the blocks of P in the two-wave matrix sweep; 2: + 0.8 %, 3: no change (headline, round 5)
@@ -1204,7 +1204,6 @@ struct upr_qp3 {
             if (!ok) L[O::misc] = 1.0;
         } else
 #endif
-        if (UPR_QP3_PRIO_SERIAL != 0 && C::NKB <= 64 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_SERIAL);
         UPR_FORT(kb, C::NKB) {
             double* Ls = G + F::lsi + kb * SB * SB;
             double Lr[SB * SB];                                   // the inverse factor stays in registers for the two products
@@ -1301,7 +1300,6 @@ struct upr_qp3 {
                 for (int m = r; m < SB; ++m) v += Lr[m * SB + r] * yv[m];
                 L[O::ys + kb * SB + r] = yv[r]; L[O::zt + kb * SB + r] = v; }
         }
-        if (UPR_QP3_PRIO_SERIAL != 0 && C::NKB <= 64 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         UPR_SYNC(); toc(4);
         // E: cs = C' zt
 #pragma unroll
