@@ -2235,8 +2235,10 @@ def test_value_function_against_finite_differences(arrangements):
         h_fd, h_vf = Vp + Vm - 2.0 * V0, float(d @ Pk[0] @ d)
         worst_g = max(worst_g, abs(g_fd - g_vf) / max(abs(g_fd), 1e-12))
         worst_h = max(worst_h, abs(h_fd - h_vf) / max(abs(h_fd), 1e-12))
-        assert abs(g_fd - g_vf) < 1e-3 * abs(g_fd) + 1e-10, (trial, g_fd, g_vf)
-        assert abs(h_fd - h_vf) < 0.05 * abs(h_fd) + 1e-10, (trial, h_fd, h_vf)
+        # (measured, six directions: gradient 1.5e-4, curvature 6.8e-3 relative -- the finite differences carry the third-order
+        #  terms of the barrier and the 1e-8 accuracy of three separately converged QPs; bounds 3x / 3x the measured values)
+        assert abs(g_fd - g_vf) < 5e-4 * abs(g_fd) + 1e-10, (trial, g_fd, g_vf)
+        assert abs(h_fd - h_vf) < 0.02 * abs(h_fd) + 1e-10, (trial, h_fd, h_vf)
     print("value function vs finite differences: gradient %.1e, curvature %.1e (relative)" % (worst_g, worst_h))
     mpc.close()
 
