@@ -59,3 +59,70 @@ class StandInEngine:
 
         ctypes.memmove(xp, self.xs.ctypes.data, self.xs.nbytes)
         ctypes.memmove(up, self.us.ctypes.data, self.us.nbytes)
+
+
+def _plain(v):
+    """Settings field -> JSON-able (numbers, strings, lists, dicts), recursively over the settings classes."""
+    import enum
+
+    if isinstance(v, enum.Enum):
+        return v.name
+    if isinstance(v, (bool, int, float, str)) or v is None:
+        return v
+    if isinstance(v, (np.floating, np.integer, np.bool_)):
+        return v.item()
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, dict):
+        return {str(k): _plain(x) for k, x in sorted(v.items())}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    if hasattr(v, "get_parameters"):          # RigidBody: its ten inertial parameters (rigid_body.h:47-51)
+        return _plain(v.get_parameters())
+    if hasattr(v, "__dict__"):
+        return {k: _plain(x) for k, x in sorted(vars(v).items()) if not k.startswith("_")}
+    raise TypeError(type(v))
+
+
+# fields of ControllerSettings that are file paths of the reference's tool chain (URDF compilation, CppAD library folder):
+# not inputs of the accelerated path
+SETTINGS_PATH_FIELDS = ("robot_urdf_path", "lib_folder")
+
+
+def dump_settings(s):
+    """Every field of a `ControllerSettings` (control_bindings.py) as plain data, for the field-for-field comparison between the
+    reference's wrappers.py and upright_amd/control.py (tests/golden/make_caller_fixtures.py, tests/test_host.py)."""
+    d = _plain(s)
+    d["dims_totals"] = {k: getattr(s.dims, k)() for k in ("q", "v", "x", "f", "u")}
+    return d
+
+
+class RecordingControllerInterface:
+    """Stand-in for `bindings.ControllerInterface` that records every call its caller makes (name + arguments) and returns a
+    deterministic 'policy': after n solves, at (t, x), x_opt = 0.5 x + n, u_opt = -n - t.  TEST INFRASTRUCTURE for the
+    call-sequence comparison of manager.py against upright_amd/control.py; never a measurement."""
+
+    def __init__(self, settings):
+        self.nx, self.nu = settings.dims.x(), settings.dims.u()
+        self.calls = [["ControllerInterface", self.nx, self.nu]]
+        self.solves = 0
+
+    def reset(self, target):
+        self.calls.append(["reset", [float(t) for t in target.ts], [np.asarray(x).tolist() for x in target.xs], [np.asarray(u).tolist() for u in target.us]])
+
+    def setObservation(self, t, x, u):
+        self.calls.append(["setObservation", float(t), np.asarray(x).tolist(), np.asarray(u).tolist()])
+
+    def advanceMpc(self):
+        self.solves += 1
+        self.calls.append(["advanceMpc"])
+
+    def evaluateMpcSolution(self, t, x, x_opt, u_opt):
+        self.calls.append(["evaluateMpcSolution", float(t), np.asarray(x).tolist()])
+        x_opt[:] = 0.5 * np.asarray(x) + self.solves
+        u_opt[:] = -self.solves - t
+
+    def getMpcSolution(self, ts, xs, us):
+        self.calls.append(["getMpcSolution"])
+        for k in range(3):
+            ts.push_back(0.1 * k); xs.push_back(np.full(self.nx, float(k))); us.push_back(np.full(self.nu, -float(k)))

@@ -518,3 +518,105 @@ def test_value_function_recursion_against_a_dense_solve():
     assert np.abs(Pk[0] - V).max() < 1e-7 * np.abs(V).max(), (np.abs(Pk[0] - V).max(), np.abs(V).max())
     assert np.abs(Pk[N] - (np.diag(w[N][:nx] + w[N][nx:2 * nx]) + CN.T @ CN / 1e-6)).max() == 0.0
     assert np.array_equal(pk[2], sol["pi"][2])
+
+
+# ---- the reference's own caller against the shims (tests/golden/make_caller_fixtures.py) ---------------------------------------------
+def _tree_diff(a, b, path="", tol=None):
+    """Paths at which two JSON trees differ (numbers under a `tol` prefix: to that absolute tolerance)."""
+    out = []
+    if isinstance(a, dict) and isinstance(b, dict):
+        for k in sorted(set(a) | set(b)):
+            if k not in a or k not in b:
+                out.append(path + "/" + k + (" (missing here)" if k not in a else " (missing in the reference's)"))
+            else:
+                out += _tree_diff(a[k], b[k], path + "/" + k, tol)
+    elif isinstance(a, list) and isinstance(b, list) and len(a) == len(b):
+        for i, (x, y) in enumerate(zip(a, b)):
+            out += _tree_diff(x, y, path + "/%d" % i, tol)
+    elif a != b:
+        t = next((v for p, v in (tol or {}).items() if path.startswith(p)), None)
+        if not (t is not None and isinstance(a, float) and isinstance(b, float) and abs(a - b) <= t):
+            out.append(f"{path}: {a!r} != {b!r}")
+    return out
+
+
+_CALLER_CONFIGS = ["ur10_demo", "thing_demo", "full_bottle_point1", "full_arch_point3", "static_arch_point3", "projectile_head_on",
+                   "robust_sim", "sudden_t1.0", "full_cups_point1", "full_dice_point1", "full_bottle_arm_only"]
+
+
+@pytest.mark.parametrize("name", _CALLER_CONFIGS)
+def test_settings_field_for_field_against_the_references_wrappers(name):
+    """Row P / b2 (VERDICT r05 missing 4): `settings_from_reference_wrappers.json` is what the REFERENCE's
+    `wrappers.ControllerSettings.__init__` (wrappers.py:81-399, imported unmodified from /root/reference in the build container with
+    `upright_control.bindings := upright_amd.control_bindings`, `upright_core.bindings := upright_amd.core_bindings`) leaves in this
+    build's settings struct; `upright_amd.control.ControllerSettings` must fill the same struct identically from the same merged
+    dict -- every field, exactly, except: the arrangement parser's lengths (its own arithmetic: 1e-15) and the URDF path (the
+    reference compiles xacro files; the engine selects its chain by `robot.base_type` / `dims.q`)."""
+    import standin
+
+    ref = json.load(open(GOLD / "settings_from_reference_wrappers.json"))[name]
+    c = json.load(open(GOLD / "configs.json"))[name]["controller"]
+    ours = standin.dump_settings(control.ControllerSettings(c))
+    for k in standin.SETTINGS_PATH_FIELDS:
+        ours.pop(k), ref.pop(k)
+    d = _tree_diff(ours, ref, tol={"/balancing_settings/bodies": 1e-15, "/balancing_settings/contacts": 1e-15})
+    assert not d, d[:10]
+    assert len(ref) >= 30 and ref["dims_totals"]["x"] == len(ref["initial_state"])   # (the fixture is not empty)
+
+
+@pytest.mark.parametrize("name", ["thing_demo", "projectile_head_on", "ur10_demo"])
+def test_manager_call_sequence_equals_the_references(name, monkeypatch):
+    """`manager_call_sequence.json` records what the REFERENCE's `manager.ControllerManager` (manager.py:105-209: `from_config`,
+    `warmstart`, 50 x `step` at a 4 ms simulator period against the 10 ms controller period, `get_mpc_trajectory`, `plan`) calls on
+    `bindings.ControllerInterface`, argument by argument, and what it hands back per tick; `upright_amd.control.ControllerManager`
+    driven by the same loop against the same recording stand-in must make the same calls with the same numbers."""
+    import standin
+
+    g = json.load(open(GOLD / "manager_call_sequence.json"))[name]
+    c = json.load(open(GOLD / "configs.json"))[name]["controller"]
+    monkeypatch.setattr(control_bindings, "ControllerInterface", standin.RecordingControllerInterface)
+    mgr = control.ControllerManager.from_config(c)
+    rec = mgr.mpc
+    mgr.warmstart()
+    outs = []
+    x = np.array(mgr.model.settings.initial_state, dtype=np.float64)
+    t = 0.0
+    for i in range(50):
+        xo, uo = mgr.step(t, x)
+        outs.append([t, xo.tolist(), uo.tolist()])
+        x = xo + 1e-3 * np.cos(np.arange(len(xo)) + i)
+        t += 0.004
+    ts, xs, us = mgr.get_mpc_trajectory()
+    plan = mgr.plan(0.005, 0.1)
+    assert mgr.timestep == g["timestep"]
+    assert [cl[0] for cl in rec.calls] == [cl[0] for cl in g["calls"]]                 # the sequence itself
+    # the target handed to reset(): the reference forms it with core.math.quat_multiply on the stub robot's pose
+    d = _tree_diff(rec.calls, g["calls"], tol={"/1": 1e-14})
+    assert not d, d[:10]
+    assert not _tree_diff(outs, g["step_outputs"])
+    assert list(mgr.replanning_times) == g["replanning_times"] and mgr.last_planning_time == g["last_planning_time"]
+    assert [list(np.shape(v)) for v in (ts, xs, us)] == g["trajectory_shapes"]
+    for k, v in (("ts", plan.ts), ("xs", plan.xs), ("us", plan.us)):
+        assert np.array_equal(np.asarray(v), np.asarray(g["plan"][k])), k
+    assert sum(cl[0] == "advanceMpc" for cl in g["calls"]) > 10                           # (it did re-plan)
+
+
+def test_controller_model_kinematics_for_the_callers_logging():
+    """manager.py:14-97 (`ControllerModel.update`, `angle_between_acc_and_normal`, `ddC_we_norm`) on the chain: velocity and
+    classical acceleration of the tool link against central differences of the pose along q(t) = q + v t + a t^2 / 2."""
+    c = json.load(open(GOLD / "configs.json"))["thing_demo"]["controller"]
+    m = control.ControllerModel.from_config(c)
+    rng = np.random.default_rng(5)
+    q, v, a = rng.normal(size=9), rng.normal(size=9), rng.normal(size=9)
+    m.update(np.concatenate([q, v, a]))
+    p0, C0 = m.robot.link_pose(rotation_matrix=True)
+    ch, h = m.robot.chain, 1e-4
+    (pm, Cm), (pp, Cp) = ch.forward(q - v * h + 0.5 * a * h * h), ch.forward(q + v * h + 0.5 * a * h * h)
+    assert np.allclose((pp - pm) / (2 * h), m.robot.link_velocity()[0], atol=1e-6)
+    assert np.allclose((pp - 2 * p0 + pm) / h ** 2, m.robot.link_classical_acceleration()[0], atol=1e-5)
+    W = (Cp - Cm) / (2 * h) @ C0.T
+    assert np.allclose([W[2, 1], W[0, 2], W[1, 0]], m.robot.link_velocity()[1], atol=1e-6)
+    ddC = (Cp - 2 * C0 + Cm) / h ** 2
+    assert abs(np.linalg.norm(ddC, ord=2) - m.ddC_we_norm()) < 1e-4 * max(1.0, m.ddC_we_norm())
+    m.update(np.concatenate([q, 0 * v, 0 * a]))
+    assert abs(m.angle_between_acc_and_normal() - np.arccos(C0[2, 2])) < 1e-12           # at rest: the tray's tilt against gravity

@@ -230,13 +230,74 @@ class StateInputTrajectory:
         self.ts, self.xs, self.us = np.array(ts), np.array(xs), np.array(us)
 
 
+class ChainRobot:
+    """The part of robot.py's `PinocchioRobot` the callers of the controller use (mpc_sim.py:76,184; manager.py:31-97,
+    140-150): `forward_xu`, then the tool link's pose / velocity / classical acceleration in the world frame -- on the serial
+    chain of upright_amd/robots.py (Pinocchio and the URDF are absent here)."""
+
+    def __init__(self, settings):
+        self.dims = settings.dims
+        self.chain = robots.from_config({"base_type": bindings.robot_base_type_to_string(settings.robot_base_type),
+                                         "dims": {"q": settings.dims.robot.q}, "base_pose": list(settings.base_pose)})
+        self._m = None
+
+    def forward_xu(self, x, u=None):
+        d = self.dims.robot
+        x = np.asarray(x, dtype=np.float64)
+        self._m = self.chain.forward_motion(x[: d.q], x[d.q: d.q + d.v], x[d.q + d.v: d.q + 2 * d.v])
+
+    forward = forward_xu
+
+    def link_pose(self, rotation_matrix=False):
+        p, C = self._m[0], self._m[1]
+        return (p, C) if rotation_matrix else (p, rot_to_quat_xyzw(C))
+
+    def link_velocity(self):
+        return self._m[2], self._m[3]
+
+    def link_classical_acceleration(self):
+        return self._m[4], self._m[5]
+
+
+class ControllerModel:
+    """manager.py:14-97: the settings plus a kinematic model of the robot for the caller's own logging."""
+
+    def __init__(self, settings):
+        self.settings = settings
+        self.robot, self.geom = ChainRobot(settings), None
+
+    @classmethod
+    def from_config(cls, config, x0=None, bodies=None, contacts=None):
+        return cls(ControllerSettings(config, x0=x0, bodies=bodies, contacts=contacts))
+
+    def update(self, x, u=None):
+        self.robot.forward_xu(x, u)
+
+    def angle_between_acc_and_normal(self):
+        """manager.py:66-86: angle between the tray normal and the total (inertial + gravitational) acceleration."""
+        C_we = self.robot.link_pose(rotation_matrix=True)[1]
+        a_ew_w, _ = self.robot.link_classical_acceleration()
+        total = a_ew_w - np.asarray(self.settings.gravity)
+        return np.arccos(C_we[:, 2] @ (total / np.linalg.norm(total)))
+
+    def ddC_we_norm(self):
+        """manager.py:88-97: spectral norm of the second time derivative of the tray's rotation matrix."""
+        C_we = self.robot.link_pose(rotation_matrix=True)[1]
+        w = self.robot.link_velocity()[1]
+        al = self.robot.link_classical_acceleration()[1]
+        S = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])   # noqa: E731
+        return np.linalg.norm((S(al) + S(w) @ S(w)) @ C_we, ord=2)
+
+
 class ControllerManager:
     """One controller in closed loop (the role of manager.py:100-209): owns a `bindings.ControllerInterface`, feeds
     it every observation, re-solves on the schedule above and hands back the policy's state / input for the tick.
-    Attribute and method names are the reference's, so mpc_sim.py-style loops run unchanged."""
+    Attribute and method names are the reference's, so mpc_sim.py-style loops run unchanged; the first argument is a
+    `ControllerModel` as in the reference (a bare `ControllerSettings` is wrapped into one)."""
 
-    def __init__(self, settings, ref_trajectory, timestep):
-        self.settings = settings
+    def __init__(self, model, ref_trajectory, timestep):
+        self.model = model if hasattr(model, "settings") else ControllerModel(model)
+        settings = self.settings = self.model.settings
         self.ref = ref_trajectory
         self.timestep = timestep
         self.schedule = ReplanSchedule(timestep)
@@ -255,11 +316,11 @@ class ControllerManager:
     def from_config(cls, config, x0=None, bodies=None, contacts=None):
         """Controller dict -> manager whose target is the configured waypoints relative to the end-effector pose at
         the initial state (wrappers.py:31-43)."""
-        settings = ControllerSettings(config, x0=x0, bodies=bodies, contacts=contacts)
-        q0 = settings.initial_state[: settings.dims.robot.q]
-        r_ew_w, C_we = robots.from_config(config["robot"]).forward(q0)
-        target = TargetTrajectories.from_config(config, r_ew_w, rot_to_quat_xyzw(C_we), np.zeros(settings.dims.u()))
-        return cls(settings, target, config["tracking"]["min_policy_update_time"])
+        model = ControllerModel.from_config(config, x0=x0, bodies=bodies, contacts=contacts)
+        model.update(x=model.settings.initial_state)          # manager.py:131-133
+        r_ew_w, Q_we = model.robot.link_pose()
+        target = TargetTrajectories.from_config(config, r_ew_w, Q_we, np.zeros(model.settings.dims.u()))
+        return cls(model, target, config["tracking"]["min_policy_update_time"])
 
     def update(self, ref):
         self.ref = ref

@@ -118,6 +118,32 @@ class Chain:
         R = R @ self.tool_R
         return o, R
 
+    def forward_motion(self, q, v, a):
+        """EE pose, spatial velocity and CLASSICAL acceleration in the world frame: (p, C, v, omega, a, alpha) -- what
+        robot.py's `link_pose`, `link_velocity` and `link_classical_acceleration` return for the tool link.  Plain numpy
+        outward recursion over the serial chain (the host-side twin of upr_kin.h's value walk)."""
+        R = np.eye(3)
+        o = np.zeros(3); vo = np.zeros(3); ao = np.zeros(3); w = np.zeros(3); al = np.zeros(3)
+
+        def shift(r):   # the point at r (world coordinates, from o) of the body that carries (vo, ao, w, al)
+            return o + r, vo + np.cross(w, r), ao + np.cross(al, r) + np.cross(w, np.cross(w, r))
+
+        for j, qi, vi, ai in zip(self.joints, q, v, a):
+            o, vo, ao = shift(R @ j.p)
+            R = R @ j.R
+            z = R @ j.axis
+            if j.kind == REVOLUTE:
+                al = al + z * ai + np.cross(w, z) * vi
+                w = w + z * vi
+                R = R @ _axis_rot(j.axis, qi)
+            else:
+                o = o + z * qi
+                ao = ao + z * ai + 2.0 * np.cross(w, z) * vi
+                vo = vo + z * vi
+        o, vo, ao = shift(R @ self.tool_p)
+        R = R @ self.tool_R
+        return o, R, vo, w, ao, al
+
 
 def _axis_rot(ax, th):
     ax = np.asarray(ax, dtype=float)
