@@ -236,6 +236,10 @@ double upr_batch_last_solve_ms(const upr_batch* h);
  *  qp_res_stat, qp_res_eq, qp_res_ineq, qp_res_comp, dx_norm, du_norm] */
 #define UPR_NSTATS 12
 int upr_batch_get_stats(upr_batch* h, double* stats);
+/* restore == 0: keep a copy of the statistics and of the QP dispatch keys of the last advance; restore != 0: put it back.  Brackets
+ * a solver-level query that solves one more QP on the handle (upr_batch_qp_kkt behind ControllerInterface.valueFunction,
+ * pybindings.cpp:398-403): afterwards the statistics describe the solve again (ocs2's getValueFunction does not disturb its solver). */
+int upr_batch_hold_stats(upr_batch* h, int restore);
 
 /* ------------------------------------------------------------------------------------------------
  * Term-level access (ControllerInterface.getStateInputEqualityConstraintValue("object_dynamics"),

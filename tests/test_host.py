@@ -462,7 +462,9 @@ def test_value_function_recursion_against_a_dense_solve():
     """upright_amd/value_function.py::riccati_value_function (the host-side Riccati recursion behind ControllerInterface.valueFunction*)
     on a small synthetic problem against the brute-force answer: the Hessian of the minimised quadratic in x_0 computed by condensing
     the whole horizon into one dense system (dynamics eliminated, softened equality rows as the penalty Z, barrier weights lam / t on
-    boxes and friction rows, proximal terminal equality).  No GPU, no oracle."""
+    HARD boxes and friction rows, proximal terminal equality).  No GPU, no oracle.  (Softened inequality rows are factored with a
+    different weight, which needs the slack's own barrier pair: ControllerInterface refuses the queries for such problems --
+    test_value_function_queries_refused_with_softened_inequality_rows.)"""
     import types
 
     from upright_amd.value_function import _dynamics, record_layout, riccati_value_function
@@ -472,7 +474,7 @@ def test_value_function_recursion_against_a_dense_solve():
     nx, nfc, ne = 3 * nq, nf * nc, 6 * nb
     nu = nq + nfc
     P = types.SimpleNamespace(nq=nq, nx=nx, nu=nu, N=N, dt=h, nb=nb, nf=nf, nc=nc, pair_a=[], proj_sph=[], terminal_constraint=True,
-                              slacks={"poly_ineq": True, "lower_L2_penalty": 100.0}, Qdiag=rng.uniform(0.1, 1.0, nx), Rdiag=rng.uniform(0.1, 1.0, nu),
+                              slacks={"equality": True, "lower_L2_penalty": 100.0}, Qdiag=rng.uniform(0.1, 1.0, nx), Rdiag=rng.uniform(0.1, 1.0, nu),
                               xd=rng.normal(size=nx))
     o = record_layout(P)
     stride = o["hess"] + max(o["nh"], 3 * nq)   # (the terminal record keeps the 3 x nq position Jacobian in the Hessian slot)
@@ -518,6 +520,22 @@ def test_value_function_recursion_against_a_dense_solve():
     assert np.abs(Pk[0] - V).max() < 1e-7 * np.abs(V).max(), (np.abs(Pk[0] - V).max(), np.abs(V).max())
     assert np.abs(Pk[N] - (np.diag(w[N][:nx] + w[N][nx:2 * nx]) + CN.T @ CN / 1e-6)).max() == 0.0
     assert np.array_equal(pk[2], sol["pi"][2])
+
+
+def test_value_function_queries_refused_with_softened_inequality_rows(arrangements):
+    """with HPIPM slacks on inequality rows (thing_demo.yaml, upright_robust's _base.yaml) the rebuilt cost-to-go would use
+    lam / t where the kernels factor w0 (Z + gam / tau) / (Z + w0 + gam / tau): the three solver-level queries raise instead of
+    answering wrongly; likewise with dynamic obstacles (no multiplier export), and before any solve on the current target."""
+    g = json.load(open(GOLD / "configs.json"))
+    for name, msg in (("thing_demo", "HPIPM slacks"), ("projectile_head_on", "dynamic obstacles"), ("full_bottle_point1", "no MPC solve yet")):
+        ci = control_bindings.ControllerInterface(control.ControllerSettings(g[name]["controller"]))
+        x = np.array(ci.settings.initial_state)
+        for call in (lambda: ci.valueFunction(0.0, x), lambda: ci.valueFunctionStateDerivative(0.0, x)):
+            with pytest.raises(RuntimeError, match=msg):
+                call()
+        # the equality multipliers need no barrier weights: with slacks that query only waits for a solve
+        with pytest.raises(RuntimeError, match="no MPC solve yet" if name != "projectile_head_on" else msg):
+            ci.stateInputEqualityConstraintLagrangian(0.0, x, np.zeros(ci.problem.nu))
 
 
 # ---- the reference's own caller against the shims (tests/golden/make_caller_fixtures.py) ---------------------------------------------

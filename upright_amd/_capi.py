@@ -133,6 +133,7 @@ PROTOTYPES = [
     ("upr_batch_get_feedback", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_last_solve_ms", C.c_double, [C.c_void_p]),
     ("upr_batch_get_stats", C.c_int, [C.c_void_p, dp]),
+    ("upr_batch_hold_stats", C.c_int, [C.c_void_p, C.c_int]),
     ("upr_batch_linearize_points", C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
     ("upr_batch_set_projectile_flag", C.c_int, [C.c_void_p, dp]),
     ("upr_batch_obstacle_rows", C.c_int, [C.c_void_p, C.c_int, dp, dp, dp]),

@@ -382,6 +382,7 @@ class ControllerInterface:
         self._t = 0.0
         self._x = np.array(settings.initial_state, dtype=np.float64)
         self._first = True
+        self._solves, self._vf, self._vf_key = 0, None, None
         self.last_qp_status = 0   # hpipm status of the last solve's final QP: 0 solved, 1 iteration limit, 2 numerical failure
 
     def _set_target(self, target):
@@ -402,6 +403,7 @@ class ControllerInterface:
             x0t = np.asarray(target.xs[0], dtype=np.float64)
             self._mpc.set_projectile_flag(float(x0t[7]) if x0t.size > 7 else 0.0)
         self._first = True
+        self._solves, self._vf, self._vf_key = 0, None, None   # solver-level queries describe a solve on THIS target / handle
 
     def reset(self, targetTrajectories):
         self._set_target(targetTrajectories)
@@ -429,7 +431,7 @@ class ControllerInterface:
         self._mpc.set_observation(self._t, self._x)
         self._mpc.advance()
         self._first = False
-        self._solves = getattr(self, "_solves", 0) + 1   # (what the value function of the last QP is cached against)
+        self._solves += 1   # (what the value function of the last QP is cached against)
         self.last_qp_status = int(self._mpc.stats()["qp_status_last"][0])
         if self.last_qp_status != 0 and self.settings.sqp.print_solver_status:
             # what ocs2 prints from hpipm's return code when print_solver_status is set
@@ -574,17 +576,23 @@ class ControllerInterface:
     def _outside(self, name):
         raise RuntimeError(f"ControllerInterface.{name} is outside the accelerated path of the MI355X engine")
 
-    def _value_function(self):
+    def _value_function(self, riccati=True):
         """upright_amd/value_function.py: the Riccati cost-to-go of the QP at the plan the last advanceMpc ended with, rebuilt on the
         host from the primal-dual point the kernel exports (costates, multipliers and slacks); cached per solve."""
         from .value_function import ValueFunction
 
-        if self._mpc is None or getattr(self, "_solves", 0) == 0:
-            raise RuntimeError("no MPC solve yet: call advanceMpc first")
-        key = (id(self._mpc), self._solves)
-        if getattr(self, "_vf_key", None) != key:
-            # (one more QP is solved at the plan: the handle's QP statistics afterwards describe that QP; last_qp_status keeps the solve's)
-            self._vf, self._vf_key = ValueFunction(self._mpc, 0), key
+        if self.problem.n_dyn:
+            raise RuntimeError("value function / Lagrangian queries are not available with dynamic obstacles (upr_batch_qp_kkt does not export the interface states' rows)")
+        sl = self.problem.slacks or {}
+        if riccati and (sl.get("state_box") or sl.get("input_box") or sl.get("poly_ineq")):
+            # a softened inequality row is factored with w0 (Z + gam / tau) / (Z + w0 + gam / tau), w0 = lam / t (upr_qp3.h row_soft); the
+            # kernels export (t, lam) only, so the cost-to-go rebuilt on the host would overstate the curvature of every active soft row
+            raise RuntimeError("value function queries need hard inequality rows: this problem carries HPIPM slacks "
+                               "(sqp.hpipm.slacks.{state_box, input_box, poly_ineq}) whose barrier pairs the engine does not export")
+        if self._mpc is None or self._solves == 0:
+            raise RuntimeError("no MPC solve yet on the current target: call advanceMpc first")
+        if self._vf_key != self._solves or (riccati and self._vf.Pk is None):
+            self._vf, self._vf_key = ValueFunction(self._mpc, 0, riccati=riccati), self._solves
         return self._vf
 
     def valueFunction(self, t, x):
@@ -599,7 +607,7 @@ class ControllerInterface:
 
     def stateInputEqualityConstraintLagrangian(self, t, x, u):
         """pybindings.cpp:409-412: multipliers of the state-input equality (the object-dynamics rows) of the last QP at time t."""
-        return self._value_function().equality_multiplier(t).copy()
+        return self._value_function(riccati=False).equality_multiplier(t).copy()   # (the multipliers alone: also with softened rows)
 
     def getStateInequalityConstraintValue(self, name, t, x):
         # the reference looks `name` up among the STATE-ONLY constraints, of which the OCP has none

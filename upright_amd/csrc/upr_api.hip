@@ -290,6 +290,7 @@ struct upr_batch {
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
+    std::vector<double> held_stats; std::vector<unsigned char> held_keys;   // upr_batch_hold_stats
     std::vector<double> kkt_slack;   // slacks of the rows at the exit of the last upr_batch_qp_kkt ([B][N+1][ni]; upr_batch_qp_slacks)
     std::string qp_name;   // the QP kernel instantiation this handle launches
     std::vector<hipEvent_t> ev_pool, ev_free;   // events in use (pairs, in launch order) / harvested ones waiting for reuse
@@ -1135,6 +1136,26 @@ static int get_feedback_core(upr_batch* h, double* K) {
 double upr_batch_last_solve_ms(const upr_batch* h) { return h ? h->last_ms : 0.0; }
 
 const char* upr_batch_qp_kernel_name(const upr_batch* h) { return h ? h->qp_name.c_str() : ""; }
+
+/* restore == 0: keep a copy of the per-instance statistics and of the QP dispatch keys of the last advance; restore != 0: put that
+ * copy back.  Brackets a query that solves one more QP on the handle (upr_batch_qp_kkt behind valueFunction): afterwards
+ * upr_batch_get_stats and the longest-first dispatch order describe the SOLVE again, not the query's QP. */
+int upr_batch_hold_stats(upr_batch* h, int restore) {
+    UPR_ENTER(h);
+    const size_t ns = sizeof(double) * h->B * UPR_NSTATS, nk = ((size_t)h->B + 3) & ~(size_t)3;
+    UPR_HIP(hipStreamSynchronize(h->stream));
+    if (!restore) {
+        h->held_stats.resize((size_t)h->B * UPR_NSTATS); h->held_keys.resize(nk);
+        UPR_HIP(hipMemcpy(h->held_stats.data(), h->stats, ns, hipMemcpyDeviceToHost));
+        UPR_HIP(hipMemcpy(h->held_keys.data(), h->iter_key, nk, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (h->held_stats.empty()) return fail("upr_batch_hold_stats: nothing held on this handle");
+    UPR_HIP(hipMemcpy(h->stats, h->held_stats.data(), ns, hipMemcpyHostToDevice));
+    UPR_HIP(hipMemcpy(h->iter_key, h->held_keys.data(), nk, hipMemcpyHostToDevice));
+    h->held_stats.clear(); h->held_keys.clear();
+    return 0;
+}
 
 int upr_batch_get_stats(upr_batch* h, double* stats) {
     UPR_ENTER(h);

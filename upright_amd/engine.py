@@ -132,6 +132,21 @@ class BatchMPC:
         check(self._lib.upr_batch_get_stats(self._h, ptr(s)))
         return {name: s[:, i] for i, name in enumerate(_capi.STAT_NAMES)}
 
+    def preserved_stats(self):
+        """Context manager: statistics and QP dispatch keys of the last advance are put back on exit (upr_batch_hold_stats) --
+        around a query that solves one more QP on the handle."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            check(self._lib.upr_batch_hold_stats(self._h, 0))
+            try:
+                yield
+            finally:
+                check(self._lib.upr_batch_hold_stats(self._h, 1))
+
+        return hold()
+
     # -- term-level access ----------------------------------------------------------------------------
     def linearize_points(self, x, u, t=None, inst=None):
         x = cont(x).reshape(-1, self.nxf)

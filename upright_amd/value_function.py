@@ -16,7 +16,9 @@ object-dynamics rows, multipliers lam and slacks t of every inequality row.  Fro
     terminal         P_N = diag(w_x) + (1 / rho_N) C_N' C_N                    (proximal terminal equality, rho_N = 1e-6)
     recursion        P_k = Hxx + A' P+ A - G' M^-1 G,   M = [[Huu + B' P+ B, D'], [D, -rho I]],   G = [B' P+ A; C]
 
-and the gradient of the cost-to-go at the plan's own state is the costate pi_k.  Around the plan
+(softened INEQUALITY rows are not covered: their factored weight needs the slack's own barrier pair, which the kernels do not
+export -- control_bindings.ControllerInterface refuses the queries for such problems) and the gradient of the cost-to-go at the
+plan's own state is the costate pi_k.  Around the plan
     V(t, x) ~ J(t) + pi(t)' (x - x*(t)) + 1/2 (x - x*(t))' P(t) (x - x*(t)),     dV/dx = pi(t) + P(t) (x - x*(t))
 with pi, P, x*, J interpolated linearly between the knots (ocs2 LinearInterpolation).  Checked against finite differences of the
 QP's optimal value over the observed state (tests/test_gpu_parity.py::test_value_function_against_finite_differences).
@@ -128,23 +130,29 @@ def qp_objective(P, xs, lin, X, U):
 class ValueFunction:
     """Value function of the last QP of a solved `BatchMPC` handle (one instance), interpolated over the plan's knots."""
 
-    def __init__(self, mpc, inst=0):
+    def __init__(self, mpc, inst=0, riccati=True):
         from .engine import core_friction_rows
 
         P = mpc.problem
         ts, xs_sol, us_sol = mpc.solution()
-        # the QP at the plan the solve ended with: linearised there, solved once more (its step is ~ 0 at a converged plan)
-        sol = {k: v[inst] for k, v in mpc.qp_kkt().items()}
+        # the QP at the plan the solve ended with: linearised there, solved once more (its step is ~ 0 at a converged plan) -- ONE SQP
+        # iteration past the QP ocs2's getValueFunction describes (the last one its solve ran); INTEGRATION.md section 2.  The handle's
+        # statistics and its dispatch order keep describing the solve: the extra QP's are discarded
+        with mpc.preserved_stats():
+            sol = {k: v[inst] for k, v in mpc.qp_kkt().items()}
         lin = mpc.lin_records()[inst]
         nfc = P.nf * P.nc
         E = core_friction_rows(P, np.eye(nfc)).T if P.nf == 3 else np.zeros((0, nfc))
         Df = mpc.eq_input_jacobian(inst)[:, P.nq:]
         self.P = P
         self.t = np.asarray(ts[inst], dtype=float)
+        self.nu = sol["nu"]
+        self.Pk = None
+        if not riccati:      # the equality multipliers alone (they need no barrier weights)
+            return
         self.Pk, self.pk, self.X, self.U = riccati_value_function(P, xs_sol[inst][:, :P.nx], us_sol[inst], lin, sol, E, Df)
         stage = qp_objective(P, xs_sol[inst][:, :P.nx], lin, self.X, self.U)
         self.J = np.array([stage[k:].sum() for k in range(P.N + 1)])   # cost-to-go of the plan from knot k
-        self.nu = sol["nu"]
 
     def _seg(self, t):
         ts = self.t
