@@ -47,17 +47,27 @@ class OrcStats(C.Structure):
 
 
 def build(force=False):
-    src = [HERE / "upright_oracle.cpp", HERE / "upright_oracle.h"]
-    if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in src):
+    src = [HERE / "upright_oracle.cpp", HERE / "upright_oracle.h", HERE / "Makefile"]
+    libs = [LIB, HERE / "_build" / "libupright_oracle_ngam0.so"]
+    if force or any(not l.exists() or any(s.stat().st_mtime > l.stat().st_mtime for s in src) for l in libs):
         subprocess.check_call(["make", "-s", "-C", str(HERE)])
     return LIB
 
 
 _lib = None
+_variants = {}
 
 
-def lib():
+def lib(variant=None):
+    """The oracle library; variant "ngam0": the build without the centrality safeguard (oracle/Makefile)."""
     global _lib
+    if variant:
+        if variant not in _variants:
+            build()
+            v = C.CDLL(str(HERE / "_build" / f"libupright_oracle_{variant}.so"))
+            v.orc_stage_cost.restype = d
+            _variants[variant] = v
+        return _variants[variant]
     if _lib is None:
         build()
         _lib = C.CDLL(str(LIB))
@@ -132,10 +142,10 @@ def _c(a):
 
 
 class Oracle:
-    def __init__(self, P):
+    def __init__(self, P, variant=None):
         self.P = P
         self.o = to_orc(P)
-        self.L = lib()
+        self.L = lib(variant)
         self.nx, self.nu = P.nx, P.nu
 
     def object_dynamics(self, forces, Cm, w, al, a):

@@ -1002,7 +1002,10 @@ int ipm_solve(const QP& qp, int iter_max, double tol, double tol_stat, QPSol& so
         // instances needed 16 iterations and three 14; now none more than 12, the mean is unchanged).  Same constants in the
         // kernels (UPR_QP_NGAM, UPR_QP_NBT, UPR_QP_NIT in upr_qp.h).
         {
-            static const double ngam = getenv("ORC_NGAM") ? atof(getenv("ORC_NGAM")) : 0.02;
+#ifndef ORC_NGAM_DEFAULT
+#define ORC_NGAM_DEFAULT 0.02   /* oracle/Makefile builds a second library with 0.0: the same QPs along a DIFFERENT interior-point path (tests: the minimiser does not depend on the path) */
+#endif
+            static const double ngam = getenv("ORC_NGAM") ? atof(getenv("ORC_NGAM")) : ORC_NGAM_DEFAULT;
             static const int nit = getenv("ORC_NIT") ? atoi(getenv("ORC_NIT")) : 4;
             if (ngam > 0.0 && it < nit) {
                 double mn = 1e300, sm = 0.0;

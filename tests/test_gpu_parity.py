@@ -202,6 +202,35 @@ def test_qp_step_converged(arrangements):
     mpc.close()
 
 
+def test_converged_qps_do_not_depend_on_the_interior_point_path(arrangements):
+    """VERDICT r05 item 8 (oracle independence for algorithm changes): the centrality safeguard of the step length went into the
+    oracle and the kernels TOGETHER, so their agreement says nothing about it.  oracle/_build/libupright_oracle_ngam0.so is the
+    oracle WITHOUT the safeguard (the rule of rounds 1-4, `-DORC_NGAM_DEFAULT=0.0`): its iterates take another path to the same
+    strictly convex QP's one minimiser.  64 headline QPs: production kernel against that library, 2e-5.
+    Both run at qp_tol = 1e-12 with HPIPM's cap of 30 iterations: at the production tolerance (1e-8 on the residuals, 1e-6 on
+    stationarity) two paths stop up to 1.5e-4 (states) / 5.5e-4 (inputs, relative) apart -- the contact forces carry a weight of 1e-3
+    -- which would test the stopping rule, not the minimiser; pushed to the roundoff floor the two oracle builds agree to 3e-8 / 5e-7."""
+    B = 64
+    P, x0, way = _setup(arrangements, B, seed=7, qp_tol=1e-12, qp_iter_max=30)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    mpc = BatchMPC(P, B, way_p=way)
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xs0, us0)
+    dxs, dus = mpc.qp_step()
+    st = mpc.stats()
+    assert np.all(st["qp_status_last"] <= 1)     # (1: the cap -- a tolerance of 1e-12 is below the residuals' roundoff floor for most instances)
+    differ = 0
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, so, rc = Oracle(P, variant="ngam0").qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert rc in (0, 1)
+        differ += int(st["qp_iters_last"][b] != so.qp_iters_last)
+        assert np.abs(dxs[b] - dxo).max() < 2e-5 * max(1, np.abs(dxo).max()), b
+        assert np.abs(dus[b] - duo).max() < 2e-5 * max(1, np.abs(duo).max()), b
+    print("instances whose iteration count differs between the two rules:", differ)
+    mpc.close()
+
+
 @pytest.mark.parametrize("kernel,nt", [("1", "64"), ("2", "256"), ("3", "128"), ("3", "512")])
 def test_mpc_solve_one_iteration(arrangements, kernel, nt, monkeypatch):
     """advanceMpc with sqp_iteration = 1 (controller.yaml:56): GPU vs oracle, every QP kernel structure."""

@@ -402,3 +402,22 @@ def test_friction_rows_against_reference_cone_generators(arrangements, name):
         assert O.friction_rows(f)[5 * ci:5 * ci + 5].min() > 0.0               # the interior of the span is inside the faces
         f[3 * ci:3 * ci + 3] = S @ np.array([1.0, 1.0, -0.2, 0.0])
         assert O.friction_rows(f)[5 * ci:5 * ci + 5].min() < 0.0               # outside the span: a facet is violated
+
+
+def test_oracle_minimiser_does_not_depend_on_the_centrality_safeguard(arrangements):
+    """The two oracle builds (with and without the step-length safeguard of round 5, oracle/Makefile) reach the same minimiser of the
+    same headline QPs along different paths -- the CPU half of test_converged_qps_do_not_depend_on_the_interior_point_path (why
+    qp_tol = 1e-12 with the cap of 30: see there)."""
+    P = thing_problem(arrangements["pink_bottle"], qp_tol=1e-12, qp_iter_max=30)
+    x0 = level_tray_states(6, seed=7)
+    way = waypoints_for(P, x0)
+    xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    paths_differ = False
+    for b in range(6):
+        P.way_p = way[b]
+        dxa, dua, sa, rca = Oracle(P).qp_step(0.0, x0[b], xs0[b], us0[b])
+        dxb, dub, sb, rcb = Oracle(P, variant="ngam0").qp_step(0.0, x0[b], xs0[b], us0[b])
+        assert rca in (0, 1) and rcb in (0, 1)
+        assert np.abs(dxa - dxb).max() < 2e-5 * max(1, np.abs(dxb).max()) and np.abs(dua - dub).max() < 2e-5 * max(1, np.abs(dub).max())
+        paths_differ |= not np.array_equal(dxa, dxb)
+    assert paths_differ     # (bitwise different results: the second library really runs another rule)
