@@ -38,7 +38,7 @@ def demangle(n):
 
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-")]
-    parts = [a for a in sys.argv[1:] if not a.startswith("-")] or [str(k) for k in range(7)]
+    parts = [a for a in sys.argv[1:] if not a.startswith("-")] or [str(k) for k in range(6)]
     with ThreadPoolExecutor(4) as ex:
         res = list(ex.map(lambda p: usage(p, extra), parts))
     for p, r in zip(parts, res):

@@ -490,7 +490,7 @@ int launch_qp3(upr_batch* h, const upr_qp_args& A) {
     return (h->d.no > 0) ? launch_qp3_rows<NT, true>(h, A) : launch_qp3_rows<NT, false>(h, A);
 }
 size_t qp3_ws_doubles(const upr_problem& P, const upr_dims& d, int variant) {
-    if (variant == 1) return upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 512>>::total;   // (the far arrays grow with the lanes: largest NT)
+    if (variant == 1) return upr_qp3_ws<upr_qp3_cfg<9, 1, 4, 3, 20, 256>>::total;
 #define X(a, b, c, e, n, rows, sf, dense) if (qp3_match(P, d, a, b, c, e, n, rows, sf, dense)) return upr_qp3_ws<upr_qp3_cfg<a, b, c, e, n, 256, rows, sf, dense>>::total;
     UPR_QP3_EXTRA(X)
 #undef X
@@ -675,11 +675,7 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
     if (h->use_qp3 == 1) {
         switch (h->qp_nt) {
             case 256: return launch_qp3<256>(h, A);
-#ifndef UPR_HEADLINE_ONLY
-            case 128: return launch_qp3<128>(h, A);
-            case 512: return launch_qp3<512>(h, A);
-#endif
-            default: return fail("UPR_QP_NT must be 128, 256 or 512 for the headline-shape kernel");
+            default: return fail("the production QP kernel ships at 256 lanes (UPR_QP_NT = 128 | 512 were A/B instantiations of rounds 1 - 5; UPR_QP3_JIT=2 UPR_JIT_NT=... instantiates one at run time)");
         }
     }
     if (h->use_qp3 == 2) {

@@ -21,12 +21,6 @@
 #include "upr_qp.h"
 #include "upr_qp2.h"
 
-#ifndef UPR_QP3_OFFL_PRIO
-#define UPR_QP3_OFFL_PRIO 0
-#endif
-#ifndef UPR_QP3_OFFLOAD
-#define UPR_QP3_OFFLOAD 0   // 2 (round 5): the side work of the factoring wave on WAVE 2, handed over through LDS (V and the columns of Lj^-1) -- measured no gain, see backward_mat_sw2;  1 (round 4): on waves 2 / 3 with the factorisation repeated there -- bit-identical and MEASURED SLOWER (2.195 -> 2.235 .. 2.244 ms per headline launch); both kept for A/B runs
-#endif
 // ROWS_: the instantiation takes state-polytopic rows (collision / projectile).  Problems without such rows run the
 // ROWS_ = false instantiation, in which every trace of them folds away (their runtime trip counts and the runtime
 // Hessian offset cost 1.8 % of the headline solve when they were compiled in unconditionally); layouts do not depend on it.
@@ -45,9 +39,6 @@
 #endif
 #ifndef UPR_QP3_GQ
 #define UPR_QP3_GQ 5   /* rows of C a lane requests together in the multi-body shapes' passes over C (prep C, forward tail) */
-#endif
-#ifndef UPR_QP3_SCHUR_KQ
-#define UPR_QP3_SCHUR_KQ 1   /* knots a lane carries side by side in the cooperative Schur factorisation (2: measured 5x slower, see there) */
 #endif
 #ifndef UPR_QP3_SOFT_ROWMEM
 #define UPR_QP3_SOFT_ROWMEM 1
@@ -148,7 +139,7 @@ struct upr_qp3_lds {
                          // K = Lj^-T V of the previous knot is formed by an idle wave while wave 0 factors the next)
                          vm = hux + r2(C::NQ * C::NX), lk = vm + 2 * r2(C::NQ * C::NX),
                          hjj = lk + 2 * r2(C::NH), vc = hjj + r2(C::NQ * C::NQ), ck = vc + r2(C::NE * C::NX),
-                         // single-wave sweep (C::SW): Vc = Lsi C of knots 1 .. N-1, [col][ne] each -- the first KS of them in the step array
+                         // two-wave sweep (C::SW): Vc = Lsi C of knots 1 .. N-1, [col][ne] each -- the first KS of them in the step array
                          // (dead between prep and the vector sweep), the rest from Pa on -- then the sweep's staging: packed Hjj,
                          // Hux / V by columns [nx][HXS], the partial sums of P+ b [nx][HXS]
                          VCS = (C::NE * 2 % 64 == 32 || C::NE * 2 % 64 == 0) ? C::NE + 2 : C::NE /* column stride of Vc: 48 rows = 96 dwords would put every column on the same two bank groups */,
@@ -156,16 +147,9 @@ struct upr_qp3_lds {
                          sw0 = C::VCPRE ? Pa + (C::N - 1 - KS) * VCN : Pa, sw_vcb = sw0 /* (!VCPRE: Vc of the knot in work and of the next one) */,
                          sw_hj = C::VCPRE ? sw0 : sw0 + 2 * VCN, sw_hx = sw_hj + r2(C::NH), sw_pb = sw_hx + (C::NX + C::NQ) * HXS /* (rows nx ..: the identity) */, sw_w = sw_pb + C::NX * HXS /* (the costate of the fused predictor sweep) */,
                          sw_pq = sw_w + r2(C::NX) /* (!VCPRE: the shares of Vc'Vc of waves 2 and 3, [wave][entry][lane]) */,
-                         // OFFL (one-body shapes at 256 lanes and more, UPR_QP3_OFFLOAD): V = Lj^-1 Hux in an area of its own, [column][nq] -- Hux
-                         // then has one writer (wave 1, before barrier A) and readers only between A and B (wave 0 and the wave that repeats
-                         // the factorisation for the side work)
-                         sw_v = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
-                         // (UPR_QP3_OFFLOAD == 2: the side work's wave also needs the nq columns of Lj^-1: those live where the four-wave form
-                         // keeps Ls^-1 and Hee of the knot in work (lsik, heek: unused by the one- / two-wave sweeps) -- a separate area would
-                         // put the headline shapes over the 80 KB that two workgroups per CU leave)
-                         sw_end = sw_v + ((C::VCPRE && C::NT >= 256 && UPR_QP3_OFFLOAD) ? r2(C::NX * C::NQ) : 0),
+                         sw_end = sw_pq + (C::VCPRE ? 0 : 2 * 9 * 64),
                          // the scratch region Pa .. yN serves, at different times: the four-wave sweep's working set (Pa .. ck), the
-                         // one- / two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
+                         // two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
                          // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
                          scr_sweep = ck + r2(C::NE * C::NX), scr_sw = C::SW ? (sw_end > sw0 + C::NKB * (C::SB * (C::SB + 1) / 2) ? sw_end : sw0 + r2(C::NKB * (C::SB * (C::SB + 1) / 2))) : 0,
                          // prep's staging of the one-body shapes: Z = Lf^-1 Df' of all knots from Pa, the Schur complements behind it -- at
@@ -176,7 +160,7 @@ struct upr_qp3_lds {
                          yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
-                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), sw_vi = lsik /* (UPR_QP3_OFFLOAD == 2, see sw_v) */, Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
                          // multi-body shapes: the contacts that load each body (indices as doubles) and their number
                          clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
@@ -245,27 +229,18 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 #ifndef UPR_QP3_PRIO
 #define UPR_QP3_PRIO 1
 #endif
-#ifndef UPR_QP3_FUSEVEC
-#define UPR_QP3_FUSEVEC 1   // the predictor's vector sweep rides on wave 0 of the two-wave matrix sweep (K_k out of registers)
-#endif
-#ifndef UPR_QP3_SW2
-#define UPR_QP3_SW2 1   // the single-wave matrix sweep split over two waves (blocks of P | factorisation): 0 for A/B runs
-#endif
-#ifndef UPR_QP3_FUSERES
+// (Compile-time knobs that measured worse and are gone, with their tables in DESIGN.md section 7: the side work of the factoring wave on
+//  waves 2 / 3 (UPR_QP3_OFFLOAD 1 | 2), the feed-forward phase a row per lane (KFF_ROWS), the block wave on another physical wave
+//  (PWAVE), raised priorities in the serial feed-forward phase and in the flat phases (PRIO_SERIAL, PRIO_FLAT), two knots per lane in
+//  the cooperative Schur factorisation (SCHUR_KQ), the two-pass predictor average (FUSEAFF 0), the separate residual pass (FUSERES 0),
+//  the one-wave and the unfused forms of the matrix sweep (SW2 0, FUSEVEC 0), the 128- and 512-lane instantiations.)
+// s_setprio of the factoring wave / of the wave that holds the blocks of P in the two-wave matrix sweep, and of the wave that runs the
+// corrector's vector sweep / the forward sweeps (the other waves and phases run at 0)
 #ifndef UPR_QP3_PRIO_W0
-#define UPR_QP3_PRIO_W0 3   // s_setprio of the factoring wave / of the wave that holds P in the two-wave matrix sweep (A/B runs)
-#endif
-#ifndef UPR_QP3_PRIO_SERIAL
-#define UPR_QP3_PRIO_SERIAL 0   // s_setprio of wave 0 in the feed-forward phase, whose work sits on twenty lanes of that wave (round 5: with the Schur-factor phase as well, 2 / 3 measured 0.7 - 1.1 % SLOWER on the headline): off
-#endif
-#ifndef UPR_QP3_PWAVE
-#define UPR_QP3_PWAVE 1   // which physical wave holds the blocks of P in the two-wave matrix sweep; 2: + 0.8 %, 3: no change (headline, round 5)
-#endif
-#ifndef UPR_QP3_PRIO_FLAT
-#define UPR_QP3_PRIO_FLAT 0   // ... of every wave outside the sweeps (the knot-parallel phases)
+#define UPR_QP3_PRIO_W0 3
 #endif
 #ifndef UPR_QP3_PRIO_VEC
-#define UPR_QP3_PRIO_VEC 3   // ... of the wave that runs the corrector's vector sweep / the forward sweeps
+#define UPR_QP3_PRIO_VEC 3
 #endif
 #ifndef UPR_QP3_PRIO_FWD
 #define UPR_QP3_PRIO_FWD 3
@@ -277,28 +252,11 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 // W1 = 3: + 2.2 %; the vector / forward sweep waves at 2 or 1: no change).  The SOFT kernels measured 1.1 % slower with it and keep 3.
 #define UPR_QP3_PRIO_W1 (C::SOFT ? 3 : 1)
 #endif
-#ifndef UPR_QP3_KFF_ROWS
-#define UPR_QP3_KFF_ROWS 0   // 1 (round 5): feed-forward phase with the two triangular products a row per lane, Lj^-1 staged in LDS -- bit-identical and MEASURED SLOWER (headline launch + 1.6 % fetching the factor by the row lanes themselves: eleven cache lines per lane; + 4.8 % with the staging: its index arithmetic and one more barrier cost more than twenty lanes running 90 operations behind 45 requests); kept for A/B runs
-#endif
-#ifndef UPR_QP3_FUSEAFF
-#define UPR_QP3_FUSEAFF 1   // (round 5) the predictor's complementarity average from the SAME pass over the rows that finds its step length: for the affine direction lam dt + t dlam = -lam t row by row, so sum (lam + a dlam)(t + a dt) = (1 - a) sum lam t + a^2 sum dt dlam -- the pass of what == 1 and its reduction are gone (0: the two-pass form, A/B runs)
-#endif
-#define UPR_QP3_FUSERES 1   // the step of the rows (ineq_sweep 2) also leaves the next iteration's inequality residual and complementarity sum (what 4)
-#endif
 #ifndef UPR_QP3_PREC_MAX
 #define UPR_QP3_PREC_MAX 4   /* quad slots of rows of C per lane up to which prep fetches them into registers ahead of phase C */
 #endif
 #ifndef UPR_QP3_PREV_MAX
 #define UPR_QP3_PREV_MAX 8   /* the same for the forward sweep's tail (fetched during the sweep; 8: box_arch since its kernel has no spills, -1 %) */
-#endif
-#ifndef UPR_QP3_FUSERES_SOFT
-#define UPR_QP3_FUSERES_SOFT 1   // also in the SOFT instantiations (measured 4 % slower while their rows lived in scratch; now -4 % on the softened thrown-ball workload)
-#endif
-#ifndef UPR_QP3_COOP_SCHUR
-#define UPR_QP3_COOP_SCHUR 1   // dense Schur complement (stacked bodies): cooperative factorisation, SB lanes per knot (0: a lane per knot, rounds 2 - 3; A/B runs)
-#endif
-#ifndef UPR_QP3_PRIO_MAT
-#define UPR_QP3_PRIO_MAT 0   // every wave during the matrix sweep: 2 measured no different from 0 (3.235 vs 3.230 ms)
 #endif
 #if defined(UPR_HOST_EMU) || !UPR_QP3_PRIO
 #define UPR_SETPRIO(p) ((void)0)
@@ -314,11 +272,12 @@ struct upr_qp3 {
     typedef upr_qp3_far<C> F;
     static constexpr int NQ = C::NQ, NX = C::NX, NU = C::NU, NE = C::NE, NFC = C::NFC, NC = C::NC, NF = C::NF, N = C::N, N1 = C::N1, NT = C::NT;
 #ifndef UPR_HOST_EMU
-    // which form of the matrix sweep this instantiation runs: two waves (SW2), one wave (one-body shapes below 128 lanes, or
-    // UPR_QP3_SW2=0), or the four-wave form further down
-    static constexpr bool SW2 = C::SW && NT >= 128 && UPR_QP3_SW2 != 0, SWANY = SW2 || C::VCPRE;
+    // which form of the matrix sweep this instantiation runs: two waves (SW2: every device instantiation) or the four-wave form
+    // further down (the host emulation)
+    static constexpr bool SW2 = C::SW;
+    static_assert(!C::SW || NT >= 128, "the two-wave matrix sweep needs two waves");
 #else
-    static constexpr bool SW2 = false, SWANY = false;
+    static constexpr bool SW2 = false;
 #endif
     upr_ctx ctx;
     int wb;   // first lane of this wave (uniform; lives in a scalar register)
@@ -1078,7 +1037,7 @@ struct upr_qp3 {
             ftoc(6, 3);
         }
 #ifndef UPR_HOST_EMU
-        if constexpr (C::COUPLED && UPR_QP3_COOP_SCHUR) {
+        if constexpr (C::COUPLED) {
             // Cooperative form of phase D for the dense Schur complement (round 4): SB lanes per knot, lane i owns ROW i of S through a
             // right-looking Cholesky factorisation -- the pivot column crosses the group through a slot per wave, the reciprocal
             // pivot by a lane shuffle -- then COLUMN i of the inverse factor by forward substitution out of the packed factor in
@@ -1090,7 +1049,7 @@ struct upr_qp3 {
             // (KQ: knots a lane carries side by side.  The chain of a pivot -- reciprocal square root, shuffle, LDS round trip: 640
             // cycles -- is latency, and two independent chains would share it; measured with KQ = 2 the 72 extra registers go to
             // scratch in this 512-register kernel and the phase takes 240 k cycles instead of 68 k: one knot per lane, two passes.)
-            constexpr int GP = 64 / SB, KW = GP * (NT / 64), KQ = UPR_QP3_SCHUR_KQ, KPP = KW * KQ, NPS = (N + KPP - 1) / KPP, NPK = SB * (SB + 1) / 2;
+            constexpr int GP = 64 / SB, KW = GP * (NT / 64), KQ = 1, KPP = KW * KQ, NPS = (N + KPP - 1) / KPP, NPK = SB * (SB + 1) / 2;
             static_assert(GP >= 1 && O::Pa + 64 * KQ * (NT / 64) <= O::yN, "a group per knot inside a wave; pivot-column slots in the sweeps' working set");
             const int ln = lane(), g = ln / SB, i = ln - g * SB, wv = wb >> 6;
             const int gc = (g < GP) ? g : 0, ri = i * (i + 1) / 2;
@@ -1372,232 +1331,27 @@ struct upr_qp3 {
         for (int i = 0; i < NQ; ++i) G[F::Ks + k * NQ * NX + i * NX + c] = kk[i];
     }
 #ifndef UPR_HOST_EMU
-    // ---- backward sweep, matrix part, on ONE wave (C::SW: one-body shapes) ---------------------------------------------------
-    // The four-wave form below spends a knot in three workgroup barriers and five LDS round trips, with eight waves of two
-    // co-resident workgroups hitting the LDS at the same moments (~9 k cycles per knot).  Here wave 0 carries the whole
-    // recursion and the other waves wait at the end:
-    //   * lane (bi, bj), bi <= bj (nq (nq + 1) / 2 = 45 lanes) keeps the 3 x 3 block P+[(a, bi)][(c, bj)] in REGISTERS: A'P+A, its
-    //     rows of Hux = B'P+A (for both (bi, bj) and the mirrored block), its entry of Hjj = B'P+B + R + W and its partial sums of
+    // ---- backward sweep, matrix part, on TWO waves with the cost-to-go in registers (C::SW) ---------------------------------------
+    // The four-wave form below (now the host emulation's) spends a knot in three workgroup barriers and five LDS round trips, with
+    // eight waves of two co-resident workgroups hitting the LDS at the same moments (~9 k cycles per knot).  Here:
+    //   * wave 1, lane (bi, bj), bi <= bj (nq (nq + 1) / 2 = 45 lanes) keeps the 3 x 3 block P+[(a, bi)][(c, bj)] in REGISTERS: A'P+A,
+    //     its rows of Hux = B'P+A (for both (bi, bj) and the mirrored block), its entry of Hjj = B'P+B + R + W and its partial sums of
     //     P+ b are in-lane arithmetic on nine values (block-scalar structure of the triple integrator, system_dynamics.h:15-22);
-    //   * Hjj (packed), Hux (by columns) and the partial sums cross the lanes through LDS once (wave-local: LDS operations of a
-    //     wave execute in order, no barrier); every lane then factors Hjj for itself (9 dependent pivots) and lane c < nx carries
-    //     column c of Hux through the eliminations: V = Lj^-1 Hux; lanes nx .. nx + nq - 1 carry the columns of the identity instead
-    //     and end with Lj^-1, which the feed-forward phase multiplies with (kff = Lj^-T Lj^-1 r);
+    //   * Hjj (packed), Hux (by columns) and the partial sums cross to wave 0 through LDS (barrier A); every lane of wave 0 factors
+    //     Hjj for itself (9 dependent pivots) and lane c < nx carries column c of Hux through the eliminations: V = Lj^-1 Hux; lanes
+    //     nx .. nx + nq - 1 carry the columns of the identity instead and end with Lj^-1, which the feed-forward phase multiplies
+    //     with (kff = Lj^-T Lj^-1 r);
     //   * the same lanes back-substitute their column of the feedback K = Lj^-T V in registers and store it (coalesced);
-    //   * V goes back through LDS by columns, and lane (bi, bj) updates its block: P = A'P+A + Q~ + Vc'Vc - V'V with the six
-    //     columns of V and of Vc = Lsi C it needs (Vc of every knot was left in LDS by prep's phase E).
+    //   * V goes back through LDS by columns (barrier B), and lane (bi, bj) of wave 1 updates its block: P = A'P+A + Q~ + Vc'Vc - V'V
+    //     with the six columns of V and of Vc = Lsi C it needs (one-body shapes: Vc of every knot was left in LDS by prep's phase E).
+    // (A one-wave form of the same sweep -- rounds 3 - 5, UPR_QP3_SW2 = 0 -- was bound by instruction issue: ~960 per knot, a third of
+    //  them the factorisation; deleted in round 6.)
     UPR_HDI static int vca(int k) { return (k <= O::KS) ? O::S + (k - 1) * O::VCN : O::Pa + (k - 1 - O::KS) * O::VCN; }
-    UPR_HDI void backward_mat_sw() {
-        constexpr int NBK = C::NH, HXS = O::HXS;
-        static_assert(!C::VCPRE || (O::sw_end <= O::yN && (O::VCN % 2) == 0 && O::KS * O::VCN <= O::r2(C::NZ)), "staging of the single-wave sweep");
-        if (wave0()) {
-            UPR_SETPRIO(3);
-            const double irho = 1.0 / UPR_QP_RHO_N;
-            const int l = lane();
-            const bool blk = l < NBK;
-            const int lc = blk ? l : NBK - 1;      // = upr_tri(NQ, bi, bj)
-            int bi = 0, b0 = 0;
-#pragma unroll
-            for (int i = 1; i < NQ; ++i) { const int st = i * NQ - i * (i - 1) / 2; if (lc >= st) { bi = i; b0 = st; } }
-            const int bj = bi + (lc - b0);
-            const bool dg = bi == bj;
-            const bool vl = l < NX;                // lanes that carry a column of Hux
-            const int vcl = (l < NX + NQ) ? l : 0;  // (lanes nx .. nx + nq - 1 read a column of the identity, kept behind Hux)
-            if (l >= NX && l < NX + NQ) {
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) L[O::sw_hx + l * HXS + i] = (l - NX == i) ? 1.0 : 0.0;
-            }
-            double p[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p[a][c] = 0.0;
-            {
-                double v = dg ? L[O::wx + N * NX + bi] : 0.0;
-                if (neN > 0) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + bi] * L[O::jN + q * NQ + bj]; }
-                p[0][0] = v;
-                const double d1 = L[O::wx + N * NX + NQ + bi] + ((neN > 0) ? irho : 0.0), d2 = L[O::wx + N * NX + 2 * NQ + bi] + ((neN > 0) ? irho : 0.0);
-                p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
-            }
-            bool ok = true;
-            // every global load issued so far has landed before the loop: a first use inside it would put a wait for ALL memory
-            // operations in flight into every trip (behind the back edge those are the stores of the previous knot)
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            // The column of K (of Lj^-1) a lane ends a knot with is STORED AT THE TOP OF THE NEXT KNOT, right behind that knot's one
-            // global load: loads and stores share a counter that the compiler can only wait out completely once both kinds are in
-            // flight, so stores issued at the end of a knot were waited for at the register copies of the loop's back edge.
-            double ks[NQ];
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) ks[i] = 0.0;
-#pragma nounroll
-            for (int k = N - 1; k >= 0; --k) {
-                // operands that do not depend on the recursion
-                const double wuk = L[O::wu + k * NU + bi], rdk = L[O::rd + bi];
-                double bjv[3], biv[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
-                // (the knot's entry of the end-effector Hessian: the only global operand of the loop, used at the very end of the
-                // knot -- a value requested for the NEXT knot would be waited for at the loop's back edge)
-                const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;
-                if (k < N - 1 && l < NX + NQ) {
-                    double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX)) + (k + 1) * NQ * NX;
-                    constexpr int str = NX;
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
-                }
-                // in-lane: T = P+ A, B'T (both orientations of the block), B'P+B, P+ b
-                double hxa[3], hxb[3], up[3], r1[3], r2[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double t0 = (c == 0) ? p[0][0] : ((c == 1) ? h * p[0][0] + p[0][1] : h2 * p[0][0] + h * p[0][1] + p[0][2]);
-                    const double t1 = (c == 0) ? p[1][0] : ((c == 1) ? h * p[1][0] + p[1][1] : h2 * p[1][0] + h * p[1][1] + p[1][2]);
-                    const double t2 = (c == 0) ? p[2][0] : ((c == 1) ? h * p[2][0] + p[2][1] : h2 * p[2][0] + h * p[2][1] + p[2][2]);
-                    hxa[c] = h3 * t0 + h2 * t1 + h * t2;                                // Hux[bi][(c, bj)]
-                    up[c] = h3 * p[c][0] + h2 * p[c][1] + h * p[c][2];
-                    r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
-                    r2[c] = p[0][c] * biv[0] + p[1][c] * biv[1] + p[2][c] * biv[2];     // -> (P+ b)[(c, bj)]   (bi < bj)
-                }
-                hxb[0] = up[0]; hxb[1] = h * up[0] + up[1]; hxb[2] = h2 * up[0] + h * up[1] + up[2];   // Hux[bj][(c, bi)]
-                double hj = h3 * up[0] + h2 * up[1] + h * up[2];
-                if (dg) hj += h * rdk + wuk;
-                if (blk) {
-                    L[O::sw_hj + bj * (bj + 1) / 2 + bi] = hj;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { L[O::sw_hx + (c * NQ + bj) * HXS + bi] = hxa[c]; L[O::sw_pb + (c * NQ + bi) * HXS + bj] = r1[c]; }
-                    if (!dg) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c]; L[O::sw_pb + (c * NQ + bj) * HXS + bi] = r2[c]; }
-                    }
-                }
-                UPR_WSYNC();
-                // everything of the new block that does not wait for the factorisation, in the shadow of that LDS round trip:
-                // p1 = sym(A'P+A) + Q~ + Vc'Vc (block (bi, bj); Vc = Lsi C of this knot was left in LDS by prep's phase E)
-                double p1[3][3];
-                if (k > 0) {
-                    double wxk[3], qdk[3], o2[3][3], cj[3][NE], ci[3][NE];
-                    const double* Vk = L + vca(k);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
-#pragma unroll
-                        for (int r = 0; r < NE; ++r) { cj[c][r] = Vk[(c * NQ + bj) * O::VCS + r]; ci[c][r] = Vk[(c * NQ + bi) * O::VCS + r]; }
-                    }
-                    {
-                        double t[3][3];
-#pragma unroll
-                        for (int a3 = 0; a3 < 3; ++a3) { t[a3][0] = p[a3][0]; t[a3][1] = h * p[a3][0] + p[a3][1]; t[a3][2] = h2 * p[a3][0] + h * p[a3][1] + p[a3][2]; }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { o2[0][c] = t[0][c]; o2[1][c] = h * t[0][c] + t[1][c]; o2[2][c] = h2 * t[0][c] + h * t[1][c] + t[2][c]; }
-                        if (dg) { o2[1][0] = o2[0][1]; o2[2][0] = o2[0][2]; o2[2][1] = o2[1][2]; }   // a diagonal block stays exactly symmetric
-                    }
-#pragma unroll
-                    for (int a3 = 0; a3 < 3; ++a3)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            double acc = o2[a3][c];
-                            if (a3 == c) acc += dg ? (h * qdk[a3] + wxk[a3]) : 0.0;
-#pragma unroll
-                            for (int r = 0; r < NE; ++r) acc += ci[a3][r] * cj[c][r];
-                            p1[a3][c] = acc;
-                        }
-                }
-                toc(6);
-                // every lane: Hjj; lanes < nx: their column of Hux; lanes nx .. nx + nq - 1: a column of the identity
-                double a[NQ][NQ], hx[NQ];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_hj + i * (i + 1) / 2 + j];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) hx[i] = L[O::sw_hx + vcl * HXS + i];
-                if (vl) {
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NQ; q += 3) { s0 += L[O::sw_pb + l * HXS + q]; if (q + 1 < NQ) s1 += L[O::sw_pb + l * HXS + q + 1]; if (q + 2 < NQ) s2 += L[O::sw_pb + l * HXS + q + 2]; }
-                    L[O::Pbs + k * NX + l] = (s0 + s1) + s2;
-                }
-#pragma unroll
-                for (int p2 = 0; p2 < NQ; ++p2) {
-                    const double piv = a[p2][p2];
-                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
-                    const double idg = upr_rsqrt(piv);
-#pragma unroll
-                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
-                    hx[p2] *= idg;
-#pragma unroll
-                    for (int j = p2 + 1; j < NQ; ++j) {
-#pragma unroll
-                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
-                        hx[j] -= a[j][p2] * hx[p2];
-                    }
-                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal
-                }
-                toc(7);
-                // V to LDS first (the update waits for it); its round trip is covered by the back substitution of the feedback column
-                if (k > 0) {
-                    UPR_WSYNC();
-                    if (vl) {
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
-                    }
-                    UPR_WSYNC();
-                }
-                int bio = bi, bjo = bj;
-                double kk[NQ];
-#pragma unroll
-                for (int i = NQ - 1; i >= 0; --i) {
-                    double tt = hx[i];
-#pragma unroll
-                    for (int m = i + 1; m < NQ; ++m) tt -= a[m][i] * kk[m];
-                    kk[i] = vl ? tt * a[i][i] : hx[i];   // (lanes nx ..: their column of Lj^-1 is what is stored)
-                }
-                // (the loads of the update are tied to the end of the back substitution: requested earlier, their 108 registers
-                // overlap the factor's 90 and the loop's invariants are spilled -- every reload then waits for all stores in flight)
-                asm volatile("" : "+v"(kk[0]), "+v"(bio), "+v"(bjo));
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) ks[i] = kk[i];
-                toc(8);
-                if (k == 0) break;
-                // P = p1 - V'V
-                {
-                    double vj[3][NQ], vi[3][NQ];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) { vj[c][m] = L[O::sw_hx + (c * NQ + bjo) * HXS + m]; vi[c][m] = L[O::sw_hx + (c * NQ + bio) * HXS + m]; }
-#pragma unroll
-                    for (int a3 = 0; a3 < 3; ++a3)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            double acc = p1[a3][c];
-#pragma unroll
-                            for (int m = 0; m < NQ; ++m) acc -= vi[a3][m] * vj[c][m];
-                            if (a3 == 0 && c == 0) acc += h * heek;
-                            p[a3][c] = acc;
-                        }
-                }
-                UPR_WSYNC();
-                toc(9);
-            }
-            if (l < NX + NQ) {   // knot 0's column
-                double* const dst = G + (vl ? F::Ks + l : F::Ljis + (l - NX));
-                constexpr int str = NX;
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) dst[i * str] = ks[i];
-            }
-            if (!ok && l == 0) L[O::misc] = 1.0;
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
-        }
-        UPR_SYNC();
-    }
-
     // (P+ b: wave 1 writes its partial sums BEHIND barrier A and wave 0 reads them behind barrier B of the same knot, i.e. before it
     // arrives at the next barrier A, behind which wave 1 writes the next ones.)
-    // ---- the same sweep on TWO waves (UPR_QP3_SW2, default): the single wave above is bound by instruction issue (~960 per knot, a
-    // third of them the factorisation).  Here wave 1 keeps the blocks of P (A'P+A, Hux, Hjj, P+ b partial sums; the Vc'Vc part of
-    // the update while wave 0 factors; then the V'V part) and wave 0 the columns (factorisation, V, K).  Two LDS-only workgroup
-    // barriers per knot hand Hjj / Hux over (A) and V back (B); the remaining waves only take part in the barriers.
-    // pieces of the two-wave matrix sweep that either wave 0 or (OFFL) waves 2 / 3 run -----------------------------------------
+    // Wave 1 keeps the blocks of P (A'P+A, Hux, Hjj, P+ b partial sums; the Vc'Vc part of the update while wave 0 factors; then the V'V
+    // part) and wave 0 the columns (factorisation, V, K).  Two LDS-only workgroup barriers per knot hand Hjj / Hux over (A) and V back
+    // (B); the remaining waves only take part in the barriers (multi-body shapes: they form Vc of the next knot and take shares of Vc'Vc).
     // start value of the fused predictor recursion, lane c < nx
     UPR_HDI double wt_terminal(int l) const {
         const double irho = 1.0 / UPR_QP_RHO_N;
@@ -1636,22 +1390,9 @@ struct upr_qp3 {
     }
     // the side work of knot k: feedback column (or column of Lj^-1) by back substitution and its store, the sum of P+ b, the fused
     // predictor step (wt: w~_k in, w~_{k-1} out)
-    // LINV (UPR_QP3_OFFLOAD == 2): a holds Lj^-1 (lower triangle, from the identity columns) instead of the factor: K = Lj^-T V as a
-    // triangular PRODUCT, the way the feed-forward phase forms kff (the factor itself stays in the factoring wave's registers)
-    template <bool LINV = false>
     UPR_HDI void sw2_side(int k, const double (&a)[NQ][NQ], const double (&hx)[NQ], const double (&pbv)[NQ], double& wt, int l, bool vl, int vj_,
                           double ca0, double ca1, double ca2) {
-        constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
-                double kk[NQ];
-        if (LINV) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                double tt = a[i][i] * hx[i];
-#pragma unroll
-                for (int m = i + 1; m < NQ; ++m) tt += a[m][i] * hx[m];
-                kk[i] = vl ? tt : hx[i];
-            }
-        } else
+        double kk[NQ];
 #pragma unroll
         for (int i = NQ - 1; i >= 0; --i) {
             double tt = hx[i];
@@ -1672,7 +1413,8 @@ struct upr_qp3 {
             pbs = (s0 + s1) + s2;
             if (vl) L[O::Pbs + k * NX + l] = pbs;
         }
-        if (FUSE) {
+        {
+            // the predictor's vector sweep (backward_vec's recursion, mode 0) rides along, K_k out of registers:
             // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
             const double gk = (k >= 1) ? L[O::gxs + k * NX + (vl ? l : 0)] + L[O::cs + k * NX + (vl ? l : 0)] : 0.0;
             const double uk = L[O::gus + k * NU + vj_];
@@ -1696,39 +1438,10 @@ struct upr_qp3 {
     UPR_HDI void backward_mat_sw2() {
         constexpr int NBK = C::NH, HXS = O::HXS;
         static_assert(!SW2 || NT >= (C::VCPRE ? 128 : 256), "two waves (four where Vc is formed inside the sweep)");
-        // (UPR_QP3_PWAVE: which PHYSICAL wave holds the blocks of P -- the roles of waves 1 and PWAVE are exchanged, A/B runs)
-        const int pw_ = wb >> 6;
-        const int wave = (NT >= 256 && UPR_QP3_PWAVE != 1) ? (pw_ == 1 ? UPR_QP3_PWAVE : (pw_ == UPR_QP3_PWAVE ? 1 : pw_)) : pw_;
+        const int wave = wb >> 6;
         const int l = lane();
-        constexpr bool FUSE = UPR_QP3_FUSEVEC != 0;
-        // OFFL (round 4): wave 0 only factors.  Its side work per knot -- the feedback column by back substitution and its store, the
-        // sum of P+ b, the fused predictor step -- sat between barrier B and the next barrier A on the wave every other wave waits
-        // for (measured: doing the back substitution twice costs 240 cycles per knot).  Waves 2 and 3 take it, a knot each in turn:
-        // the owner of knot k repeats the factorisation of knot k between A_k and B_k (the same instructions on the same operands:
-        // the same factor and column, no hand-over), picks up the partial sums of P+ b behind B_k and does the side work between
-        // A_{k-1} and B_{k-1}, while wave 0 factors the next knot.  The predictor's running costate passes between the two waves
-        // through the slot the step uses anyway (sw_w).  V goes to an area of its own (sw_v) so that Hux has readers only between
-        // A and B.  Same arithmetic, same order: bit-identical to the round-3 form (UPR_QP3_OFFLOAD=0).
-        // MEASURED (tools/exp_ab.py, headline B = 1024): 1.6 % (waves 2 / 3 at raised priority) to 2.1 % SLOWER than the round-3
-        // form: the third busy wave per workgroup (six latency-bound waves on the four SIMDs of a CU with its co-resident
-        // workgroup) costs the factoring waves more than the 700 cycles per knot taken off wave 0.  Off by default.
-        constexpr bool OFFL = C::VCPRE && NT >= 256 && UPR_QP3_OFFLOAD != 0;
-        // OFFL2 (round 5, UPR_QP3_OFFLOAD == 2): the same division of labour WITHOUT the repeated factorisation: wave 0 leaves what the
-        // side work needs in LDS -- its column of V = Lj^-1 [Hux | I] (it writes V for wave 1 anyway; now all nx + nq columns, the
-        // last nq of them, Lj^-1 itself, where the four-wave form keeps lsik / heek) -- and WAVE 2 alone does the side work of knot k
-        // between barriers A and B of knot k - 1 out of registers it loaded behind barrier B of knot k (before wave 0 overwrites the
-        // areas behind the next barrier A), the feedback column as the triangular PRODUCT Lj^-T V (as kff is formed) instead of a back
-        // substitution with the factor, which stays in wave 0's registers (handing the packed factor over as well -- 45 stores by one
-        // lane -- cost wave 0 1.1 k cycles per knot: 2.16 against 1.99 ms per launch).  The predictor's costate recursion stays in
-        // wave 2's registers.  Plans equal to 3e-11, iteration counts equal.
-        // MEASURED (tools/exp_flags.py, headline B = 1024): 1.9633 against 1.9705 ms per launch, i.e. nothing -- and the per-wave
-        // table (tools/r5_prof.sh, profiles/r05_offl2_phase_cycles.txt) says why: with the side work gone wave 0 waits 1.65 k cycles
-        // per knot at barrier A for wave 1, whose interval B -> A (reads of V, update of its block of P, the next Hjj / Hux: 1.3 k
-        // cycles net of the counters) was the longer of the two all along; the side work ran in its shadow.  What a knot of the sweep
-        // costs is the factorisation on wave 0 (1.8 k) plus that interval on wave 1 (1.3 k), strictly in turn.  Off by default.
-        constexpr bool OFFL2 = OFFL && UPR_QP3_OFFLOAD == 2;
         const double irho = 1.0 / UPR_QP_RHO_N;
-        if (FUSE) terminal_residual();
+        terminal_residual();
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
         UPR_SYNC_LDS();
         if (wave == 1) {
@@ -1866,8 +1579,8 @@ struct upr_qp3 {
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
                         for (int m = 0; m < NQ; ++m) {
-                            vj[c][m] = OFFL ? L[O::sw_v + (c * NQ + bj) * NQ + m] : L[O::sw_hx + (c * NQ + bj) * HXS + m];
-                            vi[c][m] = OFFL ? L[O::sw_v + (c * NQ + bi) * NQ + m] : L[O::sw_hx + (c * NQ + bi) * HXS + m];
+                            vj[c][m] = L[O::sw_hx + (c * NQ + bj) * HXS + m];
+                            vi[c][m] = L[O::sw_hx + (c * NQ + bi) * HXS + m];
                         }
 #pragma unroll
                     for (int a3 = 0; a3 < 3; ++a3)
@@ -1883,7 +1596,7 @@ struct upr_qp3 {
                 UPR_WSYNC();   // (the reads of V precede the next knot's stores of Hux: same wave, in order)
                 toc(9);
             }
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
+            UPR_SETPRIO(0);
         } else if (wave == 0) {
             UPR_SETPRIO(UPR_QP3_PRIO_W0);
             const bool vl = l < NX;                // lanes that carry a column of Hux
@@ -1897,29 +1610,21 @@ struct upr_qp3 {
             const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
             const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
             double wt = 0.0;
-            if (FUSE && vl && !OFFL) wt = wt_terminal(l);
+            if (vl) wt = wt_terminal(l);
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 UPR_SYNC_LDS();   // A
                 toc(6);
                 double a[NQ][NQ], hx[NQ];
                 sw2_factor(a, hx, vcl, ok);
-                if (OFFL2) {
-                    static_assert(!OFFL2 || (C::NQ * C::NQ <= O::r2(C::NLS) + 2 * O::r2(C::NH)), "the columns of Lj^-1 fit the area of lsik, heek");
-                    if (l < NX + NQ) {
-                        double* const dst = L + (vl ? O::sw_v + l * NQ : O::sw_vi + (l - NX) * NQ);
-#pragma unroll
-                        for (int m = 0; m < NQ; ++m) dst[m] = hx[m];
-                    }
-                } else
                 if (k > 0 && vl) {
 #pragma unroll
-                    for (int m = 0; m < NQ; ++m) { if (OFFL) L[O::sw_v + l * NQ + m] = hx[m]; else L[O::sw_hx + l * HXS + m] = hx[m]; }
+                    for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
                 }
                 toc(7);
                 UPR_SYNC_LDS();   // B
                 toc(8);
-                if (!OFFL) {
+                {
                     // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
                     double pbv[NQ];
 #pragma unroll
@@ -1929,81 +1634,7 @@ struct upr_qp3 {
                 toc(9);
             }
             if (!ok && l == 0) L[O::misc] = 1.0;
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
-        } else if (OFFL2) {
-            if (wave == 2) {
-                const bool vl = l < NX;
-                const int vcl = (l < NX + NQ) ? l : 0;
-                const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
-                const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
-#if UPR_QP3_OFFL_PRIO
-                UPR_SETPRIO(UPR_QP3_OFFL_PRIO);
-#endif
-                double a[NQ][NQ], hx[NQ], pbv[NQ];
-                double wt = (FUSE && vl) ? wt_terminal(l) : 0.0;
-#pragma nounroll
-                for (int k = N - 1; k >= 0; --k) {
-                    UPR_SYNC_LDS();   // A_k
-                    toc(6);
-                    if (k + 1 <= N - 1) sw2_side<true>(k + 1, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);   // (its operands were loaded behind B_{k+1})
-                    toc(7);
-                    UPR_SYNC_LDS();   // B_k: V, the factor and the partial sums of P+ b of knot k are in LDS until the next barrier A
-                    toc(8);
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i)
-#pragma unroll
-                        for (int j = 0; j <= i; ++j) a[i][j] = L[O::sw_vi + j * NQ + i];   // (Lj^-1)[i][j]: row i of the identity column j
-#pragma unroll
-                    for (int m = 0; m < NQ; ++m) { hx[m] = L[(vl ? O::sw_v + l * NQ : O::sw_vi + ((l < NX + NQ) ? l - NX : 0) * NQ) + m]; pbv[m] = L[O::sw_pb + (vl ? l : 0) * HXS + m]; }
-                    // (the loads are complete before this wave arrives at the next barrier A: UPR_SYNC_LDS waits for them)
-                    toc(9);
-                }
-                sw2_side<true>(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
-#if UPR_QP3_OFFL_PRIO
-                UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
-#endif
-            } else {
-#pragma nounroll
-                for (int k = N - 1; k >= 0; --k) { UPR_SYNC_LDS(); toc(6); toc(7); UPR_SYNC_LDS(); toc(8); toc(9); }
-            }
-        } else if (OFFL) {
-            // the side work of the factoring wave, a knot each in turn (wave 2: knots N-1, N-3, ...; wave 3: N-2, N-4, ...)
-            const bool vl = l < NX;
-            const int vcl = (l < NX + NQ) ? l : 0;
-            const int vj_ = vl ? l % NQ : 0, vb_ = vl ? l / NQ : 0;
-            const double ca0 = coefA(0, vb_), ca1 = (vb_ >= 1) ? coefA(1, vb_) : 0.0, ca2 = (vb_ >= 2) ? 1.0 : 0.0;
-            const int par = wave - 2;
-            bool okw = true;
-#if UPR_QP3_OFFL_PRIO
-            UPR_SETPRIO(UPR_QP3_OFFL_PRIO);
-#endif
-            double a[NQ][NQ], hx[NQ], pbv[NQ];
-            if (FUSE && vl && par == 0) L[O::sw_w + l] = wt_terminal(l);   // (the running costate of the predictor: handed from wave to wave in sw_w)
-#pragma nounroll
-            for (int k = N - 1; k >= 0; --k) {
-                const bool mine = ((N - 1 - k) & 1) == par;
-                UPR_SYNC_LDS();   // A_k
-                if (mine) sw2_factor(a, hx, vcl, okw);
-                else if (k + 1 <= N - 1) {   // the side work of my knot k + 1 (its partial sums were picked up behind B_{k+1})
-                    double wt = (FUSE && vl) ? L[O::sw_w + l] : 0.0;
-                    UPR_WSYNC();
-                    sw2_side(k + 1, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
-                    if (FUSE && vl) L[O::sw_w + l] = wt;
-                }
-                UPR_SYNC_LDS();   // B_k
-                if (mine) {
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
-                }
-            }
-            if (((N - 1) & 1) == par) {   // the owner of knot 0: its side work has no later interval
-                double wt = (FUSE && vl) ? L[O::sw_w + l] : 0.0;
-                UPR_WSYNC();
-                sw2_side(0, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
-            }
-#if UPR_QP3_OFFL_PRIO
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
-#endif
+            UPR_SETPRIO(0);
         } else {
             vc_regs vq;
             vcm_regs vm;
@@ -2193,12 +1824,10 @@ struct upr_qp3 {
     UPR_HDI void backward_mat() {
 #ifndef UPR_HOST_EMU
         if constexpr (SW2) { backward_mat_sw2(); return; }
-        else if constexpr (C::VCPRE) { backward_mat_sw(); return; }
         else
 #endif
         {   // (the four-wave form: the host emulation, and instantiations without the one- / two-wave sweep -- discarded, with its
             // shape-specific assertions, for every device instantiation that runs those)
-        UPR_SETPRIO(UPR_QP3_PRIO_MAT);
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
         {
@@ -2524,8 +2153,7 @@ struct upr_qp3 {
                 }
 #endif
             }
-            UPR_SETPRIO(UPR_QP3_PRIO_MAT);
-            if (k == 0) break;
+                if (k == 0) break;
             mtoc(2);
             UPR_SYNC_LDS();
             toc(8);
@@ -2577,7 +2205,7 @@ struct upr_qp3 {
             UPR_SYNC_LDS();
             toc(9);
         }
-        UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
+        UPR_SETPRIO(0);
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
         if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
@@ -2678,53 +2306,15 @@ struct upr_qp3 {
                 }
             }
 #endif
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
+            UPR_SETPRIO(0);
         }
         UPR_SYNC();
         toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
 #ifndef UPR_HOST_EMU
-        if constexpr (SWANY && UPR_QP3_KFF_ROWS && (NT / 64) * (64 / NQ) >= N) {
-            // (round 5, OFF: measured slower, see UPR_QP3_KFF_ROWS) the two triangular products a ROW per lane: lane (k, i) forms
-            // y_i = sum_{m <= i} Li[i][m] tv[m] and then kff_i = sum_{m >= i} Li[m][i] y[m] -- 18 of the 45 entries of Lj^-1 and 18
-            // operations where the lane-per-knot form below fetches all 45 into twenty lanes and runs 90 operations behind them.
-            // The lanes of a knot sit in one wave: the vectors cross through the feed-forward slots with wave-local ordering
-            // points.  Every sum in the order of the one-lane form: bit-identical.
-            constexpr int KPW = 64 / NQ;
-            const int ln = lane(), kl = ln / NQ, i = ln - kl * NQ;
-            const int k = (wb >> 6) * KPW + kl;
-            const bool act = kl < KPW && k < N;
-            const int kc = act ? k : 0;
-            // Lj^-1 of every knot staged in the sweeps' working set (dead here) with coalesced requests: fetched by the row lanes
-            // themselves, every lane touched eleven cache lines of its own (measured 1.6 % slower than the lane-per-knot form)
-            static_assert(O::Pa + N * NQ * NQ <= O::yN, "staging of Lj^-1");
-            UPR_FORT(e, N * NQ * NQ) { const int kk = e / (NQ * NQ), r = (e % (NQ * NQ)) / NQ, c = e % NQ; L[O::Pa + e] = G[F::Ljis + kk * NQ * NX + r * NX + c]; }
-            UPR_SYNC_LDS();
-            const double* Li = L + O::Pa + kc * NQ * NQ;
-            double lrow[NQ], lcol[NQ];
-#pragma unroll
-            for (int m = 0; m < NQ; ++m) { lrow[m] = Li[i * NQ + m]; lcol[m] = Li[m * NQ + i]; }
-            if (!fused) {
-                const double* w = Wk(kc);
-                const double tvi = L[O::gus + kc * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
-                UPR_WSYNC_LDS();
-                if (act) L[O::kffs + kc * NQ + i] = tvi;
-            }
-            UPR_WSYNC_LDS();
-            double y = 0.0;
-#pragma unroll
-            for (int m = 0; m < NQ; ++m) { const double tv = L[O::kffs + kc * NQ + m]; const double yn = y + lrow[m] * tv; y = (m <= i) ? yn : y; }
-            UPR_WSYNC_LDS();
-            if (act) L[O::kffs + kc * NQ + i] = y;
-            UPR_WSYNC_LDS();
-            double t = 0.0;
-#pragma unroll
-            for (int m = 0; m < NQ; ++m) { const double ym = L[O::kffs + kc * NQ + m]; const double tn = t + lcol[m] * ym; t = (m >= i) ? tn : t; }
-            UPR_WSYNC_LDS();
-            if (act) L[O::kffs + kc * NQ + i] = t;
-        } else if constexpr (SWANY) {
-            // (single-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products)
-            if (UPR_QP3_PRIO_SERIAL != 0 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_SERIAL);   // (the lanes with work sit in wave 0: A/B runs)
+        if constexpr (SW2) {
+            // (two-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products, a lane per knot.  A row
+            //  per lane with Lj^-1 staged in LDS was measured 1.6 - 4.8 % slower on the headline launch: DESIGN.md section 7)
             UPR_FORT(k, N) {
                 const double* Li = G + F::Ljis + k * NQ * NX;
                 const double* w = Wk(k);
@@ -2746,7 +2336,6 @@ struct upr_qp3 {
                     for (int m = i; m < NQ; ++m) t += li[m][i] * y[m];
                     L[O::kffs + k * NQ + i] = t; }
             }
-            if (UPR_QP3_PRIO_SERIAL != 0 && wave0()) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         } else
 #endif
         UPR_FORT(k, N) {
@@ -2875,7 +2464,7 @@ struct upr_qp3 {
                 }
             }
 #endif
-            UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
+            UPR_SETPRIO(0);
 #ifndef UPR_HOST_EMU
             if (!ROWMEM) load_rows();   // (wave 0: in flight while the other waves run the tail)
 #endif
@@ -3238,7 +2827,7 @@ struct upr_qp3 {
     }
 
     // ---- sweeps over the lane-owned rows with the current step ------------------------------------------------
-    //   what 0: alpha_max partial ; 1: partial sum (lam + a dlam)(t + a dt) ; 2: apply ; 3: partial max |rp|, aux += lam t ;
+    //   what 0: alpha_max partial (aux += dt dlam) ; 2: apply ; 3: partial max |rp|, aux += lam t ; 4: 2 then 3 at the new iterate ;
     //   5: partial MIN of the trial products (lam + a dlam)(t + a dt), aux += their sum (the centrality safeguard, UPR_QP_NGAM)
     UPR_HDI void sweep_row(int what, double alpha, double c, double ds, double& t, double& lam, double cterm, double& acc, double* aux) const {
         const double rp = c - t;
@@ -3250,8 +2839,8 @@ struct upr_qp3 {
         if (what == 0) {
             // acc carries 1 / alpha_max: the row's limits are t / -dt and lam / -dlam (no division, no branch)
             acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
-            if (aux) *aux += dt * dl;   // (predictor, UPR_QP3_FUSEAFF: the second-order term of the complementarity average)
-        } else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt);
+            if (aux) *aux += dt * dl;   // (predictor: the second-order term of the complementarity average, see solve())
+        }
         else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt); acc = fmin(acc, v); *aux += v; }
         else { t += alpha * dt; lam += alpha * dl; }
     }
@@ -3274,7 +2863,6 @@ struct upr_qp3 {
         const double dt = ds + rp + dsg, dtau = dsg + rps;
         const double dl = -(rc + lam * dt) * rt, dg = -(rcs + gam * dtau) * rtau;
         if (what == 0) { acc = fmax(fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam))), fmax(-dtau * rtau, -dg * upr_rcp(gam))); if (aux) *aux += dt * dl + dtau * dg; }
-        else if (what == 1) acc += (lam + alpha * dl) * (t + alpha * dt) + (gam + alpha * dg) * (tau + alpha * dtau);
         else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt), vs = (gam + alpha * dg) * (tau + alpha * dtau); acc = fmin(acc, fmin(v, vs)); *aux += v + vs; }
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
     }
@@ -3655,7 +3243,6 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         ZL = P->soft_L2_lower; ZU = P->soft_L2_upper; zL = P->soft_L1_lower; zU = P->soft_L1_upper; soft_stat = 0.0;
         rho_eq = upr_qp_rho_soft(P); rho_s = upr_qp_rho_s(P, NE, NFC); rho_px = upr_qp_rho_prox(P, NE, NFC);
         prof = A.prof ? A.prof + (size_t)b * 64 : nullptr;
-        if (UPR_QP3_PRIO_FLAT != 0) UPR_SETPRIO(UPR_QP3_PRIO_FLAT);
         if (prof) UPR_FORT(i, 64) L[O::prf + i] = 0.0;
         tic();
         // ---- constants and linearisation-point data into LDS
@@ -3789,7 +3376,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             prep(2);
             backward_mat(); toc(11);
 #ifndef UPR_HOST_EMU
-            backward_vec(SW2 && UPR_QP3_FUSEVEC); toc(11);
+            backward_vec(SW2); toc(11);
 #else
             backward_vec(); toc(11);
 #endif
@@ -3802,17 +3389,15 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             }
             { double unused[NCT]; forward<false>(unused); } toc(13);
             double a_aff, mu_aff;
-            if (UPR_QP3_FUSEAFF) {
+            {
+                // step length of the predictor and its complementarity average from ONE pass over the rows: for the affine direction
+                // lam dt + t dlam = -lam t row by row, so sum (lam + a dlam)(t + a dt) = (1 - a) sum lam t + a^2 sum dt dlam
                 double v4[4] = {0.0, 0.0, 0.0, 0.0};
                 v4[0] = -ineq_sweep(0, 0.0, &v4[3], zero_targets());   // (max of -alpha = -min alpha; v4[3]: sum of dt dlam)
                 reduce4(v4);
                 a_aff = -v4[0];
                 if (a_aff > 1.0) a_aff = 1.0;
                 mu_aff = (1.0 - a_aff) * mu + a_aff * a_aff * (v4[3] / ntot);
-            } else {
-                a_aff = reduce(ineq_sweep(0, 0.0, nullptr, zero_targets()), 2);
-                if (a_aff > 1.0) a_aff = 1.0;
-                mu_aff = reduce(ineq_sweep(1, a_aff, nullptr, zero_targets(), false), 0) / ntot;
             }
             const double sg = mu_aff / mu;
             sigma_mu = sg * sg * sg * mu;
@@ -3840,12 +3425,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 if (!(-v4[0] >= UPR_QP_NGAM * (v4[3] / (ntot > 0 ? ntot : 1)))) a *= UPR_QP_NBT;
             }
             // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass.  (The SOFT
-            // instantiations too since their rows no longer live in scratch -- UPR_QP3_FUSERES_SOFT: 3.20 -> 3.07 ms; before: 3.77 -> 3.92.)
-            constexpr bool FUSER = UPR_QP3_FUSERES && (!C::SOFT || UPR_QP3_FUSERES_SOFT);
-            if (FUSER) {
-                res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
-                res_next[2] = ineq_sweep(4, a, &res_next[3], ctm, false);
-            } else ineq_sweep(2, a, nullptr, ctm, false);
+            // instantiations too since their rows no longer live in scratch: 3.20 -> 3.07 ms; before: 3.77 -> 3.92.)
+            res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
+            res_next[2] = ineq_sweep(4, a, &res_next[3], ctm, false);
             store_rows();
             // (the multipliers' old values are requested in front of the barrier: their round trip overlaps it)
             constexpr int QPI = (N1 * NX + NT - 1) / NT, QNU = (N * NE + NT - 1) / NT;
@@ -3857,10 +3439,8 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
 #pragma unroll
                 for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT, ec = (e < N * NE) ? e : 0; nuo[q] = ws[W::nu + ec]; nun_[q] = G[F::nun + ec]; }
             }
-            if (FUSER) {
-                reduce4(res_next);   // (its barriers are the one the update of the iterate needs: every lane is through with Z and S)
-                have_next = true;
-            } else UPR_SYNC();
+            reduce4(res_next);   // (its barriers are the one the update of the iterate needs: every lane is through with Z and S)
+            have_next = true;
             ftoc(8);
             {
                 const int tid_ = tid();

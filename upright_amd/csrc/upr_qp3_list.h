@@ -1,7 +1,9 @@
 // upr_qp3_list.h -- the instantiations of the production QP kernel (upr_qp3.h) that libupright_mi carries, in PARTS: every part
 // is compiled as a translation unit of its own (upr_qp3_inst.hip with -DUPR_QP3_PART=k; __graft_entry__.build() runs them side by
 // side), upr_api.hip only declares the launchers.  X(nq, nb, nc, nf, N, ROWS, SOFT, DENSE) at 256 lanes; the headline shape
-// (9, 1, 4, 3; N = 20; hard rows) also at 128 and 512 lanes, with and without state-polytopic rows: Y(NT, ROWS).
+// (9, 1, 4, 3; N = 20; hard rows) with and without state-polytopic rows: Y(NT, ROWS).  (Rounds 1 - 5 also shipped it at 128 and 512
+// lanes for A/B runs: both slower, 512 - 655 spilled registers, selected by nothing but UPR_QP_NT -- dropped in round 6;
+// UPR_JIT_NT still instantiates them at run time for an experiment.)
 // A problem takes the FIRST entry of UPR_QP3_EXTRA that matches it (upr_api.hip, qp3_match).
 #pragma once
 
@@ -25,15 +27,10 @@
 #define UPR_QP3_PART4(X) X(6, 1, 4, 1, 20, false, true, false) X(6, 1, 4, 1, 10, false, true, false) X(6, 1, 4, 3, 20, false, false, false)
 // part 5 (round 4): the paper's dice (two stacked bodies, dense 12 x 12) and seven cups (star with friction: upr_qp3_cfg::BIGF)
 #define UPR_QP3_PART5(X) X(9, 2, 8, 3, 20, false, false, true) X(9, 7, 28, 3, 20, false, false, false)
-#define UPR_QP3_NPARTS 7   /* part 0: the headline at 256 lanes; part 6: the headline at 128 and 512 lanes */
+#define UPR_QP3_NPARTS 6   /* part 0: the headline */
 #define UPR_QP3_EXTRA(X) UPR_QP3_PART1(X) UPR_QP3_PART2(X) UPR_QP3_PART3(X) UPR_QP3_PART4(X) UPR_QP3_PART5(X)
 #endif
 
 // the headline's own instantiations: Y(NT, ROWS)
 #define UPR_QP3_PART0(Y) Y(256, false) Y(256, true)
-#ifdef UPR_HEADLINE_ONLY
-#define UPR_QP3_PART6(Y)
-#else
-#define UPR_QP3_PART6(Y) Y(128, false) Y(128, true) Y(512, false) Y(512, true)
-#endif
-#define UPR_QP3_HEADLINE(Y) UPR_QP3_PART0(Y) UPR_QP3_PART6(Y)
+#define UPR_QP3_HEADLINE(Y) UPR_QP3_PART0(Y)
