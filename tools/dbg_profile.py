@@ -1,4 +1,5 @@
 import sys, json, os
+os.environ["UPR_QP3_JIT"] = "2"; os.environ["UPR_JIT_FLAGS"] = (os.environ.get("UPR_JIT_FLAGS", "") + " -DUPR_QP3_PROF").strip()   # the stamps exist in run-time instantiations only
 sys.path.insert(0,'.')
 import numpy as np
 from upright_amd.engine import BatchMPC

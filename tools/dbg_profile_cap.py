@@ -2,6 +2,7 @@
 residuals behind it; the difference to cap 2 is one more iteration, so what cap 1 has on top of that is set-up (the feedback gains are
 written after the counters are read and are not in the table)."""
 import sys, json, os
+os.environ["UPR_QP3_JIT"] = "2"; os.environ["UPR_JIT_FLAGS"] = (os.environ.get("UPR_JIT_FLAGS", "") + " -DUPR_QP3_PROF").strip()   # the stamps exist in run-time instantiations only
 sys.path.insert(0, '.')
 import numpy as np
 import bench

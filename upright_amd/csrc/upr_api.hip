@@ -1327,9 +1327,15 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us) {
     return 0;
 }
 
-/* debug: per-phase cycle counters of the production QP kernel, prof[B][4 waves][16]; allocate on first use */
+/* debug: per-phase cycle counters of the production QP kernel, prof[B][4 waves][16]; allocate on first use.  The stamps are compiled
+ * into run-time instantiations only (UPR_QP3_JIT=2 UPR_JIT_FLAGS="-DUPR_QP3_PROF ..."): the library's own kernels carry none. */
 int upr_batch_qp_profile(upr_batch* h, double* out) {
     UPR_ENTER(h);
+    {
+        const char* f = getenv("UPR_JIT_FLAGS");
+        if (h->use_qp3 != 3 || !f || !strstr(f, "-DUPR_QP3_PROF"))
+            return fail("upr_batch_qp_profile: the phase stamps exist in run-time instantiations only: create the handle with UPR_QP3_JIT=2 UPR_JIT_FLAGS=-DUPR_QP3_PROF");
+    }
     if (!h->prof) { if (dev_alloc(&h->prof, (size_t)h->B * 64)) return 1; return 0; }
     UPR_HIP(hipStreamSynchronize(h->stream));
     if (out) UPR_HIP(hipMemcpy(out, h->prof, sizeof(double) * h->B * 64, hipMemcpyDeviceToHost));

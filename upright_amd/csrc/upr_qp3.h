@@ -158,7 +158,7 @@ struct upr_qp3_lds {
                          scr_prep = sst + r2((C::MULTI || C::COUPLED) ? 0 : C::N * C::NE * C::NE), scr_rows = hux + (C::ROWS ? 2 * (C::N - 1) * UPR_QP3_NOMAX : 0),
                          scr_a = scr_sweep > scr_sw ? scr_sweep : scr_sw, scr_b = scr_prep > scr_rows ? scr_prep : scr_rows,
                          yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
-                         eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), misc = red + (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16),
+                         eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), RSET = (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16) /* two sets of reduction slots */, misc = red + 2 * RSET,
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
                          prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
@@ -350,6 +350,24 @@ struct upr_qp3 {
         for (int i = 0; i < NCT; ++i) ctm[i] = G[F::cxr + i * NT + tid_];
     }
 
+    // the corrector's step on the lane-owned rows in one evaluation (rows_dir / rows_trial / rows_apply further down): which
+    // instantiations run it, and what a lane keeps between its three parts
+    static constexpr bool ONEPASS = !C::SOFT && !C::ROWS && !(NF == 3 && C::QC > 1);
+    static constexpr int OP_QR5 = (NF == 3) ? (5 * C::NCI + NT - 1) / NT : 0;
+    static constexpr int OP_NB = 2 * C::QX + 2 * C::QU, OP_NR = OP_NB + (OP_QR5 > 0 ? OP_QR5 : 1);
+    struct row_dirs { double dt[OP_NR], dl[OP_NR], ft[OP_QR5 > 0 ? OP_QR5 : 1], fl[OP_QR5 > 0 ? OP_QR5 : 1], fc[OP_QR5 > 0 ? OP_QR5 : 1]; };
+    // the far operands of the rows' step: the corrector targets of the box rows and (ONEPASS) the friction rows' (t, lam, target)
+    UPR_HDI void prefetch_step(double (&ctm)[NCT], row_dirs& D) const {
+        load_targets(ctm);
+        if (ONEPASS) {
+            const int tid_ = tid();
+#pragma unroll
+            for (int q = 0; q < OP_QR5; ++q) {
+                const int e = tid_ + q * NT, ec = (e < 5 * C::NCI) ? e : 0;
+                D.ft[q] = G[F::ct + ec]; D.fl[q] = G[F::cl + ec]; D.fc[q] = G[F::cc + ec];
+            }
+        }
+    }
     // The box rows live in registers through the flat phases only.  Around the sweeps (which need every register) they
     // are parked in global memory [slot][lane]: written once per iteration after the step, read back behind the two
     // forward sweeps (by the idle waves during the sweep, by wave 0 right after it).
@@ -426,20 +444,35 @@ struct upr_qp3 {
         return v;
     }
 
-    // workgroup reductions: butterfly inside each wave (ds_bpermute), one LDS slot per wave, two LDS-only barriers
+    // workgroup reductions.  Inside a wave: four DPP steps (neighbours, pairs, the two quads of a half row, the two halves of a row of
+    // sixteen) leave every row's result in all its lanes, the four rows meet through scalar registers (v_readlane) -- no LDS
+    // crossbar: the ds_bpermute butterfly of rounds 1 - 5 was twelve dependent permutes, ~1.2 k cycles of the ~1.7 k a reduction
+    // cost.  Across the waves: one LDS slot per wave and ONE LDS-only barrier; consecutive reductions alternate between two sets of
+    // slots (a wave can only reach the reduction after next through the next one's barrier, behind which nobody reads this one's
+    // slots any more).  All lanes must be active.
+    int red_par;   // which set of slots the next reduction uses (uniform)
     UPR_HDI static double comb(double a, double b, int op) { return (op == 0) ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
+#ifndef UPR_HOST_EMU
+    UPR_HDI static double wave_reduce(double v, int op) {
+        v = comb(v, upr_dpp_quad<0xB1>(v), op);    // quad_perm [1 0 3 2]
+        v = comb(v, upr_dpp_quad<0x4E>(v), op);    // quad_perm [2 3 0 1]
+        v = comb(v, upr_dpp_quad<0x141>(v), op);   // row_half_mirror
+        v = comb(v, upr_dpp_quad<0x140>(v), op);   // row_mirror
+        return comb(comb(upr_readlane(v, 0), upr_readlane(v, 16), op), comb(upr_readlane(v, 32), upr_readlane(v, 48), op), op);
+    }
+#endif
     UPR_HDI double reduce(double v, int op /*0 sum 1 max 2 min*/) {
 #ifdef UPR_HOST_EMU
         return upr_reduce(ctx, L + O::red, v, op);
 #else
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v = comb(v, __shfl_xor(v, off), op);
-        if (lane() == 0) L[O::red + (wb >> 6)] = v;
+        v = wave_reduce(v, op);
+        double* slot = L + O::red + red_par * O::RSET;
+        red_par ^= 1;
+        if (lane() == 0) slot[wb >> 6] = v;
         UPR_SYNC_LDS();
-        double r = L[O::red];
+        double r = slot[0];
 #pragma unroll
-        for (int w = 1; w < (NT >> 6); ++w) r = comb(r, L[O::red + w], op);
-        UPR_SYNC_LDS();
+        for (int w = 1; w < (NT >> 6); ++w) r = comb(r, slot[w], op);
         return r;
 #endif
     }
@@ -450,23 +483,21 @@ struct upr_qp3 {
         v[2] = upr_reduce(ctx, L + O::red, v[2], 1); v[3] = upr_reduce(ctx, L + O::red, v[3], 0);
 #else
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = comb(v[q], __shfl_xor(v[q], off), q < 3 ? 1 : 0);
-        }
+        for (int q = 0; q < 4; ++q) v[q] = wave_reduce(v[q], q < 3 ? 1 : 0);
+        double* slot = L + O::red + red_par * O::RSET;
+        red_par ^= 1;
         if (lane() == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) L[O::red + 4 * (wb >> 6) + q] = v[q];
+            for (int q = 0; q < 4; ++q) slot[4 * (wb >> 6) + q] = v[q];
         }
         UPR_SYNC_LDS();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            double r = L[O::red + q];
+            double r = slot[q];
 #pragma unroll
-            for (int w = 1; w < (NT >> 6); ++w) r = comb(r, L[O::red + 4 * w + q], q < 3 ? 1 : 0);
+            for (int w = 1; w < (NT >> 6); ++w) r = comb(r, slot[4 * w + q], q < 3 ? 1 : 0);
             v[q] = r;
         }
-        UPR_SYNC_LDS();
 #endif
     }
 
@@ -534,6 +565,11 @@ struct upr_qp3 {
             }
         }
         double ctP[C::QC][5], clP[C::QC][5];
+        // (round 6) the corrector's phase B multiplies with the inverse contact factor the predictor's call stored: requested here with
+        // the rows' operands instead of at its use (with the feed-forward phase's Lj^-1, backward_vec: -0.6 % on the headline launch;
+        // the same for the corrector's inverse SCHUR factor of phase D measured neutral to slower and is not done)
+        constexpr bool PREF_B = NF == 3 && C::QC == 1;
+        double BvP[PREF_B ? C::QC : 1][9];
         constexpr int QCS_ = C::SOFT ? C::QC : 1;
         double csP[QCS_][5], caP[QCS_][5], cgP[QCS_][5];   // softened friction rows: slack, its barrier pair
         if (NF == 3) {
@@ -543,6 +579,10 @@ struct upr_qp3 {
                 if (ic < C::NCI) {
 #pragma unroll
                     for (int r = 0; r < 5; ++r) { ctP[q][r] = G[F::ct + 5 * ic + r]; clP[q][r] = G[F::cl + 5 * ic + r]; }
+                    if (PREF_B && level == 1) {   // (the corrector's call multiplies with the inverse contact factor the predictor's call stored)
+#pragma unroll
+                        for (int a = 0; a < 9; ++a) BvP[q % (PREF_B ? C::QC : 1)][a] = G[F::lfi + (ic / NC) * C::NLF + 9 * (ic % NC) + a];
+                    }
                     if (C::SOFT && softp) {
 #pragma unroll
                         for (int r = 0; r < 5; ++r) { csP[q % QCS_][r] = G[F::sfr + 5 * ic + r]; caP[q % QCS_][r] = G[F::sfr + F::sfs + 5 * ic + r]; cgP[q % QCS_][r] = G[F::sfr + 2 * F::sfs + 5 * ic + r]; }
@@ -764,7 +804,7 @@ struct upr_qp3 {
                     double Bv[9];
                     if (!factor) {
 #pragma unroll
-                        for (int a = 0; a < 9; ++a) Bv[a] = Bk[a];
+                        for (int a = 0; a < 9; ++a) Bv[a] = PREF_B ? BvP[q % (PREF_B ? C::QC : 1)][a] : Bk[a];
                     }
                     if (factor) {
                         if (!upr_chol_inv3(Hc)) L[O::misc] = 1.0;
@@ -2308,6 +2348,22 @@ struct upr_qp3 {
 #endif
             UPR_SETPRIO(0);
         }
+#ifndef UPR_HOST_EMU
+        // (round 6) the corrector's call: the feed-forward phase below runs on the first lanes of WAVE 1, which request their knot's
+        // Lj^-1 (45 values out of the far arrays, stored by the matrix sweep) here, while wave 0 runs the sweep -- on wave 0 those
+        // requests went out behind the sweep and the phase waited one far round trip for them
+        constexpr bool KFFW1 = SW2 && N <= 64 && NT >= 128;
+        const bool kfw = KFFW1 && !fused;
+        double liP[KFFW1 ? NQ : 1][KFFW1 ? NQ : 1];
+        if (kfw && wb == 64) {
+            const int k = (lane() < N) ? lane() : 0;
+            const double* Li = G + F::Ljis + k * NQ * NX;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                for (int m = 0; m <= i; ++m) liP[i % (KFFW1 ? NQ : 1)][m % (KFFW1 ? NQ : 1)] = Li[i * NX + m];
+        }
+#endif
         UPR_SYNC();
         toc(10);
         // feed-forward of every knot: kff = Lj^-T (Lj^-1 huj) by substitution with the packed factor
@@ -2315,14 +2371,14 @@ struct upr_qp3 {
         if constexpr (SW2) {
             // (two-wave matrix sweep: the store holds the dense inverse factor Lj^-1 -- two triangular products, a lane per knot.  A row
             //  per lane with Lj^-1 staged in LDS was measured 1.6 - 4.8 % slower on the headline launch: DESIGN.md section 7)
-            UPR_FORT(k, N) {
+            for (int k = kfw ? tid() - 64 : tid(); k >= 0 && k < N; k += kfw ? N : stride()) {
                 const double* Li = G + F::Ljis + k * NQ * NX;
                 const double* w = Wk(k);
                 double li[NQ][NQ], tv[NQ], y[NQ];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
 #pragma unroll
-                    for (int m = 0; m <= i; ++m) li[i][m] = Li[i * NX + m];
+                    for (int m = 0; m <= i; ++m) li[i][m] = kfw ? liP[i % (KFFW1 ? NQ : 1)][m % (KFFW1 ? NQ : 1)] : Li[i * NX + m];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) tv[i] = fused ? L[O::kffs + k * NQ + i] : L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
 #pragma unroll
@@ -2363,7 +2419,7 @@ struct upr_qp3 {
     // COST: the corrector's pass -- the costates of the full step follow the tail (their rows of C and of the end-effector
     // Hessian are fetched by the idle waves as well)
     template <bool COST>
-    UPR_HDI void forward(double (&ctm)[NCT]) {   // ctm: the corrector targets for the step sweeps that follow (COST only)
+    UPR_HDI void forward() {
 #ifndef UPR_HOST_EMU
         // The flat tail's global data (rows of C, the Schur factors, the contact factors and yf) are constants of this
         // call: the waves that idle during the serial sweep fetch them into registers meanwhile, and the tail runs on
@@ -3041,6 +3097,120 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         return acc;
     }
 
+    // ---- the corrector's step on the lane-owned rows in ONE evaluation (round 6; hard rows without state-polytopic rows) -------------
+    // ineq_sweep runs three times behind the corrector's forward sweep -- step length (what 0), the safeguard's trial products
+    // (what 5, first iterations), the step itself with the new residuals (what 4) -- and every run forms the row's direction anew:
+    // c and ds out of LDS, two reciprocals, the friction rows' (t, lam, target) out of the far arrays.  Here the direction (dt, dlam)
+    // of every row of the lane is formed ONCE and kept in registers (twelve rows a lane for the headline shape: 24 values) across the
+    // two reductions; the trial products and the step are then two or three operations a row.  Same arithmetic per row as
+    // sweep_row (what 0 | 5 | 2 + 3), so iterates are bit-identical to the three-pass form.
+    UPR_HDI static void dir_row(double c, double ds, double t, double lam, double cterm, double& dt, double& dl, double& acc) {
+        const double rp = c - t;
+        dt = ds + rp;
+        const double rc = lam * t + cterm;
+        const double rt = upr_rcp(t);
+        dl = -(rc + lam * dt) * rt;
+        acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
+    }
+    // directions of all rows of the lane; returns the lane's largest admissible step (as ineq_sweep what 0, mode 3)
+    UPR_HDI double rows_dir(const double (&ctm)[NCT], row_dirs& D) {
+        const int tid_ = tid();
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) {
+            const int ix = tid_ + q * NT;
+            D.dt[2 * q] = 0.0; D.dl[2 * q] = 0.0; D.dt[2 * q + 1] = 0.0; D.dl[2 * q + 1] = 0.0;
+            if (ix < C::NXI) {
+                const int zo = NX + ix, i = ix % NX;
+                const double X = L[O::Z + zo], dS = L[O::S + zo];
+                dir_row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], D.dt[2 * q], D.dl[2 * q], acc);
+                dir_row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], D.dt[2 * q + 1], D.dl[2 * q + 1], acc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) {
+            const int iu = tid_ + q * NT, o = 2 * C::QX + 2 * q;
+            D.dt[o] = 0.0; D.dl[o] = 0.0; D.dt[o + 1] = 0.0; D.dl[o + 1] = 0.0;
+            if (iu < C::NUI) {
+                const int i = iu % NU;
+                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                dir_row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[o], D.dt[o], D.dl[o], acc);
+                dir_row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[o + 1], D.dt[o + 1], D.dl[o + 1], acc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OP_QR5; ++q) {
+            const int e = tid_ + q * NT;
+            D.dt[OP_NB + q] = 0.0; D.dl[OP_NB + q] = 0.0;
+            if (e < 5 * C::NCI) {
+                const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
+                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                dir_row(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], D.ft[q], D.fl[q], D.fc[q], D.dt[OP_NB + q], D.dl[OP_NB + q], acc);
+            }
+        }
+        return acc > 1e-30 ? 1.0 / acc : 1e30;
+    }
+    // smallest trial product (lam + a dlam)(t + a dt) of the lane's rows and their sum (the centrality safeguard: ineq_sweep what 5)
+    UPR_HDI double rows_trial(double alpha, const row_dirs& D, double* aux) const {
+        const int tid_ = tid();
+        double acc = 1e300;
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) if (tid_ + q * NT < C::NXI) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const double v = (lx[q][s2] + alpha * D.dl[2 * q + s2]) * (tx[q][s2] + alpha * D.dt[2 * q + s2]); acc = fmin(acc, v); *aux += v; }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) if (tid_ + q * NT < C::NUI) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const int o = 2 * C::QX + 2 * q + s2; const double v = (lu[q][s2] + alpha * D.dl[o]) * (tu[q][s2] + alpha * D.dt[o]); acc = fmin(acc, v); *aux += v; }
+        }
+#pragma unroll
+        for (int q = 0; q < OP_QR5; ++q) if (tid_ + q * NT < 5 * C::NCI) { const double v = (D.fl[q] + alpha * D.dl[OP_NB + q]) * (D.ft[q] + alpha * D.dt[OP_NB + q]); acc = fmin(acc, v); *aux += v; }
+        return acc;
+    }
+    // the step of the rows, and with the row's value at the NEW iterate the next iteration's first residuals (ineq_sweep what 4):
+    // returns the lane's largest |c - t|, adds lam t to *aux
+    UPR_HDI double rows_apply(double alpha, row_dirs& D, double* aux) {
+        const int tid_ = tid();
+        double acc = 0.0;
+        auto res = [&](double cn, double t, double lam) { const double a = fabs(cn - t); if (a > acc) acc = a; *aux += lam * t; };
+#pragma unroll
+        for (int q = 0; q < C::QX; ++q) {
+            const int ix = tid_ + q * NT;
+            if (ix < C::NXI) {
+                const int zo = NX + ix, i = ix % NX;
+                const double Xn = upr_step(L[O::Z + zo], alpha, L[O::S + zo]);
+                tx[q][0] += alpha * D.dt[2 * q]; lx[q][0] += alpha * D.dl[2 * q]; tx[q][1] += alpha * D.dt[2 * q + 1]; lx[q][1] += alpha * D.dl[2 * q + 1];
+                res(Xn - L[O::xlb + i], tx[q][0], lx[q][0]); res(L[O::xub + i] - Xn, tx[q][1], lx[q][1]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::QU; ++q) {
+            const int iu = tid_ + q * NT, o = 2 * C::QX + 2 * q;
+            if (iu < C::NUI) {
+                const int i = iu % NU;
+                const double Un = upr_step(L[O::Z + N1 * NX + iu], alpha, L[O::S + N1 * NX + iu]);
+                tu[q][0] += alpha * D.dt[o]; lu[q][0] += alpha * D.dl[o]; tu[q][1] += alpha * D.dt[o + 1]; lu[q][1] += alpha * D.dl[o + 1];
+                res(Un - L[O::ulb + i], tu[q][0], lu[q][0]); res(L[O::uub + i] - Un, tu[q][1], lu[q][1]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OP_QR5; ++q) {
+            const int e = tid_ + q * NT;
+            if (e < 5 * C::NCI) {
+                const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
+                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* e3 = L + O::erow + 3 * (5 * ci + r);
+                const double fn0 = upr_step(f[0], alpha, sf[0]), fn1 = upr_step(f[1], alpha, sf[1]), fn2 = upr_step(f[2], alpha, sf[2]);
+                const double t = D.ft[q] + alpha * D.dt[OP_NB + q], lam = D.fl[q] + alpha * D.dl[OP_NB + q];
+                res(e3[0] * fn0 + e3[1] * fn1 + e3[2] * fn2, t, lam);
+                G[F::ct + e] = t; G[F::cl + e] = lam;
+            }
+        }
+        return acc;
+    }
+
     // full == false: only the inequality residual and the complementarity average (what the step needs and what
     // decides whether the expensive stationarity / equality residuals can matter at all)
     UPR_HDI void residuals(int ntot, double* res, bool full) {
@@ -3171,9 +3341,12 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         }
     }
 
+    // Cycle stamps per phase (upr_batch_qp_profile, tools/dbg_profile.py): compiled in with -DUPR_QP3_PROF only -- a run-time
+    // instantiation, UPR_QP3_JIT=2 UPR_JIT_FLAGS=-DUPR_QP3_PROF.  Rounds 1 - 5 shipped them behind a null-pointer test; the ~150
+    // uniform branches per interior-point iteration cut the schedule into that many pieces: 1.8 % of the headline launch.
     double* prof; long long tlast;
     UPR_HDI void tic() {
-#ifndef UPR_HOST_EMU
+#if !defined(UPR_HOST_EMU) && defined(UPR_QP3_PROF)
         if (prof && lane() == 0) tlast = (long long)__builtin_readcyclecounter();
 #endif
     }
@@ -3204,7 +3377,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         toc_raw(id);
     }
     UPR_HDI void toc_raw(int id) {
-#ifndef UPR_HOST_EMU
+#if !defined(UPR_HOST_EMU) && defined(UPR_QP3_PROF)
 #ifdef UPR_QP3_PROF_MAT
         id = (id >= 100) ? id - 100 : ((id == 6) ? 1 : ((id == 8) ? 3 : ((id == 9) ? 5 : ((id == 7) ? 7 : 15))));
 #endif
@@ -3221,7 +3394,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
     }
 
     UPR_HDI void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
-        ctx = c; P = A.P; L = lds;
+        ctx = c; P = A.P; L = lds; red_par = 0;
 #ifdef UPR_HOST_EMU
         wb = 0;
 #else
@@ -3387,7 +3560,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
 #endif
                 break;
             }
-            { double unused[NCT]; forward<false>(unused); } toc(13);
+            forward<false>(); toc(13);
             double a_aff, mu_aff;
             {
                 // step length of the predictor and its complementarity average from ONE pass over the rows: for the affine direction
@@ -3408,9 +3581,11 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             backward_vec(); toc(11);
             mode = 3;
             double ctm[NCT];
-            forward<true>(ctm); toc(13);
-            load_targets(ctm);
-            const double a_loc = ineq_sweep(0, 0.0, nullptr, ctm);
+            forward<true>(); toc(13);
+            // (requested here, not ahead of the forward sweep's costates: that measured 0.6 - 0.8 % SLOWER on the headline launch)
+            row_dirs rd;
+            prefetch_step(ctm, rd);
+            const double a_loc = ONEPASS ? rows_dir(ctm, rd) : ineq_sweep(0, 0.0, nullptr, ctm);
             ftoc(6);
             double a = reduce(a_loc, 2);
             ftoc(7);
@@ -3420,14 +3595,14 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             // product and their sum through one combined reduction
             if (UPR_QP_NGAM > 0.0 && it < UPR_QP_NIT) {
                 double v4[4] = {0.0, 0.0, 0.0, 0.0};
-                v4[0] = -ineq_sweep(5, a, &v4[3], ctm, ROWMEM);   // (ROWMEM: the rows come from their parked copy again -- kept live across the reduction they go to scratch)
+                v4[0] = ONEPASS ? -rows_trial(a, rd, &v4[3]) : -ineq_sweep(5, a, &v4[3], ctm, ROWMEM);   // (ROWMEM: the rows come from their parked copy again -- kept live across the reduction they go to scratch)
                 reduce4(v4);
                 if (!(-v4[0] >= UPR_QP_NGAM * (v4[3] / (ntot > 0 ? ntot : 1)))) a *= UPR_QP_NBT;
             }
             // the rows' step also leaves |c - t| and lam t at the NEW iterate: the next iteration's first residual pass.  (The SOFT
             // instantiations too since their rows no longer live in scratch: 3.20 -> 3.07 ms; before: 3.77 -> 3.92.)
             res_next[0] = 0.0; res_next[1] = 0.0; res_next[3] = 0.0;
-            res_next[2] = ineq_sweep(4, a, &res_next[3], ctm, false);
+            res_next[2] = ONEPASS ? rows_apply(a, rd, &res_next[3]) : ineq_sweep(4, a, &res_next[3], ctm, false);
             store_rows();
             // (the multipliers' old values are requested in front of the barrier: their round trip overlaps it)
             constexpr int QPI = (N1 * NX + NT - 1) / NT, QNU = (N * NE + NT - 1) / NT;
