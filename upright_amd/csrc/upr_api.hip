@@ -530,7 +530,9 @@ bool jit_read(const std::string& path, std::string* out) {
 // can the production structure take this problem at all?  (what upr_qp3.h asserts or assumes; the LDS is checked after the compile)
 bool jit_capable(const upr_problem& P, const upr_dims& d) {
     if (P.nq != 6 && P.nq != 9) return false;
-    if (d.no > UPR_QP3_NOMAX || P.N < 2 || P.N > 64) return false;
+    // (horizons beyond 64 knots: the far-array form of the kernel, upr_qp3_cfg::KFAR -- star arrangements without friction and rows)
+    if (d.no > UPR_QP3_NOMAX || P.N < 2 || P.N > 128) return false;
+    if (P.N > 64) { for (int i = 0; i < P.nc; ++i) if (P.contact_body1[i] >= 0) return false; if (P.nb < 2 || P.nf != 1 || d.no != 0) return false; }
     if (d.nfc < d.ne && !P.soft_eq && P.nb > 1) return false;
     return true;
 }

@@ -60,6 +60,15 @@ struct upr_qp3_cfg {
     // factors where it accumulates S_b), and the force part of the back-substitution hf and the equality residual ek -- touched
     // by the flat phases only -- live in the far arrays
     static constexpr bool BIGF = MULTI && NF_ == 3;
+    // KFAR (round 6: the reference's own horizon for upright_robust, time_horizon 10 s = 100 knots, _base.yaml:62-66): the whole-horizon
+    // arrays -- iterate, step, gradients, barrier diagonals, residuals, P+ b, feed-forward, defects: 475 doubles a knot for the robust
+    // shape, 617 KB at N = 100 -- do not fit the LDS.  They live in a far array behind the instance's other far arrays and every
+    // access goes through the pointer LK (= the LDS base in all other instantiations: same code, same code objects); LDS keeps the
+    // constants, the sweeps' per-knot staging and the reductions.  The lane-owned box rows are streamed slot by slot out of their
+    // parked copy instead of living in registers (28 slots of ten values a lane at 256 lanes).  What it costs is latency -- every
+    // LDS-ordered hand-over becomes a global one -- and that is accepted: the alternative is the generic kernel, 40x slower per knot.
+    static constexpr bool KFAR = N_ > 64;
+    static_assert(!KFAR || (MULTI && !BIGF && !ROWS_), "long horizons: star arrangements without friction and without state-polytopic rows (the upright_robust shape)");
     static constexpr int SB = COUPLED ? 6 * NB_ : 6, NKB = COUPLED ? N_ : N_ * NB_;   // Schur block size; number of blocks
     static constexpr int NLS = COUPLED ? 36 * NB_ * NB_ : NB_ * 36;                   // doubles of the inverse Schur factor(s) of a knot
     static constexpr int N1 = N + 1;
@@ -113,25 +122,19 @@ struct upr_qp3_far {
     static constexpr int sfs = r2(5 * C::NCI), sos = (C::N - 1) * UPR_QP3_NOMAX;   // strides between the four arrays
 };
 
-// global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
-template <class C>
-struct upr_qp3_ws {
-    static constexpr int dx = 0, du = C::N1 * C::NX;
-    static constexpr int a0 = (C::NZ + 1) & ~1;
-    static constexpr int pi = a0, pin = pi + C::N1 * C::NX + (C::N1 * C::NX & 1), nu = pin + C::N1 * C::NX + (C::N1 * C::NX & 1),
-                         store = nu + ((C::N * C::NE + 1) & ~1), far = store /* the old per-knot store is gone */, total = ((far + upr_qp3_far<C>::total + 15) & ~15);
-};
-
-// LDS layout (doubles), all compile-time
+// LDS layout (doubles), all compile-time.  KFAR instantiations: the whole-horizon arrays (Z .. dek, Pbs .. gee, prep's staging of
+// Z = Lf^-1 Df' and the costates of the full step) are offsets into the far array behind LK instead, the rest is the LDS
 template <class C>
 struct upr_qp3_lds {
     static constexpr int r2(int n) { return (n + 1) & ~1; }
+    static constexpr bool KF = C::KFAR;
     static constexpr int Z = 0, S = Z + r2(C::NZ), gxs = S + r2(C::NZ), wx = gxs + r2(C::N1 * C::NX), gus = wx + r2(C::N1 * C::NX),
                          wu = gus + r2(C::N * C::NU), cs = wu + r2(C::N * C::NU), hf = cs + r2(C::N * C::NX), ys = hf + r2(C::BIGF ? 0 : C::N * C::NFC),
                          zt = ys + r2(C::N * C::NE), cv = zt, ek = zt + r2(C::N * C::NE),
                          dek = ek + r2(C::BIGF ? 0 : C::N * C::NE),   // INCEK: C sx of the step that was taken (the equality residual follows the iterate without a pass over C)
+                         kend = dek + r2(C::INCEK ? C::N * C::NE : 0),
                          // constants
-                         xlb = dek + r2(C::INCEK ? C::N * C::NE : 0), xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
+                         xlb = KF ? 0 : kend, xub = xlb + r2(C::NX), ulb = xub + r2(C::NX), uub = ulb + r2(C::NU), qd = uub + r2(C::NU),
                          rd = qd + r2(C::NX), xd = rd + r2(C::NU), erow = xd + r2(C::NX), df = erow + r2(3 * (C::NP > 0 ? C::NP : 1)),
                          // working set of the sweeps
                          Pa = df + r2(C::BIGF ? 6 * C::NFC : C::NE * C::NFC), Pb = Pa + r2(C::NX * C::NX), hux = Pb + r2(C::NX * C::NX),
@@ -151,7 +154,7 @@ struct upr_qp3_lds {
                          // the scratch region Pa .. yN serves, at different times: the four-wave sweep's working set (Pa .. ck), the
                          // two-wave sweep's staging (sw0 .. sw_end), prep's staging (Z = Lf^-1 Df' at Pa, the Schur complements of
                          // all knots and the state-polytopic rows' (s, w) at hux) and the costates (Pa): sized for the largest of them
-                         scr_sweep = ck + r2(C::NE * C::NX), scr_sw = C::SW ? (sw_end > sw0 + C::NKB * (C::SB * (C::SB + 1) / 2) ? sw_end : sw0 + r2(C::NKB * (C::SB * (C::SB + 1) / 2))) : 0,
+                         scr_sweep = ck + r2(C::NE * C::NX), scr_sw = C::SW ? ((KF || sw_end > sw0 + C::NKB * (C::SB * (C::SB + 1) / 2)) ? sw_end : sw0 + r2(C::NKB * (C::SB * (C::SB + 1) / 2))) : 0,
                          // prep's staging of the one-body shapes: Z = Lf^-1 Df' of all knots from Pa, the Schur complements behind it -- at
                          // hux where Z ends before it (nine joints), right behind Z otherwise (six joints with friction: P is 18 x 18)
                          sst = (C::MULTI || C::COUPLED) ? hux : (Pa + r2(C::N * C::NE * C::NFC) > hux ? Pa + r2(C::N * C::NE * C::NFC) : hux),
@@ -160,16 +163,28 @@ struct upr_qp3_lds {
                          yN = scr_a > scr_b ? scr_a : scr_b, dyN = yN + r2(C::NEN),
                          eN = dyN + r2(C::NEN), jN = eN + r2(C::NEN), red = jN + r2(3 * C::NQ), RSET = (4 * (C::NT / 64) > 16 ? 4 * (C::NT / 64) : 16) /* two sets of reduction slots */, misc = red + 2 * RSET,
                          // LDS-resident per-knot vectors of the sweeps: P+ b, feed-forward kff = Hjj^-1 huj, dynamics residual
-                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), Pbs = heek + 2 * r2(C::NH), kffs = Pbs + r2(C::N * C::NX),
+                         prf = misc + 16, lsik = prf + 4 * 16,   /* prf: cycle counters, 16 phases x the first 4 waves */ heek = lsik + r2(C::NLS), lend = heek + 2 * r2(C::NH), Pbs = KF ? kend : lend, kffs = Pbs + r2(C::N * C::NX),
                          bks = kffs + r2(C::N * C::NQ), gee = bks + r2(C::N * C::NX),   // gee: end-effector part of the cost gradient
                          // multi-body shapes: the contacts that load each body (indices as doubles) and their number
-                         clist = gee + r2(C::N * C::NQ), ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
+                         kend2 = gee + r2(C::N * C::NQ), clist = KF ? lend : kend2, ccnt = clist + r2(C::NB > 1 ? C::NB * C::NC : 0),
                          // stacked bodies (COUPLED): the dense Schur complement of every knot, packed lower triangle, assembled block by block
                          // by a lane per (knot, body pair) and factored by the knot's lane (prep D)
                          sdn = ccnt + r2(C::NB > 1 ? C::NB : 0),
                          // ... and, per body pair (bi >= bj), the contacts that load BOTH bodies (indices as doubles) and their number
                          plist = sdn + r2(C::COUPLED ? C::N * (C::SB * (C::SB + 1) / 2) : 0), pcnt = plist + r2(C::COUPLED ? (C::NB * (C::NB + 1) / 2) * C::NC : 0),
-                         total = pcnt + r2(C::COUPLED ? C::NB * (C::NB + 1) / 2 : 0);
+                         total = pcnt + r2(C::COUPLED ? C::NB * (C::NB + 1) / 2 : 0),
+                         // prep's staging of Z = Lf^-1 Df' [knot][force][6] (star arrangements) and the costates of the full step: in the
+                         // sweeps' working set -- KFAR: whole-horizon arrays of their own
+                         zst = KF ? kend2 : Pa, pin = KF ? zst + r2(C::N * C::NFC * 6) : Pa, ktotal = KF ? pin + r2(C::N1 * C::NX) : 0;
+};
+
+// global workspace per instance (doubles).  dx / du sit where the line-search kernel expects them.
+template <class C>
+struct upr_qp3_ws {
+    static constexpr int dx = 0, du = C::N1 * C::NX;
+    static constexpr int a0 = (C::NZ + 1) & ~1;
+    static constexpr int pi = a0, pin = pi + C::N1 * C::NX + (C::N1 * C::NX & 1), nu = pin + C::N1 * C::NX + (C::N1 * C::NX & 1),
+                         store = nu + ((C::N * C::NE + 1) & ~1), far = store /* the old per-knot store is gone */, kfar = far + upr_qp3_far<C>::total /* KFAR: the whole-horizon arrays (upr_qp3_lds::ktotal doubles) */, total = ((kfar + upr_qp3_lds<C>::ktotal + 15) & ~15);
 };
 
 // Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
@@ -279,6 +294,10 @@ struct upr_qp3 {
 #else
     static constexpr bool SW2 = false;
 #endif
+    // LDS-ordered barriers / wave-level ordering points.  KFAR: the whole-horizon arrays are global memory, so every one of them also
+    // waits for the global traffic in flight (a full barrier / fence); all other instantiations: exactly the macros
+    UPR_HDI static void sync_lds() { if (C::KFAR) { UPR_SYNC(); } else { UPR_SYNC_LDS(); } }
+    UPR_HDI static void wsync_lds() { if (C::KFAR) { UPR_WSYNC(); } else { UPR_WSYNC_LDS(); } }
     upr_ctx ctx;
     int wb;   // first lane of this wave (uniform; lives in a scalar register)
     // Lane / work-item index recomputed from the hardware where it is needed: a work-item id kept in a vector
@@ -316,6 +335,7 @@ struct upr_qp3 {
     UPR_HDI upr_ctx ctxv() const { upr_ctx c; c.tid = tid(); c.nt = stride(); return c; }
     const upr_problem* P;
     double* L;
+    double* LK;  // the whole-horizon arrays: = L (LDS), or a far array of their own (C::KFAR, long horizons)
     double* G;   // far arrays (global)
     const double* xs; const double* us; const double* x0; const double* lin; const double* Dfg;
     double* ws;
@@ -326,10 +346,12 @@ struct upr_qp3 {
     int mode;
     bool fbk;   // the feedback gain of the first knot is wanted (use_feedback_policy)
     // lane-owned box rows: [item][0 = lower, 1 = upper]
-    double tx[C::QX][2], lx[C::QX][2];
-    double tu[C::QU][2], lu[C::QU][2];
+    // (KFAR: ONE slot of each class in registers at a time -- the loops over the slots are rolled and fetch / park their slot, ldx .. stu)
+    static constexpr int QXR = C::KFAR ? 1 : C::QX, QUR = C::KFAR ? 1 : C::QU;
+    double tx[QXR][2], lx[QXR][2];
+    double tu[QUR][2], lu[QUR][2];
     // SOFT: slack sigma of a softened box row, its own barrier pair (tau, gam); untouched otherwise
-    static constexpr int QXS = C::SOFT ? C::QX : 1, QUS = C::SOFT ? C::QU : 1;
+    static constexpr int QXS = C::SOFT ? QXR : 1, QUS = C::SOFT ? QUR : 1;
     double sgx[QXS][2], tax[QXS][2], gax[QXS][2];
     double sgu[QUS][2], tau_[QUS][2], gau[QUS][2];
     bool softx, softu;      // which box classes carry slacks (uniform over the workgroup)
@@ -342,12 +364,14 @@ struct upr_qp3 {
     bool have_ek;           // INCEK: ek is current (updated with the step) -- prep does not form it again
     static constexpr int NCT0 = 2 * C::QX + 2 * C::QU;                // corrector targets of the rows per lane (F::cxr)
     static constexpr int NCT = (C::SOFT ? 2 : 1) * NCT0;             // SOFT: + the targets of the slack pairs, behind them
-    struct zero_targets_t { double v[NCT]; };
-    UPR_HDI static const double (&zero_targets())[NCT] { static constexpr zero_targets_t z = {}; return z.v; }
-    UPR_HDI void load_targets(double (&ctm)[NCT]) const {
+    static constexpr int NCTR = C::KFAR ? 1 : NCT;                   // ... of them in registers (KFAR: none, see ineq_sweep's tgt)
+    struct zero_targets_t { double v[NCTR]; };
+    UPR_HDI static const double (&zero_targets())[NCTR] { static constexpr zero_targets_t z = {}; return z.v; }
+    UPR_HDI void load_targets(double (&ctm)[NCTR]) const {
+        if (C::KFAR) { ctm[0] = 1.0; return; }
         const int tid_ = tid();
 #pragma unroll
-        for (int i = 0; i < NCT; ++i) ctm[i] = G[F::cxr + i * NT + tid_];
+        for (int i = 0; i < NCTR; ++i) ctm[i] = G[F::cxr + i * NT + tid_];
     }
 
     // the corrector's step on the lane-owned rows in one evaluation (rows_dir / rows_trial / rows_apply further down): which
@@ -357,7 +381,7 @@ struct upr_qp3 {
     static constexpr int OP_NB = 2 * C::QX + 2 * C::QU, OP_NR = OP_NB + (OP_QR5 > 0 ? OP_QR5 : 1);
     struct row_dirs { double dt[OP_NR], dl[OP_NR], ft[OP_QR5 > 0 ? OP_QR5 : 1], fl[OP_QR5 > 0 ? OP_QR5 : 1], fc[OP_QR5 > 0 ? OP_QR5 : 1]; };
     // the far operands of the rows' step: the corrector targets of the box rows and (ONEPASS) the friction rows' (t, lam, target)
-    UPR_HDI void prefetch_step(double (&ctm)[NCT], row_dirs& D) const {
+    UPR_HDI void prefetch_step(double (&ctm)[NCTR], row_dirs& D) const {
         load_targets(ctm);
         if (ONEPASS) {
             const int tid_ = tid();
@@ -377,7 +401,41 @@ struct upr_qp3 {
     // together at its top, and they are dead in between.
     static constexpr bool ROWMEM = C::SOFT && C::NB == 1 && C::QX >= 3 && UPR_QP3_SOFT_ROWMEM;   // (the shapes that spilled; the others measured 5 % slower with it)
     static constexpr int QO = ((C::N - 1) * UPR_QP3_NOMAX + C::NT - 1) / C::NT;   // state-polytopic rows per lane (at most)
+    // KFAR: slot q of the state / input box rows of this lane out of / into the parked copy (same layout as store_rows)
+    UPR_HDI void ldx(int q) {
+        if (!C::KFAR) return;
+        const double* R = G + F::rows + tid();
+        tx[0][0] = R[(4 * q) * NT]; tx[0][1] = R[(4 * q + 1) * NT]; lx[0][0] = R[(4 * q + 2) * NT]; lx[0][1] = R[(4 * q + 3) * NT];
+        if (C::SOFT) { const double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { sgx[0][s2] = Q[(6 * q + 3 * s2) * NT]; tax[0][s2] = Q[(6 * q + 3 * s2 + 1) * NT]; gax[0][s2] = Q[(6 * q + 3 * s2 + 2) * NT]; } }
+    }
+    UPR_HDI void stx(int q) const {
+        if (!C::KFAR) return;
+        double* R = G + F::rows + tid();
+        R[(4 * q) * NT] = tx[0][0]; R[(4 * q + 1) * NT] = tx[0][1]; R[(4 * q + 2) * NT] = lx[0][0]; R[(4 * q + 3) * NT] = lx[0][1];
+        if (C::SOFT) { double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { Q[(6 * q + 3 * s2) * NT] = sgx[0][s2]; Q[(6 * q + 3 * s2 + 1) * NT] = tax[0][s2]; Q[(6 * q + 3 * s2 + 2) * NT] = gax[0][s2]; } }
+    }
+    UPR_HDI void ldu(int q) {
+        if (!C::KFAR) return;
+        const double* R = G + F::rows + tid();
+        tu[0][0] = R[(4 * C::QX + 4 * q) * NT]; tu[0][1] = R[(4 * C::QX + 4 * q + 1) * NT]; lu[0][0] = R[(4 * C::QX + 4 * q + 2) * NT]; lu[0][1] = R[(4 * C::QX + 4 * q + 3) * NT];
+        if (C::SOFT) { const double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { sgu[0][s2] = Q[(6 * C::QX + 6 * q + 3 * s2) * NT]; tau_[0][s2] = Q[(6 * C::QX + 6 * q + 3 * s2 + 1) * NT]; gau[0][s2] = Q[(6 * C::QX + 6 * q + 3 * s2 + 2) * NT]; } }
+    }
+    UPR_HDI void stu(int q) const {
+        if (!C::KFAR) return;
+        double* R = G + F::rows + tid();
+        R[(4 * C::QX + 4 * q) * NT] = tu[0][0]; R[(4 * C::QX + 4 * q + 1) * NT] = tu[0][1]; R[(4 * C::QX + 4 * q + 2) * NT] = lu[0][0]; R[(4 * C::QX + 4 * q + 3) * NT] = lu[0][1];
+        if (C::SOFT) { double* Q = R + NROWV * NT;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { Q[(6 * C::QX + 6 * q + 3 * s2) * NT] = sgu[0][s2]; Q[(6 * C::QX + 6 * q + 3 * s2 + 1) * NT] = tau_[0][s2]; Q[(6 * C::QX + 6 * q + 3 * s2 + 2) * NT] = gau[0][s2]; } }
+    }
     UPR_HDI void store_rows() const {
+        if (C::KFAR) return;   // (every loop over the slots parks its own slot)
         const int tid_ = tid();
         double* R = G + F::rows + tid_;
         if (C::SOFT) {
@@ -392,11 +450,12 @@ struct upr_qp3 {
                 for (int s2 = 0; s2 < 2; ++s2) { Q[(6 * QXS + 6 * q + 3 * s2) * NT] = sgu[q][s2]; Q[(6 * QXS + 6 * q + 3 * s2 + 1) * NT] = tau_[q][s2]; Q[(6 * QXS + 6 * q + 3 * s2 + 2) * NT] = gau[q][s2]; }
         }
 #pragma unroll
-        for (int q = 0; q < C::QX; ++q) { R[(4 * q) * NT] = tx[q][0]; R[(4 * q + 1) * NT] = tx[q][1]; R[(4 * q + 2) * NT] = lx[q][0]; R[(4 * q + 3) * NT] = lx[q][1]; }
+        for (int q = 0; q < C::QX; ++q) { R[(4 * q) * NT] = tx[q % QXR][0]; R[(4 * q + 1) * NT] = tx[q % QXR][1]; R[(4 * q + 2) * NT] = lx[q % QXR][0]; R[(4 * q + 3) * NT] = lx[q % QXR][1]; }
 #pragma unroll
-        for (int q = 0; q < C::QU; ++q) { R[(4 * C::QX + 4 * q) * NT] = tu[q][0]; R[(4 * C::QX + 4 * q + 1) * NT] = tu[q][1]; R[(4 * C::QX + 4 * q + 2) * NT] = lu[q][0]; R[(4 * C::QX + 4 * q + 3) * NT] = lu[q][1]; }
+        for (int q = 0; q < C::QU; ++q) { R[(4 * C::QX + 4 * q) * NT] = tu[q % QUR][0]; R[(4 * C::QX + 4 * q + 1) * NT] = tu[q % QUR][1]; R[(4 * C::QX + 4 * q + 2) * NT] = lu[q % QUR][0]; R[(4 * C::QX + 4 * q + 3) * NT] = lu[q % QUR][1]; }
     }
     UPR_HDI void load_rows() {
+        if (C::KFAR) return;
         const int tid_ = tid();
         const double* R = G + F::rows + tid_;
         if (C::SOFT) {
@@ -411,23 +470,23 @@ struct upr_qp3 {
                 for (int s2 = 0; s2 < 2; ++s2) { sgu[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2) * NT]; tau_[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2 + 1) * NT]; gau[q][s2] = Q[(6 * QXS + 6 * q + 3 * s2 + 2) * NT]; }
         }
 #pragma unroll
-        for (int q = 0; q < C::QX; ++q) { tx[q][0] = R[(4 * q) * NT]; tx[q][1] = R[(4 * q + 1) * NT]; lx[q][0] = R[(4 * q + 2) * NT]; lx[q][1] = R[(4 * q + 3) * NT]; }
+        for (int q = 0; q < C::QX; ++q) { tx[q % QXR][0] = R[(4 * q) * NT]; tx[q % QXR][1] = R[(4 * q + 1) * NT]; lx[q % QXR][0] = R[(4 * q + 2) * NT]; lx[q % QXR][1] = R[(4 * q + 3) * NT]; }
 #pragma unroll
-        for (int q = 0; q < C::QU; ++q) { tu[q][0] = R[(4 * C::QX + 4 * q) * NT]; tu[q][1] = R[(4 * C::QX + 4 * q + 1) * NT]; lu[q][0] = R[(4 * C::QX + 4 * q + 2) * NT]; lu[q][1] = R[(4 * C::QX + 4 * q + 3) * NT]; }
+        for (int q = 0; q < C::QU; ++q) { tu[q % QUR][0] = R[(4 * C::QX + 4 * q) * NT]; tu[q % QUR][1] = R[(4 * C::QX + 4 * q + 1) * NT]; lu[q % QUR][0] = R[(4 * C::QX + 4 * q + 2) * NT]; lu[q % QUR][1] = R[(4 * C::QX + 4 * q + 3) * NT]; }
     }
     UPR_HDI const double* rec(int k) const { return lin + (size_t)k * lin_stride; }
-    UPR_HDI double* Zx(int k) const { return L + O::Z + k * NX; }
-    UPR_HDI double* Zu(int k) const { return L + O::Z + N1 * NX + k * NU; }
-    UPR_HDI double* Sx(int k) const { return L + O::S + k * NX; }
-    UPR_HDI double* Su(int k) const { return L + O::S + N1 * NX + k * NU; }
+    UPR_HDI double* Zx(int k) const { return LK + O::Z + k * NX; }
+    UPR_HDI double* Zu(int k) const { return LK + O::Z + N1 * NX + k * NU; }
+    UPR_HDI double* Sx(int k) const { return LK + O::S + k * NX; }
+    UPR_HDI double* Su(int k) const { return LK + O::S + N1 * NX + k * NU; }
     // entries of A = [[1,h,h2],[0,1,h],[0,0,1]] and B = [h3;h2;h] in arithmetic form: a select between the members
     // h, h2, h3 on a lane-dependent index would be turned into an indexed load and pin the whole object in scratch
     UPR_HDI double coefA(int a, int b) const { return ((a == b) ? 1.0 : 0.0) + (((a == 0 && b == 1) || (a == 1 && b == 2)) ? 1.0 : 0.0) * h + ((a == 0 && b == 2) ? 1.0 : 0.0) * h2; }
     UPR_HDI double coefB(int a) const { return ((a == 0) ? 1.0 : 0.0) * h3 + ((a == 1) ? 1.0 : 0.0) * h2 + ((a == 2) ? 1.0 : 0.0) * h; }
     // entry (r, col) of Df (BIGF: compact, valid for the rows of the body the column's contact loads); hf and ek (BIGF: far arrays)
     UPR_HDI double DF(int r, int col) const { return C::BIGF ? L[O::df + col * 6 + (r - 6 * (r / 6))] : L[O::df + r * NFC + col]; }
-    UPR_HDI double* hfp() const { return C::BIGF ? G + F::hf : L + O::hf; }
-    UPR_HDI double* ekp() const { return C::BIGF ? G + F::ek : L + O::ek; }
+    UPR_HDI double* hfp() const { return C::BIGF ? G + F::hf : LK + O::hf; }
+    UPR_HDI double* ekp() const { return C::BIGF ? G + F::ek : LK + O::ek; }
     // row r of Df times a force-indexed vector.  Multi-body shapes: the row of body r / 6 has entries at the contacts that
     // load that body only (O::clist), four of 32 columns for the robust arrangement
     UPR_HDI double df_dot(int r, const double* vf) const {
@@ -469,7 +528,7 @@ struct upr_qp3 {
         double* slot = L + O::red + red_par * O::RSET;
         red_par ^= 1;
         if (lane() == 0) slot[wb >> 6] = v;
-        UPR_SYNC_LDS();
+        sync_lds();
         double r = slot[0];
 #pragma unroll
         for (int w = 1; w < (NT >> 6); ++w) r = comb(r, slot[w], op);
@@ -490,7 +549,7 @@ struct upr_qp3 {
 #pragma unroll
             for (int q = 0; q < 4; ++q) slot[4 * (wb >> 6) + q] = v[q];
         }
-        UPR_SYNC_LDS();
+        sync_lds();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double r = slot[q];
@@ -639,7 +698,7 @@ struct upr_qp3 {
                 const int k = 1 + e / no, r = e % no, ei = (k - 1) * UPR_QP3_NOMAX + r;
                 double c = od[q], ds = 0.0;
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) { c += gq[q][i] * L[O::Z + k * NX + i]; ds += gq[q][i] * L[O::S + k * NX + i]; }
+                for (int i = 0; i < NQ; ++i) { c += gq[q][i] * LK[O::Z + k * NX + i]; ds += gq[q][i] * LK[O::S + k * NX + i]; }
                 double sr, wr, ct_ = 0.0;
                 if (C::SOFT && C::ROWS && softp) {
                     double cts_ = 0.0;
@@ -653,50 +712,52 @@ struct upr_qp3 {
         ftoc(6, 2);
         if (ROWMEM) load_rows();
         // A: box rows (registers)
-#pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QX)
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, k = 1 + ix / NX, i = ix % NX;
-                const double X = L[O::Z + zo], dS = L[O::S + zo];
+                ldx(q);
+                const double X = LK[O::Z + zo], dS = LK[O::S + zo];
                 double s0, s1, w0, w1;
                 double c0 = 0.0, c1 = 0.0;
                 if (C::SOFT && softx) {
                     double d0 = 0.0, d1 = 0.0;
-                    row_soft(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, c0, d0, s0, w0);
-                    row_soft(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, c1, d1, s1, w1);
+                    row_soft(X - L[O::xlb + i], dS, tx[q % QXR][0], lx[q % QXR][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, c0, d0, s0, w0);
+                    row_soft(L[O::xub + i] - X, -dS, tx[q % QXR][1], lx[q % QXR][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, c1, d1, s1, w1);
                     if (mode == 1) { G[F::cxr + (NCT0 + 2 * q) * NT + tid_] = d0; G[F::cxr + (NCT0 + 2 * q + 1) * NT + tid_] = d1; }
                 } else {
-                    row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], c0, s0, w0);
-                    row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], c1, s1, w1);
+                    row(X - L[O::xlb + i], dS, tx[q % QXR][0], lx[q % QXR][0], c0, s0, w0);
+                    row(L[O::xub + i] - X, -dS, tx[q % QXR][1], lx[q % QXR][1], c1, s1, w1);
                 }
                 if (mode == 1) { G[F::cxr + (2 * q) * NT + tid_] = c0; G[F::cxr + (2 * q + 1) * NT + tid_] = c1; }
                 const double g = (k < N) ? h * L[O::qd + i] * (X - L[O::xd + i]) : 0.0;   // (the end-effector part is added behind the barrier)
-                L[O::gxs + zo] = g + s0 - s1;
-                L[O::wx + zo] = w0 + w1;
+                LK[O::gxs + zo] = g + s0 - s1;
+                LK[O::wx + zo] = w0 + w1;
             }
         }
         ftoc(7, 2);
-#pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QU)
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid() + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
-                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                ldu(q);
+                const double U = LK[O::Z + N1 * NX + iu], dS = LK[O::S + N1 * NX + iu];
                 double s0, s1, w0, w1;
                 double c0 = 0.0, c1 = 0.0;
                 if (C::SOFT && softu) {
                     double d0 = 0.0, d1 = 0.0;
-                    row_soft(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, c0, d0, s0, w0);
-                    row_soft(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, c1, d1, s1, w1);
+                    row_soft(U - L[O::ulb + i], dS, tu[q % QUR][0], lu[q % QUR][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, c0, d0, s0, w0);
+                    row_soft(L[O::uub + i] - U, -dS, tu[q % QUR][1], lu[q % QUR][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, c1, d1, s1, w1);
                     if (mode == 1) { G[F::cxr + (NCT0 + 2 * C::QX + 2 * q) * NT + tid_] = d0; G[F::cxr + (NCT0 + 2 * C::QX + 2 * q + 1) * NT + tid_] = d1; }
                 } else {
-                    row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], c0, s0, w0);
-                    row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], c1, s1, w1);
+                    row(U - L[O::ulb + i], dS, tu[q % QUR][0], lu[q % QUR][0], c0, s0, w0);
+                    row(L[O::uub + i] - U, -dS, tu[q % QUR][1], lu[q % QUR][1], c1, s1, w1);
                 }
                 if (mode == 1) { G[F::cxr + (2 * C::QX + 2 * q) * NT + tid_] = c0; G[F::cxr + (2 * C::QX + 2 * q + 1) * NT + tid_] = c1; }
-                L[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
-                L[O::wu + iu] = w0 + w1;
+                LK[O::gus + iu] = h * L[O::rd + i] * U + s0 - s1;
+                LK[O::wu + iu] = w0 + w1;
             }
         }
         ftoc(8, 2);
@@ -708,9 +769,9 @@ struct upr_qp3 {
             const int k = e / NQ, j = e % NQ;
             const double* X = Zx(k); const double* Xn = Zx(k + 1); const double* U = Zu(k);
             const double q = X[j], v = X[NQ + j], a = X[2 * NQ + j], u = U[j];
-            L[O::bks + k * NX + j] = q + h * v + h2 * a + h3 * u - Xn[j];
-            L[O::bks + k * NX + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
-            L[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
+            LK[O::bks + k * NX + j] = q + h * v + h2 * a + h3 * u - Xn[j];
+            LK[O::bks + k * NX + NQ + j] = v + h * a + h2 * u - Xn[NQ + j];
+            LK[O::bks + k * NX + 2 * NQ + j] = a + h * u - Xn[2 * NQ + j];
         }
         ftoc(9, 2);
         UPR_SYNC(); toc(1);
@@ -724,9 +785,9 @@ struct upr_qp3 {
                 if (fresh) {
                     a = heeP[q][NQ];
 #pragma unroll
-                    for (int j = 0; j < NQ; ++j) a += heeP[q][j] * L[O::Z + k * NX + j];
-                    L[O::gee + e] = a;
-                } else a = L[O::gee + e];
+                    for (int j = 0; j < NQ; ++j) a += heeP[q][j] * LK[O::Z + k * NX + j];
+                    LK[O::gee + e] = a;
+                } else a = LK[O::gee + e];
                 double go = 0.0;   // G' s of the state-polytopic rows (five rows requested together: one exposed latency per group)
                 for (int r0 = 0; r0 < no; r0 += 5) {
                     double gv[5], sv[5];
@@ -735,7 +796,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int u = 0; u < 5; ++u) go += gv[u] * sv[u];
                 }
-                L[O::gxs + k * NX + i] += h * a + go;
+                LK[O::gxs + k * NX + i] += h * a + go;
             }
         }
         if (no > 0 && factor) UPR_FORT(e, (N - 1) * C::NH) {   // barrier Hessian of those rows next to the end-effector Hessian
@@ -769,11 +830,11 @@ struct upr_qp3 {
                 const int k = ic / NC, ci = ic % NC;
                 if (NF == 3) {
                     const int uo = k * NU + NQ + 3 * ci;
-                    const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
-                    double guf[3] = {L[O::gus + uo], L[O::gus + uo + 1], L[O::gus + uo + 2]};
+                    const double* f = LK + O::Z + N1 * NX + uo; const double* sf = LK + O::S + N1 * NX + uo;
+                    double guf[3] = {LK[O::gus + uo], LK[O::gus + uo + 1], LK[O::gus + uo + 2]};
                     double Hc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) Hc[4 * a] = h * L[O::rd + NQ + 3 * ci + a] + L[O::wu + uo + a];
+                    for (int a = 0; a < 3; ++a) Hc[4 * a] = h * L[O::rd + NQ + 3 * ci + a] + LK[O::wu + uo + a];
 #pragma unroll
                     for (int r = 0; r < 5; ++r) {
                         const double* e3 = L + O::erow + 3 * (5 * ci + r);
@@ -794,7 +855,7 @@ struct upr_qp3 {
                         }
                     }
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) L[O::gus + uo + a] = guf[a];
+                    for (int a = 0; a < 3; ++a) LK[O::gus + uo + a] = guf[a];
                     ftoc(7, 6);   // (-DUPR_QP3_PROF_FLAT=6: prep B -- 6: up to its start, 7: the five rows, 8: contact factor and Z, 9: the two products)
                     if (level == 0) continue;
                     double* Bk = G + F::lfi + k * C::NLF + 9 * ci;
@@ -820,7 +881,7 @@ struct upr_qp3 {
                             for (int r6 = 0; r6 < 6; ++r6) {
                                 const double* dr = L + O::df + (6 * b2 + r6) * NFC + 3 * ci;
                                 const double d0 = dr[0], d1 = dr[1], d2 = dr[2];
-                                double* zr = L + O::Pa + (k * NFC + 3 * ci) * 6 + r6;
+                                double* zr = LK + O::zst + (k * NFC + 3 * ci) * 6 + r6;
                                 zr[0] = Hc[0] * d0; zr[6] = Hc[3] * d0 + Hc[4] * d1; zr[12] = Hc[6] * d0 + Hc[7] * d1 + Hc[8] * d2;
                             }
                         } else if (!C::COUPLED) {
@@ -856,13 +917,13 @@ struct upr_qp3 {
                     if (level == 0) continue;
                     const int uo = k * NU + NQ + ci;
                     if (factor) {
-                        const double lf0 = 1.0 / sqrt(h * L[O::rd + NQ + ci] + L[O::wu + uo]);
+                        const double lf0 = 1.0 / sqrt(h * L[O::rd + NQ + ci] + LK[O::wu + uo]);
                         G[F::lfi + k * C::NLF + ci] = lf0;
-                        if (C::MULTI) { const int b2 = P->contact_body2[ci]; for (int r6 = 0; r6 < 6; ++r6) L[O::Pa + (k * NFC + ci) * 6 + r6] = lf0 * L[O::df + (6 * b2 + r6) * NFC + ci]; }
+                        if (C::MULTI) { const int b2 = P->contact_body2[ci]; for (int r6 = 0; r6 < 6; ++r6) LK[O::zst + (k * NFC + ci) * 6 + r6] = lf0 * L[O::df + (6 * b2 + r6) * NFC + ci]; }
                         else if (!C::COUPLED) for (int r = 0; r < NE; ++r) L[O::Pa + (k * NE + r) * NFC + ci] = lf0 * L[O::df + r * NFC + ci];
                     }
                     const double lf = G[F::lfi + k * C::NLF + ci];
-                    const double yv = lf * L[O::gus + uo];
+                    const double yv = lf * LK[O::gus + uo];
                     G[F::yf + k * NFC + ci] = yv; hfp()[k * NFC + ci] = lf * yv;
                 }
             }
@@ -881,7 +942,7 @@ struct upr_qp3 {
                     const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
                     double v = 0.0;
                     {   // (branch-free, as the quads of the forward tail: see there)
-                        const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+                        const double* zx = LK + O::Z + (e / NE) * NX + part * CH;
                         double zv[CH];
 #pragma unroll
                         for (int c = 0; c < CH; ++c) zv[c] = zx[c];
@@ -913,7 +974,7 @@ struct upr_qp3 {
                         const int e4 = tid_ + (q0 + g) * NT;
                         const bool act = (q0 + g < QR) && e4 < N * NE * 4;
                         const int e = act ? (e4 >> 2) : 0, part = e4 & 3;
-                        const double* zx = L + O::Z + (e / NE) * NX + part * CH;
+                        const double* zx = LK + O::Z + (e / NE) * NX + part * CH;
                         double v = 0.0;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? zx[c] : 0.0);
@@ -922,17 +983,17 @@ struct upr_qp3 {
                     }
                 }
             }
-            if (C::BIGF) UPR_SYNC(); else UPR_SYNC_LDS();   // (BIGF: ek is a far array -- its stores are global)
+            if (C::BIGF) UPR_SYNC(); else sync_lds();   // (BIGF: ek is a far array -- its stores are global)
         }
         UPR_FORT(e, N * NE) {
             const int k = e / NE, r = e % NE;
             double v = ekp()[e], v2 = 0.0;
             if (fresh_ek) {
-                v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
+                v += df_dot(r, LK + O::Z + N1 * NX + k * NU + NQ);
                 ekp()[e] = v;
             }
             if (level > 0) v2 = df_dot(r, hfp() + k * NFC);
-            L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
+            LK[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #else
         UPR_FORT(e, N * NE) {
@@ -941,12 +1002,12 @@ struct upr_qp3 {
             double v, v2 = 0.0;
             if (fresh_ek) {
                 v = G[F::e0 + e];
-                for (int j = 0; j < NX; ++j) v += Ck[j] * L[O::Z + k * NX + j];
-                v += df_dot(r, L + O::Z + N1 * NX + k * NU + NQ);
+                for (int j = 0; j < NX; ++j) v += Ck[j] * LK[O::Z + k * NX + j];
+                v += df_dot(r, LK + O::Z + N1 * NX + k * NU + NQ);
                 ekp()[e] = v;
             } else v = ekp()[e];
             if (level > 0) v2 = df_dot(r, hfp() + k * NFC);
-            L[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
+            LK[O::ys + e] = (rho_px != 0.0 ? v + rho_px * ws[W::nu + e] : v) - v2;
         }
 #endif
         if (factor && !C::MULTI && !C::COUPLED) {
@@ -1127,14 +1188,14 @@ struct upr_qp3 {
                         if (p + 1 < SB) {
 #pragma unroll
                             for (int q = 0; q < KQ; ++q) colb[64 * q + ln] = lp[q];
-                            UPR_WSYNC_LDS();
+                            wsync_lds();
                             // (no test on c <= i: the entries of a row beyond its diagonal are never used, and a test would put every
                             //  one of these reads into a branch of its own with a full LDS round trip: measured 2.3 k cycles per pivot)
 #pragma unroll
                             for (int q = 0; q < KQ; ++q)
 #pragma unroll
                                 for (int c = p + 1; c < SB; ++c) row[q][c] -= lp[q] * colb[64 * q + gc * SB + c];
-                            UPR_WSYNC_LDS();
+                            wsync_lds();
                         }
                     }
                     ftoc(7, 3);
@@ -1144,7 +1205,7 @@ struct upr_qp3 {
 #pragma unroll
                         for (int c = 0; c < SB; ++c) if (c <= i) Sk[q][ri + c] = row[q][c];
                     }
-                    UPR_WSYNC_LDS();
+                    wsync_lds();
                     // forward substitution in axpy form: once entry r of the column is known it goes into the running sums of all
                     // later entries (seventeen independent operations) -- the dot-product form made every one of its 153 operations
                     // wait for its own LDS read behind the previous one (19 k cycles for two passes); each sum still takes its terms
@@ -1163,7 +1224,7 @@ struct upr_qp3 {
 #pragma unroll
                             for (int s2 = r + 1; s2 < SB; ++s2) col[q][s2] += Sk[q][s2 * (s2 + 1) / 2 + r] * col[q][r];   // (col[r] = 0 above the lane's own column: exact zeros)
                         }
-                    UPR_WSYNC_LDS();   // every lane is through with the factor: the packed inverse takes its place
+                    wsync_lds();   // every lane is through with the factor: the packed inverse takes its place
 #pragma unroll
                     for (int q = 0; q < KQ; ++q) if (act[q]) {
                         double* Lsg = G + F::lsi + kq[q] * SB * SB;
@@ -1177,27 +1238,27 @@ struct upr_qp3 {
 #pragma unroll
                         for (int r = 0; r < SB; ++r) { const double v = Sk[q][r * (r + 1) / 2 + ((r >= i) ? i : 0)]; col[q][r] = (r >= i) ? v : 0.0; }
                 }
-                UPR_WSYNC_LDS();
+                wsync_lds();
                 ftoc(8, 3);
                 double yv[KQ], zv[KQ];
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     yv[q] = 0.0;
 #pragma unroll
-                    for (int m = 0; m < SB; ++m) { const double e = L[O::ys + kq[q] * SB + m], a = Sk[q][ri + m]; yv[q] += ((m <= i) ? a : 0.0) * e; }
+                    for (int m = 0; m < SB; ++m) { const double e = LK[O::ys + kq[q] * SB + m], a = Sk[q][ri + m]; yv[q] += ((m <= i) ? a : 0.0) * e; }
                 }
-                UPR_WSYNC_LDS();
+                wsync_lds();
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) if (act[q]) L[O::ys + kq[q] * SB + i] = yv[q];
-                UPR_WSYNC_LDS();
+                for (int q = 0; q < KQ; ++q) if (act[q]) LK[O::ys + kq[q] * SB + i] = yv[q];
+                wsync_lds();
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     zv[q] = 0.0;
 #pragma unroll
-                    for (int m = 0; m < SB; ++m) zv[q] += col[q][m] * L[O::ys + kq[q] * SB + m];
-                    if (act[q]) L[O::zt + kq[q] * SB + i] = zv[q];
+                    for (int m = 0; m < SB; ++m) zv[q] += col[q][m] * LK[O::ys + kq[q] * SB + m];
+                    if (act[q]) LK[O::zt + kq[q] * SB + i] = zv[q];
                 }
-                UPR_WSYNC_LDS();
+                wsync_lds();
                 ftoc(9, 3);
             }
             if (!ok) L[O::misc] = 1.0;
@@ -1224,7 +1285,7 @@ struct upr_qp3 {
                             for (int a9 = 0; a9 < 9; ++a9) Bk[a9 % (C::BIGF ? 9 : 1)] = G[F::lfi + k * C::NLF + 9 * ci + a9];
                         }
                         for (int a = 0; a < NF; ++a) {
-                            const double* z = L + O::Pa + (k * NFC + NF * ci + a) * 6;
+                            const double* z = LK + O::zst + (k * NFC + NF * ci + a) * 6;
                             double zv[SB];
                             if (C::BIGF) {
                                 // column a of Z = Lf^-1 Df' of this contact: row a of the inverse factor times the body's rows of Df
@@ -1287,7 +1348,7 @@ struct upr_qp3 {
 #endif
             double ee[SB], yv[SB];
 #pragma unroll
-            for (int r = 0; r < SB; ++r) ee[r] = L[O::ys + kb * SB + r];
+            for (int r = 0; r < SB; ++r) ee[r] = LK[O::ys + kb * SB + r];
 #pragma unroll
             for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
@@ -1297,7 +1358,7 @@ struct upr_qp3 {
             for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
                 for (int m = r; m < SB; ++m) v += Lr[m * SB + r] * yv[m];
-                L[O::ys + kb * SB + r] = yv[r]; L[O::zt + kb * SB + r] = v; }
+                LK[O::ys + kb * SB + r] = yv[r]; LK[O::zt + kb * SB + r] = v; }
         }
         UPR_SYNC(); toc(4);
         // E: cs = C' zt
@@ -1317,7 +1378,7 @@ struct upr_qp3 {
                     for (int r = 0; r < NE; ++r) cr[r] = Ck[r * NX];
                 }
 #pragma unroll
-                for (int r = 0; r < NE; ++r) v += cr[r] * L[O::zt + k * NE + r];
+                for (int r = 0; r < NE; ++r) v += cr[r] * LK[O::zt + k * NE + r];
 #ifndef UPR_HOST_EMU
                 if (C::VCPRE && factor && k >= 1) {
                     // column e % NX of Vc_k = Lsi_k C_k for the single-wave matrix sweep (its lanes read whole columns)
@@ -1332,7 +1393,7 @@ struct upr_qp3 {
                     }
                 }
 #endif
-                L[O::cs + e] = v;
+                LK[O::cs + e] = v;
             }
         }
         UPR_SYNC(); toc(5);
@@ -1395,7 +1456,7 @@ struct upr_qp3 {
     // start value of the fused predictor recursion, lane c < nx
     UPR_HDI double wt_terminal(int l) const {
         const double irho = 1.0 / UPR_QP_RHO_N;
-        double v = L[O::gxs + N * NX + l];
+        double v = LK[O::gxs + N * NX + l];
         if (neN > 0) {
             if (l < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + l] * (L[O::yN + q] + irho * L[O::eN + q]); }
             else v += L[O::yN + 3 + (l - NQ)] + irho * L[O::eN + 3 + (l - NQ)];
@@ -1451,19 +1512,19 @@ struct upr_qp3 {
 #pragma unroll
             for (int q = 0; q < NQ; q += 3) { s0 += pbv[q]; if (q + 1 < NQ) s1 += pbv[q + 1]; if (q + 2 < NQ) s2 += pbv[q + 2]; }
             pbs = (s0 + s1) + s2;
-            if (vl) L[O::Pbs + k * NX + l] = pbs;
+            if (vl) LK[O::Pbs + k * NX + l] = pbs;
         }
         {
             // the predictor's vector sweep (backward_vec's recursion, mode 0) rides along, K_k out of registers:
             // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
-            const double gk = (k >= 1) ? L[O::gxs + k * NX + (vl ? l : 0)] + L[O::cs + k * NX + (vl ? l : 0)] : 0.0;
-            const double uk = L[O::gus + k * NU + vj_];
+            const double gk = (k >= 1) ? LK[O::gxs + k * NX + (vl ? l : 0)] + LK[O::cs + k * NX + (vl ? l : 0)] : 0.0;
+            const double uk = LK[O::gus + k * NU + vj_];
             const double wk = wt + pbs;
             if (vl) L[O::sw_w + l] = wk;
             UPR_WSYNC();
             const double w0 = L[O::sw_w + vj_], w1 = L[O::sw_w + NQ + vj_], w2 = L[O::sw_w + 2 * NQ + vj_];
             const double rq = ((h3 * w0 + h2 * w1) + h * w2) + uk;
-            if (l < NQ) L[O::kffs + k * NQ + l] = rq;
+            if (l < NQ) LK[O::kffs + k * NQ + l] = rq;
             double v0 = gk + ca0 * w0, v1 = ca1 * w1, v2 = ca2 * w2;
 #pragma unroll
             for (int m = 0; m < NQ; m += 3) {
@@ -1483,7 +1544,7 @@ struct upr_qp3 {
         const double irho = 1.0 / UPR_QP_RHO_N;
         terminal_residual();
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
-        UPR_SYNC_LDS();
+        sync_lds();
         if (wave == 1) {
             UPR_SETPRIO(UPR_QP3_PRIO_W1);
             const bool blk = l < NBK;
@@ -1499,14 +1560,14 @@ struct upr_qp3 {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) p[a][c] = 0.0;
             {
-                double v = dg ? L[O::wx + N * NX + bi] : 0.0;
+                double v = dg ? LK[O::wx + N * NX + bi] : 0.0;
                 if (neN > 0) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + bi] * L[O::jN + q * NQ + bj]; }
                 p[0][0] = v;
-                const double d1 = L[O::wx + N * NX + NQ + bi] + ((neN > 0) ? irho : 0.0), d2 = L[O::wx + N * NX + 2 * NQ + bi] + ((neN > 0) ? irho : 0.0);
+                const double d1 = LK[O::wx + N * NX + NQ + bi] + ((neN > 0) ? irho : 0.0), d2 = LK[O::wx + N * NX + 2 * NQ + bi] + ((neN > 0) ? irho : 0.0);
                 p[1][1] = dg ? d1 : 0.0; p[2][2] = dg ? d2 : 0.0;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no wait for earlier global loads inside the loop
-            double hjd = h * L[O::rd + bi] + L[O::wu + (N - 1) * NU + bi];
+            double hjd = h * L[O::rd + bi] + LK[O::wu + (N - 1) * NU + bi];
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 // critical path first: Hux (both orientations of the block) and Hjj, straight from the registers of P+
@@ -1531,14 +1592,14 @@ struct upr_qp3 {
                         for (int c = 0; c < 3; ++c) L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c];
                     }
                 }
-                UPR_SYNC_LDS();   // A: Hjj, Hux are in LDS
+                sync_lds();   // A: Hjj, Hux are in LDS
                 toc(6);
                 // while wave 0 factors: the partial sums of P+ b (wave 0 adds them up behind barrier B) ...
                 const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;   // (used at the very end of the knot)
                 {
                     double bjv[3], biv[3], r1[3], r2[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { bjv[c] = L[O::bks + k * NX + c * NQ + bj]; biv[c] = L[O::bks + k * NX + c * NQ + bi]; }
+                    for (int c = 0; c < 3; ++c) { bjv[c] = LK[O::bks + k * NX + c * NQ + bj]; biv[c] = LK[O::bks + k * NX + c * NQ + bi]; }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
@@ -1564,7 +1625,7 @@ struct upr_qp3 {
                     int bic = bi, bjc = bj;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        wxk[c] = L[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
+                        wxk[c] = LK[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
 #pragma unroll
                         for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * O::VCS + r]; ci[0][c][r] = Vk[(c * NQ + bi) * O::VCS + r]; }
                     }
@@ -1609,10 +1670,10 @@ struct upr_qp3 {
                     }
                 }
                 toc(7);
-                UPR_SYNC_LDS();   // B: V is in LDS
+                sync_lds();   // B: V is in LDS
                 toc(8);
                 if (k == 0) break;
-                hjd = h * L[O::rd + bi] + L[O::wu + (k - 1) * NU + bi];
+                hjd = h * L[O::rd + bi] + LK[O::wu + (k - 1) * NU + bi];
                 {
                     double vj[3][NQ], vi[3][NQ];
 #pragma unroll
@@ -1653,7 +1714,7 @@ struct upr_qp3 {
             if (vl) wt = wt_terminal(l);
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
-                UPR_SYNC_LDS();   // A
+                sync_lds();   // A
                 toc(6);
                 double a[NQ][NQ], hx[NQ];
                 sw2_factor(a, hx, vcl, ok);
@@ -1662,7 +1723,7 @@ struct upr_qp3 {
                     for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
                 }
                 toc(7);
-                UPR_SYNC_LDS();   // B
+                sync_lds();   // B
                 toc(8);
                 {
                     // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
@@ -1689,7 +1750,7 @@ struct upr_qp3 {
             if (!C::VCPRE && N - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(N - 2, vm); } else form_vc_load(N - 2, vq); }
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
-                UPR_SYNC_LDS();   // A
+                sync_lds();   // A
                 toc(6);
                 // Vc of knot k - 1 goes into the buffer whose last readers (knot k + 1) finished before barrier B of that knot; its
                 // operands were requested behind that barrier.  Stacked bodies: wave 2 forms it on the matrix cores now, in the
@@ -1697,7 +1758,7 @@ struct upr_qp3 {
                 if (C::COUPLED && wave == 2 && k - 1 >= 1) form_vcm_store(k - 1, vm);
                 if (!C::VCPRE && k >= 1) { if (wave == 2) vc_share<0>(k, bi, bj); else vc_share<1>(k, bi, bj); }   // (added by wave 1 behind barrier B)
                 toc(7);
-                UPR_SYNC_LDS();   // B
+                sync_lds();   // B
                 toc(8);
                 if (!C::VCPRE && !C::COUPLED && k - 1 >= 1) form_vc_store(k - 1, vq);                                   // (read behind the NEXT barrier A)
                 if (!C::VCPRE && k - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(k - 2, vm); } else form_vc_load(k - 2, vq); }
@@ -1878,7 +1939,7 @@ struct upr_qp3 {
         }
         UPR_FORT(e, NX * NX) {
             const int i = e / NX, j = e % NX;
-            double v = (i == j) ? L[O::wx + N * NX + i] : 0.0;
+            double v = (i == j) ? LK[O::wx + N * NX + i] : 0.0;
             if (neN > 0) {
                 if (i < NQ && j < NQ) { for (int q = 0; q < 3; ++q) v += irho * L[O::jN + q * NQ + i] * L[O::jN + q * NQ + j]; }
                 else if (i == j) v += irho;
@@ -1925,7 +1986,7 @@ struct upr_qp3 {
             constexpr int NPB = NX;
 #endif
             static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::sst - O::Pa && N * NE * NE <= O::yN - O::sst), "prep stages Z and S in the scratch region");
-            static_assert(!C::MULTI || C::BIGF || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
+            static_assert(!C::MULTI || C::BIGF || C::KFAR || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
             static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
 #ifndef UPR_HOST_EMU
             // dense Schur complement (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x 27) as 18
@@ -2013,7 +2074,7 @@ struct upr_qp3 {
                     double v = 0.0;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) v += coefB(a) * (h3 * p[a][0] + h2 * p[a][1] + h * p[a][2]);
-                    if (ii == jj) v += h * L[O::rd + ii] + L[O::wu + k * NU + ii];
+                    if (ii == jj) v += h * L[O::rd + ii] + LK[O::wu + k * NU + ii];
                     // lower triangle, packed: the factoring wave reads it with paired 128-bit loads (it is the wave phase 2 waits for)
                     if (jj <= ii) L[O::hjj + ii * (ii + 1) / 2 + jj] = v;
                 } else if (e >= VC0 && e < ((NVC <= PB0 - VC0) ? VC0 + NVC : PB0)) {
@@ -2056,27 +2117,27 @@ struct upr_qp3 {
                     double q0 = 0.0, q1 = 0.0;         // two independent chains
 #pragma unroll
                     for (int j = 0; j < HL; j += 2) {
-                        q0 += ((c0 + j < NX) ? Pc[i * NX + c0 + j] : 0.0) * L[O::bks + k * NX + ((c0 + j < NX) ? c0 + j : 0)];
-                        if (j + 1 < HL) q1 += ((c0 + j + 1 < NX) ? Pc[i * NX + c0 + j + 1] : 0.0) * L[O::bks + k * NX + ((c0 + j + 1 < NX) ? c0 + j + 1 : 0)];
+                        q0 += ((c0 + j < NX) ? Pc[i * NX + c0 + j] : 0.0) * LK[O::bks + k * NX + ((c0 + j < NX) ? c0 + j : 0)];
+                        if (j + 1 < HL) q1 += ((c0 + j + 1 < NX) ? Pc[i * NX + c0 + j + 1] : 0.0) * LK[O::bks + k * NX + ((c0 + j + 1 < NX) ? c0 + j + 1 : 0)];
                     }
                     double pb = q0 + q1;
                     pb += upr_dpp_quad<0xB1>(pb);      // the partner lane of the pair (both are active)
-                    if (hf == 0) L[O::Pbs + k * NX + i] = pb;
+                    if (hf == 0) LK[O::Pbs + k * NX + i] = pb;
 #else
                     const int i = e - PB0;
                     double p0 = 0.0, p1 = 0.0, p2 = 0.0;   // three independent chains
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) {
-                        p0 += Pc[i * NX + j] * L[O::bks + k * NX + j];
-                        p1 += Pc[i * NX + NQ + j] * L[O::bks + k * NX + NQ + j];
-                        p2 += Pc[i * NX + 2 * NQ + j] * L[O::bks + k * NX + 2 * NQ + j];
+                        p0 += Pc[i * NX + j] * LK[O::bks + k * NX + j];
+                        p1 += Pc[i * NX + NQ + j] * LK[O::bks + k * NX + NQ + j];
+                        p2 += Pc[i * NX + 2 * NQ + j] * LK[O::bks + k * NX + 2 * NQ + j];
                     }
-                    L[O::Pbs + k * NX + i] = (p0 + p1) + p2;
+                    LK[O::Pbs + k * NX + i] = (p0 + p1) + p2;
 #endif
                 }
             }
             mtoc(0);
-            UPR_SYNC_LDS();
+            sync_lds();
             toc(6);
 #ifndef UPR_HOST_EMU
             // Matrix-core path.  The 32 x 32 padded result is three 16 x 16 tiles ((0,0), (0,1), (1,1); the lower
@@ -2107,7 +2168,7 @@ struct upr_qp3 {
                         const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
                         if (i < NX && j < NX && i <= j) {
                             double v = Pn[i * NX + j];
-                            if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
+                            if (i == j) v += h * L[O::qd + i] + LK[O::wx + k * NX + i];
                             if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
                             a4[r] += v;
                         }
@@ -2195,7 +2256,7 @@ struct upr_qp3 {
             }
                 if (k == 0) break;
             mtoc(2);
-            UPR_SYNC_LDS();
+            sync_lds();
             toc(8);
             // P = sym(A'P+A) + Q~ + Vc'Vc - V'V (upper triangle, mirrored)
 #ifndef UPR_HOST_EMU
@@ -2225,7 +2286,7 @@ struct upr_qp3 {
                 const int i = e / NX, j = e % NX;
                 if (i <= j) {
                     double v = Pn[i * NX + j];
-                    if (i == j) v += h * L[O::qd + i] + L[O::wx + k * NX + i];
+                    if (i == j) v += h * L[O::qd + i] + LK[O::wx + k * NX + i];
                     if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
                     for (int q = 0; q < NE; ++q) v += L[O::vc + q * NX + i] * L[O::vc + q * NX + j];
                     for (int m = 0; m < NQ; ++m) v -= L[vmb(k) + m * NX + i] * L[vmb(k) + m * NX + j];
@@ -2242,7 +2303,7 @@ struct upr_qp3 {
                 }
             }
             mtoc(4);
-            UPR_SYNC_LDS();
+            sync_lds();
             toc(9);
         }
         UPR_SETPRIO(0);
@@ -2261,7 +2322,7 @@ struct upr_qp3 {
     // one wave-local phase per knot (lane i < nx owns p_k[i] and column i of K_k, prefetched one
     // knot ahead).  w_k is kept (in the step array, which the forward sweep overwrites afterwards) for the
     // feed-forward  kff_k = Hjj_k^-1 (gu_k[jerk] + B'w_k)  of all knots at once.
-    UPR_HDI double* Wk(int k) const { return L + O::S + (k + 1) * NX; }
+    UPR_HDI double* Wk(int k) const { return LK + O::S + (k + 1) * NX; }
     // fused: the recursion ran on wave 0 of the two-wave matrix sweep (backward_mat_sw2) and left rq_k = gu_k[jerk] + B'w_k in the
     // feed-forward slots: only the feed-forward phase is left
     UPR_HDI void backward_vec(bool fused = false) {
@@ -2274,12 +2335,12 @@ struct upr_qp3 {
         if (!fused && wave0()) {
             UPR_SETPRIO(UPR_QP3_PRIO_VEC);
             UPR_FORT(i, NX) {
-                double v = L[O::gxs + N * NX + i];
+                double v = LK[O::gxs + N * NX + i];
                 if (neN > 0) {
                     if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + irho * L[O::eN + q]); }
                     else v += L[O::yN + 3 + (i - NQ)] + irho * L[O::eN + 3 + (i - NQ)];
                 }
-                Wk(N - 1)[i] = v + L[O::Pbs + (N - 1) * NX + i];
+                Wk(N - 1)[i] = v + LK[O::Pbs + (N - 1) * NX + i];
             }
             UPR_WSYNC();
 #ifndef UPR_HOST_EMU
@@ -2297,7 +2358,7 @@ struct upr_qp3 {
                 double kc[UPR_QP3_KSTAGES][NQ];   // column i of K_k, ..., K_{k-S+1}: S knots of register prefetch cover the L2 / fabric latency
 #define UPR_LOADKC(dst, kk) do { if (act && (kk) >= 1) { _Pragma("unroll") for (int m = 0; m < NQ; ++m) dst[m] = G[F::Ks + (kk) * NQ * NX + m * NX + i]; } } while (0)
                 // operands of a step that do not depend on the recursion (fetched one step ahead)
-#define UPR_LOADST(gk, pk, uk, kk) do { if ((kk) >= 1) { gk = L[O::gxs + (kk) * NX + i] + L[O::cs + (kk) * NX + i]; pk = L[O::Pbs + ((kk) - 1) * NX + i]; uk = L[O::gus + (kk) * NU + j]; } } while (0)
+#define UPR_LOADST(gk, pk, uk, kk) do { if ((kk) >= 1) { gk = LK[O::gxs + (kk) * NX + i] + LK[O::cs + (kk) * NX + i]; pk = LK[O::Pbs + ((kk) - 1) * NX + i]; uk = LK[O::gus + (kk) * NU + j]; } } while (0)
 #define UPR_VECSTEP(kcx, gk, pk, uk, kk) do { \
                     double rq = cbq * wv; \
                     rq += upr_dpp_quad<0xB1>(rq); rq += upr_dpp_quad<0x4E>(rq); \
@@ -2339,10 +2400,10 @@ struct upr_qp3 {
                 const double* w = Wk(k);
                 UPR_FORT(i, NX) {
                     const int b = i / NQ, j = i % NQ;
-                    double v = L[O::gxs + k * NX + i] + L[O::cs + k * NX + i];
+                    double v = LK[O::gxs + k * NX + i] + LK[O::cs + k * NX + i];
                     for (int a = 0; a <= b; ++a) v += coefA(a, b) * w[a * NQ + j];
-                    for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * (L[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
-                    Wk(k - 1)[i] = v + L[O::Pbs + (k - 1) * NX + i];
+                    for (int m = 0; m < NQ; ++m) v -= G[F::Ks + k * NQ * NX + m * NX + i] * (LK[O::gus + k * NU + m] + h3 * w[m] + h2 * w[NQ + m] + h * w[2 * NQ + m]);
+                    Wk(k - 1)[i] = v + LK[O::Pbs + (k - 1) * NX + i];
                 }
             }
 #endif
@@ -2380,7 +2441,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int m = 0; m <= i; ++m) li[i][m] = kfw ? liP[i % (KFFW1 ? NQ : 1)][m % (KFFW1 ? NQ : 1)] : Li[i * NX + m];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) tv[i] = fused ? L[O::kffs + k * NQ + i] : L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+                for (int i = 0; i < NQ; ++i) tv[i] = fused ? LK[O::kffs + k * NQ + i] : LK[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) { double t = 0.0;
 #pragma unroll
@@ -2390,7 +2451,7 @@ struct upr_qp3 {
                 for (int i = 0; i < NQ; ++i) { double t = 0.0;
 #pragma unroll
                     for (int m = i; m < NQ; ++m) t += li[m][i] * y[m];
-                    L[O::kffs + k * NQ + i] = t; }
+                    LK[O::kffs + k * NQ + i] = t; }
             }
         } else
 #endif
@@ -2399,7 +2460,7 @@ struct upr_qp3 {
             const double* w = Wk(k);
             double y[NQ], kk[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) { double t = L[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
+            for (int i = 0; i < NQ; ++i) { double t = LK[O::gus + k * NU + i] + h3 * w[i] + h2 * w[NQ + i] + h * w[2 * NQ + i];
 #pragma unroll
                 for (int m = 0; m < i; ++m) t -= Lp[i * (i + 1) / 2 + m] * y[m];
                 y[i] = t * Lp[i * (i + 1) / 2 + i]; }
@@ -2409,7 +2470,7 @@ struct upr_qp3 {
                 for (int m = i + 1; m < NQ; ++m) t -= Lp[m * (m + 1) / 2 + i] * kk[m];
                 kk[i] = t * Lp[i * (i + 1) / 2 + i]; }
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) L[O::kffs + k * NQ + i] = kk[i];
+            for (int i = 0; i < NQ; ++i) LK[O::kffs + k * NQ + i] = kk[i];
         }
         UPR_SYNC();
     }
@@ -2425,7 +2486,7 @@ struct upr_qp3 {
         // call: the waves that idle during the serial sweep fetch them into registers meanwhile, and the tail runs on
         // those waves (lane index tl) out of registers and LDS.
         constexpr int NTL = NT - 64, CH = (NX + 3) / 4, QV = (N * NE * 4 + NTL - 1) / NTL, QCT = (C::NCI + NTL - 1) / NTL;
-        static_assert(C::NKB <= NTL && NTL % 4 == 0, "tail lanes: one per Schur block");
+        static_assert((C::KFAR || C::NKB <= NTL) && NTL % 4 == 0, "tail lanes: one per Schur block (KFAR: a loop over the blocks)");
         const int tl = tid() - 64;
         constexpr int QCS = (N * NX + NTL - 1) / NTL;
         constexpr int QH = (N * NQ + NTL - 1) / NTL;
@@ -2445,9 +2506,9 @@ struct upr_qp3 {
             // knot 0: sx_0 = 0
             UPR_FORT(i, NX) {
                 const int b = i / NQ, j = i % NQ;
-                const double uj = -L[O::kffs + j];
+                const double uj = -LK[O::kffs + j];
                 Sx(0)[i] = 0.0;
-                Sx(1)[i] = coefB(b) * uj + L[O::bks + i];
+                Sx(1)[i] = coefB(b) * uj + LK[O::bks + i];
                 if (b == 0) Su(0)[j] = uj;
             }
             UPR_WSYNC();
@@ -2466,7 +2527,7 @@ struct upr_qp3 {
                 const int i = (act ? b : 0) * NQ + j;
                 double kq[UPR_QP3_KSTAGES][NQ];
 #define UPR_LOADKQ(dst, kk) do { if (act && (kk) < N) { _Pragma("unroll") for (int c = 0; c < NQ; ++c) dst[c] = G[F::Ks + (kk) * NQ * NX + j * NX + b * NQ + c]; } } while (0)
-#define UPR_LOADST(bk, fk, kk) do { if ((kk) < N) { bk = L[O::bks + (kk) * NX + i]; fk = L[O::kffs + (kk) * NQ + j]; } } while (0)
+#define UPR_LOADST(bk, fk, kk) do { if ((kk) < N) { bk = LK[O::bks + (kk) * NX + i]; fk = LK[O::kffs + (kk) * NQ + j]; } } while (0)
 #define UPR_FWDSTEP(kqx, bk, fk, kk) do { \
                     double xs[NQ]; \
                     _Pragma("unroll") for (int c = 0; c < NQ; ++c) xs[c] = upr_bpermute(xv, src + 16 * c); \
@@ -2510,10 +2571,10 @@ struct upr_qp3 {
                 UPR_FORT(i, NX) {
                     const int b = i / NQ, j = i % NQ;
                     const double* Kr = G + F::Ks + k * NQ * NX + j * NX;
-                    double d0 = L[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
+                    double d0 = LK[O::kffs + k * NQ + j], d1 = 0.0, d2 = 0.0;
                     for (int c = 0; c < NQ; ++c) { d0 += Kr[c] * sx[c]; d1 += Kr[NQ + c] * sx[NQ + c]; d2 += Kr[2 * NQ + c] * sx[2 * NQ + c]; }
                     const double uj = -(d0 + d1 + d2);
-                    double r = coefB(b) * uj + L[O::bks + k * NX + i];
+                    double r = coefB(b) * uj + LK[O::bks + k * NX + i];
                     for (int a = b; a < 3; ++a) r += coefA(b, a) * sx[a * NQ + j];
                     Sx(k + 1)[i] = r;
                     if (b == 0) Su(k)[j] = uj;
@@ -2540,7 +2601,7 @@ struct upr_qp3 {
                     }
                 }
             }
-            if (!DIST && tl < C::NKB) {
+            if (!DIST && !C::KFAR && tl < C::NKB) {
 #pragma unroll
                 for (int r = 0; r < SB; ++r)
 #pragma unroll
@@ -2608,7 +2669,7 @@ struct upr_qp3 {
                     for (int c = 0; c < CH; ++c) v += (act ? ckq[q % (PRE_V ? QV : 1)][c] : 0.0) * sv[c];
                 }
                 v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                if (act && part == 0) { L[O::cv + e] = v; if (C::INCEK && COST) L[O::dek + e] = v; }
+                if (act && part == 0) { LK[O::cv + e] = v; if (C::INCEK && COST) LK[O::dek + e] = v; }
             }
         } else {
             constexpr int GQ = UPR_QP3_GQ;   // (as in prep: GQ rows of a lane requested together)
@@ -2634,7 +2695,7 @@ struct upr_qp3 {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) v += cb[g][c] * ((part * CH + c < NX) ? sx[c] : 0.0);
                     v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v);
-                    if (act && part == 0) { L[O::cv + e] = v; if (C::INCEK && COST) L[O::dek + e] = v; }
+                    if (act && part == 0) { LK[O::cv + e] = v; if (C::INCEK && COST) LK[O::dek + e] = v; }
                 }
             }
         }
@@ -2647,11 +2708,11 @@ struct upr_qp3 {
                     double v = 0.0;
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) v += heeq[q][j] * sx[j];
-                    L[O::gee + e] = h * v;
+                    LK[O::gee + e] = h * v;
                 }
             }
         }
-        UPR_SYNC_LDS();
+        sync_lds();
         // nu+ of a knot by its lane: in place over cv (LDS, what the contact step and the costates read) and to global
         if (DIST) {
             constexpr int NROW = C::NKB * SB, QD = (NROW + NTL - 1) / NTL;
@@ -2666,29 +2727,34 @@ struct upr_qp3 {
                         const double* Ls = G + F::lsi + kb * SB * SB;
                         double lv[SB], xv[SB];
 #pragma unroll
-                        for (int m = 0; m < SB; ++m) { lv[m] = (pass == 0) ? Ls[r * SB + m] : Ls[m * SB + r]; xv[m] = L[O::cv + kb * SB + m]; }
-                        double v = (pass == 0) ? L[O::ys + e] : 0.0;
+                        for (int m = 0; m < SB; ++m) { lv[m] = (pass == 0) ? Ls[r * SB + m] : Ls[m * SB + r]; xv[m] = LK[O::cv + kb * SB + m]; }
+                        double v = (pass == 0) ? LK[O::ys + e] : 0.0;
 #pragma unroll
                         for (int m = 0; m < SB; ++m) v += (((pass == 0) ? (m <= r) : (m >= r)) ? lv[m] : 0.0) * xv[m];
                         tv1[q] = v;
                     }
                 }
-                UPR_SYNC_LDS();   // (every row of the block has read cv / the first product)
+                sync_lds();   // (every row of the block has read cv / the first product)
 #pragma unroll
                 for (int q = 0; q < QD; ++q) {
                     const int e = tl + q * NTL;
-                    if (tl >= 0 && e < NROW) { L[O::cv + e] = tv1[q]; if (pass == 1) G[F::nun + e] = tv1[q]; }
+                    if (tl >= 0 && e < NROW) { LK[O::cv + e] = tv1[q]; if (pass == 1) G[F::nun + e] = tv1[q]; }
                 }
-                if (pass == 0) UPR_SYNC_LDS();
+                if (pass == 0) sync_lds();
             }
         } else
-        if (tl >= 0 && tl < C::NKB) {
-            const int kb = tl;   // Schur block: a knot, or a (knot, body) pair
+        for (int kb = tl; kb >= 0 && kb < C::NKB; kb += NTL) {   // Schur block: a knot, or a (knot, body) pair (one per lane; KFAR: several, its factor fetched here)
+            if (C::KFAR) {
+#pragma unroll
+                for (int r = 0; r < SB; ++r)
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) lsr[r * SB + m] = G[F::lsi + kb * SB * SB + r * SB + m];
+            }
             double cvr[SB], t1[SB];
 #pragma unroll
-            for (int r = 0; r < SB; ++r) cvr[r] = L[O::cv + kb * SB + r];
+            for (int r = 0; r < SB; ++r) cvr[r] = LK[O::cv + kb * SB + r];
 #pragma unroll
-            for (int r = 0; r < SB; ++r) { double v = L[O::ys + kb * SB + r];
+            for (int r = 0; r < SB; ++r) { double v = LK[O::ys + kb * SB + r];
 #pragma unroll
                 for (int m = 0; m <= r; ++m) v += lsr[r * SB + m] * cvr[m];
                 t1[r] = v; }
@@ -2696,9 +2762,9 @@ struct upr_qp3 {
             for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
                 for (int m = r; m < SB; ++m) v += lsr[m * SB + r] * t1[m];
-                L[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
+                LK[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
         }
-        UPR_SYNC_LDS();
+        sync_lds();
 #pragma unroll
         for (int q = 0; q < QCT; ++q) {
             const int ic = tl + q * NTL;
@@ -2710,14 +2776,14 @@ struct upr_qp3 {
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = 0.0;
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) v += DF(rb + r, 3 * ci + a) * L[O::cv + k * NE + rb + r];
+                        for (int r = 0; r < 6; ++r) v += DF(rb + r, 3 * ci + a) * LK[O::cv + k * NE + rb + r];
                         dfn[a] = v; }
                     if (C::COUPLED && P->contact_body1[ci] >= 0) {   // ... and of the body underneath
                         const int rb1 = 6 * P->contact_body1[ci];
 #pragma unroll
                         for (int a = 0; a < 3; ++a)
 #pragma unroll
-                            for (int r = 0; r < 6; ++r) dfn[a] += L[O::df + (rb1 + r) * NFC + 3 * ci + a] * L[O::cv + k * NE + rb1 + r];
+                            for (int r = 0; r < 6; ++r) dfn[a] += L[O::df + (rb1 + r) * NFC + 3 * ci + a] * LK[O::cv + k * NE + rb1 + r];
                     }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { double v = yfq[q][a];
@@ -2733,11 +2799,11 @@ struct upr_qp3 {
                     double dfn = 0.0;
                     const int rb = (C::NB > 1) ? 6 * P->contact_body2[ci] : 0;
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb + r) * NFC + ci] * L[O::cv + k * NE + rb + r];
+                    for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb + r) * NFC + ci] * LK[O::cv + k * NE + rb + r];
                     if (C::COUPLED && P->contact_body1[ci] >= 0) {
                         const int rb1 = 6 * P->contact_body1[ci];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb1 + r) * NFC + ci] * L[O::cv + k * NE + rb1 + r];
+                        for (int r = 0; r < 6; ++r) dfn += L[O::df + (rb1 + r) * NFC + ci] * LK[O::cv + k * NE + rb1 + r];
                     }
                     const double lf = bkq[q][0];
                     Su(k)[NQ + ci] = -lf * (yfq[q][0] + lf * dfn);
@@ -2750,8 +2816,8 @@ struct upr_qp3 {
             const double* Ck = rec(k) + lin_gx + r * NX; const double* sx = Sx(k);
             double v = 0.0;
             for (int c = 0; c < NX; ++c) v += Ck[c] * sx[c];
-            L[O::cv + e] = v;
-            if (C::INCEK && COST) L[O::dek + e] = v;
+            LK[O::cv + e] = v;
+            if (C::INCEK && COST) LK[O::dek + e] = v;
         }
         UPR_SYNC();
         UPR_FORT(kb, C::NKB) {
@@ -2759,15 +2825,15 @@ struct upr_qp3 {
             const double* Ls = G + F::lsi + kb * SB * SB;
             double t1[SB];
 #pragma unroll
-            for (int r = 0; r < SB; ++r) { double v = L[O::ys + kb * SB + r];
+            for (int r = 0; r < SB; ++r) { double v = LK[O::ys + kb * SB + r];
 #pragma unroll
-                for (int m = 0; m <= r; ++m) v += Ls[r * SB + m] * L[O::cv + kb * SB + m];
+                for (int m = 0; m <= r; ++m) v += Ls[r * SB + m] * LK[O::cv + kb * SB + m];
                 t1[r] = v; }
 #pragma unroll
             for (int r = 0; r < SB; ++r) { double v = 0.0;
 #pragma unroll
                 for (int m = r; m < SB; ++m) v += Ls[m * SB + r] * t1[m];
-                L[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
+                LK[O::cv + kb * SB + r] = v; G[F::nun + kb * SB + r] = v; }
         }
         UPR_SYNC();
         for (int q = 0; q < C::QC; ++q) {
@@ -2799,42 +2865,42 @@ struct upr_qp3 {
             L[O::dyN + q] = v / UPR_QP_RHO_N;
         }
 #ifndef UPR_HOST_EMU
-        UPR_SYNC_LDS();
+        sync_lds();
         if (COST) {
             // costates of the full step, staged where the sweeps keep P (LDS; the update reads them there)
-            double* pin = L + O::Pa;
+            double* pin = LK + O::pin;
 #pragma unroll
             for (int q = 0; q < QCS; ++q) {
                 const int e = tl + q * NTL;
                 if (tl >= 0 && e < N * NX) {
                     const int k = e / NX, i = e % NX;
                     const double sxi = Sx(k)[i];
-                    double v = L[O::gxs + e] + L[O::wx + e] * sxi + h * L[O::qd + i] * sxi;
-                    if (i < NQ) v += L[O::gee + k * NQ + i];
+                    double v = LK[O::gxs + e] + LK[O::wx + e] * sxi + h * L[O::qd + i] * sxi;
+                    if (i < NQ) v += LK[O::gee + k * NQ + i];
                     if (PRE_K) {
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) v += ckc[q % (PRE_K ? QCS : 1)][r % (PRE_K ? NE : 1)] * L[O::cv + k * NE + r];
+                        for (int r = 0; r < NE; ++r) v += ckc[q % (PRE_K ? QCS : 1)][r % (PRE_K ? NE : 1)] * LK[O::cv + k * NE + r];
                     } else {
                         const double* Ck = rec(k) + lin_gx + i;
                         double cr[NE];
 #pragma unroll
                         for (int r = 0; r < NE; ++r) cr[r] = Ck[r * NX];
 #pragma unroll
-                        for (int r = 0; r < NE; ++r) v += cr[r] * L[O::cv + k * NE + r];
+                        for (int r = 0; r < NE; ++r) v += cr[r] * LK[O::cv + k * NE + r];
                     }
                     pin[e] = v;
                 }
             }
             if (tl < 0 && tl + 64 < NX) {
                 const int i = tl + 64, e = N * NX + i;
-                double v = L[O::gxs + e] + L[O::wx + e] * Sx(N)[i];
+                double v = LK[O::gxs + e] + LK[O::wx + e] * Sx(N)[i];
                 if (neN > 0) {
                     if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
                     else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
                 }
                 pin[e] = v;
             }
-            UPR_SYNC_LDS();
+            sync_lds();
             costate_sums();
         }
 #else
@@ -2845,7 +2911,7 @@ struct upr_qp3 {
 
     // pi_k = r_k + A' pi_{k+1}: three running sums per joint, in place (LDS)
     UPR_HDI void costate_sums() {
-        double* pin = L + O::Pa;
+        double* pin = LK + O::pin;
         UPR_FORT(j, NQ) {
             double pq = pin[N * NX + j], pvv = pin[N * NX + NQ + j], pa = pin[N * NX + 2 * NQ + j];
 #pragma unroll
@@ -2857,21 +2923,21 @@ struct upr_qp3 {
                 pin[k * NX + j] = pq; pin[k * NX + NQ + j] = pvv; pin[k * NX + 2 * NQ + j] = pa;
             }
         }
-        UPR_SYNC_LDS();
+        sync_lds();
     }
 
     // costates of the full step (host emulation: the same sums out of global memory)
     UPR_HDI void costates() {
-        double* pin = L + O::Pa;
+        double* pin = LK + O::pin;
         UPR_FORT(e, N1 * NX) {
             const int k = e / NX, i = e % NX;
             const double* sx = Sx(k);
-            double v = L[O::gxs + e] + L[O::wx + e] * sx[i];
+            double v = LK[O::gxs + e] + LK[O::wx + e] * sx[i];
             if (k < N) {
                 v += h * L[O::qd + i] * sx[i];
                 if (i < NQ) for (int j = 0; j < NQ; ++j) v += h * G[hee_w + k * C::NH + upr_tri(NQ, i, j)] * sx[j];
                 const double* Ck = rec(k) + lin_gx;
-                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * L[O::cv + k * NE + q];
+                for (int q = 0; q < NE; ++q) v += Ck[q * NX + i] * LK[O::cv + k * NE + q];
             } else if (neN > 0) {
                 if (i < NQ) { for (int q = 0; q < 3; ++q) v -= L[O::jN + q * NQ + i] * (L[O::yN + q] + L[O::dyN + q]); }
                 else v += L[O::yN + 3 + (i - NQ)] + L[O::dyN + 3 + (i - NQ)];
@@ -2922,7 +2988,7 @@ struct upr_qp3 {
         else if (what == 5) { const double v = (lam + alpha * dl) * (t + alpha * dt), vs = (gam + alpha * dg) * (tau + alpha * dtau); acc = fmin(acc, fmin(v, vs)); *aux += v + vs; }
         else { t += alpha * dt; lam += alpha * dl; sig += alpha * dsg; tau += alpha * dtau; gam += alpha * dg; }
     }
-    UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCT], bool reload = true) {
+    UPR_HDI double ineq_sweep(int what, double alpha, double* aux, const double (&ctm)[NCTR], bool reload = true) {
         ftoc(10, 4);
         if (ROWMEM && reload) load_rows();   // (reload == false: the rows are still those of the sweep just before)
         double acc = (what == 5) ? 1e300 : 0.0;
@@ -2966,6 +3032,8 @@ struct upr_qp3 {
         // operation as the update of the iterate in solve()), then the row.
         const bool w4 = what == 4;
         const int wstep = w4 ? 2 : what;
+        // corrector target i of this lane (KFAR: the targets stay in their far array, ctm[0] only says whether there are any)
+        auto tgt = [&](int i) -> double { return C::KFAR ? ((ctm[0] != 0.0) ? G[F::cxr + i * NT + tid_] : 0.0) : ctm[i % NCTR]; };
         auto hard = [&](double c, double ds, double cn, double& t, double& lam, double ct) {
             if (!w4) { sweep_row(what, alpha, c, ds, t, lam, ct, acc, aux); return; }
             double unused = 0.0;
@@ -2978,37 +3046,41 @@ struct upr_qp3 {
             sweep_row_soft(2, alpha, c, ds, t, lam, sg, ta, ga, Zp, zp, ct, cts, unused, nullptr);
             sweep_row_soft(3, 0.0, cn, 0.0, t, lam, sg, ta, ga, Zp, zp, 0.0, 0.0, acc, aux);
         };
-#pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QX)
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
-                const double X = L[O::Z + zo], dS = L[O::S + zo];
+                ldx(q);
+                const double X = LK[O::Z + zo], dS = LK[O::S + zo];
                 const double Xn = w4 ? upr_step(X, alpha, dS) : X;
                 if (C::SOFT && softx) {
-                    soft(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q][0], lx[q][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, ctm[2 * q], ctm[(NCT0 + 2 * q) % NCT]);
-                    soft(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q][1], lx[q][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, ctm[2 * q + 1], ctm[(NCT0 + 2 * q + 1) % NCT]);
+                    soft(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q % QXR][0], lx[q % QXR][0], sgx[q % QXS][0], tax[q % QXS][0], gax[q % QXS][0], ZL, zL, tgt(2 * q), tgt(NCT0 + 2 * q));
+                    soft(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q % QXR][1], lx[q % QXR][1], sgx[q % QXS][1], tax[q % QXS][1], gax[q % QXS][1], ZU, zU, tgt(2 * q + 1), tgt(NCT0 + 2 * q + 1));
                 } else {
-                    hard(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q][0], lx[q][0], ctm[2 * q]);
-                    hard(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q][1], lx[q][1], ctm[2 * q + 1]);
+                    hard(X - L[O::xlb + i], dS, Xn - L[O::xlb + i], tx[q % QXR][0], lx[q % QXR][0], tgt(2 * q));
+                    hard(L[O::xub + i] - X, -dS, L[O::xub + i] - Xn, tx[q % QXR][1], lx[q % QXR][1], tgt(2 * q + 1));
                 }
+                if (wstep == 2) stx(q);
             }
         }
 ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- slots 6 .. 9: state boxes, input boxes, friction rows, state-polytopic rows)
-        #pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QU)
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid() + q * NT;
             if (iu < C::NUI) {
                 const int i = iu % NU;
-                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
+                ldu(q);
+                const double U = LK[O::Z + N1 * NX + iu], dS = LK[O::S + N1 * NX + iu];
                 const double Un = w4 ? upr_step(U, alpha, dS) : U;
                 if (C::SOFT && softu) {
-                    soft(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q][0], lu[q][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, ctm[2 * C::QX + 2 * q], ctm[(NCT0 + 2 * C::QX + 2 * q) % NCT]);
-                    soft(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q][1], lu[q][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, ctm[2 * C::QX + 2 * q + 1], ctm[(NCT0 + 2 * C::QX + 2 * q + 1) % NCT]);
+                    soft(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q % QUR][0], lu[q % QUR][0], sgu[q % QUS][0], tau_[q % QUS][0], gau[q % QUS][0], ZL, zL, tgt(2 * C::QX + 2 * q), tgt(NCT0 + 2 * C::QX + 2 * q));
+                    soft(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q % QUR][1], lu[q % QUR][1], sgu[q % QUS][1], tau_[q % QUS][1], gau[q % QUS][1], ZU, zU, tgt(2 * C::QX + 2 * q + 1), tgt(NCT0 + 2 * C::QX + 2 * q + 1));
                 } else {
-                    hard(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q][0], lu[q][0], ctm[2 * C::QX + 2 * q]);
-                    hard(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q][1], lu[q][1], ctm[2 * C::QX + 2 * q + 1]);
+                    hard(U - L[O::ulb + i], dS, Un - L[O::ulb + i], tu[q % QUR][0], lu[q % QUR][0], tgt(2 * C::QX + 2 * q));
+                    hard(L[O::uub + i] - U, -dS, L[O::uub + i] - Un, tu[q % QUR][1], lu[q % QUR][1], tgt(2 * C::QX + 2 * q + 1));
                 }
+                if (wstep == 2) stu(q);
             }
         }
         ftoc(7, 4);
@@ -3027,7 +3099,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 const int ic = tid_ + q * NT;
                 if (ic >= C::NCI) continue;
                 const int k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
-                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* f = LK + O::Z + N1 * NX + uo; const double* sf = LK + O::S + N1 * NX + uo;
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
@@ -3053,7 +3125,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 const int e = tid_ + q * NT;
                 if (e >= NR5) continue;
                 const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
-                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* f = LK + O::Z + N1 * NX + uo; const double* sf = LK + O::S + N1 * NX + uo;
                 const double* e3 = L + O::erow + 3 * (5 * ci + r);
                 double t = tv[q], lam = lv[q];
                 const double fn0 = w4 ? upr_step(f[0], alpha, sf[0]) : f[0], fn1 = w4 ? upr_step(f[1], alpha, sf[1]) : f[1], fn2 = w4 ? upr_step(f[2], alpha, sf[2]) : f[2];
@@ -3078,7 +3150,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 double c = od[q], ds = 0.0, cn = od[q];
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
-                    const double z = L[O::Z + k * NX + i], sz = L[O::S + k * NX + i];
+                    const double z = LK[O::Z + k * NX + i], sz = LK[O::S + k * NX + i];
                     c += gq[q][i] * z; ds += gq[q][i] * sz;
                     if (w4) cn += gq[q][i] * upr_step(z, alpha, sz);
                 }
@@ -3113,7 +3185,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         acc = fmax(acc, fmax(-dt * rt, -dl * upr_rcp(lam)));
     }
     // directions of all rows of the lane; returns the lane's largest admissible step (as ineq_sweep what 0, mode 3)
-    UPR_HDI double rows_dir(const double (&ctm)[NCT], row_dirs& D) {
+    UPR_HDI double rows_dir(const double (&ctm)[NCTR], row_dirs& D) {
         const int tid_ = tid();
         double acc = 0.0;
 #pragma unroll
@@ -3122,9 +3194,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             D.dt[2 * q] = 0.0; D.dl[2 * q] = 0.0; D.dt[2 * q + 1] = 0.0; D.dl[2 * q + 1] = 0.0;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
-                const double X = L[O::Z + zo], dS = L[O::S + zo];
-                dir_row(X - L[O::xlb + i], dS, tx[q][0], lx[q][0], ctm[2 * q], D.dt[2 * q], D.dl[2 * q], acc);
-                dir_row(L[O::xub + i] - X, -dS, tx[q][1], lx[q][1], ctm[2 * q + 1], D.dt[2 * q + 1], D.dl[2 * q + 1], acc);
+                const double X = LK[O::Z + zo], dS = LK[O::S + zo];
+                dir_row(X - L[O::xlb + i], dS, tx[q % QXR][0], lx[q % QXR][0], ctm[(2 * q) % NCTR], D.dt[2 * q], D.dl[2 * q], acc);
+                dir_row(L[O::xub + i] - X, -dS, tx[q % QXR][1], lx[q % QXR][1], ctm[(2 * q + 1) % NCTR], D.dt[2 * q + 1], D.dl[2 * q + 1], acc);
             }
         }
 #pragma unroll
@@ -3133,9 +3205,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             D.dt[o] = 0.0; D.dl[o] = 0.0; D.dt[o + 1] = 0.0; D.dl[o + 1] = 0.0;
             if (iu < C::NUI) {
                 const int i = iu % NU;
-                const double U = L[O::Z + N1 * NX + iu], dS = L[O::S + N1 * NX + iu];
-                dir_row(U - L[O::ulb + i], dS, tu[q][0], lu[q][0], ctm[o], D.dt[o], D.dl[o], acc);
-                dir_row(L[O::uub + i] - U, -dS, tu[q][1], lu[q][1], ctm[o + 1], D.dt[o + 1], D.dl[o + 1], acc);
+                const double U = LK[O::Z + N1 * NX + iu], dS = LK[O::S + N1 * NX + iu];
+                dir_row(U - L[O::ulb + i], dS, tu[q % QUR][0], lu[q % QUR][0], ctm[o % NCTR], D.dt[o], D.dl[o], acc);
+                dir_row(L[O::uub + i] - U, -dS, tu[q % QUR][1], lu[q % QUR][1], ctm[(o + 1) % NCTR], D.dt[o + 1], D.dl[o + 1], acc);
             }
         }
 #pragma unroll
@@ -3144,7 +3216,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             D.dt[OP_NB + q] = 0.0; D.dl[OP_NB + q] = 0.0;
             if (e < 5 * C::NCI) {
                 const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
-                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* f = LK + O::Z + N1 * NX + uo; const double* sf = LK + O::S + N1 * NX + uo;
                 const double* e3 = L + O::erow + 3 * (5 * ci + r);
                 dir_row(e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2], e3[0] * sf[0] + e3[1] * sf[1] + e3[2] * sf[2], D.ft[q], D.fl[q], D.fc[q], D.dt[OP_NB + q], D.dl[OP_NB + q], acc);
             }
@@ -3158,12 +3230,12 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
 #pragma unroll
         for (int q = 0; q < C::QX; ++q) if (tid_ + q * NT < C::NXI) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) { const double v = (lx[q][s2] + alpha * D.dl[2 * q + s2]) * (tx[q][s2] + alpha * D.dt[2 * q + s2]); acc = fmin(acc, v); *aux += v; }
+            for (int s2 = 0; s2 < 2; ++s2) { const double v = (lx[q % QXR][s2] + alpha * D.dl[2 * q + s2]) * (tx[q % QXR][s2] + alpha * D.dt[2 * q + s2]); acc = fmin(acc, v); *aux += v; }
         }
 #pragma unroll
         for (int q = 0; q < C::QU; ++q) if (tid_ + q * NT < C::NUI) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) { const int o = 2 * C::QX + 2 * q + s2; const double v = (lu[q][s2] + alpha * D.dl[o]) * (tu[q][s2] + alpha * D.dt[o]); acc = fmin(acc, v); *aux += v; }
+            for (int s2 = 0; s2 < 2; ++s2) { const int o = 2 * C::QX + 2 * q + s2; const double v = (lu[q % QUR][s2] + alpha * D.dl[o]) * (tu[q % QUR][s2] + alpha * D.dt[o]); acc = fmin(acc, v); *aux += v; }
         }
 #pragma unroll
         for (int q = 0; q < OP_QR5; ++q) if (tid_ + q * NT < 5 * C::NCI) { const double v = (D.fl[q] + alpha * D.dl[OP_NB + q]) * (D.ft[q] + alpha * D.dt[OP_NB + q]); acc = fmin(acc, v); *aux += v; }
@@ -3180,9 +3252,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             const int ix = tid_ + q * NT;
             if (ix < C::NXI) {
                 const int zo = NX + ix, i = ix % NX;
-                const double Xn = upr_step(L[O::Z + zo], alpha, L[O::S + zo]);
-                tx[q][0] += alpha * D.dt[2 * q]; lx[q][0] += alpha * D.dl[2 * q]; tx[q][1] += alpha * D.dt[2 * q + 1]; lx[q][1] += alpha * D.dl[2 * q + 1];
-                res(Xn - L[O::xlb + i], tx[q][0], lx[q][0]); res(L[O::xub + i] - Xn, tx[q][1], lx[q][1]);
+                const double Xn = upr_step(LK[O::Z + zo], alpha, LK[O::S + zo]);
+                tx[q % QXR][0] += alpha * D.dt[2 * q]; lx[q % QXR][0] += alpha * D.dl[2 * q]; tx[q % QXR][1] += alpha * D.dt[2 * q + 1]; lx[q % QXR][1] += alpha * D.dl[2 * q + 1];
+                res(Xn - L[O::xlb + i], tx[q % QXR][0], lx[q % QXR][0]); res(L[O::xub + i] - Xn, tx[q % QXR][1], lx[q % QXR][1]);
             }
         }
 #pragma unroll
@@ -3190,9 +3262,9 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             const int iu = tid_ + q * NT, o = 2 * C::QX + 2 * q;
             if (iu < C::NUI) {
                 const int i = iu % NU;
-                const double Un = upr_step(L[O::Z + N1 * NX + iu], alpha, L[O::S + N1 * NX + iu]);
-                tu[q][0] += alpha * D.dt[o]; lu[q][0] += alpha * D.dl[o]; tu[q][1] += alpha * D.dt[o + 1]; lu[q][1] += alpha * D.dl[o + 1];
-                res(Un - L[O::ulb + i], tu[q][0], lu[q][0]); res(L[O::uub + i] - Un, tu[q][1], lu[q][1]);
+                const double Un = upr_step(LK[O::Z + N1 * NX + iu], alpha, LK[O::S + N1 * NX + iu]);
+                tu[q % QUR][0] += alpha * D.dt[o]; lu[q % QUR][0] += alpha * D.dl[o]; tu[q % QUR][1] += alpha * D.dt[o + 1]; lu[q % QUR][1] += alpha * D.dl[o + 1];
+                res(Un - L[O::ulb + i], tu[q % QUR][0], lu[q % QUR][0]); res(L[O::uub + i] - Un, tu[q % QUR][1], lu[q % QUR][1]);
             }
         }
 #pragma unroll
@@ -3200,7 +3272,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             const int e = tid_ + q * NT;
             if (e < 5 * C::NCI) {
                 const int ic = e / 5, r = e % 5, k = ic / NC, ci = ic % NC, uo = k * NU + NQ + 3 * ci;
-                const double* f = L + O::Z + N1 * NX + uo; const double* sf = L + O::S + N1 * NX + uo;
+                const double* f = LK + O::Z + N1 * NX + uo; const double* sf = LK + O::S + N1 * NX + uo;
                 const double* e3 = L + O::erow + 3 * (5 * ci + r);
                 const double fn0 = upr_step(f[0], alpha, sf[0]), fn1 = upr_step(f[1], alpha, sf[1]), fn2 = upr_step(f[2], alpha, sf[2]);
                 const double t = D.ft[q] + alpha * D.dt[OP_NB + q], lam = D.fl[q] + alpha * D.dl[OP_NB + q];
@@ -3231,7 +3303,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         double r_stat = 0.0, r_eq = 0.0;
         UPR_FORT(e, N * NX) {
             const int k = 1 + e / NX, i = e % NX;
-            double v = L[O::gxs + k * NX + i] - pi[k * NX + i];
+            double v = LK[O::gxs + k * NX + i] - pi[k * NX + i];
             if (k < N) {
                 const double* pn = pi + (k + 1) * NX; const double* Ck = rec(k) + lin_gx;
                 const int blk = i / NQ, j = i % NQ;
@@ -3245,7 +3317,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         }
         UPR_FORT(e, N * NU) {
             const int k = e / NU, i = e % NU;
-            double v = L[O::gus + e];
+            double v = LK[O::gus + e];
             if (i < NQ) { const double* pn = pi + (k + 1) * NX; v += h3 * pn[i] + h2 * pn[NQ + i] + h * pn[2 * NQ + i]; }
             else if (C::NB == 1) { for (int q = 0; q < NE; ++q) v += L[O::df + q * NFC + (i - NQ)] * nu[k * NE + q]; }
             else {   // (the column of a force has entries in the rows of the bodies its contact loads only)
@@ -3401,7 +3473,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
         wb = __builtin_amdgcn_readfirstlane(c.tid & ~63);
 #endif
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
-        lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far;
+        lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far; LK = C::KFAR ? ws + W::kfar : lds;
 #ifdef UPR_QP3_EXP_SHARELIN   // experiment only: every instance reads instance 0's record (what would the kernel gain if that traffic hit L2?)
         lin = A.lin;
 #endif
@@ -3442,8 +3514,8 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             if (n == 0) for (int t = 0; t < NC; ++t) L[O::plist + bl * NC + t] = 0.0;
             L[O::pcnt + bl] = (double)n;
         }
-        UPR_FORT(e, N1 * NX) { const int k = e / NX; L[O::Z + e] = (k == 0) ? x0[e] : xs[e]; L[O::S + e] = 0.0; }
-        UPR_FORT(e, N * NU) { L[O::Z + N1 * NX + e] = us[e]; L[O::S + N1 * NX + e] = 0.0; }
+        UPR_FORT(e, N1 * NX) { const int k = e / NX; LK[O::Z + e] = (k == 0) ? x0[e] : xs[e]; LK[O::S + e] = 0.0; }
+        UPR_FORT(e, N * NU) { LK[O::Z + N1 * NX + e] = us[e]; LK[O::S + N1 * NX + e] = 0.0; }
         UPR_FORT(e, N * C::NH) { const int k = e / C::NH; G[F::hee + e] = rec(k)[lin_hess + e % C::NH]; }
         UPR_FORT(e, 3 * NQ) L[O::jN + e] = rec(N)[lin_hess + e];
         UPR_FORT(q, 3) L[O::misc + 4 + q] = rec(N)[lin_grad + q];
@@ -3481,36 +3553,38 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             UPR_FORT(e, C::NH) G[F::heew + e] = G[F::hee + e];   // knot 0 carries no such rows
         }
         // ---- initial slacks / multipliers
-#pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QX)
         for (int q = 0; q < C::QX; ++q) {
             const int ix = tid() + q * NT;
-            tx[q][0] = tx[q][1] = 1.0; lx[q][0] = lx[q][1] = 0.0;
+            tx[q % QXR][0] = tx[q % QXR][1] = 1.0; lx[q % QXR][0] = lx[q % QXR][1] = 0.0;
             if (ix < C::NXI) {
-                const int i = ix % NX; const double X = L[O::Z + NX + ix];
+                const int i = ix % NX; const double X = LK[O::Z + NX + ix];
                 const double c0 = X - L[O::xlb + i], c1 = L[O::xub + i] - X;
-                tx[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tx[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
-                lx[q][0] = UPR_QP_MU0 / tx[q][0]; lx[q][1] = UPR_QP_MU0 / tx[q][1];
+                tx[q % QXR][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tx[q % QXR][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
+                lx[q % QXR][0] = UPR_QP_MU0 / tx[q % QXR][0]; lx[q % QXR][1] = UPR_QP_MU0 / tx[q % QXR][1];
             }
             if (C::SOFT) for (int s2 = 0; s2 < 2; ++s2) { sgx[q % QXS][s2] = 0.0; tax[q % QXS][s2] = (softx && ix < C::NXI) ? UPR_QP_THR : 1.0; gax[q % QXS][s2] = (softx && ix < C::NXI) ? UPR_QP_MU0 / UPR_QP_THR : 0.0; }
+            stx(q);
         }
-#pragma unroll
+#pragma unroll (C::KFAR ? 1 : C::QU)
         for (int q = 0; q < C::QU; ++q) {
             const int iu = tid() + q * NT;
-            tu[q][0] = tu[q][1] = 1.0; lu[q][0] = lu[q][1] = 0.0;
+            tu[q % QUR][0] = tu[q % QUR][1] = 1.0; lu[q % QUR][0] = lu[q % QUR][1] = 0.0;
             if (iu < C::NUI) {
-                const int i = iu % NU; const double U = L[O::Z + N1 * NX + iu];
+                const int i = iu % NU; const double U = LK[O::Z + N1 * NX + iu];
                 const double c0 = U - L[O::ulb + i], c1 = L[O::uub + i] - U;
-                tu[q][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tu[q][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
-                lu[q][0] = UPR_QP_MU0 / tu[q][0]; lu[q][1] = UPR_QP_MU0 / tu[q][1];
+                tu[q % QUR][0] = c0 > UPR_QP_THR ? c0 : UPR_QP_THR; tu[q % QUR][1] = c1 > UPR_QP_THR ? c1 : UPR_QP_THR;
+                lu[q % QUR][0] = UPR_QP_MU0 / tu[q % QUR][0]; lu[q % QUR][1] = UPR_QP_MU0 / tu[q % QUR][1];
             }
             if (C::SOFT) for (int s2 = 0; s2 < 2; ++s2) { sgu[q % QUS][s2] = 0.0; tau_[q % QUS][s2] = (softu && iu < C::NUI) ? UPR_QP_THR : 1.0; gau[q % QUS][s2] = (softu && iu < C::NUI) ? UPR_QP_MU0 / UPR_QP_THR : 0.0; }
+            stu(q);
         }
         store_rows();
         if (NF == 3) for (int q = 0; q < C::QC; ++q) {
             const int ic = tid() + q * NT;
             if (ic < C::NCI) {
                 const int k = ic / NC, ci = ic % NC;
-                const double* f = L + O::Z + N1 * NX + k * NU + NQ + 3 * ci;
+                const double* f = LK + O::Z + N1 * NX + k * NU + NQ + 3 * ci;
                 for (int r = 0; r < 5; ++r) {
                     const double* e3 = L + O::erow + 3 * (5 * ci + r);
                     const double c0 = e3[0] * f[0] + e3[1] * f[1] + e3[2] * f[2];
@@ -3580,7 +3654,7 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
             prep(1);
             backward_vec(); toc(11);
             mode = 3;
-            double ctm[NCT];
+            double ctm[NCTR];
             forward<true>(); toc(13);
             // (requested here, not ahead of the forward sweep's costates: that measured 0.6 - 0.8 % SLOWER on the headline launch)
             row_dirs rd;
@@ -3623,26 +3697,26 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
                 for (int q = 0; q < QPI; ++q) {
                     const int e = tid_ + q * NT;
                     if (e < N1 * NX) {
-                        if (e >= NX) L[O::Z + e] = upr_step(L[O::Z + e], a, L[O::S + e]);
-                        ws[W::pi + e] = pio[q] + a * (L[O::Pa + e] - pio[q]);
+                        if (e >= NX) LK[O::Z + e] = upr_step(LK[O::Z + e], a, LK[O::S + e]);
+                        ws[W::pi + e] = pio[q] + a * (LK[O::pin + e] - pio[q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < QNU; ++q) { const int e = tid_ + q * NT; if (e < N * NE) ws[W::nu + e] = nuo[q] + a * (nun_[q] - nuo[q]); }
             }
             if (C::INCEK) {   // the equality residual at the new iterate: ek += a (C sx + Df sf)
-                UPR_FORT(e, N * NE) { const int k = e / NE, r = e % NE; L[O::ek + e] += a * (L[O::dek + e] + df_dot(r, L + O::S + N1 * NX + k * NU + NQ)); }
+                UPR_FORT(e, N * NE) { const int k = e / NE, r = e % NE; LK[O::ek + e] += a * (LK[O::dek + e] + df_dot(r, LK + O::S + N1 * NX + k * NU + NQ)); }
                 have_ek = true;
             }
-            UPR_FORT(e, N * NU) L[O::Z + N1 * NX + e] = upr_step(L[O::Z + N1 * NX + e], a, L[O::S + N1 * NX + e]);
+            UPR_FORT(e, N * NU) LK[O::Z + N1 * NX + e] = upr_step(LK[O::Z + N1 * NX + e], a, LK[O::S + N1 * NX + e]);
             UPR_FORT(q, C::NEN) L[O::yN + q] += a * L[O::dyN + q];
             UPR_SYNC();
             ftoc(9);
             toc(15);
         }
         // ---- result: step from the linearisation point
-        UPR_FORT(e, N1 * NX) ws[W::dx + e] = L[O::Z + e] - xs[e];
-        UPR_FORT(e, N * NU) ws[W::du + e] = L[O::Z + N1 * NX + e] - us[e];
+        UPR_FORT(e, N1 * NX) ws[W::dx + e] = LK[O::Z + e] - xs[e];
+        UPR_FORT(e, N * NU) ws[W::du + e] = LK[O::Z + N1 * NX + e] - us[e];
         if (prof) UPR_FORT(i, 64) prof[i] += L[O::prf + i];
         if (A.fb) write_feedback(A.fb + (size_t)b * N * NU * NX, status);
         if (A.kkt) {   // multipliers for upr_batch_qp_kkt, in the generic kernel's slot layout

@@ -24,6 +24,8 @@ UPR_QP3_PART3(UPR_X_)
 UPR_QP3_PART4(UPR_X_)
 #elif UPR_QP3_PART == 5
 UPR_QP3_PART5(UPR_X_)
+#elif UPR_QP3_PART == 6
+UPR_QP3_PART6(UPR_X_)
 #else
 #error "UPR_QP3_PART out of range (upr_qp3_list.h: UPR_QP3_NPARTS)"
 #endif

@@ -27,8 +27,11 @@
 #define UPR_QP3_PART4(X) X(6, 1, 4, 1, 20, false, true, false) X(6, 1, 4, 1, 10, false, true, false) X(6, 1, 4, 3, 20, false, false, false)
 // part 5 (round 4): the paper's dice (two stacked bodies, dense 12 x 12) and seven cups (star with friction: upr_qp3_cfg::BIGF)
 #define UPR_QP3_PART5(X) X(9, 2, 8, 3, 20, false, false, true) X(9, 7, 28, 3, 20, false, false, false)
-#define UPR_QP3_NPARTS 6   /* part 0: the headline */
-#define UPR_QP3_EXTRA(X) UPR_QP3_PART1(X) UPR_QP3_PART2(X) UPR_QP3_PART3(X) UPR_QP3_PART4(X) UPR_QP3_PART5(X)
+// part 6 (round 6): upright_robust at the reference's OWN horizon (upright_robust/config/demos/_base.yaml:62-66: time_horizon 10 s, dt 0.1:
+// N = 100) -- the whole-horizon arrays in a far array (upr_qp3_cfg::KFAR)
+#define UPR_QP3_PART6(X) X(9, 8, 32, 1, 100, false, true, false)
+#define UPR_QP3_NPARTS 7   /* part 0: the headline */
+#define UPR_QP3_EXTRA(X) UPR_QP3_PART1(X) UPR_QP3_PART2(X) UPR_QP3_PART3(X) UPR_QP3_PART4(X) UPR_QP3_PART5(X) UPR_QP3_PART6(X)
 #endif
 
 // the headline's own instantiations: Y(NT, ROWS)
