@@ -645,11 +645,11 @@ def softened_row_violation(mpc, w):
     return np.abs(out["g"]).reshape(B, N, -1).max(axis=2)      # [B][N]
 
 
-def config4_horizon_entry(B_long=64):
-    """configs[3] at BASELINE's horizon (N = 20, production kernel) and at the reference's own horizon for upright_robust
-    (upright_robust/config/demos/_base.yaml:62: T = 10 s, N = 100 -- the production kernel keeps the whole horizon in LDS and cannot
-    take it, DESIGN.md 7: the generic kernel runs it): how far the plans violate the softened balance rows.  At 2 s for a 2.2 m move
-    the rows are traded against the end-effector cost; at 10 s the same move balances."""
+def config4_horizon_entry(B_long=256):
+    """configs[3] at BASELINE's horizon (N = 20) and at the reference's own horizon for upright_robust
+    (upright_robust/config/demos/_base.yaml:62: T = 10 s, N = 100 -- since round 6 on the production kernel too, with the whole-horizon
+    arrays in a far array: upr_qp3_cfg::KFAR, DESIGN.md 3): how far the plans violate the softened balance rows.  At 2 s for a 2.2 m
+    move the rows are traded against the end-effector cost; at 10 s the same move balances."""
     out = {"workload": "configs[3] plans at N = 20 (BASELINE) and N = 100 (the reference's own horizon): violation of the softened object-dynamics rows along the plan",
            "unit": "max |row| (rows normalised as balancing_constraints.cpp:144-151)"}
     for N, B in ((20, 256), (100, B_long)):
