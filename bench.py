@@ -37,6 +37,11 @@ sys.path.insert(0, str(ROOT))
 METRIC = "batched MPC solves/sec + ms/SQP-iter, Thing 1-obj horizon=20, 1/2/4/8 GPU"   # BASELINE.json:metric verbatim; value = solves/s
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_FP64_TFLOPS = 78.6    # public MI355X fp64 vector = matrix peak (not in the local guide)
+# tools/probe/mall_probe (profiles/r06_mall_probe.txt): 512 workgroups re-streaming a private 216 KB set (the QP kernel's far-array
+# pattern: 110 MB live, missing the L2, fitting the 256 MiB Infinity Cache) read it at 7.06 TB/s; the same bytes streamed from DRAM
+# at 3.98 TB/s -- with identical FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_DRAM: the counters sit in front of the Infinity Cache
+MALL_PROBE_GBS = 7060.9
+MALL_STREAM_GBS = 3975.6
 
 
 # ---- algorithmic bytes / flops ------------------------------------------------------------
@@ -523,6 +528,25 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
         "avg_launch_ms": kt["qp_ms"],
         "algorithmic_flops_per_launch": qp_flops,
     }
+    # What the counter traffic is.  FETCH_SIZE / WRITE_SIZE count requests at the L2's fabric side: Infinity-Cache
+    # hits included, and no gfx950 counter splits them from DRAM (rocprofv3 --list-avail: TCC_EA0_RDREQ_DRAM = "destined for DRAM",
+    # equal to RDREQ for an Infinity-Cache-resident set too -- profiles/r06_mall_probe.txt).  The split is therefore a MODEL, with
+    # the probe as its evidence: the workgroups resident at a time (one or two per CU) re-stream a private workspace each; their
+    # live set (resident workgroups x workspace) fits the 256 MiB cache, so after the first touch the far traffic is cache
+    # traffic, and DRAM sees every byte once: the linearisation records and trajectories read, the workspace written back.
+    lin_stride = 6 * P.nb * (1 + P.nx) + 1 + P.nq + P.nq * (P.nq + 1) // 2 + (len(P.pair_a) + len(P.proj_sph)) * (1 + P.nq)
+    ws_d = kt.get("ws_doubles") or 0
+    per_inst = 8.0 * ((P.N + 1) * lin_stride + (P.N + 1) * P.nx + P.N * P.nu + ws_d)
+    resident = min(B, 256 * (2 if ("upr_qp3_cfg<9, 1," in kname or "upr_qp3_cfg<6, 1," in kname) else 1))
+    roof["traffic_is"] = "bytes at the L2's fabric side (2 x FETCH_SIZE + WRITE_SIZE): Infinity-Cache hits are counted, no gfx950 counter splits them off"
+    roof["traffic_dram"] = B * per_inst
+    roof["traffic_dram_basis"] = ("model: every instance's records, trajectories and workspace (%d doubles) cross the DRAM interface once; the live set of the "
+                                  "%d resident workgroups is %.0f MB < 256 MiB Infinity Cache, which serves the re-streamed far arrays "
+                                  "(profiles/r06_mall_probe.txt: that pattern reads at %.1f TB/s from the cache, %.1f TB/s from DRAM, same counters)"
+                                  % (ws_d, resident, resident * 8.0 * ws_d / 1e6, MALL_PROBE_GBS / 1e3, MALL_STREAM_GBS / 1e3))
+    if traffic.get("qp") and kt["qp_ms"] > 0:
+        roof["frac_infinity_cache"] = traffic["qp"] / (kt["qp_ms"] * 1e-3) / 1e9 / MALL_PROBE_GBS   # of the probe's measured rate for this access pattern
+        roof["frac_hbm_dram_model"] = roof["traffic_dram"] / (kt["qp_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
     if issued is not None and kt["qp_ms"] > 0:
         # flops the kernel actually issued (committed instruction-mix counters of the same kernel; for workloads whose
         # launches differ in IPM iterations, e.g. configs[2] cold / warm, the mean over the dispatches of the counter pass):
@@ -542,8 +566,14 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
         roof["frac_basis"] = "issued flops (the SURVEY 8(d) dense count is %.1fx what the structured kernel executes)" % (qp_flops / roof["issued_flops_per_launch"])
     f_exec = roof.get("frac_issued", frac)
     roof["nearest_roofline"] = "hbm" if (frac_hbm is not None and frac_hbm > f_exec) else "mfma"
-    if max(f_exec, frac_hbm or 0.0) >= 0.5:
-        roof["bound"] = roof["nearest_roofline"]
+    if (roof.get("frac_infinity_cache") or 0.0) >= 0.5 and (roof.get("frac_infinity_cache") or 0.0) > f_exec:
+        # more than half of what the Infinity Cache delivered to the probe's copy of this access pattern: bandwidth of the cache, not of
+        # the HBM (whose share is `frac_hbm_dram_model`), and not latency
+        roof["bound"] = "infinity-cache"
+        roof["bound_detail"] = ("fabric traffic at %.0f %% of the rate the Infinity Cache sustained for the same re-streaming pattern (tools/probe/mall_probe); "
+                                "DRAM itself carries the modelled %.2f GB per launch" % (100 * roof["frac_infinity_cache"], roof["traffic_dram"] / 1e9))
+    elif f_exec >= 0.5:
+        roof["bound"] = "mfma"
     lin = {
         "kernel": "upr_linearize_kernel",
         "bound": "hbm",
@@ -617,6 +647,11 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
             "value": B * n_timed / el, "unit": "solves/s", "ms_per_step": 1e3 * el / n_timed,
             "qp_converged_fraction": float(np.mean(sw["qp_status_last"] == 0)), "qp_iters_mean": float(np.mean(sw["qp_iters_last"])),
             "constraint_violation_max": float(np.max(sw["constraint_violation"])),
+            # the rate of the instances whose QP converged, and how the plans' constraint violation is spread
+            "value_converged_subset": float(np.sum(sw["qp_status_last"] == 0)) * n_timed / el,
+            "constraint_violation_quantiles": {q: float(np.quantile(sw["constraint_violation"], float(q))) for q in ("0.5", "0.9", "0.99", "1.0")},
+            "constraint_violation_of_the_not_converged": (float(np.max(sw["constraint_violation"][sw["qp_status_last"] != 0])) if np.any(sw["qp_status_last"] != 0) else None),
+            "constraint_violation_max_of_the_converged": (float(np.max(sw["constraint_violation"][sw["qp_status_last"] == 0])) if np.any(sw["qp_status_last"] == 0) else None),
             "roofline": roof_w,
             "kernel_ms": {"linearize": kw["linearize_ms"], "qp": kw["qp_ms"], "linesearch": kw["linesearch_ms"], "launches": kw["launches"]},
         }
@@ -627,7 +662,8 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
             out["cold_start_at_the_iteration_cap"] = cold
             wv = out["warm"]
             out.update(value=wv["value"], ms_per_step=wv["ms_per_step"], ms_per_sqp_iter=wv["ms_per_step"], qp_converged_fraction=wv["qp_converged_fraction"],
-                       qp_iters_mean=wv["qp_iters_mean"], roofline=wv["roofline"], kernel_ms=wv["kernel_ms"], steps=n_timed)
+                       qp_iters_mean=wv["qp_iters_mean"], roofline=wv["roofline"], kernel_ms=wv["kernel_ms"], steps=n_timed,
+                       value_converged_subset=wv["value_converged_subset"], constraint_violation_quantiles=wv["constraint_violation_quantiles"])
             out["value_is"] = "the converging regime (`warm`): " + wv["what"]
             del out["note"]
     mpc.close()

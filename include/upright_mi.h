@@ -288,6 +288,9 @@ int upr_batch_enable_timing(upr_batch* h, int on);
 /* name of the QP kernel instantiation this handle launches (as rocprofv3 prints it): bench.py's roofline.kernel */
 const char* upr_batch_qp_kernel_name(const upr_batch* h);
 int upr_batch_device(const upr_batch* h);   /* the HIP device the handle lives on; -1 for a null handle */
+/* doubles of device workspace per instance (QP result, multipliers, the QP kernel's far arrays): what an instance writes once and
+ * re-streams every interior-point iteration -- bench.py's model of the compulsory DRAM traffic of a launch */
+long long upr_batch_ws_doubles(const upr_batch* h);
 
 /* copy the current solution into caller-owned DEVICE buffers (torch tensors handed to the RCCL
  * all-gather of solved trajectories): xs_dst[B][N+1][nx], us_dst[B][N][nu]; asynchronous on the

@@ -929,6 +929,7 @@ def test_config3_shape_three_objects_and_static_obstacles(arrangements):
     _, xs, us = mpc.solution()
     st = mpc.stats()
     xs0, us0 = stationary_guess(x0, P.N, P.nu)
+    plans = []
     for b in range(B):
         P.way_p = way[b]
         xo, uo, so, rc = Oracle(P).solve(0.0, x0[b], xs0[b], us0[b])
@@ -945,6 +946,24 @@ def test_config3_shape_three_objects_and_static_obstacles(arrangements):
         # polynomial, UPR_QP3_FUSEAFF) moves the kernel's plan by up to 6e-3 along that valley; the bound is ten step tolerances,
         # and what makes the plans GOOD -- converged, feasible, collision-free, on target -- is asserted tightly above.
         assert np.abs(xs[b] - xo).max() < 10 * P.delta_tol
+        plans.append((xo, uo))
+    # ... and the comparison that does NOT go through the chaotic leg: ONE more QP from the ORACLE's
+    # converged plan, on both sides.  There the sub-problem is feasible and converges, its minimiser is unique, and the two solvers
+    # are fed the same linearisation point: the steps agree like those of any converged QP.
+    xg = np.stack([p[0] for p in plans]); ug = np.stack([p[1] for p in plans])
+    mpc.set_observation(0.0, x0)
+    mpc.set_guess(xg, ug)
+    dxs, dus = mpc.qp_step()
+    stq = mpc.stats()
+    assert np.all(stq["qp_status_last"] == 0)
+    for b in range(B):
+        P.way_p = way[b]
+        dxo, duo, soq, rc = Oracle(P).qp_step(0.0, x0[b], xg[b], ug[b])
+        assert rc == 0
+        ex, eu = np.abs(dxs[b] - dxo).max(), np.abs(dus[b] - duo).max() / max(1.0, np.abs(ug[b] + duo).max())
+        print("config3 shape, QP at the oracle's converged plan: |dx - dx_oracle| %.2e, |du - du_oracle| / max|u| %.2e, iterations %d / %d" % (ex, eu, stq["qp_iters_last"][b], soq.qp_iters_last))
+        assert ex < 0.1 * P.delta_tol and eu < 1e-4
+        assert abs(stq["qp_iters_last"][b] - soq.qp_iters_last) <= 1
     mpc.close()
 
 

@@ -149,6 +149,7 @@ PROTOTYPES = [
     ("upr_batch_copy_policy_device", C.c_int, [C.c_void_p, C.c_void_p]),
     ("upr_set_device", C.c_int, [C.c_int]),
     ("upr_batch_device", C.c_int, [C.c_void_p]),
+    ("upr_batch_ws_doubles", C.c_longlong, [C.c_void_p]),
     ("upr_batch_reset_async", C.c_int, [C.c_void_p]),
     ("upr_batch_stream", C.c_void_p, [C.c_void_p]),
     ("upr_batch_qp_profile", C.c_int, [C.c_void_p, dp]),

@@ -1407,6 +1407,7 @@ int upr_set_device(int device) {
     return 0;
 }
 int upr_batch_device(const upr_batch* h) { return h ? h->device : -1; }
+long long upr_batch_ws_doubles(const upr_batch* h) { return h ? (long long)h->d.ws_stride : -1; }
 
 /* forget the previous solution without a host synchronisation (cold start for the next advance) */
 int upr_batch_reset_async(upr_batch* h) {

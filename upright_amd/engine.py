@@ -246,7 +246,7 @@ class BatchMPC:
         n = np.zeros(3, dtype=np.int32)
         check(self._lib.upr_batch_kernel_times(self._h, ptr(ms), iptr(n)))
         return dict(linearize_ms=ms[0], qp_ms=ms[1], linesearch_ms=ms[2], launches=n.tolist(),
-                    qp_kernel=self._lib.upr_batch_qp_kernel_name(self._h).decode())
+                    qp_kernel=self._lib.upr_batch_qp_kernel_name(self._h).decode(), ws_doubles=int(self._lib.upr_batch_ws_doubles(self._h)))
 
 
 def core_object_dynamics(problem, body_params, forces, Cm, w, al, a):
