@@ -11,7 +11,9 @@ B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
 import bench
 bp=None
 if "config3" in sys.argv: w=bench.config3_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
-elif "config4" in sys.argv: w=bench.config4_workload(B); P,x0,way,bp=w["P"],w["x0"],w["way"],w["body_params"]; P.sqp_iters=1
+elif "config4" in sys.argv:
+    w=bench.config4_workload(B); P,x0,way,bp=w["P"],w["x0"],w["way"],w["body_params"]; P.sqp_iters=1
+    if "N100" in sys.argv: P.N=100   # (the reference's own horizon: the far-array form of the kernel, upr_qp3_cfg::KFAR)
 elif "config5s" in sys.argv: w=bench.config5_workload(B, slacks=True); P,x0,way=w["P"],w["x0"],w["way"]
 elif "config5" in sys.argv: w=bench.config5_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
 else:
