@@ -566,9 +566,10 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
         roof["frac_basis"] = "issued flops (the SURVEY 8(d) dense count is %.1fx what the structured kernel executes)" % (qp_flops / roof["issued_flops_per_launch"])
     f_exec = roof.get("frac_issued", frac)
     roof["nearest_roofline"] = "hbm" if (frac_hbm is not None and frac_hbm > f_exec) else "mfma"
-    if (roof.get("frac_infinity_cache") or 0.0) >= 0.5 and (roof.get("frac_infinity_cache") or 0.0) > f_exec:
-        # more than half of what the Infinity Cache delivered to the probe's copy of this access pattern: bandwidth of the cache, not of
-        # the HBM (whose share is `frac_hbm_dram_model`), and not latency
+    if (roof.get("frac_infinity_cache") or 0.0) >= 0.75 and (roof.get("frac_infinity_cache") or 0.0) > f_exec:
+        # three quarters and more of what the Infinity Cache delivered to the probe's copy of this access pattern: bandwidth of the
+        # cache, not of the HBM (whose share is `frac_hbm_dram_model`), and not latency.  (The hard-row kernels sit at ~0.5 of it and
+        # stay "latency": a fully L2-resident batch is only 10 % faster per round, and far-memory prefetches measured +- 0.5 %.)
         roof["bound"] = "infinity-cache"
         roof["bound_detail"] = ("fabric traffic at %.0f %% of the rate the Infinity Cache sustained for the same re-streaming pattern (tools/probe/mall_probe); "
                                 "DRAM itself carries the modelled %.2f GB per launch" % (100 * roof["frac_infinity_cache"], roof["traffic_dram"] / 1e9))
