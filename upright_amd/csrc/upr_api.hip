@@ -560,7 +560,7 @@ int jit_get(const upr_problem& P, const upr_dims& d, upr_jit_kernel** out) {
     const std::string src =
         "#include \"upr_qp3.h\"\n"
         "typedef upr_qp3_cfg<UPR_QP3_JIT_CFG> upr_jit_cfg;\n"
-        "extern \"C\" __global__ void __launch_bounds__(upr_jit_cfg::NT, (upr_jit_cfg::NT <= 256 && upr_jit_cfg::NB == 1) ? 2 : 1) upr_qp3_jit(upr_qp_args A) {\n"
+        "extern \"C\" __global__ void __launch_bounds__(upr_jit_cfg::NT, (upr_jit_cfg::NT <= 256 && upr_jit_cfg::NB == 1) ? UPR_QP3_OCC1 : 1) upr_qp3_jit(upr_qp_args A) {\n"
         "    extern __shared__ __attribute__((aligned(16))) double smem[];\n"
         "    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = upr_jit_cfg::NT;\n"
         "    upr_qp3_solve<upr_jit_cfg>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);\n"

@@ -267,6 +267,9 @@ static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
 // W1 = 3: + 2.2 %; the vector / forward sweep waves at 2 or 1: no change).  The SOFT kernels measured 1.1 % slower with it and keep 3.
 #define UPR_QP3_PRIO_W1 (C::SOFT ? 3 : 1)
 #endif
+#ifndef UPR_QP3_OCC1
+#define UPR_QP3_OCC1 2   /* workgroups per CU the one-body instantiations are compiled for (register budget 512 / (4 waves x this) per SIMD lane) */
+#endif
 #ifndef UPR_QP3_PREC_MAX
 #define UPR_QP3_PREC_MAX 4   /* quad slots of rows of C per lane up to which prep fetches them into registers ahead of phase C */
 #endif
@@ -2384,12 +2387,23 @@ struct upr_qp3 {
                 double gs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0}, us2[2] = {0.0, 0.0};
                 UPR_LOADST(gs[(N - 1) & 1], ps[(N - 1) & 1], us2[(N - 1) & 1], N - 1);
                 // fully unrolled (static register indices; inside a loop the compiler's s_waitcnt bookkeeping would also
-                // collapse the prefetch stages into one)
+                // collapse the prefetch stages into one).  KFAR (N = 100): unrolled in groups of KSTAGES knots inside a rolled loop --
+                // the stage indices are still static (the group length is the ring's), and the hundred knots' global addresses are
+                // formed where they are used: fully unrolled the compiler hoisted and SPILLED them (1 400 scratch instructions inside
+                // the two sweeps, every reload a vmcnt(0): 8 k cycles a knot)
+                constexpr int UG = C::KFAR ? UPR_QP3_KSTAGES : N - 1;
+                static_assert(!C::KFAR || UPR_QP3_KSTAGES % 2 == 0, "the two operand slots keep their parity over a group");
+#pragma unroll 1
+                for (int k0 = N - 1; k0 >= 1; k0 -= UG) {
 #pragma unroll
-                for (int k = N - 1; k >= 1; --k) {
-                    UPR_LOADST(gs[(k - 1) & 1], ps[(k - 1) & 1], us2[(k - 1) & 1], k - 1);
-                    UPR_VECSTEP(kc[(N - 1 - k) % UPR_QP3_KSTAGES], gs[k & 1], ps[k & 1], us2[k & 1], k);
-                    UPR_LOADKC(kc[(N - 1 - k) % UPR_QP3_KSTAGES], k - UPR_QP3_KSTAGES);
+                    for (int sg = 0; sg < UG; ++sg) {
+                        const int k = k0 - sg;
+                        if (k >= 1) {
+                            UPR_LOADST(gs[(N - sg) & 1], ps[(N - sg) & 1], us2[(N - sg) & 1], k - 1);
+                            UPR_VECSTEP(kc[sg % UPR_QP3_KSTAGES], gs[(N - 1 - sg) & 1], ps[(N - 1 - sg) & 1], us2[(N - 1 - sg) & 1], k);
+                            UPR_LOADKC(kc[sg % UPR_QP3_KSTAGES], k - UPR_QP3_KSTAGES);
+                        }
+                    }
                 }
 #undef UPR_LOADKC
 #undef UPR_LOADST
@@ -2555,11 +2569,18 @@ struct upr_qp3 {
                 double xv = Sx(1)[i];
                 double bs[2] = {0.0, 0.0}, fs[2] = {0.0, 0.0};
                 UPR_LOADST(bs[1], fs[1], 1);
+                constexpr int UG = C::KFAR ? UPR_QP3_KSTAGES : N - 1;   // (as in the vector sweep)
+#pragma unroll 1
+                for (int k0 = 1; k0 < N; k0 += UG) {
 #pragma unroll
-                for (int k = 1; k < N; ++k) {
-                    UPR_LOADST(bs[(k + 1) & 1], fs[(k + 1) & 1], k + 1);
-                    UPR_FWDSTEP(kq[(k - 1) % UPR_QP3_KSTAGES], bs[k & 1], fs[k & 1], k);
-                    UPR_LOADKQ(kq[(k - 1) % UPR_QP3_KSTAGES], k + UPR_QP3_KSTAGES);
+                    for (int sg = 0; sg < UG; ++sg) {
+                        const int k = k0 + sg;
+                        if (k < N) {
+                            UPR_LOADST(bs[(sg + 2) & 1], fs[(sg + 2) & 1], k + 1);
+                            UPR_FWDSTEP(kq[sg % UPR_QP3_KSTAGES], bs[(sg + 1) & 1], fs[(sg + 1) & 1], k);
+                            UPR_LOADKQ(kq[sg % UPR_QP3_KSTAGES], k + UPR_QP3_KSTAGES);
+                        }
+                    }
                 }
 #undef UPR_LOADKQ
 #undef UPR_LOADST
@@ -3773,7 +3794,7 @@ static UPR_HDI void upr_qp3_solve(const upr_ctx& ctx, const upr_qp_args& A, int 
 // sweep waves of co-resident workgroups never share a SIMD: every such assignment measured 6 - 9 % SLOWER than logical =
 // physical (1.90 ms -> 2.01 .. 2.07 ms); the sweep waves want to be the two oldest waves of their workgroup.)
 template <class C>
-__global__ void __launch_bounds__(C::NT, (C::NT <= 256 && C::NB == 1) ? 2 : 1) upr_qp3_kernel(upr_qp_args A) {
+__global__ void __launch_bounds__(C::NT, (C::NT <= 256 && C::NB == 1) ? UPR_QP3_OCC1 : 1) upr_qp3_kernel(upr_qp_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = C::NT;
     upr_qp3_solve<C>(ctx, A, upr_qp_instance(A, blockIdx.x), smem);
