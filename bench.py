@@ -117,7 +117,21 @@ def pmc_workload(key):
             if tag:
                 out[tag][counter] = float(mean)
                 out["batch"] = int(batch)
+    for l in open(best):
+        if l.startswith("# kernel sources sha256:"):
+            out["library"] = l.split(":", 1)[1].strip()   # the sources the counters' build was made of (tools/pmc_workloads.sh)
     return (out, best.name) if (out["qp"] or out["linearize"]) else ({}, None)
+
+
+def library_sha():
+    """sha256 over the kernel sources (csrc/*.h, csrc/*.hip, include/upright_mi.h): what a counter file names as its build."""
+    import hashlib
+
+    h = hashlib.sha256()
+    rel = sorted([str(f.relative_to(ROOT)) for f in list((ROOT / "upright_amd" / "csrc").glob("*.h")) + list((ROOT / "upright_amd" / "csrc").glob("*.hip"))] + ["include/upright_mi.h"])
+    for f in rel:
+        h.update((ROOT / f).read_bytes())
+    return h.hexdigest()[:16]
 
 
 def _hbm_bytes(c):
@@ -547,6 +561,10 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
     if traffic.get("qp") and kt["qp_ms"] > 0:
         roof["frac_infinity_cache"] = traffic["qp"] / (kt["qp_ms"] * 1e-3) / 1e9 / MALL_PROBE_GBS   # of the probe's measured rate for this access pattern
         roof["frac_hbm_dram_model"] = roof["traffic_dram"] / (kt["qp_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+    if wl.get("library"):
+        # which build the counters belong to, and whether it is the one being timed
+        roof["counters_of_build"] = "kernel sources sha256 " + wl["library"]
+        roof["counters_match_this_build"] = (wl["library"] == library_sha())
     if issued is not None and kt["qp_ms"] > 0:
         # flops the kernel actually issued (committed instruction-mix counters of the same kernel; for workloads whose
         # launches differ in IPM iterations, e.g. configs[2] cold / warm, the mean over the dispatches of the counter pass):
