@@ -2301,7 +2301,11 @@ def test_value_function_queries_of_the_controller_interface(arrangements):
     m.warmstart()
     ts, xs, us = m.get_mpc_trajectory()
     ci = m.mpc
+    before = {k: v.copy() for k, v in ci._mpc.stats().items()}
     vf = ci._value_function()
+    # (the query solves one more QP on the handle; statistics and dispatch keys of the SOLVE are put back -- upr_batch_hold_stats)
+    after = ci._mpc.stats()
+    assert all(np.array_equal(before[k], after[k]) for k in before), [k for k in before if not np.array_equal(before[k], after[k])]
     for k in (1, 5, 12):
         g = ci.valueFunctionStateDerivative(ts[k], xs[k])
         assert g.shape == (P.nx_full,) and np.abs(g[:P.nx] - vf.pk[k] - vf.Pk[k] @ (xs[k][:P.nx] - vf.X[k])).max() < 1e-9 * max(1.0, np.abs(g).max())
