@@ -17,8 +17,9 @@ elif "config4" in sys.argv:
 elif "config5s" in sys.argv: w=bench.config5_workload(B, slacks=True); P,x0,way=w["P"],w["x0"],w["way"]
 elif "config5" in sys.argv: w=bench.config5_workload(B); P,x0,way=w["P"],w["x0"],w["way"]
 else:
-    P=thing_problem(arr['pink_bottle'])
-    x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0)
+    NH=[int(a[2:]) for a in sys.argv if a.startswith("NH")]   # NH<n>: the headline shape at horizon n (a target the short horizon reaches)
+    P=thing_problem(arr['pink_bottle'], **({"N": NH[0]} if NH else {}))
+    x0=level_tray_states(B,seed=0); way=waypoints_for(P,x0, **({"offset": (-0.004*NH[0]**2, 0.002*NH[0]**2, 0.0)} if NH else {}))
 names=["residuals","prep A: box rows","prep B: contacts","prep C: eq residual, S","prep D: Schur factor","prep E: C' zt","mat: phase 1","mat: aug. Cholesky","mat: V, K store","mat: P update","vec: sweep","vec/mat: flat parts","fwd: sweep","fwd: tail + costates","aff sweeps","update + init"]
 MAT = "mat" in sys.argv[2:]
 if MAT:
