@@ -1495,7 +1495,7 @@ struct upr_qp3 {
     // the side work of knot k: feedback column (or column of Lj^-1) by back substitution and its store, the sum of P+ b, the fused
     // predictor step (wt: w~_k in, w~_{k-1} out)
     UPR_HDI void sw2_side(int k, const double (&a)[NQ][NQ], const double (&hx)[NQ], const double (&pbv)[NQ], double& wt, int l, bool vl, int vj_,
-                          double ca0, double ca1, double ca2) {
+                          double ca0, double ca1, double ca2, double gk_pre = 0.0, double uk_pre = 0.0) {
         double kk[NQ];
 #pragma unroll
         for (int i = NQ - 1; i >= 0; --i) {
@@ -1520,8 +1520,9 @@ struct upr_qp3 {
         {
             // the predictor's vector sweep (backward_vec's recursion, mode 0) rides along, K_k out of registers:
             // w_k = w~_k + (P+ b)_k ; rq = gu_k[jerk] + B'w_k (-> the feed-forward phase) ; w~_{k-1} = gx_k + C_k'zt_k + A'w_k - K_k' rq
-            const double gk = (k >= 1) ? LK[O::gxs + k * NX + (vl ? l : 0)] + LK[O::cs + k * NX + (vl ? l : 0)] : 0.0;
-            const double uk = LK[O::gus + k * NU + vj_];
+            // (KFAR: requested by the caller at the top of the knot, in front of the factorisation)
+            const double gk = C::KFAR ? gk_pre : ((k >= 1) ? LK[O::gxs + k * NX + (vl ? l : 0)] + LK[O::cs + k * NX + (vl ? l : 0)] : 0.0);
+            const double uk = C::KFAR ? uk_pre : LK[O::gus + k * NU + vj_];
             const double wk = wt + pbs;
             if (vl) L[O::sw_w + l] = wk;
             UPR_WSYNC();
@@ -1548,6 +1549,9 @@ struct upr_qp3 {
         terminal_residual();
         if (!C::VCPRE && wave >= 2) form_vc(N - 1);
         sync_lds();
+        // (the barriers A / B inside the sweep hand over LDS staging only -- Hjj, Hux, V, the shares of Vc'Vc -- in KFAR instantiations
+        //  too: the whole-horizon arrays the sweep reads were written before the barrier above, the ones it writes are read behind the
+        //  full barrier at its end.  As full barriers they made every knot wait for all four waves' far requests: 840 k -> see NOTES_r06)
         if (wave == 1) {
             UPR_SETPRIO(UPR_QP3_PRIO_W1);
             const bool blk = l < NBK;
@@ -1571,6 +1575,13 @@ struct upr_qp3 {
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no wait for earlier global loads inside the loop
             double hjd = h * L[O::rd + bi] + LK[O::wu + (N - 1) * NU + bi];
+            // KFAR: the knot's defects and barrier diagonals come out of the far array -- requested one knot ahead (out of LDS they are
+            // read where they are used)
+            double nbj[3], nbi[3], nwx[3];
+            if (C::KFAR) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { nbj[c] = LK[O::bks + (N - 1) * NX + c * NQ + bj]; nbi[c] = LK[O::bks + (N - 1) * NX + c * NQ + bi]; nwx[c] = LK[O::wx + (N - 1) * NX + c * NQ + bi]; }
+            }
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
                 // critical path first: Hux (both orientations of the block) and Hjj, straight from the registers of P+
@@ -1595,14 +1606,14 @@ struct upr_qp3 {
                         for (int c = 0; c < 3; ++c) L[O::sw_hx + (c * NQ + bi) * HXS + bj] = hxb[c];
                     }
                 }
-                sync_lds();   // A: Hjj, Hux are in LDS
+                UPR_SYNC_LDS();   // A: Hjj, Hux are in LDS
                 toc(6);
                 // while wave 0 factors: the partial sums of P+ b (wave 0 adds them up behind barrier B) ...
                 const double heek = (k > 0) ? G[hee_w + k * C::NH + lc] : 0.0;   // (used at the very end of the knot)
                 {
                     double bjv[3], biv[3], r1[3], r2[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { bjv[c] = LK[O::bks + k * NX + c * NQ + bj]; biv[c] = LK[O::bks + k * NX + c * NQ + bi]; }
+                    for (int c = 0; c < 3; ++c) { bjv[c] = C::KFAR ? nbj[c] : LK[O::bks + k * NX + c * NQ + bj]; biv[c] = C::KFAR ? nbi[c] : LK[O::bks + k * NX + c * NQ + bi]; }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         r1[c] = p[c][0] * bjv[0] + p[c][1] * bjv[1] + p[c][2] * bjv[2];     // -> (P+ b)[(c, bi)]
@@ -1628,7 +1639,7 @@ struct upr_qp3 {
                     int bic = bi, bjc = bj;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        wxk[c] = LK[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
+                        wxk[c] = C::KFAR ? nwx[c] : LK[O::wx + k * NX + c * NQ + bi]; qdk[c] = L[O::qd + c * NQ + bi];
 #pragma unroll
                         for (int r = 0; r < RC; ++r) { cj[0][c][r] = Vk[(c * NQ + bj) * O::VCS + r]; ci[0][c][r] = Vk[(c * NQ + bi) * O::VCS + r]; }
                     }
@@ -1673,10 +1684,14 @@ struct upr_qp3 {
                     }
                 }
                 toc(7);
-                sync_lds();   // B: V is in LDS
+                UPR_SYNC_LDS();   // B: V is in LDS
                 toc(8);
                 if (k == 0) break;
                 hjd = h * L[O::rd + bi] + LK[O::wu + (k - 1) * NU + bi];
+                if (C::KFAR) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { nbj[c] = LK[O::bks + (k - 1) * NX + c * NQ + bj]; nbi[c] = LK[O::bks + (k - 1) * NX + c * NQ + bi]; nwx[c] = LK[O::wx + (k - 1) * NX + c * NQ + bi]; }
+                }
                 {
                     double vj[3][NQ], vi[3][NQ];
 #pragma unroll
@@ -1717,8 +1732,10 @@ struct upr_qp3 {
             if (vl) wt = wt_terminal(l);
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
-                sync_lds();   // A
+                UPR_SYNC_LDS();   // A
                 toc(6);
+                double gk_pre = 0.0, uk_pre = 0.0;
+                if (C::KFAR) { gk_pre = (k >= 1) ? LK[O::gxs + k * NX + (vl ? l : 0)] + LK[O::cs + k * NX + (vl ? l : 0)] : 0.0; uk_pre = LK[O::gus + k * NU + vj_]; }
                 double a[NQ][NQ], hx[NQ];
                 sw2_factor(a, hx, vcl, ok);
                 if (k > 0 && vl) {
@@ -1726,14 +1743,14 @@ struct upr_qp3 {
                     for (int m = 0; m < NQ; ++m) L[O::sw_hx + l * HXS + m] = hx[m];
                 }
                 toc(7);
-                sync_lds();   // B
+                UPR_SYNC_LDS();   // B
                 toc(8);
                 {
                     // off the critical path (wave 1 updates P meanwhile): P+ b, the feedback column by back substitution, its store
                     double pbv[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) pbv[q] = L[O::sw_pb + (vl ? l : 0) * HXS + q];
-                    sw2_side(k, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2);
+                    sw2_side(k, a, hx, pbv, wt, l, vl, vj_, ca0, ca1, ca2, gk_pre, uk_pre);
                 }
                 toc(9);
             }
@@ -1753,7 +1770,7 @@ struct upr_qp3 {
             if (!C::VCPRE && N - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(N - 2, vm); } else form_vc_load(N - 2, vq); }
 #pragma nounroll
             for (int k = N - 1; k >= 0; --k) {
-                sync_lds();   // A
+                UPR_SYNC_LDS();   // A
                 toc(6);
                 // Vc of knot k - 1 goes into the buffer whose last readers (knot k + 1) finished before barrier B of that knot; its
                 // operands were requested behind that barrier.  Stacked bodies: wave 2 forms it on the matrix cores now, in the
@@ -1761,7 +1778,7 @@ struct upr_qp3 {
                 if (C::COUPLED && wave == 2 && k - 1 >= 1) form_vcm_store(k - 1, vm);
                 if (!C::VCPRE && k >= 1) { if (wave == 2) vc_share<0>(k, bi, bj); else vc_share<1>(k, bi, bj); }   // (added by wave 1 behind barrier B)
                 toc(7);
-                sync_lds();   // B
+                UPR_SYNC_LDS();   // B
                 toc(8);
                 if (!C::VCPRE && !C::COUPLED && k - 1 >= 1) form_vc_store(k - 1, vq);                                   // (read behind the NEXT barrier A)
                 if (!C::VCPRE && k - 2 >= 1) { if constexpr (C::COUPLED) { if (wave == 2) form_vcm_load(k - 2, vm); } else form_vc_load(k - 2, vq); }
