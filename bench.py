@@ -128,9 +128,14 @@ def library_sha():
     import hashlib
 
     h = hashlib.sha256()
+    import re
+
     rel = sorted([str(f.relative_to(ROOT)) for f in list((ROOT / "upright_amd" / "csrc").glob("*.h")) + list((ROOT / "upright_amd" / "csrc").glob("*.hip"))] + ["include/upright_mi.h"])
     for f in rel:
-        h.update((ROOT / f).read_bytes())
+        # (comments and white space do not make a build: an edit of a comment must not orphan the counters)
+        code = re.sub(r"/\*.*?\*/", "", (ROOT / f).read_text(), flags=re.S)
+        code = re.sub(r"//[^\n]*", "", code)
+        h.update(re.sub(r"\s+", " ", code).encode())
     return h.hexdigest()[:16]
 
 

@@ -21,10 +21,9 @@ import csv, glob, collections
 batch = {"headline": 1024, "config3": 4096, "config4": 1024, "config5": 1024, "config5s": 1024, "contract": 1024, "headline_r03": 1024}
 with open("$OUT/${TAG}_pmc_workloads.csv", "w") as fh:
     fh.write("# tools/pmc_workloads.sh: rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | instruction mix), one short run per workload\n")
-    import hashlib, glob as _g
-    _h = hashlib.sha256()
-    for _f in sorted(_g.glob("upright_amd/csrc/*.h") + _g.glob("upright_amd/csrc/*.hip") + ["include/upright_mi.h"]): _h.update(open(_f, "rb").read())
-    fh.write("# kernel sources sha256: %s\n" % _h.hexdigest()[:16])   # (the build the counters belong to: bench.py compares it with the tree's)
+    import sys as _s; _s.path.insert(0, ".")
+    import bench as _b
+    fh.write("# kernel sources sha256: %s\n" % _b.library_sha())   # (comments and white space stripped; the build the counters belong to: bench.py compares it with the tree's)
     fh.write("# FETCH_SIZE / WRITE_SIZE in KB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction, MI355X_MICROARCH.md); the rest: per-dispatch means summed over the chip\n")
     fh.write("# configs[2]: config3 = the converging regime (warm launches), config3_cold = the launches at the iteration cap\n")
     fh.write('"workload","kernel","counter","dispatches","mean","batch"\n')

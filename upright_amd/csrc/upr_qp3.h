@@ -4,18 +4,16 @@
 // data lives and how many dependent phases a knot costs:
 //
 //   * horizon N and workgroup size NT are template parameters next to (nq, nb, nc, nf);
-//   * slacks / multipliers of the state and input boxes never leave REGISTERS: every lane owns a fixed
-//     set of (knot, variable) box pairs for the whole solve; the friction-pyramid rows of a contact are
-//     owned by one lane and kept in lane-private LDS slots -- the contact-point x cone-facet loop of
-//     contact_constraints.h:50-77 runs out of LDS, as do the facet Jacobians;
-//   * iterate, step, every per-knot vector (reduced gradients, barrier diagonals, equality residuals,
-//     contact-block factors, Schur factors) and all problem constants are LDS resident; global
-//     memory only holds the read-only linearisation records and the per-knot Riccati factors that the
-//     back-substitutions re-read;
-//   * per knot the factorisation costs 6 barriers: {P+ b, A'P+A, B'P+A, B'P+B, Vc = Ls^-1 C} in one
-//     phase straight from P+ (block-scalar structure of the triple integrator, system_dynamics.h:15-22),
-//     an nq x nq Cholesky held in the registers of one lane, its inverse by nq lanes, V = Lj^-1 Hux,
-//     and the symmetric update P = A'P+A + Q~ - V'V + Vc'Vc.
+//   * slacks / multipliers of the state and input boxes live in REGISTERS through the stage-parallel phases: every lane owns a fixed
+//     set of (knot, variable) box pairs for the whole solve (parked in a far array around the sweeps, which need every register);
+//     the friction-pyramid rows -- the contact-point x cone-facet loop of contact_constraints.h:50-77 -- are a row per lane item;
+//   * iterate, step, every per-knot vector (reduced gradients, barrier diagonals, equality residuals) and all problem constants are
+//     LDS resident (KFAR instantiations: behind the pointer LK in a far array); global memory holds the read-only linearisation
+//     records and the per-knot factors / Riccati feedback that the back-substitutions re-read (Infinity-Cache resident);
+//   * the matrix part of the backward sweep runs on TWO waves with the cost-to-go in registers (block-scalar structure of the
+//     triple integrator, system_dynamics.h:15-22) and two LDS-only barriers a knot; the vector / forward sweeps on one wave with the
+//     state in registers (DPP, v_readlane, ds_bpermute).
+// DESIGN.md section 3.2 is the description; profiles/NOTES_r*.md the measurements behind every choice.
 #pragma once
 #include "upr_kin.h"
 #include "upr_qp.h"
@@ -186,53 +184,6 @@ struct upr_qp3_ws {
     static constexpr int pi = a0, pin = pi + C::N1 * C::NX + (C::N1 * C::NX & 1), nu = pin + C::N1 * C::NX + (C::N1 * C::NX & 1),
                          store = nu + ((C::N * C::NE + 1) & ~1), far = store /* the old per-knot store is gone */, kfar = far + upr_qp3_far<C>::total /* KFAR: the whole-horizon arrays (upr_qp3_lds::ktotal doubles) */, total = ((kfar + upr_qp3_lds<C>::ktotal + 15) & ~15);
 };
-
-// Cholesky factor of an SPD n x n matrix by ONE lane in registers.  Output: lower triangle L with the
-// diagonal replaced by 1 / L_ii (what the triangular inverse and solves need).
-template <int n>
-static inline UPR_HD bool upr_chol_regs(const double* M, double* Lo) {
-    double a[n][n];
-#pragma unroll
-    for (int i = 0; i < n; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) a[i][j] = M[i * n + j];
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < n; ++p) {
-        double s = a[p][p];
-#pragma unroll
-        for (int k = 0; k < p; ++k) s -= a[p][k] * a[p][k];
-        if (!(s > 0.0)) { ok = false; s = 1.0; }
-        const double idg = upr_rsqrt(s);
-        a[p][p] = idg;
-#pragma unroll
-        for (int i = p + 1; i < n; ++i) {
-            double v = a[i][p];
-#pragma unroll
-            for (int k = 0; k < p; ++k) v -= a[i][k] * a[p][k];
-            a[i][p] = v * idg;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) Lo[i * n + j] = a[i][j];
-    return ok;
-}
-// column j of L^-1 from the factor above (diagonal holds reciprocals); static indexing only
-template <int n>
-static inline UPR_HD void upr_tri_inv_col(const double* Lo, double* Li, int j) {
-    double c[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) v += Lo[i * n + k] * c[k];
-        c[i] = (i < j) ? 0.0 : ((i == j) ? Lo[i * n + i] : -v * Lo[i * n + i]);
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i) Li[i * n + j] = c[i];
-}
 
 // knots of register prefetch for the rows / columns of K in the vector and forward sweeps (a step takes 0.7 - 1.1 k
 // cycles, an L2 miss 2 - 3.5 k under load)
@@ -1944,11 +1895,12 @@ struct upr_qp3 {
 #endif
     UPR_HDI void backward_mat() {
 #ifndef UPR_HOST_EMU
-        if constexpr (SW2) { backward_mat_sw2(); return; }
-        else
-#endif
-        {   // (the four-wave form: the host emulation, and instantiations without the one- / two-wave sweep -- discarded, with its
-            // shape-specific assertions, for every device instantiation that runs those)
+        static_assert(C::SW, "device instantiations run the two-wave matrix sweep (chains of up to nine joints)");
+        backward_mat_sw2();
+#else
+        // The four-wave form of rounds 1 - 2 (three workgroup barriers and five LDS round trips a knot), kept as the HOST EMULATION's
+        // matrix sweep (tests/emu): plain loops, no cross-lane hardware.  Its device branches were deleted in round 6.
+        {
         const double irho = 1.0 / UPR_QP_RHO_N;
         double* Pc = L + O::Pa; double* Pn = L + O::Pb;
         {
@@ -2000,70 +1952,8 @@ struct upr_qp3 {
             // a wave with anything else)
             constexpr int PB0 = (NT >= 256) ? NT - 64 : ((NQ * NQ + NVC + 1) & ~1);
             static_assert(VC0 >= NQ * NQ && PB0 > VC0 && (C::NB > 1 || PB0 >= VC0 + NVC) && PB0 % 2 == 0, "jobs overlap / P+ b lane pairs start on an even lane");
-#ifndef UPR_HOST_EMU
-            constexpr int NPB = 2 * NX;   // P+ b: a lane pair per row (two halves of the 27 terms, summed by DPP): it was the late wave of phase 1
-#else
             constexpr int NPB = NX;
-#endif
-            static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::sst - O::Pa && N * NE * NE <= O::yN - O::sst), "prep stages Z and S in the scratch region");
-            static_assert(!C::MULTI || C::BIGF || C::KFAR || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
-            static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
-#ifndef UPR_HOST_EMU
-            // dense Schur complement (stacked bodies): Vc = Lsi C (18 x 18 lower triangular times 18 x 27) as 18
-            // v_mfma_f64_16x16x4_f64 on ONE wave -- as lane jobs it was 162 three-row dot products on a wave and a half,
-            // which the phase waited for (123 k of its 136 k cycles per iteration, the A'P+A lanes need 59 k)
-            constexpr bool VC_MFMA = C::COUPLED;
-            if (VC_MFMA && k > 0 && (wb >> 6) == 2) {
-                typedef double v4dv __attribute__((ext_vector_type(4)));
-                constexpr int SBV = C::SB, NTR = (SBV + 15) / 16, NTC = (NX + 15) / 16, NS = (SBV + 3) / 4;
-                const int ln = this->lane(), l15 = ln & 15, k4 = ln >> 4;
-                // every operand first (unconditional loads from clamped addresses, zeroed by select: a conditional load
-                // per step serialises load -> wait -> v_mfma), then the matrix instructions back to back, tiles interleaved
-                static_assert(!VC_MFMA || (NTR == 2 && NTC == 2 && NS == 5), "operand list of the load fence below");
-                double av[NTR][NS], bv[NTC][NS];
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) {
-                    const int m = 4 * s4 + k4, mc = (m < SBV) ? m : SBV - 1;
-#pragma unroll
-                    for (int tr = 0; tr < NTR; ++tr) { const int row = 16 * tr + l15, rc = (row < SBV) ? row : SBV - 1; av[tr][s4] = L[O::lsik + rc * SBV + mc]; }
-#pragma unroll
-                    for (int tc = 0; tc < NTC; ++tc) { const int col = 16 * tc + l15, cc = (col < NX) ? col : NX - 1; bv[tc][s4] = L[O::ck + mc * NX + cc]; }
-                }
-                // one fence behind ALL twenty loads: they stay unconditional (left alone the compiler sinks each into the
-                // branch of its select, with a wait of its own) and are in flight together
-                asm volatile("" : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(av[0][4]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(av[1][2]), "+v"(av[1][3]), "+v"(av[1][4]),
-                                  "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]), "+v"(bv[0][4]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3]), "+v"(bv[1][4]));
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) {
-                    const int m = 4 * s4 + k4;
-#pragma unroll
-                    for (int tr = 0; tr < NTR; ++tr) { const int row = 16 * tr + l15; av[tr][s4] = (row < SBV && m < SBV && m <= row) ? av[tr][s4] : 0.0; }
-#pragma unroll
-                    for (int tc = 0; tc < NTC; ++tc) { const int col = 16 * tc + l15; bv[tc][s4] = (m < SBV && col < NX) ? bv[tc][s4] : 0.0; }
-                }
-                v4dv dacc[NTR][NTC];
-#pragma unroll
-                for (int tr = 0; tr < NTR; ++tr)
-#pragma unroll
-                    for (int tc = 0; tc < NTC; ++tc) dacc[tr][tc] = v4dv{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4)
-#pragma unroll
-                    for (int tr = 0; tr < NTR; ++tr) {
-                        if (4 * s4 > 16 * tr + 15) continue;   // the rows of this tile end before these columns of the factor begin
-#pragma unroll
-                        for (int tc = 0; tc < NTC; ++tc) dacc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr][s4], bv[tc][s4], dacc[tr][tc], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int tr = 0; tr < NTR; ++tr)
-#pragma unroll
-                    for (int tc = 0; tc < NTC; ++tc)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { const int r = 16 * tr + k4 + 4 * q, col = 16 * tc + l15; if (r < NE && col < NX) L[O::vc + r * NX + col] = dacc[tr][tc][q]; }
-            }
-#else
             constexpr bool VC_MFMA = false;
-#endif
             UPR_FORT(e, PB0 + NPB) {
                 if (e < NQ * NQ) {
                     const int ii = e / NQ, jj = e % NQ;
@@ -2130,20 +2020,6 @@ struct upr_qp3 {
                         L[O::vc + r0 * NX + c] = v0; L[O::vc + (r0 + 1) * NX + c] = v1; L[O::vc + (r0 + 2) * NX + c] = v2;
                     }
                 } else if (e >= PB0) {
-#ifndef UPR_HOST_EMU
-                    const int i = (e - PB0) >> 1, hf = (e - PB0) & 1;
-                    constexpr int HL = (NX + 1) / 2;   // 14 terms for the first half, 13 for the second
-                    const int c0 = hf * HL;
-                    double q0 = 0.0, q1 = 0.0;         // two independent chains
-#pragma unroll
-                    for (int j = 0; j < HL; j += 2) {
-                        q0 += ((c0 + j < NX) ? Pc[i * NX + c0 + j] : 0.0) * LK[O::bks + k * NX + ((c0 + j < NX) ? c0 + j : 0)];
-                        if (j + 1 < HL) q1 += ((c0 + j + 1 < NX) ? Pc[i * NX + c0 + j + 1] : 0.0) * LK[O::bks + k * NX + ((c0 + j + 1 < NX) ? c0 + j + 1 : 0)];
-                    }
-                    double pb = q0 + q1;
-                    pb += upr_dpp_quad<0xB1>(pb);      // the partner lane of the pair (both are active)
-                    if (hf == 0) LK[O::Pbs + k * NX + i] = pb;
-#else
                     const int i = e - PB0;
                     double p0 = 0.0, p1 = 0.0, p2 = 0.0;   // three independent chains
 #pragma unroll
@@ -2153,109 +2029,18 @@ struct upr_qp3 {
                         p2 += Pc[i * NX + 2 * NQ + j] * LK[O::bks + k * NX + 2 * NQ + j];
                     }
                     LK[O::Pbs + k * NX + i] = (p0 + p1) + p2;
-#endif
                 }
             }
             mtoc(0);
             sync_lds();
             toc(6);
-#ifndef UPR_HOST_EMU
-            // Matrix-core path.  The 32 x 32 padded result is three 16 x 16 tiles ((0,0), (0,1), (1,1); the lower
-            // triangle is mirrored) of v_mfma_f64_16x16x4_f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15] and
-            // receives D[(l >> 4) + 4 r][l & 15].  Tile t belongs to wave 1 + t % (nwaves - 1) (wave 0 is busy
-            // with the factorisation), which keeps the accumulator in registers across the barrier.
-            typedef double v4d __attribute__((ext_vector_type(4)));
-            constexpr bool MFMA = (NX <= 32 && NQ <= 12);
-            constexpr int nwaves = NT >> 6;
-            const int wave = wb >> 6, lane = this->lane();
-            v4d acc[3];
-            if (MFMA && k > 0) {
-#pragma unroll
-                for (int tile = 0; tile < 3; ++tile) {
-                    if (wave != ((nwaves > 1) ? 1 + tile % (nwaves - 1) : 0)) continue;
-                    const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
-                    const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
-                    v4d a4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s4 = 0; s4 < (NE + 3) / 4; ++s4) {
-                        const int r = 4 * s4 + kk;   // row of Vc
-                        double a = 0.0, b = 0.0;
-                        if (r < NE) { if (ci < NX) a = L[O::vc + r * NX + ci]; if (cj < NX) b = L[O::vc + r * NX + cj]; }
-                        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
-                        if (i < NX && j < NX && i <= j) {
-                            double v = Pn[i * NX + j];
-                            if (i == j) v += h * L[O::qd + i] + LK[O::wx + k * NX + i];
-                            if (j < NQ) v += h * L[O::heek + (k & 1) * O::r2(C::NH) + upr_tri(NQ, i, j)];
-                            a4[r] += v;
-                        }
-                    }
-                    acc[tile] = a4;
-                }
-            }
-            // feedback of the PREVIOUS knot, K_{k+1} = Lj^-T V_{k+1}, on the last wave while wave 0 factors this one
-            // (the same wave copies the packed factor of that knot to global memory for the feed-forward phase: one coalesced
-            // store off the critical path instead of nine predicated ones by the factoring lanes)
-            if (k + 1 < N && wave == ((nwaves > 1) ? nwaves - 1 : 0)) {
-                if (lane < NX) feedback_column(k + 1, lane);
-                if (lane < C::NH) G[F::Ljis + (k + 1) * C::NH + lane] = L[lkb(k + 1) + lane];
-            }
-#else
             if (k + 1 < N) UPR_FORT(c, NX) feedback_column(k + 1, c);
-#endif
             // wave 0: EVERY lane factors Hjj for itself in registers (right-looking, 9 dependent pivots) and carries its own
             // column of Hux through the same eliminations: V = Lj^-1 Hux comes out with the factor and nothing is
             // exchanged between lanes.  (The one-column-per-lane form of the same elimination broadcast each multiplier
             // through a v_readlane pair: 94 of them per knot at ~20 cycles of latency each, 4.4 k cycles per knot.)
             if (wave0()) {
                 UPR_SETPRIO(3);
-#ifndef UPR_HOST_EMU
-                static_assert(NX <= 64, "one lane per column of Hux");
-                const int c = tid();
-                const int cc = (c < NX) ? c : 0;
-                const bool hasv = (k > 0 || fbk);
-                double a[NQ][NQ], hx[NQ];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) a[i][j] = L[O::hjj + i * (i + 1) / 2 + j];
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) hx[j] = hasv ? L[O::hux + j * NX + cc] : 0.0;
-                bool ok = true;
-                mtoc(6);    // (instrumented build: operand loads of the factoring wave)
-#pragma unroll
-                for (int p2 = 0; p2 < NQ; ++p2) {
-                    if (p2 >= 1 && p2 <= 7) mtoc(7 + p2);   // pivots 0 .. 6 -> slots 8 .. 14; pivots 7, 8 end in slot 7 (toc(7) below)
-                    const double piv = a[p2][p2];
-                    ok = ok && (piv > 0.0);   // off the dependent chain: a non-positive pivot poisons the factor with NaN and flags the QP
-                    const double idg = upr_rsqrt(piv);
-#pragma unroll
-                    for (int i = p2 + 1; i < NQ; ++i) a[i][p2] *= idg;
-                    hx[p2] *= idg;
-#pragma unroll
-                    for (int j = p2 + 1; j < NQ; ++j) {
-#pragma unroll
-                        for (int i = j; i < NQ; ++i) a[i][j] -= a[i][p2] * a[j][p2];
-                        hx[j] -= a[j][p2] * hx[p2];
-                    }
-                    a[p2][p2] = idg;   // the diagonal keeps its reciprocal (what the solves need)
-                }
-                if (!ok && c == 0) L[O::misc] = 1.0;
-                toc(7);
-                if (c == NX) {   // one lane outside the V columns stores the packed factor
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i)
-#pragma unroll
-                        for (int j = 0; j <= i; ++j) L[lkb(k) + i * (i + 1) / 2 + j] = a[i][j];
-                }
-                if (c < NX && hasv) {
-#pragma unroll
-                    for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + c] = hx[p2];
-                }
-#else
                 if (tid() == 0) {
                     constexpr int NM = NQ + NX;
                     double M[NQ][NM];
@@ -2272,36 +2057,12 @@ struct upr_qp3 {
                     for (int c = 0; c < NQ; ++c) for (int p2 = 0; p2 <= c; ++p2) { G[F::Ljis + k * C::NH + c * (c + 1) / 2 + p2] = M[p2][c]; L[lkb(k) + c * (c + 1) / 2 + p2] = M[p2][c]; }
                     if (k > 0 || fbk) for (int c = 0; c < NX; ++c) for (int p2 = 0; p2 < NQ; ++p2) L[vmb(k) + p2 * NX + c] = M[p2][NQ + c];
                 }
-#endif
             }
                 if (k == 0) break;
             mtoc(2);
             sync_lds();
             toc(8);
             // P = sym(A'P+A) + Q~ + Vc'Vc - V'V (upper triangle, mirrored)
-#ifndef UPR_HOST_EMU
-            if (MFMA) {
-#pragma unroll
-                for (int tile = 0; tile < 3; ++tile) {
-                    if (wave != ((nwaves > 1) ? 1 + tile % (nwaves - 1) : 0)) continue;
-                    const int ti = (tile == 2) ? 1 : 0, tj = (tile == 0) ? 0 : 1;
-                    const int ci = 16 * ti + (lane & 15), cj = 16 * tj + (lane & 15), kk = lane >> 4;
-                    v4d a4 = acc[tile];
-#pragma unroll
-                    for (int s4 = 0; s4 < (NQ + 3) / 4; ++s4) {
-                        const int r = 4 * s4 + kk;   // row of V
-                        double a = 0.0, b = 0.0;
-                        if (r < NQ) { if (ci < NX) a = -L[vmb(k) + r * NX + ci]; if (cj < NX) b = L[vmb(k) + r * NX + cj]; }
-                        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * ti + (lane >> 4) + 4 * r, j = cj;
-                        if (i < NX && j < NX && i <= j) { Pc[i * NX + j] = a4[r]; Pc[j * NX + i] = a4[r]; }
-                    }
-                }
-            } else
-#endif
             UPR_FORT(e, NX * NX) {
                 const int i = e / NX, j = e % NX;
                 if (i <= j) {
@@ -2330,11 +2091,9 @@ struct upr_qp3 {
         UPR_SYNC();
         // knot 0 has no successor in the loop: its feedback (wanted only for the linear policy) is formed here
         if (fbk) UPR_FORT(c, NX) feedback_column(0, c);
-#ifndef UPR_HOST_EMU
-        UPR_FORT(e, C::NH) G[F::Ljis + e] = L[lkb(0) + e];
-#endif
         UPR_SYNC();
         }
+#endif
     }
 
     // ---- backward sweep, vector part, for the current right-hand side ----------------------------------------
@@ -3504,6 +3263,10 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
     }
 
     UPR_HDI void solve(const upr_ctx& c, const upr_qp_args& A, int b, double* lds) {
+        // (layout: what prep stages in the sweeps' working set fits it)
+        static_assert(C::MULTI || C::COUPLED || (N * NE * NFC <= O::sst - O::Pa && N * NE * NE <= O::yN - O::sst), "prep stages Z and S in the scratch region");
+        static_assert(!C::MULTI || C::BIGF || C::KFAR || N * NFC * 6 <= O::yN - O::Pa, "multi-body shapes: Z [knot][force][6] in the sweeps' working set (P .. C_k)");
+        static_assert(!C::ROWS || 2 * (N - 1) * UPR_QP3_NOMAX <= O::yN - O::hux, "prep stages the state-polytopic rows' (s, w) there too");
         ctx = c; P = A.P; L = lds; red_par = 0;
 #ifdef UPR_HOST_EMU
         wb = 0;
