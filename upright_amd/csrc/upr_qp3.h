@@ -3275,12 +3275,6 @@ ftoc(6, 4);   // (-DUPR_QP3_PROF_FLAT=4: the classes of rows of the sweeps -- sl
 #endif
         xs = A.xs + (size_t)b * N1 * NX; us = A.us + (size_t)b * N * NU; x0 = A.x0 + (size_t)b * NX;
         lin = A.lin + (size_t)b * N1 * A.d.lin_stride; Dfg = A.Df + (size_t)b * NE * NFC; ws = A.ws + (size_t)b * A.d.ws_stride; G = ws + W::far; LK = C::KFAR ? ws + W::kfar : lds;
-#ifdef UPR_QP3_EXP_SHARELIN   // experiment only: every instance reads instance 0's record (what would the kernel gain if that traffic hit L2?)
-        lin = A.lin;
-#endif
-#ifdef UPR_QP3_EXP_SHAREG
-        G = A.ws + W::far;
-#endif
         lin_stride = A.d.lin_stride; lin_g = A.d.lin_g; lin_gx = A.d.lin_gx; lin_grad = A.d.lin_grad; lin_hess = A.d.lin_hess; neN = A.d.neN;
         no = C::ROWS ? A.d.no : 0; lin_obs = A.d.lin_obs; hee_w = (C::ROWS && no > 0) ? F::heew : F::hee;
         h = P->dt; h2 = 0.5 * h * h; h3 = h * h * h / 6.0; sigma_mu = 0.0; mode = 0; fbk = P->use_feedback_policy != 0;
