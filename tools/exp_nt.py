@@ -22,6 +22,6 @@ for B in (512, 1024):
         f = "/tmp/exp_nt.npz"
         e = dict(os.environ, UPR_QP3_JIT="2", UPR_JIT_NT=nt)
         subprocess.check_call([sys.executable, __file__, "--child", str(B), f], env=e, stderr=subprocess.DEVNULL)
-        r = np.load(f)
+        r = dict(np.load(f))
         if ref is None: ref = r
         print("B %4d NT %s: qp %.4f ms (%+.1f %%) | iterations mean %.2f | max |dx| vs NT 256 %.1e | %s" % (B, nt, r["qp_ms"], 100 * (r["qp_ms"] / ref["qp_ms"] - 1), r["its"].mean(), float(np.abs(r["xs"] - ref["xs"]).max()), str(r["kernel"])[:60]))

@@ -28,7 +28,7 @@ for rep in range(2):
         f = "/tmp/exp_occ.npz"
         e = dict(os.environ, UPR_QP3_JIT="2", UPR_JIT_FLAGS=flags)
         subprocess.check_call([sys.executable, __file__, str(N), str(B), "--child", f], env=e, stderr=subprocess.DEVNULL)
-        r = np.load(f)
+        r = dict(np.load(f))
         if ref is None: ref = r
         print("N %d B %d %-20s qp %.4f ms -> %.0f k QPs/s | iterations mean %.2f max %d | status %s | max |dx| vs first %.1e" % (
             N, B, flags, r["qp_ms"], B / r["qp_ms"], r["its"].mean(), r["its"].max(), np.bincount(r["status"].astype(int)), float(np.abs(r["xs"] - ref["xs"]).max())))
