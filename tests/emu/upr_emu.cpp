@@ -191,8 +191,9 @@ void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const d
     A.P = P; A.d = upr_make_dims(P); if (ws_stride > 0) A.d.ws_stride = (int)ws_stride; A.xs = xs; A.us = us; A.x0 = x0; A.t0 = t0; A.body_params = body_params; A.way_p = way_p;
     A.lin = lin; A.ws = ws; A.stats = stats; A.done = done; A.iter = iter; A.way_q = upr_has_orientation_cost(P) ? g_way_q : nullptr;
     if (P->n_dyn) { A.dyn = g_dyn; A.pflag = g_pflag; }
-    upr_ctx ctx; ctx.tid = 0; ctx.nt = 1;
-    std::vector<double> L(upr_ls_lds_doubles(A.d, 1) + 16);
-    for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data()); else upr_ls_instance<9>(ctx, A, b, L.data()); }
+    upr_ls_lanes ctx; ctx.tid = 0; ctx.nt = 1; ctx.ftid = 0; ctx.fnt = 1;
+    std::vector<double> L(upr_ls_lds_doubles(A.d) + 16);
+    bool acc = false;
+    for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc); else upr_ls_instance<9>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc); }
 }
 }

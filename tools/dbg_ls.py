@@ -1,16 +1,25 @@
-"""Phase cycles of the line-search kernel (instrumented build: tools/build_prof.sh with -DUPR_LS_PROF; UPR_LIB=libupright_mi_prof.so)."""
-import sys
+"""Phase cycles of the line-search kernel (instrumented build: tools/build_prof.sh lin; UPR_LIB=libupright_mi_prof.so)."""
+import ctypes as C, sys
 sys.path.insert(0, '.')
 import numpy as np
 import bench
-w = bench.headline_workload(1024)
+from upright_amd import _capi
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+w = bench.headline_workload(B)
 mpc = bench.make_engine(w)
+lib = _capi.lib()
+out = np.zeros(16)
+mpc.reset(); mpc.advance()
+lib.upr_debug_ls_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
 mpc.enable_timing(True)
 for _ in range(3):
     mpc.reset(); mpc.advance()
-st = mpc.stats()
-names = ["qp_res_stat", "qp_res_eq", "qp_res_ineq", "qp_res_comp"]
-lab = ["baseline terms + reduction", "descent / norms + reduction", "trial evaluation(s) + reduction", "apply step, statistics"]
-for n, l in zip(names, lab):
-    print("%-36s mean %9.0f  max %9.0f cycles" % (l, st[n].mean(), st[n].max()))
-print(mpc.kernel_times())
+mpc.sync()
+lib.upr_debug_ls_prof(out.ctypes.data_as(C.POINTER(C.c_double)), 0)
+lab = ["record copy, ranking, barrier", "(entry)", "staging of xs, dx, us, du", "baseline knot terms", "two reductions", "trial: targets, Xt / Ut, sin / cos, barrier",
+       "trial: knot terms (chain walk)", "trial: reduction, acceptance", "apply step, statistics", "(return)", "remembered solution"]
+n = out[15]; prev = 0.0
+for i, l in enumerate(lab):
+    t = out[i] / n
+    print("%-46s %8.0f cycles (at %8.0f)" % (l, t - prev, t)); prev = t
+print("workgroups", n, mpc.kernel_times())

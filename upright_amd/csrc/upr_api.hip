@@ -696,7 +696,7 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
 template <int NQ>
 int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     upr_ls_args A = A0;
-    size_t lds = (size_t)upr_ls_lds_doubles(h->d, 64) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
+    size_t lds = (size_t)upr_ls_lds_doubles(h->d) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
     // Three staged copies (trajectory, step, trial trajectory) pay for the small shapes only: with one wave per workgroup the LDS
     // footprint IS the occupancy, and for the large input vectors it costs more than the uncoalesced reads it replaces
     // (r04, tools/r4_lin.sh: configs[2] 1.58 ms staged / 1.01 ms not, configs[3] 0.249 / 0.171; the headline shape, 40 KB
@@ -705,20 +705,23 @@ int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     const bool stage_off = stage_env == 0 || (stage_env < 0 && lds > 41 * 1024);
     if (lds > 64 * 1024 || stage_off) {   // (also: long horizons of the large shapes, where three copies do not fit)
         A.stage_full = 0;
-        lds = (size_t)upr_ls_lds_doubles(h->d, 64, false) * sizeof(double) + sizeof(upr_problem) + 16;
+        lds = (size_t)upr_ls_lds_doubles(h->d, false) * sizeof(double) + sizeof(upr_problem) + 16;
         if (lds > 160 * 1024) return fail("horizon too long for the line-search kernel's LDS");
     }
+    // two waves per instance (wave 0: the chain walks of a trial, wave 1: its flat sums): 241 registers, four workgroups per CU by
+    // LDS.  Four waves (more flat lanes, 128 registers a lane for four workgroups per CU: 135 spilled) measured 48 against 33 us.
+    const int nt = 128;
     auto launch = [&](void (*kern)(upr_ls_args)) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(h->B), dim3(64), lds, h->stream, A);
+        hipLaunchKernelGGL(kern, dim3(h->B), dim3(nt), lds, h->stream, A);
     };
     // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
     // exactly the headline's contact structure (one body on the tray, four frictional contacts): every bound a constant
-    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(upr_linesearch_kernel<NQ, 64, 12, 1, true>);
+    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(upr_linesearch_kernel<NQ, 128, 12, 1, true>);
     // ... the same with collision / projectile rows (configs[4], the obstacle experiments: round 5)
-    else if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4) launch(upr_linesearch_kernel<NQ, 64, 12, 1, true, true>);
-    else if (h->d.nfc <= 12 && h->d.nb == 1) launch(upr_linesearch_kernel<NQ, 64, 12, 1>);
-    else launch(upr_linesearch_kernel<NQ, 64>);
+    else if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4) launch(upr_linesearch_kernel<NQ, 128, 12, 1, true, true>);
+    else if (h->d.nfc <= 12 && h->d.nb == 1) launch(upr_linesearch_kernel<NQ, 128, 12, 1>);
+    else launch(upr_linesearch_kernel<NQ, 128>);
     UPR_HIP(hipGetLastError());
     return 0;
 }
@@ -1612,6 +1615,16 @@ int upr_batch_set_projectile_flag(upr_batch* h, const double* sflag) {
 }
 }  // extern "C"
 
+#ifdef UPR_LS_PROF
+// instrumented build only: cycles from the start of the line-search kernel to each of its stamps, summed over workgroups, [15] = workgroups
+extern "C" int upr_debug_ls_prof(double* out, int reset) {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(upr_ls_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(upr_ls_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 #ifdef UPR_LIN_PROF
 // instrumented build only: cycles per phase of the linearisation kernel summed over workgroups, [7] = workgroups counted
 extern "C" int upr_debug_lin_prof(double* out, int reset) {

@@ -24,7 +24,12 @@ static UPR_HDI upr_dd upr_lift(double a, upr_dd*) { return {a, 0.0}; }
 static UPR_HDI double upr_lift(double a, double*) { return a; }
 static UPR_HDI double upr_seed(double v, bool on, double*) { return v; }
 static UPR_HDI upr_dd upr_seed(double v, bool on, upr_dd*) { return {v, on ? 1.0 : 0.0}; }
+#ifdef UPR_HOST_EMU
 static UPR_HDI void upr_sincos(double th, double* s, double* c) { *s = sin(th); *c = cos(th); }
+#else
+// (one argument reduction for both: two calls are ~1.6 times the instructions)
+static UPR_HDI void upr_sincos(double th, double* s, double* c) { sincos(th, s, c); }
+#endif
 static UPR_HDI void upr_sincos(upr_dd th, upr_dd* s, upr_dd* c) {
     double sv = sin(th.v), cv = cos(th.v);
     *s = {sv, cv * th.d};
@@ -123,12 +128,14 @@ template <class T> static UPR_HDI void upr_carry(upr_ee<T>& E, const T* r) {
 // x: the knot's state [q, v, a] (plain values); dir: tangent direction of this lane (-1: none).
 // NQ is the compile-time joint count so that the chain loop unrolls and everything stays in registers.
 // sc: optional [NQ][2] = (sin q_j, cos q_j) of the revolute joints, precomputed (NULL: computed here)
-template <class T, int NQ>
+// ROLL: the joint loop stays a loop (one joint's code instead of NQ copies with every joint's constants hoisted in front: the
+// line search's walk then fits the 128 registers that four of its workgroups per CU leave a lane)
+template <class T, int NQ, bool ROLL = false>
 static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int dir, upr_ee<T>& E, const double* sc = nullptr) {
     T* tag = nullptr;
     for (int i = 0; i < 9; ++i) E.C[i] = upr_lift((i % 4 == 0) ? 1.0 : 0.0, tag);
     for (int i = 0; i < 3; ++i) { E.p[i] = upr_lift(0.0, tag); E.v[i] = E.p[i]; E.w[i] = E.p[i]; E.a[i] = E.p[i]; E.al[i] = E.p[i]; }
-#pragma unroll
+#pragma unroll (ROLL ? 1 : NQ)
     for (int j = 0; j < NQ; ++j) {
         T q = upr_seed(x[j], dir == j, tag);
         T qd = upr_seed(x[NQ + j], dir == NQ + j, tag);

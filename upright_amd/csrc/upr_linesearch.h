@@ -37,12 +37,12 @@ struct upr_ls_args {
     int stage_full = 1;    // the instance's trajectory and step staged in LDS (upr_ls_lds_doubles)
 };
 
-// performance terms of knot k at step length alpha: out += [cost, dyn_sse, eq_sse, ineq_sse]
-// NFM / NBM: compile-time bounds of nf nc / nb (the per-lane input vector and body wrenches stay in registers for the
-// small shapes: with the library-wide maxima they lived in scratch, 2 KB per lane)
-// EXACT: the problem has exactly nf = 3, nc = NFM / 3 contacts, nb = NBM bodies (checked by the launcher; OBS: with collision / projectile rows -- round 5, the thrown-ball shape): every
-// loop bound below is then a compile-time constant, the trial state, input and wrenches stay in registers (with
-// run-time bounds they were indexed dynamically: 1.2 KB of scratch per lane)
+// lanes of a workgroup as the line search uses them: [tid, nt) strides the per-knot work (the chain walks, a lane per knot: the
+// first lanes, i.e. wave 0 for the horizons in use), [ftid, fnt) strides the FLAT work (everything that needs no walk, a lane per
+// element) -- on the device the lanes behind wave 0, so that the flat sums of a trial run beside its walks (ftid < 0: none);
+// the host emulation is one lane doing both
+struct upr_ls_lanes { int tid, nt, ftid, fnt; };
+
 // contact wrench on the single balanced body (contact_constraints.h:107-157 with nb = 1: every contact joins tray and body)
 template <int NCX>
 static UPR_HDI void upr_object_wrench_single(const upr_problem* P, const double* bp, const double* forces, double* W) {
@@ -57,30 +57,46 @@ static UPR_HDI void upr_object_wrench_single(const upr_problem* P, const double*
         W[3] -= l1 * f2 - l2 * f1; W[4] -= l2 * f0 - l0 * f2; W[5] -= l0 * f1 - l1 * f0;
     }
 }
+
+// Performance terms [cost, dyn_sse, eq_sse, ineq_sse] of a trajectory (Xs [N+1][nx], Us [N][nu]), in two parts.
+//
+// (1) upr_ls_knot: what needs the end effector's state at the knot -- end-effector cost, object-dynamics equality, collision /
+//     projectile rows, terminal position error -- a lane per knot walking the chain on plain values.
+// (2) upr_ls_flat_terms: everything else -- quadratic state-input cost, boxes, friction rows, dynamics defects, terminal
+//     velocity / acceleration -- element by element over the flat lanes (a lane per knot summing its 27 + 21 elements one
+//     after another was half of the kernel's run time: one wave, 21 of its lanes, ~500 LDS reads each).
+//     BASE: at the CURRENT iterate, where the linearisation kernel has just been, part (1) is read out of the knots' records
+//     instead of walking again, and the step norms and the Armijo descent metric (cost gradient . step) are summed in the same pass.
+//
+// NFM / NBM: compile-time bounds of nf nc / nb.  EXACT: the problem has exactly nf = 3, nc = NFM / 3 contacts, nb = NBM bodies
+// (checked by the launcher; OBS: with collision / projectile rows): every loop bound of the knot's part is then a constant and its
+// input vector and wrenches stay in registers (with run-time bounds they were indexed dynamically: 1.2 KB of scratch per lane).
+// Xt / Ut: the trial trajectory of the instance (staged by the workgroup, LDS on the device); sc: (sin, cos) of the trial joint
+// angles of every knot, [N + 1][NQ][2]; pd: the knot's target position (it does not depend on the step length)
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
-// Xt / Ut: the trial trajectory xs + alpha dx, us + alpha du of the instance (staged by the workgroup, LDS on the device);
-// sc: (sin, cos) of the trial joint angles of every knot, [N + 1][NQ][2]
-static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double* Xt, const double* Ut, const double* sc, double* out) {
+static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double* Xt, const double* Ut, const double* sc, const double* pd, double* out) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N;
     constexpr int nq = NQ, nx = 3 * NQ;
     const int nu = EXACT ? NQ + NFM : d.nu;
-    const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
-    double X[3 * NQ], U[NQ + NFM];
+    const double h = P->dt;
+    const double* X = Xt + k * nx;   // (read where it lies: the rolled joint loop indexes it by the joint)
+    double F[NFM];
+    double cost = 0.0, eq = 0.0, iq = 0.0;
+    // (the body's parameters and the wrench in front of the chain walk: their global loads fly beside it)
+    double Fw[6 * NBM];
+    const int nb = EXACT ? NBM : d.nb;
+    const double* bp = A.body_params + (size_t)b * nb * 10;
+    double bpv[EXACT ? 10 * NBM : 1];
+    if (k < N) {
 #pragma unroll
-    for (int i = 0; i < nx; ++i) X[i] = Xt[k * nx + i];
-    double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
-    const double wt = (k < N) ? h : 1.0;
-    if (k == 0) {
+        for (int i = 0; i < (EXACT ? NFM : d.nfc); ++i) F[i] = Ut[k * nu + nq + i];
+        if (EXACT) {
 #pragma unroll
-        for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - X[i]; dyn += e * e; }
-    }
-    if (k >= 1) {
-#pragma unroll
-        for (int i = 0; i < nx; ++i) {
-            double v = fmin(0.0, fmin(X[i] - P->x_lb[i], P->x_ub[i] - X[i]));
-            iq += wt * v * v;
+            for (int i = 0; i < 10 * NBM; ++i) bpv[i] = bp[i];
         }
+        if (EXACT && NBM == 1) upr_object_wrench_single<NFM / 3>(P, bpv, F, Fw);
+        else upr_object_wrenches(P, bp, F, Fw);
     }
     if (OBS && d.no > 0 && k >= 1 && k < N) {   // collision rows (knots 1..N-1); !OBS: the problem has none
         double dd[UPR_MAX_PAIRS + 8], xo[9 * UPR_MAX_DYN];
@@ -89,17 +105,9 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
         for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, dd[r]); iq += h * v * v; }
     }
     upr_ee<double> E;
-    upr_ee_kinematics<double, NQ>(P, X, -1, E, sc + k * 2 * NQ);
-    double pd[3];
-    upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * h, pd);
+    upr_ee_kinematics<double, NQ, true>(P, X, -1, E, sc + k * 2 * NQ);
     if (k < N) {
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) U[i] = Ut[k * nu + i];
         double c = 0.0;
-#pragma unroll
-        for (int i = 0; i < nx; ++i) { double e = X[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) c += 0.5 * P->Rdiag[i] * U[i] * U[i];
         for (int r = 0; r < 3; ++r) { double e = E.p[r] - pd[r]; c += 0.5 * P->Wee[r] * e * e; }
         if (A.way_q) {
             double Rr[9], eo[3];
@@ -108,233 +116,211 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
             for (int r = 0; r < 3; ++r) c += 0.5 * P->Wee[3 + r] * eo[r] * eo[r];
         }
         cost += h * c;
-        // dynamics defect against the next trial state
-#pragma unroll
-        for (int j = 0; j < nq; ++j) {
-            double q = X[j], v = X[nq + j], a = X[2 * nq + j], u = U[j];
-            const double* xn = Xt + (k + 1) * nx;
-            double e0 = q + h * v + h2 * a + h3 * u - xn[j];
-            double e1 = v + h * a + h2 * u - xn[nq + j];
-            double e2 = a + h * u - xn[2 * nq + j];
-            dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
-        }
         // object-dynamics equality
-        double Fw[6 * NBM];
-        const int nb = EXACT ? NBM : d.nb;
-        const double* bp = A.body_params + (size_t)b * nb * 10;
-        if (EXACT && NBM == 1) upr_object_wrench_single<NFM / 3>(P, bp, U + nq, Fw);
-        else upr_object_wrenches(P, bp, U + nq, Fw);
-        const double sc = A.d.eq_scale;
+        const double scl = A.d.eq_scale;
 #pragma unroll
         for (int bb = 0; bb < (EXACT ? NBM : nb); ++bb) {
             double g[6];
-            upr_body_residual<double>(E, bp + 10 * bb, P->gravity, Fw + 6 * bb, Fw + 6 * bb + 3, g);
-            for (int r = 0; r < 6; ++r) eq += h * (sc * g[r]) * (sc * g[r]);
-        }
-        // friction rows and input box
-        if (EXACT || d.np > 0) {
-#pragma unroll
-            for (int ci = 0; ci < (EXACT ? NFM / 3 : d.nc); ++ci) {
-                double hr[5];
-                upr_friction_rows_contact(P, ci, U + nq + 3 * ci, hr);
-                for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) {
-            double v = fmin(0.0, fmin(U[i] - P->u_lb[i], P->u_ub[i] - U[i]));
-            iq += h * v * v;
+            upr_body_residual<double>(E, (EXACT ? bpv : bp) + 10 * bb, P->gravity, Fw + 6 * bb, Fw + 6 * bb + 3, g);
+            for (int r = 0; r < 6; ++r) eq += h * (scl * g[r]) * (scl * g[r]);
         }
     } else if (d.neN > 0) {
         for (int r = 0; r < 3; ++r) { double e = pd[r] - E.p[r]; eq += e * e; }
-#pragma unroll
-        for (int i = 0; i < 2 * nq; ++i) eq += X[nq + i] * X[nq + i];
     }
-    out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
+    out[0] += cost; out[2] += eq; out[3] += iq;
 }
 
-// the same terms at the CURRENT iterate (alpha = 0), where the linearisation kernel has just been: the end-effector cost, the
-// object-dynamics residual, the collision rows and the terminal position error are read out of the knot's record instead
-// of walking the chain again
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, bool EXACT = false, bool OBS = !EXACT>
-static UPR_HDI void upr_ls_knot_base(const upr_ls_args& A, int b, int k, const double* xs_l, const double* us_l, double* out) {
+// aux (BASE only) += [descent metric, |dx|^2, |du|^2, -].  NU / NC / NE: nu, nc, ne where the instantiation fixes them (0: run
+// time; the element -> (knot, index) split is then an integer division by a register, ~40 instructions a trip).
+// BASE reads the knots' records and x0 from global memory: the first UPR_LS_RU trips of each such sum are REQUESTED in front of
+// the LDS-only sums and consumed behind them (inside the strided loops every trip waited for its own request: five exposed
+// memory latencies for the headline's states alone); longer sums finish in plain loops.
+#define UPR_LS_RU 2
+template <int NQ, bool BASE, int NU = 0, int NC = 0, int NE = 0>
+static UPR_HDI void upr_ls_flat_terms(const upr_ls_args& A, int b, int ftid, int fnt, const double* Xs, const double* Us, const double* dxs, const double* dus,
+                                      double* out, double* aux) {
+    if (ftid < 0) return;
     const upr_problem* P = A.P; const upr_dims& d = A.d;
-    const int N = d.N;
+    const int N = d.N, nu = NU ? NU : d.nu, nc = NC ? NC : d.nc, ne = NE ? NE : d.ne;
     constexpr int nq = NQ, nx = 3 * NQ;
-    const int nu = EXACT ? NQ + NFM : d.nu;
     const double h = P->dt, h2 = 0.5 * h * h, h3 = h * h * h / 6.0;
-    const double* X = xs_l + k * nx;   // (the instance's trajectory, staged)
-    const double* rec = A.lin + ((size_t)b * (N + 1) + k) * d.lin_stride;
-    double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0;
-    const double wt = (k < N) ? h : 1.0;
-    // (compile-time trip counts: the loads of a loop are requested together instead of one exposed latency per trip)
-    double Xr[3 * NQ];
+    const int nxs = (N + 1) * nx, nus = N * nu;
+    const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
+    double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    double gqv[UPR_LS_RU], gv[UPR_LS_RU], cv = 0.0, x0v = 0.0, tv = 0.0;
+    if (BASE) {   // (clamped addresses: every lane requests, the out-of-range ones are not used)
 #pragma unroll
-    for (int i = 0; i < nx; ++i) Xr[i] = X[i];
-    if (k == 0) {
-#pragma unroll
-        for (int i = 0; i < nx; ++i) { double e = A.x0[(size_t)b * nx + i] - Xr[i]; dyn += e * e; }
+        for (int u = 0; u < UPR_LS_RU; ++u) {
+            const int e = u * fnt + ftid, e1 = (e < N * nq) ? e : 0, k1 = e1 / nq, e2 = (e < N * ne) ? e : 0, k2 = e2 / ne;
+            gqv[u] = lin[(size_t)k1 * d.lin_stride + d.lin_grad + (e1 - k1 * nq)];
+            gv[u] = lin[(size_t)k2 * d.lin_stride + d.lin_g + (e2 - k2 * ne)];
+        }
+        cv = lin[(size_t)((ftid < N) ? ftid : 0) * d.lin_stride + d.lin_cost];
+        x0v = A.x0[(size_t)b * nx + ((ftid < nx) ? ftid : 0)];
+        tv = lin[(size_t)N * d.lin_stride + d.lin_grad + ((ftid < 3) ? ftid : 0)];
     }
-    if (k >= 1) {
-#pragma unroll
-        for (int i = 0; i < nx; ++i) {
-            double v = fmin(0.0, fmin(Xr[i] - P->x_lb[i], P->x_ub[i] - Xr[i]));
-            iq += wt * v * v;
-        }
+    // states: box, quadratic cost, terminal velocity / acceleration (+ BASE: the state part of the descent metric, |dx|^2)
+    for (int e = ftid; e < nxs; e += fnt) {
+        const int k = e / nx, i = e - k * nx;
+        const double X = Xs[e];
+        if (k >= 1) { const double v = fmin(0.0, fmin(X - P->x_lb[i], P->x_ub[i] - X)); iq += ((k < N) ? h : 1.0) * v * v; }
+        if (k < N) {
+            const double ex = X - P->xd[i];
+            cost += h * (0.5 * P->Qdiag[i] * ex * ex);
+            if (BASE) a0 += P->dt * (P->Qdiag[i] * ex) * dxs[e];
+        } else if (d.neN > 0 && i >= nq) eq += X * X;
+        if (BASE) { const double s = dxs[e]; a1 += s * s; }
     }
-    if (OBS && d.no > 0 && k >= 1 && k < N) for (int r = 0; r < d.no; ++r) { const double v = fmin(0.0, rec[d.lin_obs + r]); iq += h * v * v; }
-    if (k < N) {
-        const double* U = us_l + k * nu;
-        const double* xn = X + nx;
-        double c = rec[d.lin_cost];
+    // inputs: quadratic cost, box
+    for (int e = ftid; e < nus; e += fnt) {
+        const int k = e / nu, i = e - k * nu;
+        const double U = Us[e];
+        cost += h * (0.5 * P->Rdiag[i] * U * U);
+        const double v = fmin(0.0, fmin(U - P->u_lb[i], P->u_ub[i] - U));
+        iq += h * v * v;
+        if (BASE) { const double s = dus[e]; a2 += s * s; a0 += P->dt * P->Rdiag[i] * U * s; }
+    }
+    // dynamics defect against the next state (triple integrator, system_dynamics.h:15-22)
+    for (int e = ftid; e < N * nq; e += fnt) {
+        const int k = e / nq, j = e - k * nq;
+        const double* x = Xs + k * nx; const double* xn = x + nx;
+        const double q = x[j], v = x[nq + j], a = x[2 * nq + j], u = Us[k * nu + j];
+        const double e0 = q + h * v + h2 * a + h3 * u - xn[j], e1 = v + h * a + h2 * u - xn[nq + j], e2 = a + h * u - xn[2 * nq + j];
+        dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
+    }
+    // friction rows
+    if (d.np > 0) for (int e = ftid; e < N * nc; e += fnt) {
+        const int k = e / nc, ci = e - k * nc;
+        double hr[5];
+        upr_friction_rows_contact(P, ci, Us + k * nu + nq + 3 * ci, hr);
+        for (int r = 0; r < 5; ++r) { const double v = fmin(0.0, hr[r]); iq += h * v * v; }
+    }
+    if (!BASE) {   // initial-state defect
+        for (int i = ftid; i < nx; i += fnt) { const double ee = A.x0[(size_t)b * nx + i] - Xs[i]; dyn += ee * ee; }
+    } else {
+        // the knots' part out of the records of the linearisation kernel (end-effector cost and its gradient, equality rows,
+        // terminal position error, collision rows), the initial-state defect
 #pragma unroll
-        for (int i = 0; i < nx; ++i) { double e = Xr[i] - P->xd[i]; c += 0.5 * P->Qdiag[i] * e * e; }
-        double Ur[NQ + NFM];
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) Ur[i] = U[i];
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) c += 0.5 * P->Rdiag[i] * Ur[i] * Ur[i];
-        cost += h * c;
-#pragma unroll
-        for (int j = 0; j < nq; ++j) {
-            double q = Xr[j], v = Xr[nq + j], a = Xr[2 * nq + j], u = Ur[j];
-            double e0 = q + h * v + h2 * a + h3 * u - xn[j], e1 = v + h * a + h2 * u - xn[nq + j], e2 = a + h * u - xn[2 * nq + j];
-            dyn += h * (e0 * e0 + e1 * e1 + e2 * e2);
+        for (int u = 0; u < UPR_LS_RU; ++u) {
+            const int e = u * fnt + ftid;
+            if (e < N * nq) { const int k = e / nq, i = e - k * nq; a0 += P->dt * gqv[u] * dxs[k * nx + i]; }
+            if (e < N * ne) eq += h * gv[u] * gv[u];
         }
-        for (int r = 0; r < d.ne; ++r) eq += h * rec[d.lin_g + r] * rec[d.lin_g + r];
-        if (EXACT || d.np > 0) {
-#pragma unroll
-            for (int ci = 0; ci < (EXACT ? NFM / 3 : d.nc); ++ci) {
-                double hr[5];
-                upr_friction_rows_contact(P, ci, Ur + nq + 3 * ci, hr);
-                for (int r = 0; r < 5; ++r) { double v = fmin(0.0, hr[r]); iq += h * v * v; }
-            }
+        for (int e = UPR_LS_RU * fnt + ftid; e < N * nq; e += fnt) { const int k = e / nq, i = e - k * nq; a0 += P->dt * lin[(size_t)k * d.lin_stride + d.lin_grad + i] * dxs[k * nx + i]; }
+        for (int e = UPR_LS_RU * fnt + ftid; e < N * ne; e += fnt) { const int k = e / ne, r = e - k * ne; const double g = lin[(size_t)k * d.lin_stride + d.lin_g + r]; eq += h * g * g; }
+        if (ftid < N) cost += h * cv;
+        for (int k = fnt + ftid; k < N; k += fnt) cost += h * lin[(size_t)k * d.lin_stride + d.lin_cost];
+        if (ftid < nx) { const double ee = x0v - Xs[ftid]; dyn += ee * ee; }
+        for (int i = fnt + ftid; i < nx; i += fnt) { const double ee = A.x0[(size_t)b * nx + i] - Xs[i]; dyn += ee * ee; }
+        if (d.neN > 0 && ftid < 3) eq += tv * tv;
+        if (d.neN > 0) for (int r = fnt + ftid; r < 3; r += fnt) { const double g = lin[(size_t)N * d.lin_stride + d.lin_grad + r]; eq += g * g; }
+        if (d.no > 0) for (int e = ftid; e < (N - 1) * d.no; e += fnt) {
+            const int k = 1 + e / d.no, r = e - (k - 1) * d.no;
+            const double v = fmin(0.0, lin[(size_t)k * d.lin_stride + d.lin_obs + r]); iq += h * v * v;
         }
-#pragma unroll
-        for (int i = 0; i < (EXACT ? NQ + NFM : nu); ++i) {
-            double v = fmin(0.0, fmin(Ur[i] - P->u_lb[i], P->u_ub[i] - Ur[i]));
-            iq += h * v * v;
-        }
-    } else if (d.neN > 0) {
-        for (int r = 0; r < 3; ++r) eq += rec[d.lin_grad + r] * rec[d.lin_grad + r];
-#pragma unroll
-        for (int i = 0; i < 2 * nq; ++i) eq += Xr[nq + i] * Xr[nq + i];
+        aux[0] += a0; aux[1] += a1; aux[2] += a2;
     }
     out[0] += cost; out[1] += dyn; out[2] += eq; out[3] += iq;
 }
 
-// block reduction of 4 partials; result broadcast in res[4]
-static UPR_HDI void upr_ls_reduce4(const upr_ctx& ctx, double* red, const double* part, double* res) {
-    for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] = part[c];
-    UPR_SYNC();
-    for (int s = 1; s < ctx.nt; s <<= 1) {
-        if ((ctx.tid & (2 * s - 1)) == 0 && ctx.tid + s < ctx.nt)
-            for (int c = 0; c < 4; ++c) red[c * ctx.nt + ctx.tid] += red[c * ctx.nt + ctx.tid + s];
-        UPR_SYNC();
-    }
-    for (int c = 0; c < 4; ++c) res[c] = red[c * ctx.nt];
-    UPR_SYNC();
+// Workgroup scratch (doubles).  [0, UPR_LS_RED): reduction slots; then the trial trajectory xs + alpha dx, us + alpha du of the
+// step length in work, (sin, cos) of its joint angles (a lane per (knot, joint): inside the chain walk they were nine f64
+// sincos in series per lane), the knots' target positions, and (stage_full) the instance's trajectory and step, staged with
+// coalesced requests (stage_full = 0 -- long horizons of the large shapes, where three copies do not fit: the trajectory and
+// the step are read where they lie)
+#define UPR_LS_RED 72   // 8 sums x 4 waves, twice (alternating), + the ranks of the waves
+struct upr_ls_lay { int xt, ut, sc, pd, sx, su, sdx, sdu, total; };
+static UPR_HDI upr_ls_lay upr_ls_layout(const upr_dims& d, bool full) {
+    upr_ls_lay l;
+    const int nxs = (d.N + 1) * d.nx, nus = d.N * d.nu;
+    l.xt = UPR_LS_RED; l.ut = l.xt + nxs; l.sc = l.ut + nus; l.pd = l.sc + 2 * (d.N + 1) * d.nq;
+    l.sx = (l.pd + 3 * (d.N + 1) + 1) & ~1; l.su = l.sx + nxs; l.sdx = l.su + nus; l.sdu = l.sdx + nxs;
+    l.total = (full ? l.sdu + nus : l.sx) + 2;
+    return l;
 }
+static UPR_HDI int upr_ls_lds_doubles(const upr_dims& d, bool full = true) { return upr_ls_layout(d, full).total; }
 
-#ifndef UPR_HOST_EMU
-// one-wave workgroups: the same pairwise tree by cross-lane butterflies (no LDS, no barriers); every lane ends with the sum
-static __device__ __forceinline__ void upr_ls_reduce4_wave(const double* part, double* res) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        double v = part[c];
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-        res[c] = v;
-    }
-}
-#define UPR_LS_REDUCE4(part, res) do { if (ctx.nt == 64) upr_ls_reduce4_wave(part, res); else upr_ls_reduce4(ctx, L, part, res); } while (0)
+#if defined(UPR_LS_PROF) && !defined(UPR_HOST_EMU)
+// instrumented build (-DUPR_LS_PROF): cycles from the start of the kernel to each stamp, summed over the workgroups by lane 0
+// ([15] = workgroups counted; upr_debug_ls_prof reads them)
+__device__ unsigned long long upr_ls_prof[16];
+#define UPR_LS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); if (ctx.tid == 0) atomicAdd(&upr_ls_prof[i], (unsigned long long)(now_ - t_prof)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define UPR_LS_PROF_ARG , long long t_prof
+#define UPR_LS_PROF_PASS , t_prof
 #else
-#define UPR_LS_REDUCE4(part, res) upr_ls_reduce4(ctx, L, part, res)
+#define UPR_LS_STAMP(i) ((void)0)
+#define UPR_LS_PROF_ARG
+#define UPR_LS_PROF_PASS
 #endif
 
-// Workgroup scratch (doubles): the reduction area, then the instance's trajectory and step staged with coalesced requests
-// (a lane per knot reading its knot's 27 + 21 doubles straight from global memory touches a cache line of its own per
-// request: the address unit then serialises 21 lines per instruction -- the baseline pass alone took 24 k cycles), the
-// trial trajectory xs + alpha dx, us + alpha du of the step length in work, and (sin, cos) of its joint angles (computed
-// a lane per (knot, joint): inside the chain walk they were nine f64 sincos in series per lane)
-// (stage_full = 0 -- long horizons of the large shapes, where three copies do not fit: only the trial trajectory and the
-// sines / cosines live in LDS, the trajectory and the step are read where they lie)
-static UPR_HDI int upr_ls_lds_doubles(const upr_dims& d, int nt, bool full = true) { return 4 * nt + 8 + (full ? 3 : 1) * ((d.N + 1) * d.nx + d.N * d.nu) + 2 * (d.N + 1) * d.nq + 8; }
+// workgroup sum of NV partials, every lane ends with the sums.  Device: butterflies inside the wave, one LDS slot per wave and
+// sum, ONE barrier (the callers alternate the slot set `par`, so the next reduction's writes cannot overtake this one's reads)
+template <int NV>
+static UPR_HDI void upr_ls_reduce(const upr_ls_lanes& ctx, double* L, int par, const double* part, double* res) {
+#ifndef UPR_HOST_EMU
+    const int nw = ctx.nt >> 6, w = ctx.tid >> 6;
+    double* slot = L + par * 32;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {   // (cross-lane moves inside the VALU: quads, half rows, rows, then the four rows through scalar registers)
+        double v = part[c];
+        v += upr_dpp_quad<0xB1>(v); v += upr_dpp_quad<0x4E>(v); v += upr_dpp_quad<0x141>(v); v += upr_dpp_quad<0x140>(v);
+        v = (upr_readlane(v, 0) + upr_readlane(v, 16)) + (upr_readlane(v, 32) + upr_readlane(v, 48));
+        if ((ctx.tid & 63) == 0) slot[c * 4 + w] = v;
+    }
+    UPR_SYNC();
+#pragma unroll
+    for (int c = 0; c < NV; ++c) { double v = slot[c * 4]; for (int i = 1; i < nw; ++i) v += slot[c * 4 + i]; res[c] = v; }
+#else
+    for (int c = 0; c < NV; ++c) res[c] = part[c];
+#endif
+}
+
+// done_b: the instance's convergence flag and qp_status: the status of its QP (stats[2]); staged: the caller has already
+// staged xs, us, dx, du into the layout (the device kernel requests all of these beside its first loads); defer_store: an
+// accepted trajectory is written to xs, us by the caller (the device kernel: one pass with the remembered solution).  Returns the copy of the instance's (possibly updated) trajectory in LDS,
+// [xs (N+1) nx, us N nu], or NULL when there is none (instance done; stage_full off and the step rejected): the kernel's
+// epilogue copies the remembered solution from it.
 template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
-static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, int b, double* L) {
+static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_ls_args& A, int b, double* L, int done_b, bool staged, bool defer_store, double qp_status, bool* accepted_out UPR_LS_PROF_ARG) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
-    if (A.done[b]) return;
+    if (done_b) return nullptr;
     double* st = A.stats + (size_t)b * UPR_NSTATS;
-#if defined(UPR_LS_PROF) && !defined(UPR_HOST_EMU)
-    // instrumented build (tools/build_prof.sh): cycle stamps of the phases, returned in the QP-residual slots of the statistics
-    long long lsp[5]; int lspn = 0;
-#define UPR_LS_STAMP() do { __builtin_amdgcn_sched_barrier(0); lsp[lspn++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define UPR_LS_STAMP() ((void)0)
-#endif
-    UPR_LS_STAMP();
-    const double qp_status = st[2];
+    UPR_LS_STAMP(1);
     const double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, g_max = 1e6, g_min = 1e-6, armijo = 1e-4;
     double* xs = A.xs + (size_t)b * (N + 1) * nx; double* us = A.us + (size_t)b * N * nu;
     const double* ws = A.ws + (size_t)b * d.ws_stride;
     const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
-    const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
     const int nxs = (N + 1) * nx, nus = N * nu;
-    double* Xt = L + ((4 * ctx.nt + 8 + 1) & ~1); double* Ut = Xt + nxs; double* sc = Ut + nus;
+    const upr_ls_lay lay = upr_ls_layout(d, A.stage_full != 0);
+    double* Xt = L + lay.xt; double* Ut = L + lay.ut; double* sc = L + lay.sc; double* pdl = L + lay.pd;
     const double* xs_l = xs; const double* us_l = us; const double* dx_l = dx; const double* du_l = du;
     if (A.stage_full) {
-        double* sx_ = sc + 2 * (N + 1) * nq; double* su_ = sx_ + nxs; double* sdx_ = su_ + nus; double* sdu_ = sdx_ + nxs;
-        UPR_FOR(i, nxs) { sx_[i] = xs[i]; sdx_[i] = dx[i]; }
-        UPR_FOR(i, nus) { su_[i] = us[i]; sdu_[i] = du[i]; }
-        UPR_SYNC();
+        double* sx_ = L + lay.sx; double* su_ = L + lay.su; double* sdx_ = L + lay.sdx; double* sdu_ = L + lay.sdu;
+        if (!staged) {
+            UPR_FOR(i, nxs) { sx_[i] = xs[i]; sdx_[i] = dx[i]; }
+            UPR_FOR(i, nus) { su_[i] = us[i]; sdu_[i] = du[i]; }
+            UPR_SYNC();
+        }
         xs_l = sx_; us_l = su_; dx_l = sdx_; du_l = sdu_;
     }
-    // baseline, step norms and Armijo descent metric (cost gradient . step)
-    double part[4] = {0, 0, 0, 0}, base[4], aux[4] = {0, 0, 0, 0}, auxr[4];
-    // (one pass over the knots for both sets of sums: the requests of the second set are in flight beside the first's)
-    UPR_FOR(k, N + 1) {
-        upr_ls_knot_base<NQ, NFM, EXACT, OBS>(A, b, k, xs_l, us_l, part);
-        constexpr int nxc = 3 * NQ;
-        double sx[nxc], xv[nxc], gq[NQ];
-#pragma unroll
-        for (int i = 0; i < nxc; ++i) { sx[i] = dx_l[k * nxc + i]; xv[i] = (k < N) ? xs_l[k * nxc + i] : 0.0; }
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) gq[i] = (k < N) ? lin[(size_t)k * d.lin_stride + d.lin_grad + i] : 0.0;
-#pragma unroll
-        for (int i = 0; i < nxc; ++i) {
-            const double s = sx[i];
-            aux[1] += s * s;
-            if (k < N) {
-                double g = P->Qdiag[i] * (xv[i] - P->xd[i]);
-                if (i < NQ) g += gq[i];
-                aux[0] += P->dt * g * s;
-            }
-        }
-        if (k < N) {
-            if (EXACT) {
-                constexpr int nuc = NQ + NFM;
-                double su[nuc], uv[nuc];
-#pragma unroll
-                for (int i = 0; i < nuc; ++i) { su[i] = du_l[k * nuc + i]; uv[i] = us_l[k * nuc + i]; }
-#pragma unroll
-                for (int i = 0; i < nuc; ++i) { aux[2] += su[i] * su[i]; aux[0] += P->dt * P->Rdiag[i] * uv[i] * su[i]; }
-            } else for (int i = 0; i < nu; ++i) {
-                double s = du_l[k * nu + i];
-                aux[2] += s * s;
-                aux[0] += P->dt * P->Rdiag[i] * us_l[k * nu + i] * s;
-            }
-        }
-    }
-    UPR_LS_REDUCE4(part, base);
-    UPR_LS_STAMP();
-    UPR_LS_REDUCE4(aux, auxr);
-    UPR_LS_STAMP();
-    const double descent = auxr[0], dxn = sqrt(auxr[1]), dun = sqrt(auxr[2]);
+    UPR_LS_STAMP(2);
+    // baseline, step norms and Armijo descent metric: one flat pass over all the lanes, one reduction
+    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bs[8];
+    upr_ls_flat_terms<NQ, true, EXACT ? NQ + NFM : 0, EXACT ? NFM / 3 : 0, EXACT ? 6 * NBM : 0>(A, b, ctx.tid, ctx.nt, xs_l, us_l, dx_l, du_l, part, part + 4);
+    // the knots' target positions (a lane's own knots: written and read by the same lane; the waypoint reads fly beside the
+    // reduction and the first trial's staging)
+    if (qp_status != 2.0) { UPR_FOR(k, N + 1) upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * P->dt, pdl + 3 * k); }
+    UPR_LS_STAMP(3);
+    upr_ls_reduce<7>(ctx, L, 0, part, bs);
+    UPR_LS_STAMP(4);
+    const double base[4] = {bs[0], bs[1], bs[2], bs[3]};
+    const double descent = bs[4], dxn = sqrt(bs[5]), dun = sqrt(bs[6]);
     const double base_viol = sqrt(base[1] + base[2] + base[3]);
     double alpha = 1.0, perf[4] = {base[0], base[1], base[2], base[3]};
     bool accepted = false;
     if (qp_status != 2.0) {
+        int par = 1;
         do {
             double p2[4] = {0, 0, 0, 0};
             UPR_FOR(i, nxs) Xt[i] = xs_l[i] + alpha * dx_l[i];
@@ -346,23 +332,31 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
                 sc[2 * e] = s_; sc[2 * e + 1] = c_;
             }
             UPR_SYNC();
-            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT, OBS>(A, b, k, Xt, Ut, sc, p2);
-            UPR_LS_REDUCE4(p2, perf);
+            UPR_LS_STAMP(5);
+            UPR_FOR(k, N + 1) upr_ls_knot<NQ, NFM, NBM, EXACT, OBS>(A, b, k, Xt, Ut, sc, pdl + 3 * k, p2);
+            upr_ls_flat_terms<NQ, false, EXACT ? NQ + NFM : 0, EXACT ? NFM / 3 : 0, EXACT ? 6 * NBM : 0>(A, b, ctx.ftid, ctx.fnt, Xt, Ut, nullptr, nullptr, p2, nullptr);
+            UPR_LS_STAMP(6);
+            upr_ls_reduce<4>(ctx, L, par, p2, perf);
+            par ^= 1;
             double viol = sqrt(perf[1] + perf[2] + perf[3]);
             if (viol > g_max) accepted = false;
             else if (viol < g_min) accepted = (descent < 0.0) ? (perf[0] < base[0] + armijo * alpha * descent) : true;
             else accepted = (perf[0] < base[0] - gamma_c * base_viol) || (viol < (1.0 - gamma_c) * base_viol);
             if (accepted) break;
             alpha *= alpha_decay;
+            UPR_SYNC();   // (the next trial overwrites Xt, Ut, sc)
         } while (alpha >= alpha_min);
     }
-    UPR_LS_STAMP();
+    UPR_LS_STAMP(7);
     double cost = base[0], viol = base_viol;
     if (accepted) {
-        UPR_FOR(i, nxs) xs[i] = Xt[i];   // (the trial trajectory of the accepted step length: xs + alpha dx, as staged)
-        UPR_FOR(i, nus) us[i] = Ut[i];
+        if (!defer_store) {
+            UPR_FOR(i, nxs) xs[i] = Xt[i];   // (the trial trajectory of the accepted step length: xs + alpha dx, as staged)
+            UPR_FOR(i, nus) us[i] = Ut[i];
+        }
         cost = perf[0]; viol = sqrt(perf[1] + perf[2] + perf[3]);
     }
+    *accepted_out = accepted;
     bool conv = !accepted;                                                           // STEPSIZE
     if (accepted && fabs(base[0] - cost) < P->cost_tol && viol < g_min) conv = true;  // METRICS
     if (accepted && alpha * dxn < P->delta_tol && alpha * dun < P->delta_tol) conv = true;  // PRIMAL
@@ -370,61 +364,121 @@ static UPR_HDI void upr_ls_instance(const upr_ctx& ctx, const upr_ls_args& A, in
         st[0] = A.iter + 1; st[3] = accepted ? alpha : 0.0; st[4] = cost; st[5] = viol; st[10] = dxn; st[11] = dun;
         if (conv) A.done[b] = 1;
     }
-#if defined(UPR_LS_PROF) && !defined(UPR_HOST_EMU)
-    UPR_LS_STAMP();
-    if (ctx.tid == 0) for (int i = 0; i < 4; ++i) st[6 + i] = (double)(lsp[i + 1] - lsp[i]);
-#endif
-    UPR_SYNC();
+    UPR_LS_STAMP(8);
+    return accepted ? Xt : (A.stage_full ? xs_l : nullptr);   // (Xt, Ut contiguous; so are the staged xs, us)
 }
 
 #ifndef UPR_HOST_EMU
+// One workgroup of NT = 256 lanes per instance.  Wave 0 carries the chain walks of a trial (a lane per knot), the other waves
+// its flat sums; the prologue (copy of the problem record, dispatch rank, staging) has every global request of the workgroup in
+// flight before the first wait.
 template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
-__global__ void __launch_bounds__(NT) upr_linesearch_kernel(upr_ls_args A) {
+__global__ void __launch_bounds__(NT, NT / 64) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    upr_ctx ctx; ctx.tid = threadIdx.x; ctx.nt = NT;
-    static_assert(NT == 64, "one wave per instance (the rank below is a wave reduction)");
+    static_assert(NT % 64 == 0 && NT >= 128 && NT <= 256, "two to four waves: the rank and the reductions keep four slots; wave 0 walks");
+    upr_ls_lanes ctx; ctx.tid = threadIdx.x; ctx.nt = NT; ctx.ftid = (int)threadIdx.x - 64; ctx.fnt = NT - 64;
+#ifdef UPR_LS_PROF
+    const long long t_prof = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) atomicAdd(&upr_ls_prof[15], 1ull);
+#endif
+    // The problem record (joint frames, bounds, weights, contacts: 11 KB) is read all over the evaluation, element by element
+    // and mostly on the serial chain walk -- out of global memory every one of those reads is a vector load with a wait of
+    // its own (the record may alias the kernel's stores, so they are not scalar loads): a copy in LDS serves them instead.
+    static_assert(sizeof(upr_problem) % sizeof(double) == 0, "copied as doubles");
+    constexpr int NPD = (int)(sizeof(upr_problem) / sizeof(double)), NTR = (NPD + NT - 1) / NT;
+    double* L = smem + ((NPD + 1) & ~1);
+    const int b = blockIdx.x;
+    const upr_dims& d = A.d;
+    const int nxs = (d.N + 1) * d.nx, nus = d.N * d.nu;
+    double recv[NTR];
+    {
+        const double* src = reinterpret_cast<const double*>(A.P);
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) { const int i = t * NT + threadIdx.x; recv[t] = src[(i < NPD) ? i : 0]; }
+    }
+    const int done_b = A.done[b];
+    const double qp_status_b = A.stats[(size_t)b * UPR_NSTATS + 2];
+    // the instance's trajectory and step, requested beside the record (up to SU elements of each per lane; longer ones are
+    // staged by upr_ls_instance)
+    constexpr int SU = 1024 / NT;
+    const bool stage_here = A.stage_full && nxs <= SU * NT && nus <= SU * NT;
+    const upr_ls_lay lay = upr_ls_layout(d, A.stage_full != 0);
+    double sxv[SU], sdxv[SU], suv[SU], sduv[SU];
+    if (stage_here) {
+        const double* xs = A.xs + (size_t)b * nxs; const double* us = A.us + (size_t)b * nus;
+        const double* dx = A.ws + (size_t)b * d.ws_stride + d.ws_dx; const double* du = A.ws + (size_t)b * d.ws_stride + d.ws_du;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = u * NT + threadIdx.x, ix = (i < nxs) ? i : 0, iu = (i < nus) ? i : 0;
+            sxv[u] = xs[ix]; sdxv[u] = dx[ix]; suv[u] = us[iu]; sduv[u] = du[iu];
+        }
+    }
     if (A.order_out) {
         // B one-byte keys, read four at a time by consecutive lanes (B bytes per workgroup out of the L2: 16 MB per launch at
         // B = 4096 where ranking on stats[.][1], one 96-byte stride per instance, moved 1 GB)
-        const int B = gridDim.x, me = blockIdx.x;
+        const int B = gridDim.x, me = b;
         const int mk = A.iter_key[me];
         int cnt = 0;
         const unsigned int* k4 = reinterpret_cast<const unsigned int*>(A.iter_key);
-        for (int o4 = threadIdx.x; o4 < (B >> 2); o4 += NT) {
-            const unsigned int w = k4[o4];
+        for (int o0 = 0; o0 < (B >> 2); o0 += 4 * NT) {   // (four requests per lane in flight)
+            unsigned int w4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int k = (int)((w >> (8 * j)) & 255u), o = 4 * o4 + j; cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
+            for (int u = 0; u < 4; ++u) { const int o4 = o0 + u * NT + threadIdx.x; w4[u] = k4[(o4 < (B >> 2)) ? o4 : 0]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o4 = o0 + u * NT + threadIdx.x;
+                if (o4 < (B >> 2)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int k = (int)((w4[u] >> (8 * j)) & 255u), o = 4 * o4 + j; cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
+                }
+            }
         }
         for (int o = (B & ~3) + threadIdx.x; o < B; o += NT) { const int k = A.iter_key[o]; cnt += (k > mk || (k == mk && o < me)) ? 1 : 0; }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (threadIdx.x == 0) A.order_out[cnt] = me;
+        if ((threadIdx.x & 63) == 0) reinterpret_cast<int*>(L + 64)[threadIdx.x >> 6] = cnt;   // (summed behind the barrier below)
     }
-    // The problem record (joint frames, bounds, weights, contacts: 11 KB) is read all over the evaluation, element by element
-    // and mostly on the serial chain walk -- out of global memory every one of those reads is a vector load with a wait of
-    // its own (the record may alias the kernel's stores, so they are not scalar loads): a copy in LDS, made with coalesced
-    // requests, serves them instead.
-    static_assert(sizeof(upr_problem) % sizeof(double) == 0, "copied as doubles");
-    constexpr int NPD = (int)(sizeof(upr_problem) / sizeof(double));
     {
-        const double* src = reinterpret_cast<const double*>(A.P);
-#pragma unroll 4
-        for (int i = threadIdx.x; i < NPD; i += NT) smem[i] = src[i];   // (four requests in flight per trip: 0.062 against 0.067 ms without)
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) { const int i = t * NT + threadIdx.x; if (i < NPD) smem[i] = recv[t]; }
+        if (stage_here) {
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = u * NT + threadIdx.x;
+                if (i < nxs) { L[lay.sx + i] = sxv[u]; L[lay.sdx + i] = sdxv[u]; }
+                if (i < nus) { L[lay.su + i] = suv[u]; L[lay.sdu + i] = sduv[u]; }
+            }
+        }
         __syncthreads();
         A.P = reinterpret_cast<const upr_problem*>(smem);
     }
-    upr_ls_instance<NQ, NFM, NBM, EXACT, OBS>(ctx, A, blockIdx.x, smem + ((NPD + 1) & ~1));
-    if (A.xs_prev) {
-        __syncthreads();
-        const int b = blockIdx.x, nxs = (A.d.N + 1) * A.d.nx, nus = A.d.N * A.d.nu;
-        const double* xs = A.xs + (size_t)b * nxs; const double* us = A.us + (size_t)b * nus;
+    if (A.order_out && threadIdx.x == 0) { const int* c = reinterpret_cast<const int*>(L + 64); int r = 0; for (int w = 0; w < NT / 64; ++w) r += c[w]; A.order_out[r] = b; }
+    UPR_LS_STAMP(0);
+    bool accepted = false;
+    const double* kept = upr_ls_instance<NQ, NFM, NBM, EXACT, OBS>(ctx, A, b, L, done_b, stage_here, true, qp_status_b, &accepted UPR_LS_PROF_PASS);
+    UPR_LS_STAMP(9);
+    if (accepted) {   // the accepted trajectory: one pass over its copy in LDS for the iterate and the remembered solution
+        double* xs = A.xs + (size_t)b * nxs; double* us = A.us + (size_t)b * nus;
+        double* xp = A.xs_prev ? A.xs_prev + (size_t)b * nxs : nullptr; double* up = A.xs_prev ? A.us_prev + (size_t)b * nus : nullptr;
+        for (int e = threadIdx.x; e < nxs; e += NT) { const double v = kept[e]; xs[e] = v; if (xp) xp[e] = v; }
+        for (int e = threadIdx.x; e < nus; e += NT) { const double v = kept[nxs + e]; us[e] = v; if (up) up[e] = v; }
+        if (A.xs_prev && threadIdx.x == 0) A.tprev[b] = A.t0[b];
+    } else if (A.xs_prev) {
         double* xp = A.xs_prev + (size_t)b * nxs; double* up = A.us_prev + (size_t)b * nus;
-        for (int e = threadIdx.x; e < nxs; e += NT) xp[e] = xs[e];
-        for (int e = threadIdx.x; e < nus; e += NT) up[e] = us[e];
+        if (kept) {   // the trajectory as the line search left it lies in LDS: stores only, no round trip through memory
+            for (int e = threadIdx.x; e < nxs; e += NT) xp[e] = kept[e];
+            for (int e = threadIdx.x; e < nus; e += NT) up[e] = kept[nxs + e];
+        } else {
+            const double* xs = A.xs + (size_t)b * nxs; const double* us = A.us + (size_t)b * nus;
+            for (int e = threadIdx.x; e < nxs; e += NT) xp[e] = xs[e];
+            for (int e = threadIdx.x; e < nus; e += NT) up[e] = us[e];
+        }
         if (threadIdx.x == 0) A.tprev[b] = A.t0[b];
     }
+    UPR_LS_STAMP(10);
 }
 #endif
+
 
 // ---- warm start / policy evaluation ----------------------------------------------------------------
 // Linear interpolation of a stored solution (ts = tp0 + j dt) at time tau; beyond the stored horizon
