@@ -9,6 +9,7 @@
 #include "../../upright_amd/csrc/upr_common.h"
 #include "../../upright_amd/csrc/upr_kin.h"
 #include "../../upright_amd/csrc/upr_linearize.h"
+#include "../../upright_amd/csrc/upr_linearize2.h"
 #include "../../upright_amd/csrc/upr_linesearch.h"
 #include "../../upright_amd/csrc/upr_qp.h"
 #include "../../upright_amd/csrc/upr_qp2.h"
@@ -16,8 +17,17 @@
 
 template <int NQ, bool ORI>
 static void lin_all_o(const upr_lin_args& A);
+// (0: upr_linearize.h's phases for every shape; 1, the default: the job functions of upr_linearize2.h where the device runs them)
+static int g_lin_form = 1;
 template <int NQ>
-static void lin_all(const upr_lin_args& A) { if (A.way_q) lin_all_o<NQ, true>(A); else lin_all_o<NQ, false>(A); }
+static void lin_all(const upr_lin_args& A) {
+    if (g_lin_form && upr_lin2_eligible(A)) {
+        std::vector<double> sh(upr_lin2_layout(A.d).per + 8);
+        for (int p = 0; p < A.npoints; ++p) upr_lin2_knot<NQ>(A, upr_lin_locate(A, p), sh.data());
+        return;
+    }
+    if (A.way_q) lin_all_o<NQ, true>(A); else lin_all_o<NQ, false>(A);
+}
 template <int NQ, bool ORI>
 static void lin_all_o(const upr_lin_args& A) {
     std::vector<double> sh(upr_lin_lds_doubles(A.d, A.P->n_sph) + 8);
@@ -68,6 +78,8 @@ static void ee_tangents(const upr_problem* P, const double* x, double* snap_form
 }
 
 extern "C" {
+
+void emu_set_lin_form(int form) { g_lin_form = form; }
 
 // end-effector state [p 3, C 9, v 3, w 3, a 3, al 3] and its tangent along every state coordinate, [3 nq][2][30]: the closed
 // form out of the per-joint snapshots (upr_ee_from_snap, what the linearisation kernel runs) and the forward-mode walk
@@ -194,6 +206,6 @@ void emu_linesearch(const upr_problem* P, int B, double* xs, double* us, const d
     upr_ls_lanes ctx; ctx.tid = 0; ctx.nt = 1; ctx.ftid = 0; ctx.fnt = 1;
     std::vector<double> L(upr_ls_lds_doubles(A.d) + 16);
     bool acc = false;
-    for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc); else upr_ls_instance<9>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc); }
+    for (int b = 0; b < B; ++b) { if (P->nq == 6) upr_ls_instance<6>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc, A.way_p + (size_t)b * P->n_way * 3, A.t0[b]); else upr_ls_instance<9>(ctx, A, b, L.data(), A.done[b], false, false, A.stats[(size_t)b * UPR_NSTATS + 2], &acc, A.way_p + (size_t)b * P->n_way * 3, A.t0[b]); }
 }
 }

@@ -23,6 +23,7 @@
 #include "upr_common.h"
 #include "upr_kin.h"
 #include "upr_linearize.h"
+#include "upr_linearize2.h"
 #include "upr_linesearch.h"
 #include "upr_qp.h"
 #include "upr_qp2.h"
@@ -349,6 +350,22 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     // passes per workgroup (1, 2 or 3)
     static const int row_passes = getenv("UPR_LIN_ROW_PASSES") ? atoi(getenv("UPR_LIN_ROW_PASSES")) : UPR_LIN_ROW_PASSES_DEFAULT;
     const bool multi_rows = UPR_LIN_ANALYTIC && UPR_LIN_OBS_SNAP && !A.way_q && h->use_mfma && occ == 2 && A.d.no > 0 && (row_passes == 2 || row_passes == 3);
+    // no collision rows, no orientation cost: the one-round kernel of upr_linearize2.h, as many knots per workgroup as three
+    // workgroups per CU hold in LDS and one tangent pass takes in one trip (28 for the headline shape: 768 workgroups)
+    static const int lin2_env = getenv("UPR_LIN2") ? atoi(getenv("UPR_LIN2")) : 1;
+    if (lin2_env && upr_lin2_eligible(A) && h->use_mfma && occ == 2) {
+        const upr_lin2_lay lay = upr_lin2_layout(A.d);
+        const int npre = (UPR_LIN2_NPRE + 1) & ~1;
+        int kpw = (int)((160 * 1024 / 3 - 64 - npre * sizeof(double)) / (lay.per * sizeof(double)));
+        if (kpw > 256 / NQ) kpw = 256 / NQ;
+        if (kpw > 64) kpw = 64;
+        if (kpw >= 1) {
+            const size_t lds2 = (size_t)(npre + kpw * lay.per) * sizeof(double);
+            hipLaunchKernelGGL(upr_linearize2_kernel<NQ>, dim3((A.npoints + kpw - 1) / kpw), dim3(256), lds2, h->stream, A, kpw);
+            UPR_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     const int KPW = 8 * (multi ? UPR_LIN_PASSES : (multi_rows ? row_passes : 1));
     const int blocks = (A.npoints + KPW - 1) / KPW;
     const size_t lds = (size_t)KPW * upr_lin_lds_doubles(A.d, h->P.n_sph) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
@@ -696,6 +713,8 @@ int launch_qp(upr_batch* h, const upr_qp_args& A) {
 template <int NQ>
 int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     upr_ls_args A = A0;
+    A.n_way = h->P.n_way;
+    static_assert(3 * UPR_MAX_WAYPOINTS <= 128, "a lane per waypoint coordinate");
     size_t lds = (size_t)upr_ls_lds_doubles(h->d) * sizeof(double) + sizeof(upr_problem) + 16;   // (+ the kernel's copy of the problem record)
     // Three staged copies (trajectory, step, trial trajectory) pay for the small shapes only: with one wave per workgroup the LDS
     // footprint IS the occupancy, and for the large input vectors it costs more than the uncoalesced reads it replaces
@@ -717,11 +736,12 @@ int launch_linesearch(upr_batch* h, const upr_ls_args& A0) {
     };
     // small shapes (one body, up to four frictional contacts): per-lane vectors sized for them
     // exactly the headline's contact structure (one body on the tray, four frictional contacts): every bound a constant
-    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(upr_linesearch_kernel<NQ, 128, 12, 1, true>);
+    const bool st = A.stage_full != 0;   // (compile-time in the kernel: its staged arrays are LDS pointers, not generic ones)
+    if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4 && h->d.no == 0) launch(st ? upr_linesearch_kernel<NQ, 128, 12, 1, true, false, true> : upr_linesearch_kernel<NQ, 128, 12, 1, true, false, false>);
     // ... the same with collision / projectile rows (configs[4], the obstacle experiments: round 5)
-    else if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4) launch(upr_linesearch_kernel<NQ, 128, 12, 1, true, true>);
-    else if (h->d.nfc <= 12 && h->d.nb == 1) launch(upr_linesearch_kernel<NQ, 128, 12, 1>);
-    else launch(upr_linesearch_kernel<NQ, 128>);
+    else if (h->d.nfc == 12 && h->d.nb == 1 && h->P.nf == 3 && h->P.nc == 4) launch(st ? upr_linesearch_kernel<NQ, 128, 12, 1, true, true, true> : upr_linesearch_kernel<NQ, 128, 12, 1, true, true, false>);
+    else if (h->d.nfc <= 12 && h->d.nb == 1) launch(st ? upr_linesearch_kernel<NQ, 128, 12, 1, false, true, true> : upr_linesearch_kernel<NQ, 128, 12, 1, false, true, false>);
+    else launch(st ? upr_linesearch_kernel<NQ, 128, 3 * UPR_MAX_CONTACTS, UPR_MAX_BODIES, false, true, true> : upr_linesearch_kernel<NQ, 128, 3 * UPR_MAX_CONTACTS, UPR_MAX_BODIES, false, true, false>);
     UPR_HIP(hipGetLastError());
     return 0;
 }

@@ -1,5 +1,5 @@
-// upr_linesearch.h -- merit evaluation, filter line search and SQP convergence test, one workgroup per
-// instance, one lane per shooting knot.
+// upr_linesearch.h -- merit evaluation, filter line search and SQP convergence test, one workgroup (two waves) per
+// instance: a lane per shooting knot for the terms that need the chain walk, a lane per element for the rest.
 //
 // What it replaces: [UPSTREAM, absent] ocs2_sqp MultipleShootingSolver::takeStep / computePerformance /
 // checkConvergence with the ocs2_sqp defaults (alpha_decay 0.5, alpha_min 1e-4, gamma_c 1e-6,
@@ -35,6 +35,7 @@ struct upr_ls_args {
     const unsigned char* iter_key = nullptr;
     double* xs_prev = nullptr; double* us_prev = nullptr; double* tprev = nullptr;
     int stage_full = 1;    // the instance's trajectory and step staged in LDS (upr_ls_lds_doubles)
+    int n_way = 0;         // P->n_way (the device kernel stages the instance's waypoints before its copy of the record is readable)
 };
 
 // lanes of a workgroup as the line search uses them: [tid, nt) strides the per-knot work (the chain walks, a lane per knot: the
@@ -136,6 +137,24 @@ static UPR_HDI void upr_ls_knot(const upr_ls_args& A, int b, int k, const double
 // the LDS-only sums and consumed behind them (inside the strided loops every trip waited for its own request: five exposed
 // memory latencies for the headline's states alone); longer sums finish in plain loops.
 #define UPR_LS_RU 2
+struct upr_ls_rec { double gq[UPR_LS_RU], g[UPR_LS_RU], c, x0, t; };
+// (clamped addresses: every lane requests, the out-of-range ones are not used)
+template <int NQ, int NE>
+static UPR_HDI void upr_ls_rec_request(const upr_ls_args& A, int b, int ftid, int fnt, upr_ls_rec& R) {
+    const upr_dims& d = A.d;
+    const int N = d.N, ne = NE ? NE : d.ne;
+    constexpr int nq = NQ, nx = 3 * NQ;
+    const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
+#pragma unroll
+    for (int u = 0; u < UPR_LS_RU; ++u) {
+        const int e = u * fnt + ftid, e1 = (e < N * nq) ? e : 0, k1 = e1 / nq, e2 = (e < N * ne) ? e : 0, k2 = e2 / ne;
+        R.gq[u] = lin[(size_t)k1 * d.lin_stride + d.lin_grad + (e1 - k1 * nq)];
+        R.g[u] = lin[(size_t)k2 * d.lin_stride + d.lin_g + (e2 - k2 * ne)];
+    }
+    R.c = lin[(size_t)((ftid < N) ? ftid : 0) * d.lin_stride + d.lin_cost];
+    R.x0 = A.x0[(size_t)b * nx + ((ftid < nx) ? ftid : 0)];
+    R.t = lin[(size_t)N * d.lin_stride + d.lin_grad + ((ftid < 3) ? ftid : 0)];
+}
 template <int NQ, bool BASE, int NU = 0, int NC = 0, int NE = 0>
 static UPR_HDI void upr_ls_flat_terms(const upr_ls_args& A, int b, int ftid, int fnt, const double* Xs, const double* Us, const double* dxs, const double* dus,
                                       double* out, double* aux) {
@@ -147,18 +166,8 @@ static UPR_HDI void upr_ls_flat_terms(const upr_ls_args& A, int b, int ftid, int
     const int nxs = (N + 1) * nx, nus = N * nu;
     const double* lin = A.lin + (size_t)b * (N + 1) * d.lin_stride;
     double cost = 0.0, dyn = 0.0, eq = 0.0, iq = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    double gqv[UPR_LS_RU], gv[UPR_LS_RU], cv = 0.0, x0v = 0.0, tv = 0.0;
-    if (BASE) {   // (clamped addresses: every lane requests, the out-of-range ones are not used)
-#pragma unroll
-        for (int u = 0; u < UPR_LS_RU; ++u) {
-            const int e = u * fnt + ftid, e1 = (e < N * nq) ? e : 0, k1 = e1 / nq, e2 = (e < N * ne) ? e : 0, k2 = e2 / ne;
-            gqv[u] = lin[(size_t)k1 * d.lin_stride + d.lin_grad + (e1 - k1 * nq)];
-            gv[u] = lin[(size_t)k2 * d.lin_stride + d.lin_g + (e2 - k2 * ne)];
-        }
-        cv = lin[(size_t)((ftid < N) ? ftid : 0) * d.lin_stride + d.lin_cost];
-        x0v = A.x0[(size_t)b * nx + ((ftid < nx) ? ftid : 0)];
-        tv = lin[(size_t)N * d.lin_stride + d.lin_grad + ((ftid < 3) ? ftid : 0)];
-    }
+    upr_ls_rec R;
+    if (BASE) upr_ls_rec_request<NQ, NE>(A, b, ftid, fnt, R);
     // states: box, quadratic cost, terminal velocity / acceleration (+ BASE: the state part of the descent metric, |dx|^2)
     for (int e = ftid; e < nxs; e += fnt) {
         const int k = e / nx, i = e - k * nx;
@@ -203,16 +212,16 @@ static UPR_HDI void upr_ls_flat_terms(const upr_ls_args& A, int b, int ftid, int
 #pragma unroll
         for (int u = 0; u < UPR_LS_RU; ++u) {
             const int e = u * fnt + ftid;
-            if (e < N * nq) { const int k = e / nq, i = e - k * nq; a0 += P->dt * gqv[u] * dxs[k * nx + i]; }
-            if (e < N * ne) eq += h * gv[u] * gv[u];
+            if (e < N * nq) { const int k = e / nq, i = e - k * nq; a0 += P->dt * R.gq[u] * dxs[k * nx + i]; }
+            if (e < N * ne) eq += h * R.g[u] * R.g[u];
         }
         for (int e = UPR_LS_RU * fnt + ftid; e < N * nq; e += fnt) { const int k = e / nq, i = e - k * nq; a0 += P->dt * lin[(size_t)k * d.lin_stride + d.lin_grad + i] * dxs[k * nx + i]; }
         for (int e = UPR_LS_RU * fnt + ftid; e < N * ne; e += fnt) { const int k = e / ne, r = e - k * ne; const double g = lin[(size_t)k * d.lin_stride + d.lin_g + r]; eq += h * g * g; }
-        if (ftid < N) cost += h * cv;
+        if (ftid < N) cost += h * R.c;
         for (int k = fnt + ftid; k < N; k += fnt) cost += h * lin[(size_t)k * d.lin_stride + d.lin_cost];
-        if (ftid < nx) { const double ee = x0v - Xs[ftid]; dyn += ee * ee; }
+        if (ftid < nx) { const double ee = R.x0 - Xs[ftid]; dyn += ee * ee; }
         for (int i = fnt + ftid; i < nx; i += fnt) { const double ee = A.x0[(size_t)b * nx + i] - Xs[i]; dyn += ee * ee; }
-        if (d.neN > 0 && ftid < 3) eq += tv * tv;
+        if (d.neN > 0 && ftid < 3) eq += R.t * R.t;
         if (d.neN > 0) for (int r = fnt + ftid; r < 3; r += fnt) { const double g = lin[(size_t)N * d.lin_stride + d.lin_grad + r]; eq += g * g; }
         if (d.no > 0) for (int e = ftid; e < (N - 1) * d.no; e += fnt) {
             const int k = 1 + e / d.no, r = e - (k - 1) * d.no;
@@ -229,12 +238,13 @@ static UPR_HDI void upr_ls_flat_terms(const upr_ls_args& A, int b, int ftid, int
 // coalesced requests (stage_full = 0 -- long horizons of the large shapes, where three copies do not fit: the trajectory and
 // the step are read where they lie)
 #define UPR_LS_RED 72   // 8 sums x 4 waves, twice (alternating), + the ranks of the waves
-struct upr_ls_lay { int xt, ut, sc, pd, sx, su, sdx, sdu, total; };
+struct upr_ls_lay { int xt, ut, sc, pd, wp, sx, su, sdx, sdu, total; };
 static UPR_HDI upr_ls_lay upr_ls_layout(const upr_dims& d, bool full) {
     upr_ls_lay l;
     const int nxs = (d.N + 1) * d.nx, nus = d.N * d.nu;
     l.xt = UPR_LS_RED; l.ut = l.xt + nxs; l.sc = l.ut + nus; l.pd = l.sc + 2 * (d.N + 1) * d.nq;
-    l.sx = (l.pd + 3 * (d.N + 1) + 1) & ~1; l.su = l.sx + nxs; l.sdx = l.su + nus; l.sdu = l.sdx + nxs;
+    l.wp = l.pd + 3 * (d.N + 1);   // the instance's waypoints
+    l.sx = (l.wp + 3 * UPR_MAX_WAYPOINTS + 1) & ~1; l.su = l.sx + nxs; l.sdx = l.su + nus; l.sdu = l.sdx + nxs;
     l.total = (full ? l.sdu + nus : l.sx) + 2;
     return l;
 }
@@ -277,11 +287,15 @@ static UPR_HDI void upr_ls_reduce(const upr_ls_lanes& ctx, double* L, int par, c
 
 // done_b: the instance's convergence flag and qp_status: the status of its QP (stats[2]); staged: the caller has already
 // staged xs, us, dx, du into the layout (the device kernel requests all of these beside its first loads); defer_store: an
-// accepted trajectory is written to xs, us by the caller (the device kernel: one pass with the remembered solution).  Returns the copy of the instance's (possibly updated) trajectory in LDS,
+// accepted trajectory is written to xs, us by the caller (the device kernel: one pass with the remembered solution); way_p_b,
+// t0_b: the instance's waypoints (the device kernel's copy in LDS) and its time.  Returns the copy of the instance's (possibly updated) trajectory in LDS,
 // [xs (N+1) nx, us N nu], or NULL when there is none (instance done; stage_full off and the step rejected): the kernel's
 // epilogue copies the remembered solution from it.
-template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
-static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_ls_args& A, int b, double* L, int done_b, bool staged, bool defer_store, double qp_status, bool* accepted_out UPR_LS_PROF_ARG) {
+// STAGE = A.stage_full, at compile time on the device: the staged arrays are then LDS pointers for the compiler (chosen at run
+// time they were generic pointers -- flat loads, each waiting for every global request in flight as well)
+template <int NQ, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT, int STAGE = -1>
+static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_ls_args& A, int b, double* L, int done_b, bool staged, bool defer_store, double qp_status, bool* accepted_out,
+                                             const double* way_p_b, double t0_b UPR_LS_PROF_ARG) {
     const upr_problem* P = A.P; const upr_dims& d = A.d;
     const int N = d.N, nx = d.nx, nu = d.nu, nq = d.nq;
     if (done_b) return nullptr;
@@ -292,10 +306,11 @@ static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_
     const double* ws = A.ws + (size_t)b * d.ws_stride;
     const double* dx = ws + d.ws_dx; const double* du = ws + d.ws_du;
     const int nxs = (N + 1) * nx, nus = N * nu;
-    const upr_ls_lay lay = upr_ls_layout(d, A.stage_full != 0);
+    const bool stage_full = (STAGE < 0) ? (A.stage_full != 0) : (STAGE != 0);
+    const upr_ls_lay lay = upr_ls_layout(d, stage_full);
     double* Xt = L + lay.xt; double* Ut = L + lay.ut; double* sc = L + lay.sc; double* pdl = L + lay.pd;
     const double* xs_l = xs; const double* us_l = us; const double* dx_l = dx; const double* du_l = du;
-    if (A.stage_full) {
+    if (stage_full) {
         double* sx_ = L + lay.sx; double* su_ = L + lay.su; double* sdx_ = L + lay.sdx; double* sdu_ = L + lay.sdu;
         if (!staged) {
             UPR_FOR(i, nxs) { sx_[i] = xs[i]; sdx_[i] = dx[i]; }
@@ -310,7 +325,7 @@ static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_
     upr_ls_flat_terms<NQ, true, EXACT ? NQ + NFM : 0, EXACT ? NFM / 3 : 0, EXACT ? 6 * NBM : 0>(A, b, ctx.tid, ctx.nt, xs_l, us_l, dx_l, du_l, part, part + 4);
     // the knots' target positions (a lane's own knots: written and read by the same lane; the waypoint reads fly beside the
     // reduction and the first trial's staging)
-    if (qp_status != 2.0) { UPR_FOR(k, N + 1) upr_target_position(P, A.way_p + (size_t)b * P->n_way * 3, A.t0[b] + k * P->dt, pdl + 3 * k); }
+    if (qp_status != 2.0) { UPR_FOR(k, N + 1) upr_target_position(P, way_p_b, t0_b + k * P->dt, pdl + 3 * k); }
     UPR_LS_STAMP(3);
     upr_ls_reduce<7>(ctx, L, 0, part, bs);
     UPR_LS_STAMP(4);
@@ -365,14 +380,14 @@ static UPR_HDI const double* upr_ls_instance(const upr_ls_lanes& ctx, const upr_
         if (conv) A.done[b] = 1;
     }
     UPR_LS_STAMP(8);
-    return accepted ? Xt : (A.stage_full ? xs_l : nullptr);   // (Xt, Ut contiguous; so are the staged xs, us)
+    return accepted ? Xt : (stage_full ? xs_l : nullptr);   // (Xt, Ut contiguous; so are the staged xs, us)
 }
 
 #ifndef UPR_HOST_EMU
 // One workgroup of NT = 256 lanes per instance.  Wave 0 carries the chain walks of a trial (a lane per knot), the other waves
 // its flat sums; the prologue (copy of the problem record, dispatch rank, staging) has every global request of the workgroup in
 // flight before the first wait.
-template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT>
+template <int NQ, int NT, int NFM = 3 * UPR_MAX_CONTACTS, int NBM = UPR_MAX_BODIES, bool EXACT = false, bool OBS = !EXACT, bool STAGE = true>
 __global__ void __launch_bounds__(NT, NT / 64) upr_linesearch_kernel(upr_ls_args A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     static_assert(NT % 64 == 0 && NT >= 128 && NT <= 256, "two to four waves: the rank and the reductions keep four slots; wave 0 walks");
@@ -397,12 +412,13 @@ __global__ void __launch_bounds__(NT, NT / 64) upr_linesearch_kernel(upr_ls_args
         for (int t = 0; t < NTR; ++t) { const int i = t * NT + threadIdx.x; recv[t] = src[(i < NPD) ? i : 0]; }
     }
     const int done_b = A.done[b];
-    const double qp_status_b = A.stats[(size_t)b * UPR_NSTATS + 2];
+    const double qp_status_b = A.stats[(size_t)b * UPR_NSTATS + 2], t0_b = A.t0[b];
+    const double wpv = (A.n_way > 0) ? A.way_p[(size_t)b * A.n_way * 3 + ((int)threadIdx.x < 3 * A.n_way ? threadIdx.x : 0)] : 0.0;   // (3 n_way <= NT)
     // the instance's trajectory and step, requested beside the record (up to SU elements of each per lane; longer ones are
     // staged by upr_ls_instance)
     constexpr int SU = 1024 / NT;
-    const bool stage_here = A.stage_full && nxs <= SU * NT && nus <= SU * NT;
-    const upr_ls_lay lay = upr_ls_layout(d, A.stage_full != 0);
+    const bool stage_here = STAGE && nxs <= SU * NT && nus <= SU * NT;
+    const upr_ls_lay lay = upr_ls_layout(d, STAGE);
     double sxv[SU], sdxv[SU], suv[SU], sduv[SU];
     if (stage_here) {
         const double* xs = A.xs + (size_t)b * nxs; const double* us = A.us + (size_t)b * nus;
@@ -441,6 +457,7 @@ __global__ void __launch_bounds__(NT, NT / 64) upr_linesearch_kernel(upr_ls_args
     {
 #pragma unroll
         for (int t = 0; t < NTR; ++t) { const int i = t * NT + threadIdx.x; if (i < NPD) smem[i] = recv[t]; }
+        if ((int)threadIdx.x < 3 * A.n_way) L[lay.wp + threadIdx.x] = wpv;
         if (stage_here) {
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -455,12 +472,14 @@ __global__ void __launch_bounds__(NT, NT / 64) upr_linesearch_kernel(upr_ls_args
     if (A.order_out && threadIdx.x == 0) { const int* c = reinterpret_cast<const int*>(L + 64); int r = 0; for (int w = 0; w < NT / 64; ++w) r += c[w]; A.order_out[r] = b; }
     UPR_LS_STAMP(0);
     bool accepted = false;
-    const double* kept = upr_ls_instance<NQ, NFM, NBM, EXACT, OBS>(ctx, A, b, L, done_b, stage_here, true, qp_status_b, &accepted UPR_LS_PROF_PASS);
+    const double* kept = upr_ls_instance<NQ, NFM, NBM, EXACT, OBS, STAGE ? 1 : 0>(ctx, A, b, L, done_b, stage_here, true, qp_status_b, &accepted, L + lay.wp, t0_b UPR_LS_PROF_PASS);
     UPR_LS_STAMP(9);
     if (accepted) {   // the accepted trajectory: one pass over its copy in LDS for the iterate and the remembered solution
         double* xs = A.xs + (size_t)b * nxs; double* us = A.us + (size_t)b * nus;
         double* xp = A.xs_prev ? A.xs_prev + (size_t)b * nxs : nullptr; double* up = A.xs_prev ? A.us_prev + (size_t)b * nus : nullptr;
+#pragma unroll 4
         for (int e = threadIdx.x; e < nxs; e += NT) { const double v = kept[e]; xs[e] = v; if (xp) xp[e] = v; }
+#pragma unroll 4
         for (int e = threadIdx.x; e < nus; e += NT) { const double v = kept[nxs + e]; us[e] = v; if (up) up[e] = v; }
         if (A.xs_prev && threadIdx.x == 0) A.tprev[b] = A.t0[b];
     } else if (A.xs_prev) {
