@@ -484,7 +484,10 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
     for _ in range(args.warmup):
         step()
     fence()
-    mpc.enable_timing(True)
+    # events around the QP kernel only (the dominant kernel: roofline.achieved is its duration over THIS region); the other two
+    # kernels are timed by aux_kernel_times() behind the region -- a pair of events costs the stream ~3 us, 0.3 % of a step for
+    # the four that told nothing about the dominant kernel
+    mpc.enable_timing(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -495,6 +498,22 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, gathered[0]
+
+
+def aux_kernel_times(mpc, kt_qp, steps=10):
+    """Durations of the linearisation and line-search kernels: `steps` more cold solves of the same batch with events around
+    every kernel, BEHIND the timed region (whose events sit around the QP kernel only).  Returns the merged table: QP from the
+    timed region, the other two from this pass."""
+    mpc.enable_timing(1)
+    for _ in range(steps):
+        mpc.reset_async(); mpc.advance_async()
+    mpc.sync()
+    ka = mpc.kernel_times()
+    kt = dict(kt_qp)
+    kt["linearize_ms"], kt["linesearch_ms"] = ka["linearize_ms"], ka["linesearch_ms"]
+    kt["launches"] = [ka["launches"][0], kt_qp["launches"][1], ka["launches"][2]]
+    kt["aux_qp_ms"] = ka["qp_ms"]
+    return kt
 
 
 def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
@@ -917,6 +936,8 @@ def main():
         assert gathered[0].shape[0] == world * B and bool(torch.isfinite(gathered[0]).all())
     kt = mpc.kernel_times()
     st = mpc.stats()
+    if not dry:
+        kt = aux_kernel_times(mpc, kt)
     mpc.enable_timing(False)
     mpc.close()
 
@@ -969,7 +990,10 @@ def main():
             },
             "roofline": roof,
             "roofline_linearize": lin,
-            "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"]},
+            "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"],
+                          "source": "qp: HIP events on the engine's stream around every QP launch of the timed region; linearize, linesearch: "
+                                    "10 more solves of the same batch behind the region with events around every kernel (qp there: "
+                                    f"{kt.get('aux_qp_ms', 0.0):.4f} ms)"},
             "rank_devices": rank_devices,      # HIP device index of every engine each rank created (rank r: [LOCAL_RANK r])
         }
         if dry:

@@ -287,7 +287,7 @@ struct upr_batch {
     struct upr_jit_kernel* jit = nullptr;
     bool fb_fused = false;   // the selected QP kernel writes the feedback gains itself (upr_qp_args::fb)
     bool use_mfma = true;
-    bool timing = false;
+    int timing = 0;   // 0: no events; 1: around every kernel of an advance; 2: around the QP kernel only
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
@@ -767,9 +767,9 @@ int do_linearize(upr_batch* h, const upr_lin_args& A) {
 // Per-launch device timing with HIP events recorded on the engine's stream (no host sync inside the
 // timed region); upr_batch_kernel_times() reads them back after a stream sync.
 struct KernelTimer {
-    upr_batch* h; int slot; size_t idx;
-    KernelTimer(upr_batch* h_, int s) : h(h_), slot(s), idx(0) {
-        if (!h->timing) return;
+    upr_batch* h; int slot; size_t idx; bool on;
+    KernelTimer(upr_batch* h_, int s) : h(h_), slot(s), idx(0), on(h_->timing == 1 || (h_->timing == 2 && s == 1)) {
+        if (!on) return;
         hipEvent_t a, b;
         // (reused: upr_batch_enable_timing stocks the free list, so that a timed loop creates none)
         if (h->ev_free.size() >= 2) { a = h->ev_free.back(); h->ev_free.pop_back(); b = h->ev_free.back(); h->ev_free.pop_back(); }
@@ -778,7 +778,7 @@ struct KernelTimer {
         h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_slot.push_back(slot);
         (void)hipEventRecord(a, h->stream);
     }
-    void stop() { if (h->timing) (void)hipEventRecord(h->ev_pool[idx + 1], h->stream); }
+    void stop() { if (on) (void)hipEventRecord(h->ev_pool[idx + 1], h->stream); }
 };
 
 // where the QP kernel selected for this handle keeps its per-knot factors
@@ -1379,7 +1379,7 @@ int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
 
 int upr_batch_enable_timing(upr_batch* h, int on) {
     UPR_ENTER(h);
-    h->timing = on != 0;
+    h->timing = (on == 2) ? 2 : (on != 0 ? 1 : 0);
     if (h->timing) while (h->ev_free.size() < 512) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->ev_free.push_back(e); }
     for (int i = 0; i < 3; ++i) { h->k_ms[i] = 0; h->k_launches[i] = 0; }
     return 0;

@@ -239,6 +239,7 @@ class BatchMPC:
         return lin
 
     def enable_timing(self, on=True):
+        """on: False / 0 no events; True / 1 around every kernel of an advance; 2 around the QP kernel only."""
         check(self._lib.upr_batch_enable_timing(self._h, int(on)))
 
     def kernel_times(self):
