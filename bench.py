@@ -418,7 +418,7 @@ def make_engine(w, device_index=None):
 
 
 # ---- the timed loop of one rank -----------------------------------------------------------------------------------
-def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_exchange=False):
+def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_exchange=False, events=2):
     """W untimed + K timed steps on this rank.  `mpc` is the engine (or a stand-in with the same methods: the gloo test
     drives this function with fake solutions); `dist` a torch.distributed module with an initialised group or None.
     Returns (max-over-ranks seconds of the timed region, gathered trajectories of the last step or None).
@@ -484,10 +484,11 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
     for _ in range(args.warmup):
         step()
     fence()
-    # events around the QP kernel only (the dominant kernel: roofline.achieved is its duration over THIS region); the other two
-    # kernels are timed by aux_kernel_times() behind the region -- a pair of events costs the stream ~3 us, 0.3 % of a step for
-    # the four that told nothing about the dominant kernel
-    mpc.enable_timing(2)
+    # events = 2 (the headline): around the QP kernel only (the dominant kernel: roofline.achieved is its duration over THIS
+    # region); the other two kernels are timed by aux_kernel_times() behind the region -- a pair of events costs the stream
+    # ~3 us, 0.3 % of a step for the four that told nothing about the dominant kernel.  events = 1 (the other workloads):
+    # around every kernel
+    mpc.enable_timing(events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -651,7 +652,7 @@ def time_extra(w, steps, warmup, warm=None, dist=None, device="cuda", engine=Non
 
     # (the engine's own stream sync closes the timed region; torch's is added when torch owns a context in this process)
     elapsed, gathered = rank_main(args, mpc, w["P"], dist=dist, device=device,
-                                  sync_device=torch.cuda.synchronize if (device != "cpu" and torch.cuda.is_initialized()) else None)
+                                  sync_device=torch.cuda.synchronize if (device != "cpu" and torch.cuda.is_initialized()) else None, events=1)
     kt, st = mpc.kernel_times(), mpc.stats()
     B = mpc.B
     if world > 1:
