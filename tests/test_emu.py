@@ -98,6 +98,31 @@ def test_linearize_kernel_source(arrangements):
         assert np.abs(e.Df[b] - gu[:, 9:]).max() < 1e-15
 
 
+@pytest.mark.parametrize("name", ["pink_bottle", "blue_cups", "foam_die2", "robust_8corner"])
+def test_linearize_job_form_equals_the_phase_form(arrangements, name):
+    """Shapes without collision rows and orientation cost run the lane jobs of upr_linearize2.h on the device (a tangent class per
+    pass, the residual's tangent written out per class) instead of upr_linearize.h's phases (dual numbers in every lane).  Both
+    sources on the same random points, record by record: one body with four contacts, seven cups (star), two stacked dice, the eight-corner robust arrangement;
+    terminal records included."""
+    B = 2
+    P = thing_problem(arrangements[name])
+    x0 = level_tray_states(B, seed=5)
+    way = waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0))
+    xs, us = stationary_guess(x0, P.N, P.nu)
+    rng = np.random.default_rng(3)
+    xs = np.ascontiguousarray(xs + rng.uniform(-0.3, 0.3, xs.shape)); us = np.ascontiguousarray(rng.uniform(-1, 1, us.shape))
+    e = Emu(P, B)
+    try:
+        e.E.emu_set_lin_form(0); phases = e.linearize(way, np.zeros(B), xs, us)
+        e.E.emu_set_lin_form(1); jobs = e.linearize(way, np.zeros(B), xs, us)
+    finally:
+        e.E.emu_set_lin_form(1)
+    used = e.lin_hess + 45   # (g, gx, cost, gradient, Hessian: the record's tail is the collision rows' area, unused here)
+    assert np.abs(phases[..., :used]).max() > 1.0
+    scale = np.maximum(1.0, np.abs(phases[..., :used]))
+    assert (np.abs(jobs[..., :used] - phases[..., :used]) / scale).max() < 1e-12
+
+
 @pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_qp_kernel_source(arrangements, kernel):
     """All three QP kernel structures follow the oracle's iterate path: identical steps after a fixed

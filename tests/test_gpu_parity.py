@@ -679,6 +679,38 @@ def test_paper_arrangements_production_kernel_speed(arrangements, name, arr, ker
     assert out["generic"][0] >= 10.0 * out["production"][0], (out["generic"][0], out["production"][0])
 
 
+def test_event_timing_modes_and_the_two_linearisation_kernels(arrangements, monkeypatch):
+    """upr_batch_enable_timing: 1 = events around every kernel of an advance, 2 = around the QP kernel only (what bench.py's
+    timed region asks for), 0 = none.  And the two linearisation kernels on the device, record by record on a batch that does
+    not fill its last workgroup: shapes without collision rows run upr_linearize2_kernel (lane jobs, a tangent class per pass);
+    UPR_LIN2=0 sends them to upr_linearize_kernel (phases on dual numbers), which keeps the collision / orientation shapes."""
+    B = 37   # (37 x 21 knots = 777: 27 workgroups of 28 knots and one of 21)
+    P = thing_problem(arrangements["pink_bottle"])
+    x0 = level_tray_states(B, seed=21)
+    way = waypoints_for(P, x0)
+    recs = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("UPR_LIN2", form)
+        mpc = BatchMPC(P, B, way_p=way)
+        mpc.set_observation(0.0, x0)
+        mpc.enable_timing(2)
+        mpc.advance(); mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
+        kt = mpc.kernel_times()
+        assert kt["launches"] == [0, 2 * P.sqp_iters, 0] and kt["qp_ms"] > 0 and kt["linearize_ms"] == 0 and kt["linesearch_ms"] == 0
+        mpc.enable_timing(1)
+        mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
+        kt = mpc.kernel_times()
+        assert kt["launches"] == [P.sqp_iters] * 3 and min(kt["linearize_ms"], kt["qp_ms"], kt["linesearch_ms"]) > 0
+        mpc.enable_timing(0)
+        mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
+        assert mpc.kernel_times()["launches"] == [0, 0, 0]
+        recs[form] = mpc.lin_records()
+        mpc.close()
+    assert np.isfinite(recs["1"]).all() and np.abs(recs["1"]).max() > 1.0
+    scale = np.maximum(1.0, np.abs(recs["0"]))
+    assert (np.abs(recs["1"] - recs["0"]) / scale).max() < 1e-11
+
+
 def test_robust_arrangement_per_instance_parameters(arrangements):
     """BASELINE config 4 (upright_robust, planning_sim_loop.py:454-534): eight copies of one cuboid, one per vertex of
     the CoM box, 32 frictionless contact points (nx 27, nu 41, 48 equality rows / knot), and a DIFFERENT inertial

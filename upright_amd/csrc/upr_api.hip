@@ -287,6 +287,7 @@ struct upr_batch {
     struct upr_jit_kernel* jit = nullptr;
     bool fb_fused = false;   // the selected QP kernel writes the feedback gains itself (upr_qp_args::fb)
     bool use_mfma = true;
+    bool lin2 = true;   // shapes without collision rows / orientation cost: upr_linearize2_kernel (UPR_LIN2=0 at create: upr_linearize_kernel)
     int timing = 0;   // 0: no events; 1: around every kernel of an advance; 2: around the QP kernel only
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
@@ -352,8 +353,7 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     const bool multi_rows = UPR_LIN_ANALYTIC && UPR_LIN_OBS_SNAP && !A.way_q && h->use_mfma && occ == 2 && A.d.no > 0 && (row_passes == 2 || row_passes == 3);
     // no collision rows, no orientation cost: the one-round kernel of upr_linearize2.h, as many knots per workgroup as three
     // workgroups per CU hold in LDS and one tangent pass takes in one trip (28 for the headline shape: 768 workgroups)
-    static const int lin2_env = getenv("UPR_LIN2") ? atoi(getenv("UPR_LIN2")) : 1;
-    if (lin2_env && upr_lin2_eligible(A) && h->use_mfma && occ == 2) {
+    if (h->lin2 && upr_lin2_eligible(A) && h->use_mfma && occ == 2) {
         const upr_lin2_lay lay = upr_lin2_layout(A.d);
         const int npre = (UPR_LIN2_NPRE + 1) & ~1;
         int kpw = (int)((160 * 1024 / 3 - 64 - npre * sizeof(double)) / (lay.per * sizeof(double)));
@@ -967,6 +967,7 @@ upr_batch* upr_batch_create(const upr_problem* P, int B, const double* body_para
         h->qp_name = buf;
     }
     if (const char* e = getenv("UPR_LIN_MFMA")) h->use_mfma = atoi(e) != 0;
+    if (const char* e = getenv("UPR_LIN2")) h->lin2 = atoi(e) != 0;
     if (const char* e = getenv("UPR_QP_ORDER")) h->order_on = atoi(e) != 0;
     auto bad = [&]() { upr_batch_destroy(h); return (upr_batch*)nullptr; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { fail("hipStreamCreate failed"); return bad(); }
