@@ -90,7 +90,7 @@ def pmc_traffic(kernel=None):
     pats = ("r*_pmc_hbm.csv",) if kernel is None else ("r*_pmc_hbm_all.csv", "r*_pmc_hbm.csv")
     for vals, name in _pmc_rows(pats):
         out = {}
-        for key, tag in ((kernel or "upr_qp", "qp"), ("upr_linearize_kernel", "linearize")):
+        for key, tag in ((kernel or "upr_qp", "qp"), ("upr_linearize", "linearize")):   # (upr_linearize_kernel<...> or upr_linearize2_kernel<nq>)
             fe = [v for (k, c), v in vals.items() if key in k and c == "FETCH_SIZE"]
             wr = [v for (k, c), v in vals.items() if key in k and c == "WRITE_SIZE"]
             if fe and wr:
@@ -113,10 +113,12 @@ def pmc_workload(key):
     for row in csv.reader(l for l in open(best) if not l.startswith("#")):
         if len(row) == 6 and row[0] == key:
             _, kernel, counter, _, mean, batch = row
-            tag = "linearize" if "upr_linearize_kernel" in kernel else ("qp" if "upr_qp" in kernel else None)
+            tag = "linearize" if "upr_linearize" in kernel else ("qp" if "upr_qp" in kernel else None)
             if tag:
                 out[tag][counter] = float(mean)
                 out["batch"] = int(batch)
+                if tag == "linearize":
+                    out["linearize_kernel"] = kernel.replace("void ", "")   # (which of the two linearisation kernels the workload ran)
     for l in open(best):
         if l.startswith("# kernel sources sha256:"):
             out["library"] = l.split(":", 1)[1].strip()   # the sources the counters' build was made of (tools/pmc_workloads.sh)
@@ -619,7 +621,7 @@ def roofline_objects(P, B, kt, st, sqp_iters, headline, key=None):
     elif f_exec >= 0.5:
         roof["bound"] = "mfma"
     lin = {
-        "kernel": "upr_linearize_kernel",
+        "kernel": (wl.get("linearize_kernel") if wl else None) or "upr_linearize_kernel",
         "bound": "hbm",
         "achieved": lin_gbs,
         "peak": PEAK_HBM_GBS,
