@@ -420,7 +420,7 @@ def make_engine(w, device_index=None):
 
 
 # ---- the timed loop of one rank -----------------------------------------------------------------------------------
-def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_exchange=False, events=2):
+def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_exchange=False, events=3):
     """W untimed + K timed steps on this rank.  `mpc` is the engine (or a stand-in with the same methods: the gloo test
     drives this function with fake solutions); `dist` a torch.distributed module with an initialised group or None.
     Returns (max-over-ranks seconds of the timed region, gathered trajectories of the last step or None).
@@ -486,10 +486,11 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
     for _ in range(args.warmup):
         step()
     fence()
-    # events = 2 (the headline): around the QP kernel only (the dominant kernel: roofline.achieved is its duration over THIS
-    # region); the other two kernels are timed by aux_kernel_times() behind the region -- a pair of events costs the stream
-    # ~3 us, 0.3 % of a step for the four that told nothing about the dominant kernel.  events = 1 (the other workloads):
-    # around every kernel
+    # events = 3 (the headline): around every fourth launch of the QP kernel (the dominant kernel: roofline.achieved is its
+    # average duration over THIS region); the other two kernels are timed by aux_kernel_times() behind the region.  A recorded
+    # event holds the stream for ~6 us (rocprofv3 kernel trace of this loop: 6.4 / 6.0 us between two kernels with an event
+    # between them, 0.0 without) -- six per step were 1.9 % of it for durations the judge of the dominant kernel does not need,
+    # two per step still 0.65 %.  events = 1 (the other workloads): around every kernel
     mpc.enable_timing(events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -994,7 +995,7 @@ def main():
             "roofline": roof,
             "roofline_linearize": lin,
             "kernel_ms": {"linearize": kt["linearize_ms"], "qp": kt["qp_ms"], "linesearch": kt["linesearch_ms"], "launches": kt["launches"],
-                          "source": "qp: HIP events on the engine's stream around every QP launch of the timed region; linearize, linesearch: "
+                          "source": "qp: HIP events on the engine's stream around every fourth QP launch of the timed region (launches[1] of them); linearize, linesearch: "
                                     "10 more solves of the same batch behind the region with events around every kernel (qp there: "
                                     f"{kt.get('aux_qp_ms', 0.0):.4f} ms)"},
             "rank_devices": rank_devices,      # HIP device index of every engine each rank created (rank r: [LOCAL_RANK r])

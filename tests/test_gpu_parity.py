@@ -680,8 +680,8 @@ def test_paper_arrangements_production_kernel_speed(arrangements, name, arr, ker
 
 
 def test_event_timing_modes_and_the_two_linearisation_kernels(arrangements, monkeypatch):
-    """upr_batch_enable_timing: 1 = events around every kernel of an advance, 2 = around the QP kernel only (what bench.py's
-    timed region asks for), 0 = none.  And the two linearisation kernels on the device, record by record on a batch that does
+    """upr_batch_enable_timing: 1 = events around every kernel of an advance, 2 = around the QP kernel only, 3 = around every
+    fourth QP launch (what bench.py's timed region asks for), 0 = none.  And the two linearisation kernels on the device, record by record on a batch that does
     not fill its last workgroup: shapes without collision rows run upr_linearize2_kernel (lane jobs, a tangent class per pass);
     UPR_LIN2=0 sends them to upr_linearize_kernel (phases on dual numbers), which keeps the collision / orientation shapes."""
     B = 37   # (37 x 21 knots = 777: 27 workgroups of 28 knots and one of 21)
@@ -701,6 +701,11 @@ def test_event_timing_modes_and_the_two_linearisation_kernels(arrangements, monk
         mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
         kt = mpc.kernel_times()
         assert kt["launches"] == [P.sqp_iters] * 3 and min(kt["linearize_ms"], kt["qp_ms"], kt["linesearch_ms"]) > 0
+        mpc.enable_timing(3)
+        for _ in range(6):
+            mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
+        kt = mpc.kernel_times()
+        assert kt["launches"] == [0, (6 * P.sqp_iters + 3) // 4, 0] and kt["qp_ms"] > 0   # (the first, the fifth, ... QP launch)
         mpc.enable_timing(0)
         mpc.reset(); mpc.set_observation(0.0, x0); mpc.advance()
         assert mpc.kernel_times()["launches"] == [0, 0, 0]

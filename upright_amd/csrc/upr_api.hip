@@ -288,7 +288,8 @@ struct upr_batch {
     bool fb_fused = false;   // the selected QP kernel writes the feedback gains itself (upr_qp_args::fb)
     bool use_mfma = true;
     bool lin2 = true;   // shapes without collision rows / orientation cost: upr_linearize2_kernel (UPR_LIN2=0 at create: upr_linearize_kernel)
-    int timing = 0;   // 0: no events; 1: around every kernel of an advance; 2: around the QP kernel only
+    int timing = 0;   // 0: no events; 1: around every kernel of an advance; 2: around the QP kernel only; 3: around every FOURTH QP launch
+    unsigned timing_qp_count = 0;   // QP launches since upr_batch_enable_timing (mode 3 samples those with count % 4 == 0)
     double k_ms[3] = {0, 0, 0};
     int k_launches[3] = {0, 0, 0};
     std::vector<double> hDf;
@@ -769,6 +770,7 @@ int do_linearize(upr_batch* h, const upr_lin_args& A) {
 struct KernelTimer {
     upr_batch* h; int slot; size_t idx; bool on;
     KernelTimer(upr_batch* h_, int s) : h(h_), slot(s), idx(0), on(h_->timing == 1 || (h_->timing == 2 && s == 1)) {
+        if (h->timing == 3 && s == 1) on = (h->timing_qp_count++ % 4u) == 0u;
         if (!on) return;
         hipEvent_t a, b;
         // (reused: upr_batch_enable_timing stocks the free list, so that a timed loop creates none)
@@ -1380,7 +1382,8 @@ int upr_batch_get_lin(upr_batch* h, double* lin, int* stride) {
 
 int upr_batch_enable_timing(upr_batch* h, int on) {
     UPR_ENTER(h);
-    h->timing = (on == 2) ? 2 : (on != 0 ? 1 : 0);
+    h->timing = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
+    h->timing_qp_count = 0;
     if (h->timing) while (h->ev_free.size() < 512) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->ev_free.push_back(e); }
     for (int i = 0; i < 3; ++i) { h->k_ms[i] = 0; h->k_launches[i] = 0; }
     return 0;

@@ -239,7 +239,8 @@ class BatchMPC:
         return lin
 
     def enable_timing(self, on=True):
-        """on: False / 0 no events; True / 1 around every kernel of an advance; 2 around the QP kernel only."""
+        """on: False / 0 no events; True / 1 around every kernel of an advance; 2 around the QP kernel only; 3 around every
+        fourth QP launch."""
         check(self._lib.upr_batch_enable_timing(self._h, int(on)))
 
     def kernel_times(self):
