@@ -488,9 +488,9 @@ def rank_main(args, mpc, P, dist=None, device="cuda", sync_device=None, force_ex
     fence()
     # events = 3 (the headline): around every fourth launch of the QP kernel (the dominant kernel: roofline.achieved is its
     # average duration over THIS region); the other two kernels are timed by aux_kernel_times() behind the region.  A recorded
-    # event holds the stream for ~6 us (rocprofv3 kernel trace of this loop: 6.4 / 6.0 us between two kernels with an event
-    # between them, 0.0 without) -- six per step were 1.9 % of it for durations the judge of the dominant kernel does not need,
-    # two per step still 0.65 %.  events = 1 (the other workloads): around every kernel
+    # event holds the stream for 3 - 4 us (tools/exp_timing_modes.py: 1.8787 ms per solve without events, 1.8806 in this mode,
+    # 1.8848 with events around every QP launch, 1.9020 around every kernel) -- six per step were 1.2 % of it for durations the
+    # roofline of the dominant kernel does not need.  events = 1 (the other workloads): around every kernel
     mpc.enable_timing(events)
     t0 = time.perf_counter()
     for _ in range(args.steps):

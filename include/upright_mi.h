@@ -285,8 +285,9 @@ int upr_batch_device_ptrs(upr_batch* h, void** xs, void** us);
  * engine's stream: out[0] = linearise, out[1] = QP, out[2] = line search; launches[3] = #launches */
 int upr_batch_kernel_times(upr_batch* h, double* ms, int* launches);
 /* on: 0 no events; 1 events around every kernel; 2 around the QP kernel only; 3 around every fourth QP launch (the first, the
- * fifth, ...).  A recorded event holds the stream for ~6 us (rocprofv3 kernel trace: the gap between two kernels with an event
- * between them, none without): a throughput run that wants the dominant kernel's average duration and nothing else asks for 3 */
+ * fifth, ...).  A recorded event holds the stream for 3 - 4 us (tools/exp_timing_modes.py; 6 us under rocprofv3, whose
+ * kernel trace shows no gap between two kernels without one): a throughput run that wants the dominant kernel's average duration and
+ * nothing else asks for 3 */
 int upr_batch_enable_timing(upr_batch* h, int on);
 /* name of the QP kernel instantiation this handle launches (as rocprofv3 prints it): bench.py's roofline.kernel */
 const char* upr_batch_qp_kernel_name(const upr_batch* h);
