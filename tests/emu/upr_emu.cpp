@@ -22,7 +22,7 @@ static int g_lin_form = 1;
 template <int NQ>
 static void lin_all(const upr_lin_args& A) {
     if (g_lin_form && upr_lin2_eligible(A)) {
-        std::vector<double> sh(upr_lin2_layout(A.d).per + 8);
+        std::vector<double> sh(upr_lin2_layout(A.d, A.P->n_sph).per + 8);
         for (int p = 0; p < A.npoints; ++p) upr_lin2_knot<NQ>(A, upr_lin_locate(A, p), sh.data());
         return;
     }

@@ -98,16 +98,21 @@ def test_linearize_kernel_source(arrangements):
         assert np.abs(e.Df[b] - gu[:, 9:]).max() < 1e-15
 
 
-@pytest.mark.parametrize("name", ["pink_bottle", "blue_cups", "foam_die2", "robust_8corner"])
+@pytest.mark.parametrize("name", ["pink_bottle", "blue_cups", "foam_die2", "robust_8corner", "collision_rows"])
 def test_linearize_job_form_equals_the_phase_form(arrangements, name):
-    """Shapes without collision rows and orientation cost run the lane jobs of upr_linearize2.h on the device (a tangent class per
-    pass, the residual's tangent written out per class) instead of upr_linearize.h's phases (dual numbers in every lane).  Both
-    sources on the same random points, record by record: one body with four contacts, seven cups (star), two stacked dice, the eight-corner robust arrangement;
-    terminal records included."""
+    """Shapes without orientation cost run the lane jobs of upr_linearize2.h on the device (a tangent class per pass, the
+    residual's tangent written out per class, the collision spheres placed by the walk lane) instead of upr_linearize.h's phases
+    (dual numbers in every lane, link frames kept for the spheres).  Both sources on the same random points, record by record:
+    one body with four contacts, seven cups (star), two stacked dice, the eight-corner robust arrangement, and the bottle with a
+    collision model (world spheres, self-collision pairs; the whole record incl. the rows and their gradients); terminal records
+    included."""
     B = 2
-    P = thing_problem(arrangements[name])
-    x0 = level_tray_states(B, seed=5)
-    way = waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0))
+    if name == "collision_rows":
+        P, x0, way, _, _ = _obstacle_case(arrangements, B, 5)
+    else:
+        P = thing_problem(arrangements[name])
+        x0 = level_tray_states(B, seed=5)
+        way = waypoints_for(P, x0, offset=(-0.5, 0.5, 0.0))
     xs, us = stationary_guess(x0, P.N, P.nu)
     rng = np.random.default_rng(3)
     xs = np.ascontiguousarray(xs + rng.uniform(-0.3, 0.3, xs.shape)); us = np.ascontiguousarray(rng.uniform(-1, 1, us.shape))
@@ -117,7 +122,7 @@ def test_linearize_job_form_equals_the_phase_form(arrangements, name):
         e.E.emu_set_lin_form(1); jobs = e.linearize(way, np.zeros(B), xs, us)
     finally:
         e.E.emu_set_lin_form(1)
-    used = e.lin_hess + 45   # (g, gx, cost, gradient, Hessian: the record's tail is the collision rows' area, unused here)
+    used = e.lin_stride if name == "collision_rows" else e.lin_hess + 45   # (g, gx, cost, gradient, Hessian; + the rows' area where there are rows)
     assert np.abs(phases[..., :used]).max() > 1.0
     scale = np.maximum(1.0, np.abs(phases[..., :used]))
     assert (np.abs(jobs[..., :used] - phases[..., :used]) / scale).max() < 1e-12

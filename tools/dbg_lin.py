@@ -7,7 +7,7 @@ import bench
 from upright_amd import _capi
 name = sys.argv[1] if len(sys.argv) > 1 else "headline"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-w = {"config3": lambda: bench.config3_workload(4096), "config4": lambda: bench.config4_workload(1024), "config5": lambda: bench.config5_workload(1024),
+w = {"config3": lambda: bench.config3_workload(B if len(sys.argv) > 2 else 4096), "config4": lambda: bench.config4_workload(B), "config5": lambda: bench.config5_workload(B),
      "headline": lambda: bench.headline_workload(B)}[name]()
 mpc = bench.make_engine(w)
 if name == "config5": mpc.set_projectile_flag(1.0)

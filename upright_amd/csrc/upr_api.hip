@@ -355,14 +355,14 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     // no collision rows, no orientation cost: the one-round kernel of upr_linearize2.h, as many knots per workgroup as three
     // workgroups per CU hold in LDS and one tangent pass takes in one trip (28 for the headline shape: 768 workgroups)
     if (h->lin2 && upr_lin2_eligible(A) && h->use_mfma && occ == 2) {
-        const upr_lin2_lay lay = upr_lin2_layout(A.d);
-        const int npre = (UPR_LIN2_NPRE + 1) & ~1;
+        const upr_lin2_lay lay = upr_lin2_layout(A.d, h->P.n_sph);
+        const int npre = ((UPR_LIN2_NPRE + 1) & ~1) + (A.d.no > 0 ? ((UPR_LIN2_SPH_DOUBLES + 1) & ~1) : 0);
         int kpw = (int)((160 * 1024 / 3 - 64 - npre * sizeof(double)) / (lay.per * sizeof(double)));
         if (kpw > 256 / NQ) kpw = 256 / NQ;
         if (kpw > 64) kpw = 64;
         if (kpw >= 1) {
             const size_t lds2 = (size_t)(npre + kpw * lay.per) * sizeof(double);
-            hipLaunchKernelGGL(upr_linearize2_kernel<NQ>, dim3((A.npoints + kpw - 1) / kpw), dim3(256), lds2, h->stream, A, kpw);
+            hipLaunchKernelGGL(upr_linearize2_kernel<NQ>, dim3((A.npoints + kpw - 1) / kpw), dim3(256), lds2, h->stream, A, kpw, h->P.n_sph);
             UPR_HIP(hipGetLastError());
             return 0;
         }

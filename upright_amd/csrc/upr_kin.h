@@ -208,8 +208,11 @@ static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int
 // frames (optional, problems with collision spheres): the link frame BEHIND joint j after its motion, [j][C 9, p 3] -- the
 // spheres that ride on link j are placed from it (UPR_SNAP_F doubles per joint)
 #define UPR_SNAP_F 12
-template <int NQ>
-static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap, double* frames = nullptr) {
+struct upr_no_hook { UPR_HDI void operator()(int, const double*, const double*) const {} };
+// hook(f, C, p): called with the link frame behind joint f after its motion (f = NQ: the tool frame) -- upr_linearize2.h places
+// the collision spheres that ride on that link there, instead of keeping every frame
+template <int NQ, class HOOK = upr_no_hook>
+static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap, double* frames = nullptr, HOOK hook = HOOK()) {
     upr_ee<double> E;
     for (int i = 0; i < 9; ++i) E.C[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 3; ++i) { E.p[i] = 0.0; E.v[i] = 0.0; E.w[i] = 0.0; E.a[i] = 0.0; E.al[i] = 0.0; }
@@ -258,11 +261,13 @@ static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, cons
             for (int i = 0; i < 9; ++i) Fj[i] = E.C[i];
             for (int i = 0; i < 3; ++i) Fj[9 + i] = E.p[i];
         }
+        hook(j, E.C, E.p);
     }
     double r[3];
     upr_rot_const(E.C, P->tool_p, r);
     upr_carry(E, r);
     upr_rmul_const(E.C, P->tool_R);
+    hook(NQ, E.C, E.p);
     double* T = snap + NQ * UPR_SNAP_J;
     for (int i = 0; i < 9; ++i) T[i] = E.C[i];
     for (int i = 0; i < 3; ++i) { T[9 + i] = E.p[i]; T[12 + i] = E.v[i]; T[15 + i] = E.w[i]; T[18 + i] = E.a[i]; T[21 + i] = E.al[i]; }

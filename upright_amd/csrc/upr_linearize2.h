@@ -1,7 +1,7 @@
-// upr_linearize2.h -- the linearisation kernel for problems WITHOUT collision rows and orientation cost (the headline family):
-// the same per-knot record as upr_linearize.h, produced by lane jobs that are uniform per wave.
+// upr_linearize2.h -- the linearisation kernel for problems without orientation cost: the same per-knot record as
+// upr_linearize.h, produced by lane jobs that are uniform per wave.
 //
-// What changed against upr_linearize_kernel (which keeps the collision / orientation shapes) and why:
+// What changed against upr_linearize_kernel (which keeps the orientation-cost shapes) and why:
 //   * its 896 workgroups of 24 knots held 74 KB of LDS each -- two per CU, 512 resident: a launch of the headline batch ran as
 //     TWO rounds (31.7 us at 512 workgroups, 47.3 us at 560, tools/exp_lin_b.py).  Here a knot keeps 224 doubles (no staged
 //     x / u, sin / cos and J_p share a slot, the residual's wrench slot holds Df f only) and the workgroup copies the 1.6 KB
@@ -10,6 +10,9 @@
 //     d/dq'' -- known only at run time, three classes side by side in every wave.  Here a pass of the workgroup takes ONE class
 //     (28 knots x 9 joints = 252 of 256 lanes), with the tangent of the residual written out per class: d/dq'' needs 2 of the
 //     12 cross products of d/dq, and no lane multiplies by a zero tangent.
+//   * collision / projectile rows: the walk lane places the spheres that ride on a link right behind that link's joint (a list
+//     of spheres per frame, built once per workgroup) instead of leaving every link frame in LDS (108 doubles a knot: the knots
+//     of a workgroup would drop from 27 to 19); a row is a lane job as before, its gradient out of the snapshots.
 // Same closed-form tangents out of the per-joint snapshots (upr_kin.h, "analytic tangents"); results agree with the forward-mode
 // walk and the oracle's dual numbers to 1e-10 .. 1e-13 (tests/test_emu.py, tests/test_gpu_parity.py).
 #pragma once
@@ -21,15 +24,100 @@
 static_assert(offsetof(upr_problem, contact_body1) % sizeof(double) == 0, "copied as doubles");
 
 // per-knot LDS area (doubles): gf[ne] = Df f | e[3]: target position, then position error | js: (sin, cos)[nq] during the walk,
-// then J_p [3][nq] | the value walk's snapshots
-struct upr_lin2_lay { int gf, e, js, snap, per; };
-static UPR_HDI upr_lin2_lay upr_lin2_layout(const upr_dims& d) {
+// then J_p [3][nq] | the value walk's snapshots | (problems with collision rows) the sphere centres [n_sph][3]
+struct upr_lin2_lay { int gf, e, js, snap, obs, per; };
+static UPR_HDI upr_lin2_lay upr_lin2_layout(const upr_dims& d, int n_sph) {
     upr_lin2_lay l;
     l.gf = 0; l.e = d.ne; l.js = (l.e + 3 + 1) & ~1; l.snap = l.js + ((3 * d.nq + 1) & ~1);
-    l.per = (l.snap + d.nq * UPR_SNAP_J + UPR_SNAP_E + 1) & ~1;
+    l.obs = l.snap + d.nq * UPR_SNAP_J + UPR_SNAP_E;
+    l.per = (l.obs + (d.no > 0 ? 3 * n_sph : 0) + 1) & ~1;
     return l;
 }
-static UPR_HDI bool upr_lin2_eligible(const upr_lin_args& A) { return A.d.no == 0 && A.way_q == nullptr && A.Df != nullptr; }
+static UPR_HDI bool upr_lin2_eligible(const upr_lin_args& A) { return A.way_q == nullptr && A.Df != nullptr; }
+
+// Per-workgroup table of the collision spheres (doubles; built once, read by the walk lanes): the spheres that ride on chain
+// frames ordered by frame -- start[f] .. start[f + 1] indexes `order` for frame f = 0 .. nq (nq: the tool frame) -- and every
+// sphere's offset in its frame.  [start: UPR_MAX_JOINTS + 2 ints | order: UPR_MAX_SPHERES ints | off: UPR_MAX_SPHERES x 3]
+#define UPR_LIN2_SPH_START 0
+#define UPR_LIN2_SPH_ORDER ((UPR_MAX_JOINTS + 2 + 1) / 2)
+#define UPR_LIN2_SPH_OFF (UPR_LIN2_SPH_ORDER + (UPR_MAX_SPHERES + 1) / 2)
+#define UPR_LIN2_SPH_DOUBLES (UPR_LIN2_SPH_OFF + 3 * UPR_MAX_SPHERES)
+// entry `i` of the table's construction: i < n_sph places sphere i in `order` and copies its offset, i < nq + 2 counts start[i]
+static UPR_HDI void upr_lin2_sphere_table(const upr_problem* PG, int nq, int i, double* tab) {
+    int* start = reinterpret_cast<int*>(tab + UPR_LIN2_SPH_START); int* order = reinterpret_cast<int*>(tab + UPR_LIN2_SPH_ORDER);
+    const int ns = PG->n_sph;
+    if (i < ns) {
+        const int f = PG->sph_frame[i];
+        for (int a = 0; a < 3; ++a) tab[UPR_LIN2_SPH_OFF + 3 * i + a] = PG->sph_off[i][a];
+        if (f >= 0) {
+            int pos = 0;
+            for (int t = 0; t < ns; ++t) { const int ft = PG->sph_frame[t]; if (ft >= 0 && (ft < f || (ft == f && t < i))) ++pos; }
+            order[pos] = i;
+        }
+    }
+    if (i < nq + 2) {
+        int c = 0;
+        for (int t = 0; t < ns; ++t) { const int ft = PG->sph_frame[t]; if (ft >= 0 && ft < i) ++c; }
+        start[i] = c;
+    }
+}
+// the walk's hook (upr_kin.h): the spheres of frame f from the frame the walk has just reached
+struct upr_lin2_place {
+    const double* tab; double* cen;
+    UPR_HDI void operator()(int f, const double* C, const double* p) const {
+        const int* start = reinterpret_cast<const int*>(tab + UPR_LIN2_SPH_START); const int* order = reinterpret_cast<const int*>(tab + UPR_LIN2_SPH_ORDER);
+        for (int t = start[f]; t < start[f + 1]; ++t) {
+            const int s = order[t];
+            const double* o = tab + UPR_LIN2_SPH_OFF + 3 * s;
+            for (int i = 0; i < 3; ++i) cen[3 * s + i] = p[i] + C[3 * i] * o[0] + C[3 * i + 1] * o[1] + C[3 * i + 2] * o[2];
+        }
+    }
+};
+// a sphere that does not ride on the chain (world: frame -1; obstacle i: frame -2 - i, at the obstacle's position at the knot)
+static UPR_HDI void upr_lin2_job_fixed_sphere(const upr_lin_args& A, const upr_problem* PG, const upr_lin_point& q, int s, double* cen) {
+    const int f = PG->sph_frame[s];
+    if (f >= 0 || q.terminal) return;
+    double ro[3] = {0.0, 0.0, 0.0}, vo[3], ao[3];
+    if (f <= -2) upr_lin_obstacle(A, q, -2 - f, ro, vo, ao);
+    for (int i = 0; i < 3; ++i) cen[3 * s + i] = ro[i] + PG->sph_off[s][i];
+}
+// one collision / projectile row of one knot: value, and the gradient in closed form -- a sphere on link f moves rigidly with
+// every joint j <= f: d c / d q_j = z_j x (c - o_j) (revolute), z_j (prismatic), 0 (j > f, world and obstacle spheres)
+// (P: the record's prefix -- joint types; PG: the whole record -- pairs, radii, projectile data)
+template <int NQ>
+static UPR_HDI void upr_lin2_job_row(const upr_lin_args& A, const upr_problem* PG, const upr_problem* P, const upr_lin_point& q, int r, const double* snap, const double* cen) {
+    const upr_dims& d = A.d;
+    if (q.terminal) return;
+    // (the projectile rows follow the last obstacle: projectile_path_constraint.h:82 reads state.tail(9))
+    double ro[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0}, ao[3] = {0.0, 0.0, 0.0};
+    double flag = 0.0;
+    if (A.dyn) {
+        upr_lin_obstacle(A, q, PG->n_dyn > 0 ? PG->n_dyn - 1 : 0, ro, vo, ao);
+        if (r >= PG->n_pairs) flag = A.pflag ? A.pflag[q.b] : 0.0;
+    }
+    int sa, sb; double n[3], w;
+    q.out[d.lin_obs + r] = upr_state_row(PG, r, [&](int s, int i) { return cen[3 * s + i]; }, ro, vo, ao, flag, &sa, &sb, n, &w);
+    const int fa = PG->sph_frame[sa], fb = (sb >= 0) ? PG->sph_frame[sb] : -1;
+    double ca[3], cb[3];
+    for (int i = 0; i < 3; ++i) { ca[i] = cen[3 * sa + i]; cb[i] = (sb >= 0) ? cen[3 * sb + i] : 0.0; }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const double* S = snap + j * UPR_SNAP_J;
+        const double o[3] = {S[0], S[1], S[2]}, z[3] = {S[15], S[16], S[17]};
+        double v = 0.0;
+        if (P->joint_type[j] == 1) {   // n . (z x (c - o)) = (c - o) . (n x z): the two spheres differ only in c
+            double nz[3];
+            upr_cross(n, z, nz);
+            if (fa >= j) v += (ca[0] - o[0]) * nz[0] + (ca[1] - o[1]) * nz[1] + (ca[2] - o[2]) * nz[2];
+            if (fb >= j) v -= (cb[0] - o[0]) * nz[0] + (cb[1] - o[1]) * nz[1] + (cb[2] - o[2]) * nz[2];
+        } else {
+            const double nd = n[0] * z[0] + n[1] * z[1] + n[2] * z[2];
+            if (fa >= j) v += nd;
+            if (fb >= j) v -= nd;
+        }
+        q.out[d.lin_obs + d.no + r * NQ + j] = w * v;
+    }
+}
 
 // Tangent of the end effector's (C, w, al, a, p) along state coordinate CLS nq + j out of the snapshots (upr_kin.h: the same
 // formulas as upr_ee_from_snap, one class at compile time, tangents only).  rot: the direction turns the end effector's frame,
@@ -158,9 +246,8 @@ static UPR_HDI void upr_lin2_body_tangent(const double* T, const upr_lin2_body& 
 // ---- lane jobs (sh: the knot's LDS area; P: the record's PREFIX -- chain and gravity only) ---------------------------------
 // one tangent direction of one knot: column CLS nq + j of d g / d x for every body; CLS 0 also column j of J_p
 template <int NQ, int CLS>
-static UPR_HDI void upr_lin2_job_tangent(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int j, double* sh) {
+static UPR_HDI void upr_lin2_job_tangent(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int j, double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
-    const upr_lin2_lay lay = upr_lin2_layout(d);
     const double* snap = sh + lay.snap;
     const double* T = snap + NQ * UPR_SNAP_J;
     bool rot; double z[3], dw[3], dal[3], da[3], dp[3];
@@ -177,9 +264,8 @@ static UPR_HDI void upr_lin2_job_tangent(const upr_lin_args& A, const upr_proble
     }
 }
 // the residual's value of one body of one knot (the equality is affine in the forces: g = g(x; f = 0) + Df f)
-static UPR_HDI void upr_lin2_job_value(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int b, int nq, const double* sh) {
+static UPR_HDI void upr_lin2_job_value(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int b, int nq, const double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
-    const upr_lin2_lay lay = upr_lin2_layout(d);
     if (q.terminal) return;
     const double* T = sh + lay.snap + nq * UPR_SNAP_J;
     upr_lin2_body V; double g[6];
@@ -187,7 +273,7 @@ static UPR_HDI void upr_lin2_job_value(const upr_lin_args& A, const upr_problem*
     for (int r = 0; r < 6; ++r) q.out[d.lin_g + 6 * b + r] = d.eq_scale * g[r] + sh[lay.gf + 6 * b + r];
 }
 // Df f of one (knot, row) (the forces straight from the input vector)
-static UPR_HDI void upr_lin2_job_dff(const upr_lin_args& A, const upr_lin_point& q, int r, double* sh) {
+static UPR_HDI void upr_lin2_job_dff(const upr_lin_args& A, const upr_lin_point& q, int r, double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
     if (q.terminal) return;
     const double* f = q.u + d.nq;
@@ -207,13 +293,12 @@ static UPR_HDI void upr_lin2_job_dff(const upr_lin_args& A, const upr_lin_point&
         }
         for (; j < d.nfc; ++j) v += D[j] * f[j];
     }
-    sh[upr_lin2_layout(d).gf + r] = v;
+    sh[lay.gf + r] = v;
 }
 // gradient entry j (+ the terminal knot's record: grad[0..2] = p_d - p, hess[0..3nq) = J_p); PG: the whole record (weights)
 template <int NQ>
-static UPR_HDI void upr_lin2_job_grad(const upr_lin_args& A, const upr_problem* PG, const upr_lin_point& q, int j, const double* sh) {
+static UPR_HDI void upr_lin2_job_grad(const upr_lin_args& A, const upr_problem* PG, const upr_lin_point& q, int j, const double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
-    const upr_lin2_lay lay = upr_lin2_layout(d);
     const double* J = sh + lay.js; const double* e = sh + lay.e;
     if (!q.terminal) {
         double g = 0.0;
@@ -228,9 +313,9 @@ static UPR_HDI void upr_lin2_job_grad(const upr_lin_args& A, const upr_problem* 
 }
 // Gauss-Newton Hessian row j on the VALU (host emulation; the device kernel forms it on the matrix cores)
 template <int NQ>
-static UPR_HDI void upr_lin2_job_hess_row(const upr_lin_args& A, const upr_problem* PG, const upr_lin_point& q, int j, const double* sh) {
+static UPR_HDI void upr_lin2_job_hess_row(const upr_lin_args& A, const upr_problem* PG, const upr_lin_point& q, int j, const double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
-    const double* J = sh + upr_lin2_layout(d).js;
+    const double* J = sh + lay.js;
     if (q.terminal) return;
     for (int m = j; m < NQ; ++m) {
         double hs = 0.0;
@@ -242,19 +327,26 @@ static UPR_HDI void upr_lin2_job_hess_row(const upr_lin_args& A, const upr_probl
 template <int NQ>
 static UPR_HDI void upr_lin2_knot(const upr_lin_args& A, const upr_lin_point& q, double* sh) {
     const upr_dims& d = A.d;
-    const upr_lin2_lay lay = upr_lin2_layout(d);
+    const upr_lin2_lay lay = upr_lin2_layout(d, A.P->n_sph);
     const upr_problem* P = A.P;
     for (int j = 0; j < NQ; ++j) upr_sincos(q.x[j], sh + lay.js + 2 * j, sh + lay.js + 2 * j + 1);
-    upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
-    for (int r = 0; r < d.ne; ++r) upr_lin2_job_dff(A, q, r, sh);
+    if (d.no > 0) {
+        double tab[UPR_LIN2_SPH_DOUBLES];
+        for (int i = 0; i < UPR_MAX_SPHERES || i < NQ + 2; ++i) upr_lin2_sphere_table(P, NQ, i, tab);
+        upr_lin2_place place{tab, sh + lay.obs};
+        upr_ee_walk_snap<NQ, upr_lin2_place>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place);
+        for (int s2 = 0; s2 < P->n_sph; ++s2) upr_lin2_job_fixed_sphere(A, P, q, s2, sh + lay.obs);
+        for (int r = 0; r < d.no; ++r) upr_lin2_job_row<NQ>(A, P, P, q, r, sh + lay.snap, sh + lay.obs);
+    } else upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
+    for (int r = 0; r < d.ne; ++r) upr_lin2_job_dff(A, q, r, sh, lay);
     upr_target_position(P, A.way_p + (size_t)q.b * P->n_way * 3, q.t, sh + lay.e);
-    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 0>(A, P, q, j, sh);
-    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 1>(A, P, q, j, sh);
-    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 2>(A, P, q, j, sh);
-    for (int b = 0; b < d.nb; ++b) upr_lin2_job_value(A, P, q, b, NQ, sh);
+    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 0>(A, P, q, j, sh, lay);
+    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 1>(A, P, q, j, sh, lay);
+    for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 2>(A, P, q, j, sh, lay);
+    for (int b = 0; b < d.nb; ++b) upr_lin2_job_value(A, P, q, b, NQ, sh, lay);
     const double* T = sh + lay.snap + NQ * UPR_SNAP_J;
     for (int r = 0; r < 3; ++r) { sh[lay.e + r] = T[9 + r] - sh[lay.e + r]; if (A.ee_out) A.ee_out[(size_t)q.p * 3 + r] = T[9 + r]; }
-    for (int j = 0; j < NQ; ++j) { upr_lin2_job_grad<NQ>(A, P, q, j, sh); upr_lin2_job_hess_row<NQ>(A, P, q, j, sh); }
+    for (int j = 0; j < NQ; ++j) { upr_lin2_job_grad<NQ>(A, P, q, j, sh, lay); upr_lin2_job_hess_row<NQ>(A, P, q, j, sh, lay); }
 }
 
 #ifndef UPR_HOST_EMU
@@ -269,13 +361,14 @@ static UPR_HDI void upr_lin2_knot(const upr_lin_args& A, const upr_lin_point& q,
 // per (knot, joint), then the residuals' values and the position errors;  barrier 3;  Hessians on the matrix cores (a knot per
 // wave and trip), gradients and costs.
 template <int NQ>
-__global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, int kpw) {
+__global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, int kpw, int n_sph) {
     extern __shared__ __attribute__((aligned(16))) double smem_all[];
     constexpr int NPRE = UPR_LIN2_NPRE;
     const upr_problem* PG = A.P;
     const upr_dims& d = A.d;
-    const upr_lin2_lay lay = upr_lin2_layout(d);
-    double* smem = smem_all + ((NPRE + 1) & ~1);
+    const upr_lin2_lay lay = upr_lin2_layout(d, n_sph);
+    double* tab = smem_all + ((NPRE + 1) & ~1);   // (the sphere table: problems with collision rows only)
+    double* smem = tab + (d.no > 0 ? ((UPR_LIN2_SPH_DOUBLES + 1) & ~1) : 0);
     const int tid = threadIdx.x, base = blockIdx.x * kpw;
     const int nk = (A.npoints - base < kpw) ? A.npoints - base : kpw;
 #ifdef UPR_LIN_PROF
@@ -286,6 +379,8 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
         const double* src = reinterpret_cast<const double*>(PG);
         for (int i = tid; i < NPRE; i += 256) smem_all[i] = src[i];
     }
+    static_assert(UPR_MAX_SPHERES >= UPR_MAX_JOINTS + 2, "one lane per entry of the sphere table");
+    if (d.no > 0 && tid < UPR_MAX_SPHERES) upr_lin2_sphere_table(PG, NQ, tid, tab);
     for (int job = tid; job < nk * NQ; job += 256) {
         const int s = job / NQ, j = job - s * NQ;
         const upr_lin_point q = upr_lin_locate(A, base + s);
@@ -300,13 +395,19 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
         if (tid < nk) {
             const upr_lin_point q = upr_lin_locate(A, base + tid);
             double* sh = smem + tid * lay.per;
-            upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
+            if (d.no > 0) { upr_lin2_place place{tab, sh + lay.obs}; upr_ee_walk_snap<NQ, upr_lin2_place>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place); }
+            else upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
         }
     } else {
+        if (d.no > 0) for (int idx = tid - 64; idx < nk * n_sph; idx += 192) {   // the spheres that do not ride on the chain
+            const int s = idx / n_sph, sp = idx - s * n_sph;
+            const upr_lin_point q = upr_lin_locate(A, base + s);
+            upr_lin2_job_fixed_sphere(A, PG, q, sp, smem + s * lay.per + lay.obs);
+        }
         for (int idx = tid - 64; idx < nk * d.ne; idx += 192) {
             const int s = idx / d.ne, r = idx - s * d.ne;
             const upr_lin_point q = upr_lin_locate(A, base + s);
-            upr_lin2_job_dff(A, q, r, smem + s * lay.per);
+            upr_lin2_job_dff(A, q, r, smem + s * lay.per, lay);
         }
         for (int s = tid - 64; s < nk; s += 192) {
             const upr_lin_point q = upr_lin_locate(A, base + s);
@@ -318,23 +419,28 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
     for (int job = tid; job < nk * NQ; job += 256) {
         const int s = job / NQ, j = job - s * NQ;
         const upr_lin_point q = upr_lin_locate(A, base + s);
-        upr_lin2_job_tangent<NQ, 0>(A, P, q, j, smem + s * lay.per);
+        upr_lin2_job_tangent<NQ, 0>(A, P, q, j, smem + s * lay.per, lay);
     }
     for (int job = tid; job < nk * NQ; job += 256) {
         const int s = job / NQ, j = job - s * NQ;
         const upr_lin_point q = upr_lin_locate(A, base + s);
-        upr_lin2_job_tangent<NQ, 1>(A, P, q, j, smem + s * lay.per);
+        upr_lin2_job_tangent<NQ, 1>(A, P, q, j, smem + s * lay.per, lay);
     }
     for (int job = tid; job < nk * NQ; job += 256) {
         const int s = job / NQ, j = job - s * NQ;
         const upr_lin_point q = upr_lin_locate(A, base + s);
-        upr_lin2_job_tangent<NQ, 2>(A, P, q, j, smem + s * lay.per);
+        upr_lin2_job_tangent<NQ, 2>(A, P, q, j, smem + s * lay.per, lay);
     }
     UPR_LIN2_STAMP(2);
     for (int job = tid; job < nk * d.nb; job += 256) {
         const int s = job / d.nb, b = job - s * d.nb;
         const upr_lin_point q = upr_lin_locate(A, base + s);
-        upr_lin2_job_value(A, P, q, b, NQ, smem + s * lay.per);
+        upr_lin2_job_value(A, P, q, b, NQ, smem + s * lay.per, lay);
+    }
+    if (d.no > 0) for (int job = tid; job < nk * d.no; job += 256) {   // collision / projectile rows
+        const int s = job / d.no, r = job - s * d.no;
+        const upr_lin_point q = upr_lin_locate(A, base + s);
+        upr_lin2_job_row<NQ>(A, PG, P, q, r, smem + s * lay.per + lay.snap, smem + s * lay.per + lay.obs);
     }
     for (int s = 255 - tid; s < nk; s += 256) {   // (the last lanes: the first ones carry the values)
         double* sh = smem + s * lay.per;
@@ -368,7 +474,7 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
     for (int job = tid; job < nk * NQ; job += 256) {
         const int s = job / NQ, j = job - s * NQ;
         const upr_lin_point q = upr_lin_locate(A, base + s);
-        upr_lin2_job_grad<NQ>(A, PG, q, j, smem + s * lay.per);
+        upr_lin2_job_grad<NQ>(A, PG, q, j, smem + s * lay.per, lay);
     }
     UPR_LIN2_STAMP(4);
 }
