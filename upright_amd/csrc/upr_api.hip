@@ -356,8 +356,8 @@ int launch_linearize(upr_batch* h, const upr_lin_args& A) {
     // workgroups per CU hold in LDS and one tangent pass takes in one trip (28 for the headline shape: 768 workgroups)
     if (h->lin2 && upr_lin2_eligible(A) && h->use_mfma && occ == 2) {
         const upr_lin2_lay lay = upr_lin2_layout(A.d, h->P.n_sph);
-        const int npre = ((UPR_LIN2_NPRE + 1) & ~1) + (A.d.no > 0 ? ((UPR_LIN2_SPH_DOUBLES + 1) & ~1) : 0);
-        int kpw = (int)((160 * 1024 / 3 - 64 - npre * sizeof(double)) / (lay.per * sizeof(double)));
+        const int npre = ((UPR_LIN2_NPRE + 1) & ~1) + (A.d.no > 0 ? upr_lin2_table_doubles(h->P.n_sph) : 0);
+        int kpw = (int)((UPR_LIN2_LDS_BUDGET - npre * sizeof(double)) / (lay.per * sizeof(double)));
         if (kpw > 256 / NQ) kpw = 256 / NQ;
         if (kpw > 64) kpw = 64;
         if (kpw >= 1) {

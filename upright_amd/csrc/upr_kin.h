@@ -211,7 +211,11 @@ static UPR_HDI void upr_ee_kinematics(const upr_problem* P, const double* x, int
 struct upr_no_hook { UPR_HDI void operator()(int, const double*, const double*) const {} };
 // hook(f, C, p): called with the link frame behind joint f after its motion (f = NQ: the tool frame) -- upr_linearize2.h places
 // the collision spheres that ride on that link there, instead of keeping every frame
-template <int NQ, class HOOK = upr_no_hook>
+// COMPACT0: joint 0's snapshot keeps (o, z) only -- the link in front of the first joint is the world, at rest: v_o = a_o = w_b =
+// al_b = 0 exactly -- and the later ones follow it directly (upr_snap_at / UPR_SNAP_C0: upr_linearize2.h, 12 doubles a knot less)
+#define UPR_SNAP_C0 6
+static UPR_HDI int upr_snap_at(int j, bool compact0) { return compact0 ? (j == 0 ? 0 : UPR_SNAP_C0 + (j - 1) * UPR_SNAP_J) : j * UPR_SNAP_J; }
+template <int NQ, class HOOK = upr_no_hook, bool COMPACT0 = false>
 static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, const double* sc, double* snap, double* frames = nullptr, HOOK hook = HOOK()) {
     upr_ee<double> E;
     for (int i = 0; i < 9; ++i) E.C[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -225,8 +229,9 @@ static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, cons
         upr_rmul_const(E.C, P->joint_R[j]);
         double z[3];
         upr_rot_const(E.C, P->joint_axis[j], z);
-        double* S = snap + j * UPR_SNAP_J;
-        for (int i = 0; i < 3; ++i) { S[i] = E.p[i]; S[3 + i] = E.v[i]; S[6 + i] = E.a[i]; S[9 + i] = E.w[i]; S[12 + i] = E.al[i]; S[15 + i] = z[i]; }
+        double* S = snap + upr_snap_at(j, COMPACT0);
+        if (COMPACT0 && j == 0) { for (int i = 0; i < 3; ++i) { S[i] = E.p[i]; S[3 + i] = z[i]; } }
+        else for (int i = 0; i < 3; ++i) { S[i] = E.p[i]; S[3 + i] = E.v[i]; S[6 + i] = E.a[i]; S[9 + i] = E.w[i]; S[12 + i] = E.al[i]; S[15 + i] = z[i]; }
         if (P->joint_type[j] == 1) {
             double wz[3];
             upr_cross(E.w, z, wz);
@@ -268,7 +273,7 @@ static UPR_HDI void upr_ee_walk_snap(const upr_problem* P, const double* x, cons
     upr_carry(E, r);
     upr_rmul_const(E.C, P->tool_R);
     hook(NQ, E.C, E.p);
-    double* T = snap + NQ * UPR_SNAP_J;
+    double* T = snap + upr_snap_at(NQ, COMPACT0);
     for (int i = 0; i < 9; ++i) T[i] = E.C[i];
     for (int i = 0; i < 3; ++i) { T[9 + i] = E.p[i]; T[12 + i] = E.v[i]; T[15 + i] = E.w[i]; T[18 + i] = E.a[i]; T[21 + i] = E.al[i]; }
 }

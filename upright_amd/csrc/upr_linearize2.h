@@ -29,8 +29,8 @@ struct upr_lin2_lay { int gf, e, js, snap, obs, per; };
 static UPR_HDI upr_lin2_lay upr_lin2_layout(const upr_dims& d, int n_sph) {
     upr_lin2_lay l;
     l.gf = 0; l.e = d.ne; l.js = (l.e + 3 + 1) & ~1; l.snap = l.js + ((3 * d.nq + 1) & ~1);
-    l.obs = l.snap + d.nq * UPR_SNAP_J + UPR_SNAP_E;
-    l.per = (l.obs + (d.no > 0 ? 3 * n_sph : 0) + 1) & ~1;
+    l.obs = l.snap + upr_snap_at(d.nq, true) + UPR_SNAP_E;   // (joint 0's snapshot compact: upr_kin.h, COMPACT0)
+    l.per = (l.obs + (d.no > 0 ? 3 * n_sph : 0)) | 1;   // (odd: the walk lanes -- one per knot, the same offset in every knot's area -- then hit different LDS banks)
     return l;
 }
 static UPR_HDI bool upr_lin2_eligible(const upr_lin_args& A) { return A.way_q == nullptr && A.Df != nullptr; }
@@ -42,6 +42,10 @@ static UPR_HDI bool upr_lin2_eligible(const upr_lin_args& A) { return A.way_q ==
 #define UPR_LIN2_SPH_ORDER ((UPR_MAX_JOINTS + 2 + 1) / 2)
 #define UPR_LIN2_SPH_OFF (UPR_LIN2_SPH_ORDER + (UPR_MAX_SPHERES + 1) / 2)
 #define UPR_LIN2_SPH_DOUBLES (UPR_LIN2_SPH_OFF + 3 * UPR_MAX_SPHERES)
+static UPR_HDI int upr_lin2_table_doubles(int n_sph) { return (UPR_LIN2_SPH_OFF + 3 * n_sph + 1) & ~1; }   // (what a workgroup keeps of it)
+// dynamic LDS up to which three workgroups share a CU (measured: a launch at 53 760 B runs in one round of 768, at 54 272 B in two
+// rounds of 512 -- below the 54 592 B hipOccupancyMaxActiveBlocksPerMultiprocessor allows, tools/probe/lds_occ_probe.hip)
+#define UPR_LIN2_LDS_BUDGET 53760
 // entry `i` of the table's construction: i < n_sph places sphere i in `order` and copies its offset, i < nq + 2 counts start[i]
 static UPR_HDI void upr_lin2_sphere_table(const upr_problem* PG, int nq, int i, double* tab) {
     int* start = reinterpret_cast<int*>(tab + UPR_LIN2_SPH_START); int* order = reinterpret_cast<int*>(tab + UPR_LIN2_SPH_ORDER);
@@ -102,8 +106,9 @@ static UPR_HDI void upr_lin2_job_row(const upr_lin_args& A, const upr_problem* P
     for (int i = 0; i < 3; ++i) { ca[i] = cen[3 * sa + i]; cb[i] = (sb >= 0) ? cen[3 * sb + i] : 0.0; }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const double* S = snap + j * UPR_SNAP_J;
-        const double o[3] = {S[0], S[1], S[2]}, z[3] = {S[15], S[16], S[17]};
+        const double* S = snap + upr_snap_at(j, true);
+        const int zo = (j == 0) ? 3 : 15;
+        const double o[3] = {S[0], S[1], S[2]}, z[3] = {S[zo], S[zo + 1], S[zo + 2]};
         double v = 0.0;
         if (P->joint_type[j] == 1) {   // n . (z x (c - o)) = (c - o) . (n x z): the two spheres differ only in c
             double nz[3];
@@ -124,8 +129,15 @@ static UPR_HDI void upr_lin2_job_row(const upr_lin_args& A, const upr_problem* P
 // dC = S(z) C (a revolute joint's angle); dw, dal, da, dp: the other tangents (dp for CLS 0 only).
 template <int NQ, int CLS>
 static UPR_HDI void upr_lin2_ee_tangent(const upr_problem* P, const double* snap, int j, bool& rot, double* z, double* dw, double* dal, double* da, double* dp) {
-    const double* T = snap + NQ * UPR_SNAP_J;
-    const double* S = snap + j * UPR_SNAP_J;
+    const double* T = snap + upr_snap_at(NQ, true);
+    // (joint 0: (o, z) only, the link in front of it is the world -- read as a full snapshot whose other entries are zero)
+    double Sv[UPR_SNAP_J];
+    {
+        const double* Sj = snap + upr_snap_at(j, true);
+        if (j == 0) { for (int i = 0; i < UPR_SNAP_J; ++i) Sv[i] = 0.0; for (int i = 0; i < 3; ++i) { Sv[i] = Sj[i]; Sv[15 + i] = Sj[3 + i]; } }
+        else for (int i = 0; i < UPR_SNAP_J; ++i) Sv[i] = Sj[i];
+    }
+    const double* S = Sv;
     const bool rev = P->joint_type[j] == 1;
     double p[3], w[3], o[3], wb[3];
     for (int i = 0; i < 3; ++i) { p[i] = T[9 + i]; w[i] = T[15 + i]; o[i] = S[i]; wb[i] = S[9 + i]; z[i] = S[15 + i]; }
@@ -249,7 +261,7 @@ template <int NQ, int CLS>
 static UPR_HDI void upr_lin2_job_tangent(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int j, double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
     const double* snap = sh + lay.snap;
-    const double* T = snap + NQ * UPR_SNAP_J;
+    const double* T = snap + upr_snap_at(NQ, true);
     bool rot; double z[3], dw[3], dal[3], da[3], dp[3];
     upr_lin2_ee_tangent<NQ, CLS>(P, snap, j, rot, z, dw, dal, da, dp);
     if (CLS == 0) for (int r = 0; r < 3; ++r) sh[lay.js + r * NQ + j] = dp[r];
@@ -267,7 +279,7 @@ static UPR_HDI void upr_lin2_job_tangent(const upr_lin_args& A, const upr_proble
 static UPR_HDI void upr_lin2_job_value(const upr_lin_args& A, const upr_problem* P, const upr_lin_point& q, int b, int nq, const double* sh, const upr_lin2_lay& lay) {
     const upr_dims& d = A.d;
     if (q.terminal) return;
-    const double* T = sh + lay.snap + nq * UPR_SNAP_J;
+    const double* T = sh + lay.snap + upr_snap_at(nq, true);
     upr_lin2_body V; double g[6];
     upr_lin2_body_values(T, A.body_params + ((size_t)q.b * d.nb + b) * 10, P->gravity, V, g);
     for (int r = 0; r < 6; ++r) q.out[d.lin_g + 6 * b + r] = d.eq_scale * g[r] + sh[lay.gf + 6 * b + r];
@@ -334,17 +346,17 @@ static UPR_HDI void upr_lin2_knot(const upr_lin_args& A, const upr_lin_point& q,
         double tab[UPR_LIN2_SPH_DOUBLES];
         for (int i = 0; i < UPR_MAX_SPHERES || i < NQ + 2; ++i) upr_lin2_sphere_table(P, NQ, i, tab);
         upr_lin2_place place{tab, sh + lay.obs};
-        upr_ee_walk_snap<NQ, upr_lin2_place>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place);
+        upr_ee_walk_snap<NQ, upr_lin2_place, true>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place);
         for (int s2 = 0; s2 < P->n_sph; ++s2) upr_lin2_job_fixed_sphere(A, P, q, s2, sh + lay.obs);
         for (int r = 0; r < d.no; ++r) upr_lin2_job_row<NQ>(A, P, P, q, r, sh + lay.snap, sh + lay.obs);
-    } else upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
+    } else upr_ee_walk_snap<NQ, upr_no_hook, true>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
     for (int r = 0; r < d.ne; ++r) upr_lin2_job_dff(A, q, r, sh, lay);
     upr_target_position(P, A.way_p + (size_t)q.b * P->n_way * 3, q.t, sh + lay.e);
     for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 0>(A, P, q, j, sh, lay);
     for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 1>(A, P, q, j, sh, lay);
     for (int j = 0; j < NQ; ++j) upr_lin2_job_tangent<NQ, 2>(A, P, q, j, sh, lay);
     for (int b = 0; b < d.nb; ++b) upr_lin2_job_value(A, P, q, b, NQ, sh, lay);
-    const double* T = sh + lay.snap + NQ * UPR_SNAP_J;
+    const double* T = sh + lay.snap + upr_snap_at(NQ, true);
     for (int r = 0; r < 3; ++r) { sh[lay.e + r] = T[9 + r] - sh[lay.e + r]; if (A.ee_out) A.ee_out[(size_t)q.p * 3 + r] = T[9 + r]; }
     for (int j = 0; j < NQ; ++j) { upr_lin2_job_grad<NQ>(A, P, q, j, sh, lay); upr_lin2_job_hess_row<NQ>(A, P, q, j, sh, lay); }
 }
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
     const upr_dims& d = A.d;
     const upr_lin2_lay lay = upr_lin2_layout(d, n_sph);
     double* tab = smem_all + ((NPRE + 1) & ~1);   // (the sphere table: problems with collision rows only)
-    double* smem = tab + (d.no > 0 ? ((UPR_LIN2_SPH_DOUBLES + 1) & ~1) : 0);
+    double* smem = tab + (d.no > 0 ? upr_lin2_table_doubles(n_sph) : 0);
     const int tid = threadIdx.x, base = blockIdx.x * kpw;
     const int nk = (A.npoints - base < kpw) ? A.npoints - base : kpw;
 #ifdef UPR_LIN_PROF
@@ -395,8 +407,8 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
         if (tid < nk) {
             const upr_lin_point q = upr_lin_locate(A, base + tid);
             double* sh = smem + tid * lay.per;
-            if (d.no > 0) { upr_lin2_place place{tab, sh + lay.obs}; upr_ee_walk_snap<NQ, upr_lin2_place>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place); }
-            else upr_ee_walk_snap<NQ>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
+            if (d.no > 0) { upr_lin2_place place{tab, sh + lay.obs}; upr_ee_walk_snap<NQ, upr_lin2_place, true>(P, q.x, sh + lay.js, sh + lay.snap, nullptr, place); }
+            else upr_ee_walk_snap<NQ, upr_no_hook, true>(P, q.x, sh + lay.js, sh + lay.snap, nullptr);
         }
     } else {
         if (d.no > 0) for (int idx = tid - 64; idx < nk * n_sph; idx += 192) {   // the spheres that do not ride on the chain
@@ -444,7 +456,7 @@ __global__ void __launch_bounds__(256, 3) upr_linearize2_kernel(upr_lin_args A, 
     }
     for (int s = 255 - tid; s < nk; s += 256) {   // (the last lanes: the first ones carry the values)
         double* sh = smem + s * lay.per;
-        const double* T = sh + lay.snap + NQ * UPR_SNAP_J;
+        const double* T = sh + lay.snap + upr_snap_at(NQ, true);
         for (int r = 0; r < 3; ++r) { sh[lay.e + r] = T[9 + r] - sh[lay.e + r]; if (A.ee_out) A.ee_out[(size_t)(base + s) * 3 + r] = T[9 + r]; }
     }
     __syncthreads();
