@@ -3,16 +3,17 @@
 //
 // What changed against upr_linearize_kernel (which keeps the orientation-cost shapes) and why:
 //   * its 896 workgroups of 24 knots held 74 KB of LDS each -- two per CU, 512 resident: a launch of the headline batch ran as
-//     TWO rounds (31.7 us at 512 workgroups, 47.3 us at 560, tools/exp_lin_b.py).  Here a knot keeps 224 doubles (no staged
-//     x / u, sin / cos and J_p share a slot, the residual's wrench slot holds Df f only) and the workgroup copies the 1.6 KB
-//     chain PREFIX of the problem record instead of its 11 KB: 28 knots = 52 KB, three workgroups per CU, 768 in ONE round;
+//     TWO rounds (31.7 us at 512 workgroups, 47.3 us at 560, tools/exp_lin_b.py).  Here a knot keeps 213 doubles (no staged
+//     x / u, sin / cos and J_p share a slot, the residual's wrench slot holds Df f only, joint 0's snapshot is (o, z) alone: the
+//     world in front of it is at rest) and the workgroup copies the 1.6 KB chain PREFIX of the problem record instead of its
+//     11 KB: 28 knots = 49 KB, three workgroups per CU, 768 in ONE round;
 //   * a tangent lane of the old kernel evaluated the body residual on (value, tangent) pairs with its class -- d/dq, d/dq',
 //     d/dq'' -- known only at run time, three classes side by side in every wave.  Here a pass of the workgroup takes ONE class
 //     (28 knots x 9 joints = 252 of 256 lanes), with the tangent of the residual written out per class: d/dq'' needs 2 of the
 //     12 cross products of d/dq, and no lane multiplies by a zero tangent.
 //   * collision / projectile rows: the walk lane places the spheres that ride on a link right behind that link's joint (a list
 //     of spheres per frame, built once per workgroup) instead of leaving every link frame in LDS (108 doubles a knot: the knots
-//     of a workgroup would drop from 27 to 19); a row is a lane job as before, its gradient out of the snapshots.
+//     of a workgroup would drop from 28 to 19); a row is a lane job as before, its gradient out of the snapshots.
 // Same closed-form tangents out of the per-joint snapshots (upr_kin.h, "analytic tangents"); results agree with the forward-mode
 // walk and the oracle's dual numbers to 1e-10 .. 1e-13 (tests/test_emu.py, tests/test_gpu_parity.py).
 #pragma once
