@@ -459,6 +459,30 @@ def test_production_kernels_keep_their_registers_out_of_scratch():
             assert u["spill"] <= spill_max and u["scratch"] <= scratch_max, (part, key, u)
 
 
+def test_constraint_kernels_keep_the_occupancy_they_were_sized_for():
+    """Round 6: the linearisation kernel runs the headline batch in ONE round of 768 workgroups because three of them share a CU
+    (<= 53 760 B of LDS each, set by the launcher, and <= 168 registers a lane, set by the compiler), the line search four two-wave
+    workgroups per CU (<= 256 registers, no scratch in the shape without collision rows).  The registers are the compiler's to
+    take: asserted on the resource-usage remarks of upr_api.hip (hipcc cross-compiles gfx950 without a GPU)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    from kernel_resources import usage
+
+    res = usage("api")
+    lin = {n: u for n, u in res.items() if "upr_linearize2_kernel" in n}
+    assert len(lin) == 2, list(lin)                                        # nq = 6, 9
+    for n, u in lin.items():
+        assert u["vgpr"] + u.get("agpr", 0) <= 168 and u["spill"] == 0 and u["scratch"] == 0, (n, u)
+    ls = {n: u for n, u in res.items() if "upr_linesearch_kernel" in n}
+    assert len(ls) == 16, list(ls)                                         # nq x {exact, exact + rows, one body, generic} x {staged, not}
+    for n, u in ls.items():
+        assert u["vgpr"] + u.get("agpr", 0) <= 256, (n, u)
+        if "ELi12ELi1ELb1ELb0" in n:                                       # the headline's contact structure, no collision rows
+            assert u["spill"] == 0 and u["scratch"] == 0, (n, u)
+
+
 def test_value_function_recursion_against_a_dense_solve():
     """upright_amd/value_function.py::riccati_value_function (the host-side Riccati recursion behind ControllerInterface.valueFunction*)
     on a small synthetic problem against the brute-force answer: the Hessian of the minimised quadratic in x_0 computed by condensing
