@@ -716,6 +716,39 @@ def test_event_timing_modes_and_the_two_linearisation_kernels(arrangements, monk
     assert (np.abs(recs["1"] - recs["0"]) / scale).max() < 1e-11
 
 
+@pytest.mark.parametrize("shape", ["headline_full_batch", "thrown_ball", "robust"])
+def test_linearisation_kernels_agree_record_by_record(shape, monkeypatch):
+    """upr_linearize2_kernel against upr_linearize_kernel (UPR_LIN2=0) on the device, every double of every knot's record: the
+    headline batch at full size (1024 instances: 768 workgroups of 28 knots, one round), the thrown-ball shape (collision and
+    projectile rows with the flag on: values and gradients; spheres placed by the walk lane, a dynamic obstacle) and the
+    eight-body robust arrangement with per-instance inertial parameters -- at the cold start from the workload's states and from
+    states in motion (the second knot of the first plan; the same states for both kernels: a warm re-plan would linearise at two
+    trajectories that already differ by the first solve's roundoff)."""
+    import bench
+
+    w = {"headline_full_batch": lambda: bench.headline_workload(1024), "thrown_ball": lambda: bench.config5_workload(96),
+         "robust": lambda: bench.config4_workload(48)}[shape]()
+    recs, x1 = {}, None
+    for form in ("1", "0"):
+        monkeypatch.setenv("UPR_LIN2", form)
+        mpc = bench.make_engine(w)
+        if shape == "thrown_ball":
+            mpc.set_projectile_flag(1.0)
+        out = []
+        mpc.advance(); out.append(mpc.lin_records())
+        if x1 is None:
+            _, xs, _ = mpc.solution()
+            x1 = w["x0"].copy(); x1[:, :xs.shape[2]] = xs[:, 1]
+        mpc.reset(); mpc.set_observation(w["P"].dt, x1)
+        mpc.advance(); out.append(mpc.lin_records())
+        recs[form] = out
+        mpc.close()
+    for a_, b_ in zip(recs["1"], recs["0"]):
+        assert np.isfinite(a_).all() and np.abs(a_).max() > 1.0
+        assert (np.abs(a_ - b_) / np.maximum(1.0, np.abs(b_))).max() < 1e-10
+    assert np.abs(recs["1"][1] - recs["1"][0]).max() > 1e-3   # (the second solve linearises somewhere else)
+
+
 def test_robust_arrangement_per_instance_parameters(arrangements):
     """BASELINE config 4 (upright_robust, planning_sim_loop.py:454-534): eight copies of one cuboid, one per vertex of
     the CoM box, 32 frictionless contact points (nx 27, nu 41, 48 equality rows / knot), and a DIFFERENT inertial
